@@ -1,0 +1,304 @@
+"""ctypes binding of the CPU oracle (oracle/libtsdf_oracle.so).
+
+TEST INFRASTRUCTURE ONLY.  May be imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never by anything under tsdf_amd/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libtsdf_oracle.so")
+_REF = os.path.join(_HERE, "_ref", "libref_bilateral.so")
+
+
+def build(force=False):
+    """(Re)build the oracle .so (and oracle/_ref when /root/reference is mounted)."""
+    if force or not os.path.exists(_LIB) or \
+            os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "tsdf_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "all"])
+    return _LIB
+
+
+class Geom(C.Structure):
+    """orc_geom (oracle/tsdf_oracle.h)."""
+    _fields_ = [("dims", C.c_uint32 * 3), ("phys", C.c_float * 3), ("vs", C.c_float * 3),
+                ("offset", C.c_float * 3), ("offset_at_clear", C.c_float * 3), ("trunc", C.c_float)]
+
+
+class RayStats(C.Structure):
+    _fields_ = [("samples", C.c_int64), ("touched", C.c_int64), ("hits", C.c_int64)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB)
+        fp = C.POINTER(C.c_float)
+        L.orc_geom_init.argtypes = [C.POINTER(Geom), C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float]
+        L.orc_clear.argtypes = [fp, fp, C.c_size_t, C.c_float]
+        L.orc_voxel_centre.argtypes = [C.POINTER(Geom), C.c_int, C.c_int, C.c_int, fp]
+        L.orc_integrate.restype = C.c_int64
+        L.orc_integrate.argtypes = [fp, fp, C.POINTER(Geom), fp, fp, fp, C.POINTER(C.c_uint16), C.c_uint32, C.c_uint32,
+                                    fp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+        L.orc_raycast.argtypes = [fp, C.POINTER(Geom), fp, fp, C.c_uint32, C.c_uint32, fp, C.POINTER(C.c_int32),
+                                  C.POINTER(C.c_uint8), C.POINTER(RayStats), C.c_int]
+        L.orc_raycast_slab.argtypes = [fp, C.POINTER(Geom), fp, fp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                       C.c_uint32, fp, C.c_int]
+        L.orc_normals.argtypes = [C.c_uint32, C.c_uint32, fp, fp]
+        L.orc_ray_box.restype = C.c_int
+        L.orc_ray_box.argtypes = [fp, fp, fp, fp, fp, fp]
+        L.orc_trilinear.restype = C.c_float
+        L.orc_trilinear.argtypes = [fp, C.POINTER(C.c_uint32), fp, fp]
+        L.orc_ray_direction.argtypes = [C.c_uint16, C.c_uint16, fp, fp, fp]
+        L.orc_world_to_pixel.argtypes = [fp, fp, fp, C.POINTER(C.c_int)]
+        L.orc_bilateral_u8.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_float, C.c_float]
+        L.orc_bilateral_u16.argtypes = [C.POINTER(C.c_uint16), C.c_int, C.c_int, C.c_float, C.c_float, C.c_int]
+        L.orc_bilateral_tables.restype = C.c_int
+        L.orc_bilateral_tables.argtypes = [C.c_float, C.c_float, fp, fp, C.c_int]
+        L.orc_camera_k.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, fp, fp]
+        L.orc_mat3_inverse.argtypes = [fp, fp]
+        L.orc_mat4_inverse.argtypes = [fp, fp]
+        L.orc_look_at.argtypes = [fp, C.c_float, C.c_float, C.c_float]
+        L.orc_camera_world_to_camera.argtypes = [fp, fp, fp]
+        L.orc_pixel_to_image_plane.argtypes = [fp, C.c_uint16, C.c_uint16, fp]
+        L.orc_image_plane_to_pixel.argtypes = [fp, fp, C.POINTER(C.c_int)]
+        L.orc_max_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _f32(a, n=None):
+    a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1)
+    if n is not None:
+        assert a.size == n, (a.size, n)
+    return a
+
+
+def max_threads():
+    return lib().orc_max_threads()
+
+
+# ------------------------------------------------------------------------------ camera
+
+def camera_k(fx=591.1, fy=590.1, cx=331.0, cy=234.6):
+    """K and Kinv, column-major 9-vectors (default = Camera::default_depth_camera, Camera.hpp:41-44)."""
+    k = np.zeros(9, np.float32)
+    kinv = np.zeros(9, np.float32)
+    lib().orc_camera_k(fx, fy, cx, cy, _fp(k), _fp(kinv))
+    return k, kinv
+
+
+def mat4_inverse(m):
+    m = _f32(m, 16)
+    o = np.zeros(16, np.float32)
+    lib().orc_mat4_inverse(_fp(m), _fp(o))
+    return o
+
+
+def mat3_inverse(m):
+    m = _f32(m, 9)
+    o = np.zeros(9, np.float32)
+    lib().orc_mat3_inverse(_fp(m), _fp(o))
+    return o
+
+
+def look_at(pose, target):
+    p = _f32(pose, 16).copy()
+    lib().orc_look_at(_fp(p), float(target[0]), float(target[1]), float(target[2]))
+    return p
+
+
+def identity_pose(position=(0, 0, 0)):
+    p = np.eye(4, dtype=np.float32).T.reshape(-1).copy()  # column-major
+    p[12:15] = np.asarray(position, np.float32)
+    return p
+
+
+def pose_from_rows(rows):
+    """4x4 given in row-major maths notation -> column-major 16-vector."""
+    return np.ascontiguousarray(np.asarray(rows, np.float32).reshape(4, 4).T).reshape(-1)
+
+
+def world_to_camera(inv_pose, w):
+    ip = _f32(inv_pose, 16)
+    w = _f32(w, 3)
+    c = np.zeros(3, np.float32)
+    lib().orc_camera_world_to_camera(_fp(ip), _fp(w), _fp(c))
+    return c
+
+
+def pixel_to_image_plane(kinv, x, y):
+    out = np.zeros(2, np.float32)
+    lib().orc_pixel_to_image_plane(_fp(_f32(kinv, 9)), x, y, _fp(out))
+    return out
+
+
+def image_plane_to_pixel(k, cam):
+    out = (C.c_int * 2)()
+    lib().orc_image_plane_to_pixel(_fp(_f32(k, 9)), _fp(_f32(cam, 2)), out)
+    return int(out[0]), int(out[1])
+
+
+# ------------------------------------------------------------------------------ volume
+
+class Volume:
+    """Host-memory TSDF volume driven by the oracle; mirrors the reference's TSDFVolume state
+    (src/include/TSDFVolume.hpp:269-303).  Optionally a Z-slab [z_store_begin, z_store_end)."""
+
+    def __init__(self, size, physical_size, z_store=None):
+        X, Y, Z = (int(s) for s in size)
+        if min(X, Y, Z) <= 0 or min(physical_size) <= 0:
+            raise ValueError("Attempt to construct TSDFVolume with zero or negative size")
+        self.g = Geom()
+        lib().orc_geom_init(C.byref(self.g), X, Y, Z, *[float(p) for p in physical_size])
+        self.z0, self.z1 = (0, Z) if z_store is None else z_store
+        n = X * Y * (self.z1 - self.z0)
+        self.dist = np.empty(n, np.float32)
+        self.weight = np.empty(n, np.float32)
+        self.translation = None
+        self.clear()
+
+    # accessors named like the reference's
+    def size(self):
+        return tuple(self.g.dims)
+
+    def voxel_size(self):
+        return np.array(self.g.vs, np.float32)
+
+    def physical_size(self):
+        return np.array(self.g.phys, np.float32)
+
+    def truncation_distance(self):
+        return float(self.g.trunc)
+
+    def offset(self, *o):
+        if o:
+            for i in range(3):
+                self.g.offset[i] = float(o[i])   # setter does NOT re-init nodes (TSDFVolume.hpp:139-143)
+            return None
+        return np.array(self.g.offset, np.float32)
+
+    def clear(self):
+        lib().orc_clear(_fp(self.dist), _fp(self.weight), self.dist.size, self.g.trunc)
+        for i in range(3):
+            self.g.offset_at_clear[i] = self.g.offset[i]  # initialise_deformation bakes m_offset in
+
+    def voxel_centre(self, x, y, z):
+        out = np.zeros(3, np.float32)
+        lib().orc_voxel_centre(C.byref(self.g), x, y, z, _fp(out))
+        return out
+
+    def set_distance_data(self, d):
+        self.dist[:] = _f32(d, self.dist.size)
+
+    def set_weight_data(self, w):
+        self.weight[:] = _f32(w, self.weight.size)
+
+    def integrate(self, depth, width, height, inv_pose, k, kinv, z_range=None, nthreads=1):
+        depth = np.ascontiguousarray(depth, dtype=np.uint16).reshape(-1)
+        assert depth.size == width * height
+        zb, ze = (self.z0, self.z1) if z_range is None else z_range
+        tr = None if self.translation is None else _fp(self.translation)
+        return lib().orc_integrate(_fp(self.dist), _fp(self.weight), C.byref(self.g), _fp(_f32(inv_pose, 16)),
+                                   _fp(_f32(k, 9)), _fp(_f32(kinv, 9)),
+                                   depth.ctypes.data_as(C.POINTER(C.c_uint16)), width, height, tr,
+                                   self.z0, zb, ze, nthreads)
+
+    def raycast(self, width, height, pose, kinv, nthreads=1, stats=False):
+        assert self.z0 == 0 and self.z1 == self.g.dims[2]
+        V = np.empty(width * height * 3, np.float32)
+        sc = tm = st = None
+        if stats:
+            sc = np.zeros(width * height, np.int32)
+            tm = np.zeros(self.dist.size, np.uint8)
+            st = RayStats()
+        lib().orc_raycast(_fp(self.dist), C.byref(self.g), _fp(_f32(pose, 16)), _fp(_f32(kinv, 9)), width, height,
+                          _fp(V), None if sc is None else sc.ctypes.data_as(C.POINTER(C.c_int32)),
+                          None if tm is None else tm.ctypes.data_as(C.POINTER(C.c_uint8)),
+                          None if st is None else C.byref(st), nthreads)
+        N = np.empty_like(V)
+        lib().orc_normals(width, height, _fp(V), _fp(N))
+        V = V.reshape(-1, 3)
+        N = N.reshape(-1, 3)
+        if stats:
+            return V, N, {"samples": st.samples, "touched": st.touched, "hits": st.hits, "sample_count": sc}
+        return V, N
+
+    def raycast_slab(self, width, height, pose, kinv, own, nthreads=1):
+        hits = np.empty(width * height * 4, np.float32)
+        lib().orc_raycast_slab(_fp(self.dist), C.byref(self.g), _fp(_f32(pose, 16)), _fp(_f32(kinv, 9)), width,
+                               height, self.z0, own[0], own[1], _fp(hits), nthreads)
+        return hits.reshape(-1, 4)
+
+
+def normals(width, height, V):
+    V = _f32(V, width * height * 3)
+    N = np.empty_like(V)
+    lib().orc_normals(width, height, _fp(V), _fp(N))
+    return N.reshape(-1, 3)
+
+
+def ray_box(origin, direction, smin, smax):
+    n = C.c_float()
+    f = C.c_float()
+    r = lib().orc_ray_box(_fp(_f32(origin, 3)), _fp(_f32(direction, 3)), _fp(_f32(smin, 3)), _fp(_f32(smax, 3)),
+                          C.byref(n), C.byref(f))
+    return bool(r), n.value, f.value
+
+
+def trilinear(point, dims, vs, dist):
+    d = (C.c_uint32 * 3)(*[int(x) for x in dims])
+    return lib().orc_trilinear(_fp(_f32(point, 3)), d, _fp(_f32(vs, 3)), _fp(_f32(dist)))
+
+
+def world_to_pixel(p, inv_pose, k):
+    out = (C.c_int * 2)()
+    lib().orc_world_to_pixel(_fp(_f32(p, 3)), _fp(_f32(inv_pose, 16)), _fp(_f32(k, 9)), out)
+    return int(out[0]), int(out[1])
+
+
+# ------------------------------------------------------------------------------ bilateral
+
+def bilateral_u8(image, width, height, sigma_colour, sigma_space):
+    img = np.ascontiguousarray(image, np.uint8).reshape(-1).copy()
+    lib().orc_bilateral_u8(img.ctypes.data_as(C.POINTER(C.c_uint8)), width, height, sigma_colour, sigma_space)
+    return img.reshape(height, width)
+
+
+def bilateral_u16(image, width, height, sigma_colour, sigma_space, nthreads=1):
+    img = np.ascontiguousarray(image, np.uint16).reshape(-1).copy()
+    lib().orc_bilateral_u16(img.ctypes.data_as(C.POINTER(C.c_uint16)), width, height, sigma_colour, sigma_space,
+                            nthreads)
+    return img.reshape(height, width)
+
+
+def bilateral_tables(sigma_colour, sigma_space, n_similarity=256):
+    r = lib().orc_bilateral_tables(sigma_colour, sigma_space, None, None, 0)
+    k = np.zeros((2 * r + 1) ** 2, np.float32)
+    s = np.zeros(n_similarity, np.float32)
+    lib().orc_bilateral_tables(sigma_colour, sigma_space, _fp(k), _fp(s), n_similarity)
+    return r, k, s
+
+
+def have_ref():
+    return os.path.exists(_REF)
+
+
+def ref_bilateral_u8(image, width, height, sigma_colour, sigma_space):
+    """The reference's own BilateralFilter (oracle/_ref, built from /root/reference/src/BilateralFilter.cpp)."""
+    L = C.CDLL(_REF)
+    L.ref_bilateral_u8.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_float, C.c_float]
+    img = np.ascontiguousarray(image, np.uint8).reshape(-1).copy()
+    L.ref_bilateral_u8(img.ctypes.data_as(C.POINTER(C.c_uint8)), width, height, sigma_colour, sigma_space)
+    return img.reshape(height, width)
