@@ -1,0 +1,52 @@
+# Builds everything in-tree (no install step):
+#   tsdf_amd/lib/libtsdf_hip.so   HIP kernels + C ABI (include/tsdf_amd.h), gfx950 only
+#   tsdf_amd/lib/libtsdf_host.so  C++ class surface (TSDFVolume, GPURaycaster, Camera, ...) over the C ABI
+#   oracle/libtsdf_oracle.so      CPU oracle (test infrastructure), oracle/_ref when the reference is mounted
+HIPCC    ?= /opt/rocm/bin/hipcc
+ARCH     ?= gfx950
+# -ffp-contract=off: every fp32 op rounds on its own, in the reference's order (parity contract)
+HIPFLAGS  = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Iinclude -Itsdf_amd/csrc -Wall -Wno-unused-function
+CSRC      = tsdf_amd/csrc
+HIP_SRCS  = $(CSRC)/volume.hip $(CSRC)/integrate.hip $(CSRC)/raycast.hip $(CSRC)/bilateral.hip
+HIP_OBJS  = $(HIP_SRCS:.hip=.o)
+LIBDIR    = tsdf_amd/lib
+
+# Host C++ (class surface).  A real Eigen wins when one is installed; otherwise the bundled
+# minimal Eigen-compatible header is used.
+CXX      ?= g++
+HOSTDIR   = tsdf_amd/host
+EIGEN_INC := $(shell for d in /usr/include/eigen3 /usr/local/include/eigen3; do [ -f $$d/Eigen/Core ] && echo -I$$d && break; done)
+ifeq ($(EIGEN_INC),)
+EIGEN_INC = -I$(HOSTDIR)/eigen_compat
+endif
+HOSTFLAGS = -std=c++11 -O2 -ffp-contract=off -fPIC -Wall -Iinclude -I$(HOSTDIR)/include $(EIGEN_INC)
+HOST_SRCS = $(wildcard $(HOSTDIR)/src/*.cpp)
+HOST_OBJS = $(HOST_SRCS:.cpp=.o)
+
+all: hip host oracle
+
+host: $(LIBDIR)/libtsdf_host.so
+
+$(HOSTDIR)/src/%.o: $(HOSTDIR)/src/%.cpp $(wildcard $(HOSTDIR)/include/*.hpp) $(wildcard $(HOSTDIR)/src/*.hpp) include/tsdf_amd.h
+	$(CXX) $(HOSTFLAGS) -c $< -o $@
+
+$(LIBDIR)/libtsdf_host.so: $(HOST_OBJS) $(LIBDIR)/libtsdf_hip.so
+	$(CXX) -shared -fPIC -o $@ $(HOST_OBJS) -L$(LIBDIR) -ltsdf_hip -lz -Wl,-rpath,'$$ORIGIN'
+
+hip: $(LIBDIR)/libtsdf_hip.so
+
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.hpp include/tsdf_amd.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIBDIR)/libtsdf_hip.so: $(HIP_OBJS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(HIP_OBJS)
+
+oracle:
+	$(MAKE) -C oracle -s all
+
+clean:
+	rm -f $(HIP_OBJS) $(HOST_OBJS) $(LIBDIR)/*.so
+	$(MAKE) -C oracle clean
+
+.PHONY: all hip host oracle clean

@@ -1,0 +1,299 @@
+#!/usr/bin/env python3
+"""bench.py -- the TSDF hot path on MI355X: bilateral filter -> integrate -> raycast -> normals.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one 640x480 depth frame of the synthetic TUM surrogate (tsdf_amd/synth.py) pushed through the
+whole path on a 512^3 / 3000 mm volume (BASELINE.json configs[2]); inputs are resident in HBM before the
+timed region starts.  N > 1: the volume is split into N Z-slabs, one process per GPU (torch.distributed over
+RCCL); every rank integrates its slab (+1 halo plane), ray casts the samples it owns, and one all-gather of
+16-byte hit records per pixel is merged by a min-k select.  Total work is fixed => "strong".
+
+Rank 0 prints ONE JSON line.  `value` = voxels of the grid pushed through the whole step per second (whole
+job); per-stage figures (integrate Mvoxels/s, raycast Mrays/s), the roofline of the dominant kernel and the
+CPU baseline (the oracle, timed here on the host cores on a bounded sample) ride along in the same object.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+W, H = 640, 480
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+SEED = 0x5EED0003            # config 3 stream
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--grid", type=int, default=512)
+    ap.add_argument("--physical", type=float, default=3000.0)
+    ap.add_argument("--stream-frames", type=int, default=200, help="length of the synthetic trajectory")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        # launched without torchrun for N>1 is a usage error; N=1 runs standalone
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import tsdf_amd
+    from tsdf_amd import synth
+    from tsdf_amd._capi import check, lib
+
+    check(lib.tsdf_set_device(local_rank))
+    n = args.grid
+    N_vox = n * n * n
+    K, Wu = args.steps, args.warmup
+    n_frames = K + Wu + 1
+
+    # ---- inputs: synthetic stream, resident in HBM before timing ---------------------------------
+    frames, cams = [], []
+    for i in range(n_frames):
+        d, cam = synth.depth_frame(i % args.stream_frames, args.stream_frames, seed=SEED)
+        frames.append(d)
+        cams.append(cam)
+    depth_dev = torch.from_numpy(np.stack(frames).view(np.int16)).cuda()           # (F, H*W) uint16 bits
+    filt_dev = torch.empty((H * W,), dtype=torch.int16, device="cuda")
+    vert_dev = torch.empty((H * W, 3), dtype=torch.float32, device="cuda")
+    norm_dev = torch.empty((H * W, 3), dtype=torch.float32, device="cuda")
+
+    # ---- volume (whole, or this rank's Z-slab) -----------------------------------------------------
+    if world == 1:
+        vol = tsdf_amd.TSDFVolume((n, n, n), (args.physical,) * 3)
+    else:
+        from tsdf_amd.multi import slab_range
+        zb, ze = slab_range(n, world, rank)
+        vol = tsdf_amd.TSDFVolume((n, n, n), (args.physical,) * 3, slab=(zb, ze))
+        hits_mine = torch.empty((H * W, 4), dtype=torch.float32, device="cuda")
+        hits_all = torch.empty((world, H * W, 4), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream()
+    vol.set_stream(stream.cuda_stream)
+    bil = tsdf_amd.BilateralFilter(30.0, 4.5)
+    rc = tsdf_amd.GPURaycaster(W, H)
+
+    stage_names = ["bilateral", "integrate", "raycast", "normals"]
+    ev = {s: [] for s in stage_names}
+
+    def step(i, timed):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if timed else None
+        cam = cams[i]
+        if timed: e[0].record(stream)
+        bil.filter_device(depth_dev[i].data_ptr(), filt_dev.data_ptr(), W, H, bits=16, stream=stream.cuda_stream)
+        if timed: e[1].record(stream)
+        vol.integrate_device(filt_dev.data_ptr(), W, H, cam)
+        if timed: e[2].record(stream)
+        if world == 1:
+            rc.raycast_device(vol, cam, vert_dev.data_ptr(), None)
+            if timed: e[3].record(stream)
+        else:
+            rc.raycast_slab_device(vol, cam, hits_mine.data_ptr())
+            if timed: e[3].record(stream)
+            dist.all_gather_into_tensor(hits_all.view(-1), hits_mine.view(-1))
+            tsdf_amd.merge_hits_device(hits_all.data_ptr(), world, W, H, vert_dev.data_ptr(), stream.cuda_stream)
+        tsdf_amd.compute_normals_device(W, H, vert_dev.data_ptr(), norm_dev.data_ptr(), stream.cuda_stream)
+        if timed:
+            e[4].record(stream)
+            for j, s in enumerate(stage_names):
+                ev[s].append((e[j], e[j + 1]))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    # ---- warmup, then the timed region -------------------------------------------------------------
+    for i in range(Wu):
+        step(i, False)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(Wu, Wu + K):
+        step(i, True)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    stage_ms = {s: float(np.mean([a.elapsed_time(b) for a, b in ev[s]])) for s in stage_names}
+    ms_per_step = elapsed * 1e3 / K
+    value = N_vox * K / elapsed / 1e6
+
+    out = {
+        "metric": "Mvoxels/s integrate + Mrays/s raycast, 512^3 grid, 640x480 depth; 1/2/4/8 GPU",
+        "value": round(value, 3),
+        "unit": "Mvoxels/s",
+        "value_definition": "grid voxels pushed through the whole step (bilateral+integrate+raycast+normals) per second",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": Wu,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "configs[2]: %d^3 TSDF over %.0f mm, synthetic TUM-surrogate stream (%d-frame "
+                               "trajectory, seed 0x%X), 640x480 uint16 depth, bilateral(30,4.5) + integrate + "
+                               "raycast + normals per frame" % (n, args.physical, args.stream_frames, SEED),
+                   "grid": [n, n, n], "image": [W, H], "parallelism": "zslab%d" % world},
+        "integrate_mvoxels_per_s": round(N_vox / (stage_ms["integrate"] * 1e-3) / 1e6, 1),
+        "raycast_mrays_per_s": round(W * H / ((stage_ms["raycast"] + stage_ms["normals"]) * 1e-3) / 1e6, 2),
+        "stage_ms": {s: round(v, 4) for s, v in stage_ms.items()},
+    }
+
+    if rank == 0 and world == 1:
+        # ---- roofline of the dominant kernel (by time): HIP-event durations measured above --------------
+        last = Wu + K                                  # one more frame, untimed, for the byte counts
+        st = rc.stats(vol, cams[last - 1])             # S samples, T distinct voxels touched at the end state
+        vol.set_counting(True)
+        bil.filter_device(depth_dev[last].data_ptr(), filt_dev.data_ptr(), W, H, bits=16, stream=stream.cuda_stream)
+        vol.integrate_device(filt_dev.data_ptr(), W, H, cams[last])
+        U = vol.last_updated_voxels()
+        vol.set_counting(False)
+        ray_bytes = 4 * st["touched"] + 12 * W * H     # 4*T + vertex store (normals kernel: +12*W*H)
+        int_bytes = 16 * U + 2 * W * H                 # 16*U + depth frame
+        ray_gbs = ray_bytes / (stage_ms["raycast"] * 1e-3) / 1e9
+        int_gbs = int_bytes / (stage_ms["integrate"] * 1e-3) / 1e9
+        traffic = load_traffic()
+        dominant = "raycast" if stage_ms["raycast"] >= stage_ms["integrate"] else "integrate"
+        roof_ray = {"kernel": "process_ray_kernel", "bound": "hbm", "achieved": round(ray_gbs, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(ray_gbs / HBM_PEAK_GBS, 5), "traffic": traffic.get("process_ray_kernel"),
+                    "algorithmic_bytes": ray_bytes, "avg_launch_ms": round(stage_ms["raycast"], 4),
+                    "T_voxels_touched": st["touched"], "S_samples": st["samples"],
+                    "msamples_per_s": round(st["samples"] / (stage_ms["raycast"] * 1e-3) / 1e6, 1),
+                    "l2_level_gbs": round(32 * st["samples"] / (stage_ms["raycast"] * 1e-3) / 1e9, 1)}
+        roof_int = {"kernel": "integrate_kernel", "bound": "hbm", "achieved": round(int_gbs, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(int_gbs / HBM_PEAK_GBS, 5), "traffic": traffic.get("integrate_kernel"),
+                    "algorithmic_bytes": int_bytes, "avg_launch_ms": round(stage_ms["integrate"], 4),
+                    "U_voxels_updated": U, "dense_bytes": 16 * N_vox}
+        out["roofline"] = roof_ray if dominant == "raycast" else roof_int
+        out["roofline_other"] = roof_int if dominant == "raycast" else roof_ray
+
+        if not args.no_parity:
+            out["parity"] = parity_gate(tsdf_amd, synth, n_small=96)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(vol, frames[last], cams[last], n, args.physical, args.cpu_budget_s)
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def load_traffic():
+    """HBM bytes per launch from the PMC passes (profiles/traffic.json, written by tools/pmc_traffic.py from
+    rocprofv3 --pmc runs of this same command); empty when no counter run has been committed."""
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(p):
+        try:
+            return json.load(open(p)).get("bytes_per_launch", {})
+        except Exception:
+            return {}
+    return {}
+
+
+def parity_gate(tsdf_amd, synth, n_small):
+    """GPU vs CPU oracle on a reduced grid (first and last frame of a short stream), as SURVEY.md 8d asks.
+    The oracle is the checker here, nothing it computes is timed or reported as a result."""
+    import oracle as O
+    gv = tsdf_amd.TSDFVolume((n_small,) * 3, (3000.0,) * 3)
+    ov = O.Volume((n_small,) * 3, (3000.0,) * 3)
+    bil = tsdf_amd.BilateralFilter(30.0, 4.5)
+    res = {"grid": n_small, "frames": 3}
+    for i in (0, 1, 2):
+        d, cam = synth.depth_frame(i, 200, seed=SEED)
+        f = d.copy()
+        bil.filter(f, W, H)
+        fo = O.bilateral_u16(d, W, H, 30.0, 4.5, nthreads=O.max_threads()).reshape(-1)
+        res["bilateral_mismatch"] = res.get("bilateral_mismatch", 0) + int((f != fo).sum())
+        gv.integrate(f, W, H, cam)
+        ov.integrate(fo, W, H, cam.inverse_pose(), cam.k(), cam.kinv(), nthreads=O.max_threads())
+    gd, gw = gv.get_distance_data(), gv.get_weight_data()
+    res["weight_mismatch"] = int((gw != ov.weight).sum())
+    m = ov.weight > 0
+    rel = np.abs(gd[m] - ov.dist[m]) / np.maximum(np.abs(ov.dist[m]), 1e-6)
+    res["dist_max_rel_err"] = float(rel.max()) if m.any() else 0.0
+    res["dist_bit_mismatch"] = int((gd.view(np.uint32) != ov.dist.view(np.uint32)).sum())
+    d, cam = synth.depth_frame(0, 200, seed=SEED)
+    V, Nn = gv.raycast(W, H, cam)
+    Vo, No = ov.raycast(W, H, cam.pose(), cam.kinv(), nthreads=O.max_threads())
+    res["nan_mask_mismatch"] = int((np.isnan(V) != np.isnan(Vo)).sum())
+    ok = ~np.isnan(Vo)
+    res["vertex_max_rel_err"] = float((np.abs(V[ok] - Vo[ok]) / np.maximum(np.abs(Vo[ok]), 1e-6)).max()) if ok.any() else 0.0
+    okn = np.isfinite(No)
+    res["normal_max_abs_err"] = float(np.abs(Nn[okn] - No[okn]).max()) if okn.any() else 0.0
+    res["pass"] = bool(res["weight_mismatch"] == 0 and res["dist_max_rel_err"] <= 1e-4 and res["nan_mask_mismatch"] == 0
+                       and res["vertex_max_rel_err"] <= 1e-4 and res["normal_max_abs_err"] <= 1e-4
+                       and res["bilateral_mismatch"] == 0)
+    return res
+
+
+def cpu_baseline(vol, depth, cam, n, physical, budget_s):
+    """The oracle (a port of the reference arithmetic, oracle/tsdf_oracle.c) timed on this box's host cores on a
+    bounded sample of the same workload: one frame of bilateral + integrate over the full 512^3 grid and a ray
+    cast of every 16th image row against the GPU-built volume state.  Reported only."""
+    import oracle as O
+    cores = O.max_threads()
+    t = time.perf_counter()
+    f = O.bilateral_u16(depth, W, H, 30.0, 4.5, nthreads=cores).reshape(-1)
+    t_bil = time.perf_counter() - t
+    ov = O.Volume((n, n, n), (physical,) * 3)
+    ov.set_distance_data(vol.get_distance_data())
+    ov.set_weight_data(vol.get_weight_data())
+    t = time.perf_counter()
+    U = ov.integrate(f, W, H, cam.inverse_pose(), cam.k(), cam.kinv(), nthreads=cores)
+    t_int = time.perf_counter() - t
+    # single-thread figure on a slab of planes so it stays bounded
+    zs = max(1, n // 16)
+    t = time.perf_counter()
+    ov.integrate(f, W, H, cam.inverse_pose(), cam.k(), cam.kinv(), z_range=(n // 2, n // 2 + zs), nthreads=1)
+    t_int1 = (time.perf_counter() - t) * (n / zs)
+    row_step = 16
+    t = time.perf_counter()
+    Vs, samples = ov.raycast_rows(W, H, cam.pose(), cam.kinv(), 0, H, row_step, nthreads=cores)
+    t_ray = time.perf_counter() - t
+    rays = W * len(range(0, H, row_step))
+    t_ray_full = t_ray * (W * H / rays)
+    step_s = t_bil + t_int + t_ray_full
+    return {"value": round(n ** 3 / step_s / 1e6, 3), "unit": "Mvoxels/s", "cores": cores, "kind": "port",
+            "sample": "1 frame: bilateral 640x480 + integrate over the full %d^3 grid (%d voxels updated) + ray cast of "
+                      "every %dth row (%d rays, %d samples) scaled to 307200 rays; oracle/tsdf_oracle.c, OpenMP over "
+                      "z planes / rows, all %d host threads" % (n, U, row_step, rays, samples, cores),
+            "integrate_mvoxels_per_s": round(n ** 3 / t_int / 1e6, 2),
+            "integrate_mvoxels_per_s_1thread": round(n ** 3 / t_int1 / 1e6, 2),
+            "raycast_mrays_per_s": round(rays / t_ray / 1e6, 4),
+            "bilateral_ms": round(t_bil * 1e3, 2), "seconds_spent": round(t_bil + t_int + t_int1 * zs / n + t_ray, 2)}
+
+
+if __name__ == "__main__":
+    main()

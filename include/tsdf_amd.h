@@ -1,0 +1,189 @@
+/*
+ * tsdf_amd.h -- C ABI of the MI355X (gfx950) TSDF hot path: volume lifecycle, depth-map
+ * integration, TSDF ray casting + normals, bilateral depth filter.
+ *
+ * This is the drop-in boundary.  Everything above it (the C++ classes in
+ * tsdf_amd/host/include that keep the reference's TSDFVolume / GPURaycaster /
+ * BilateralFilter surface, and the Python mirror used by tests and bench.py) reaches the
+ * GPU only through these entry points; they take plain pointers and sizes, no C++ or
+ * torch types.  Each group names the reference interface it replaces (paths relative to
+ * the Scoobadood/TSDF tree).
+ *
+ * Conventions
+ *   - Every function returns TSDF_OK or an error code; tsdf_last_error() gives the text of
+ *     the last failure on the calling thread.  No exceptions cross the boundary.  (The C++
+ *     surface maps TSDF_ERR_INVALID to std::invalid_argument and TSDF_ERR_DEVICE to the
+ *     reference's "print and exit(-1)", src/Utilities/cuda_utilities.cu:5-11.)
+ *   - Matrices are column-major float arrays, byte-for-byte what the reference memcpy's
+ *     out of Eigen into Mat44/Mat33 (src/TSDF/TSDFVolume.cu:867-877,
+ *     src/include/cuda_utilities.hpp:12-23): 4x4 = m[col*4+row], 3x3 = m[col*3+row].
+ *   - Units are millimetres; depth is uint16 mm with 0 = invalid; pixel order y*width+x;
+ *     voxel order x + y*X + z*X*Y (src/include/TSDFVolume.hpp:165-167).
+ *   - "_device" variants take device pointers, enqueue on the volume's stream
+ *     (tsdf_volume_set_stream) and return without synchronising.  The others take host
+ *     pointers and are blocking, like the reference's methods.
+ *   - Not thread-safe per object, like the reference.
+ */
+#ifndef TSDF_AMD_H
+#define TSDF_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSDF_OK 0
+#define TSDF_ERR_INVALID 1 /* bad argument                                   */
+#define TSDF_ERR_DEVICE 2  /* a HIP call or kernel failed                    */
+#define TSDF_ERR_NOMEM 3   /* allocation failed                              */
+
+typedef struct tsdf_volume tsdf_volume;       /* opaque: one TSDFVolume (or one Z-slab of it) */
+typedef struct tsdf_bilateral tsdf_bilateral; /* opaque: one BilateralFilter                  */
+
+/* Mirror of the reference's private state, src/include/TSDFVolume.hpp:269-303. */
+typedef struct tsdf_volume_info {
+    uint32_t size[3];            /* m_size: voxels of the GLOBAL grid                          */
+    uint32_t z_begin, z_end;     /* planes this object owns (0..Z for a whole volume)           */
+    uint32_t z_store_begin, z_store_end; /* planes resident in HBM (owned + one halo plane)     */
+    float physical_size[3];      /* m_physical_size (mm)                                        */
+    float voxel_size[3];         /* m_voxel_size = physical / size                              */
+    float offset[3];             /* m_offset                                                    */
+    float offset_at_clear[3];    /* m_offset when clear() last initialised the deformation grid */
+    float truncation_distance;   /* m_truncation_distance = 1.1f * |voxel_size|                 */
+    float max_weight;            /* m_max_weight = 15 (unused by integrate, as in the reference)*/
+    float global_translation[3]; /* m_global_translation                                       */
+    float global_rotation[3];    /* m_global_rotation                                          */
+    int32_t deformation_materialised; /* 0 while the 24-B/voxel node array is still implicit    */
+} tsdf_volume_info;
+
+/* Layout of one deformation node, src/include/TSDFVolume.hpp:23-26 (2 x float3 = 24 bytes). */
+typedef struct tsdf_deformation_node {
+    float translation[3];
+    float rotation[3];
+} tsdf_deformation_node;
+
+/* ---- errors / device ------------------------------------------------------------------ */
+const char *tsdf_last_error(void);
+int tsdf_device_count(int *count);
+int tsdf_set_device(int device);
+int tsdf_get_device(int *device);
+/* Name of the GPU architecture the library was compiled for ("gfx950"). */
+const char *tsdf_build_arch(void);
+
+/* ---- volume lifecycle ------------------------------------------------------------------ */
+/* Replaces TSDFVolume::TSDFVolume / set_size (src/TSDF/TSDFVolume.cu:430-457, 679-722):
+ * validates sizes (TSDF_ERR_INVALID if any is zero/negative), computes voxel size and
+ * truncation distance, allocates distances + weights in HBM and clears them.  Dimensions
+ * above 65535 are rejected (the reference narrows them to uint16_t). */
+int tsdf_volume_create(uint32_t size_x, uint32_t size_y, uint32_t size_z, float physical_x,
+                       float physical_y, float physical_z, tsdf_volume **out);
+/* One Z-slab [z_begin, z_end) of a size_x*size_y*size_z grid, for one-process-per-GPU
+ * sharding (no reference equivalent).  Stores one halo plane above the slab. */
+int tsdf_volume_create_slab(uint32_t size_x, uint32_t size_y, uint32_t size_z, float physical_x,
+                            float physical_y, float physical_z, uint32_t z_begin, uint32_t z_end,
+                            tsdf_volume **out);
+/* Replaces TSDFVolume::~TSDFVolume / deallocate (src/TSDF/TSDFVolume.cu:396-423). */
+int tsdf_volume_destroy(tsdf_volume *volume);
+/* HIP stream (hipStream_t) used by this volume's kernels and copies; NULL = default stream. */
+int tsdf_volume_set_stream(tsdf_volume *volume, void *hip_stream);
+int tsdf_volume_synchronize(const tsdf_volume *volume);
+/* Replaces TSDFVolume::clear (src/TSDF/TSDFVolume.cu:812-845): weights <- 0,
+ * distances <- truncation distance, deformation grid <- voxel centres + current offset. */
+int tsdf_volume_clear(tsdf_volume *volume);
+/* Replaces size()/voxel_size()/physical_size()/truncation_distance()/offset()/
+ * global_rotation()/global_translation() (src/include/TSDFVolume.hpp:120-153, 216-225). */
+int tsdf_volume_get_info(const tsdf_volume *volume, tsdf_volume_info *info);
+/* Replaces TSDFVolume::offset(ox,oy,oz) (src/include/TSDFVolume.hpp:139-143); like the
+ * reference it does not re-initialise the deformation grid. */
+int tsdf_volume_set_offset(tsdf_volume *volume, float ox, float oy, float oz);
+
+/* Restores the header fields a saved volume carries (file constructor,
+ * src/TSDF/TSDFVolume.cu:463-505): offset, truncation distance, max weight, global
+ * translation / rotation.  The voxel size stays physical/size, as the reference recomputes it. */
+int tsdf_volume_set_header(tsdf_volume *volume, const float offset[3], float truncation_distance,
+                           float max_weight, const float global_translation[3],
+                           const float global_rotation[3]);
+
+/* ---- volume data access ---------------------------------------------------------------- */
+/* Replace distance_data()/weight_data()/deformation() (src/include/TSDFVolume.hpp:175-203):
+ * DEVICE pointers to the resident planes.  tsdf_volume_deformation materialises the node
+ * array on first use (until then integrate computes voxel centres analytically with the
+ * same float expression as initialise_deformation, src/TSDF/TSDFVolume.cu:783-785). */
+int tsdf_volume_distances(const tsdf_volume *volume, float **device_ptr);
+int tsdf_volume_weights(const tsdf_volume *volume, float **device_ptr);
+int tsdf_volume_deformation(tsdf_volume *volume, tsdf_deformation_node **device_ptr);
+/* Replace set_distance_data/set_weight_data/set_deformation (src/TSDF/TSDFVolume.cu:731-757):
+ * blocking H2D of every resident voxel. */
+int tsdf_volume_set_distance_data(tsdf_volume *volume, const float *host);
+int tsdf_volume_set_weight_data(tsdf_volume *volume, const float *host);
+int tsdf_volume_set_deformation(tsdf_volume *volume, const tsdf_deformation_node *host);
+/* Blocking D2H of every resident voxel (what save_to_file does, src/TSDF/TSDFVolume.cu:911-1027). */
+int tsdf_volume_get_distance_data(const tsdf_volume *volume, float *host);
+int tsdf_volume_get_weight_data(const tsdf_volume *volume, float *host);
+
+/* ---- integrate -------------------------------------------------------------------------- */
+/* Replaces TSDFVolume::integrate + integrate_kernel (src/TSDF/TSDFVolume.cu:861-902, 308-392).
+ * pose / inv_pose: 4x4, k / kinv: 3x3 (camera.pose(), inverse_pose(), k(), kinv()).
+ * Host variant: blocking, depth in host memory.  Device variant: depth in HBM, asynchronous. */
+int tsdf_integrate(tsdf_volume *volume, const uint16_t *host_depth, uint32_t width, uint32_t height,
+                   const float pose[16], const float inv_pose[16], const float k[9], const float kinv[9]);
+int tsdf_integrate_device(tsdf_volume *volume, const uint16_t *device_depth, uint32_t width,
+                          uint32_t height, const float pose[16], const float inv_pose[16],
+                          const float k[9], const float kinv[9]);
+/* Diagnostics: when enabled, integrate also counts the voxels whose weight changed (U in the
+ * roofline model).  Costs one atomic per wave; leave off when timing. */
+int tsdf_volume_set_counting(tsdf_volume *volume, int enabled);
+int tsdf_volume_last_updated_voxels(const tsdf_volume *volume, uint64_t *count);
+
+/* ---- raycast ---------------------------------------------------------------------------- */
+/* Replaces GPURaycaster::raycast = get_vertices/process_ray + compute_normals
+ * (src/RayCaster/GPURaycaster.cu:519-547, 432-486, 265-377, 393-427, 496-510).
+ * pose: camera pose (origin = translation column, rot = upper-left 3x3), kinv: 3x3.
+ * vertices / normals: 3*width*height floats each (packed float3, pixel order y*width+x);
+ * a miss is (NaN,NaN,NaN).  normals may be NULL (get_vertices only, as render_to_depth_image
+ * needs, src/RayCaster/GPURaycaster.cu:555-606). */
+int tsdf_raycast(const tsdf_volume *volume, uint32_t width, uint32_t height, const float pose[16],
+                 const float kinv[9], float *host_vertices, float *host_normals);
+int tsdf_raycast_device(const tsdf_volume *volume, uint32_t width, uint32_t height,
+                        const float pose[16], const float kinv[9], float *device_vertices,
+                        float *device_normals);
+/* compute_normals alone (src/RayCaster/GPURaycaster.cu:393-427) on device buffers. */
+int tsdf_normals_device(uint32_t width, uint32_t height, const float *device_vertices,
+                        float *device_normals, void *hip_stream);
+/* Diagnostics for the roofline model: S = trilinear samples evaluated, T = distinct voxels
+ * touched by any tap, of one raycast with these arguments (runs an instrumented kernel). */
+int tsdf_raycast_stats(const tsdf_volume *volume, uint32_t width, uint32_t height, const float pose[16],
+                       const float kinv[9], uint64_t *samples, uint64_t *touched_voxels, uint64_t *hits);
+
+/* Multi-GPU raycast: a slab evaluates only the samples whose lower trilinear
+ * tap plane it owns and writes one 16-byte record per pixel {k, x, y, z}: k = index of the
+ * first owned sample with tsdf <= 0 (+inf if none).  After an all-gather of the records,
+ * tsdf_merge_hits_device keeps, per pixel, the record with the smallest k. */
+int tsdf_raycast_slab_device(const tsdf_volume *volume, uint32_t width, uint32_t height,
+                             const float pose[16], const float kinv[9], float *device_hits);
+int tsdf_merge_hits_device(const float *device_hits_all, uint32_t n_slabs, uint32_t width,
+                           uint32_t height, float *device_vertices, void *hip_stream);
+
+/* ---- bilateral filter -------------------------------------------------------------------- */
+/* Replaces BilateralFilter::BilateralFilter / ~BilateralFilter (src/BilateralFilter.cpp:15-51):
+ * builds the spatial kernel and the similarity table on the host exactly as the reference
+ * does and uploads them. */
+int tsdf_bilateral_create(float sigma_colour, float sigma_space, tsdf_bilateral **out);
+int tsdf_bilateral_destroy(tsdf_bilateral *filter);
+/* Replace BilateralFilter::filter (src/BilateralFilter.cpp:124-130, 53-121): in place on a host
+ * image, blocking.  8 bit: bit-identical to the reference.  16 bit: the reference's path is
+ * undefined behaviour; the semantics implemented are stated in DESIGN.md. */
+int tsdf_bilateral_filter_u8(const tsdf_bilateral *filter, uint8_t *host_image, int width, int height);
+int tsdf_bilateral_filter_u16(const tsdf_bilateral *filter, uint16_t *host_image, int width, int height);
+/* Device variants: in != out, asynchronous on hip_stream. */
+int tsdf_bilateral_filter_u8_device(const tsdf_bilateral *filter, const uint8_t *device_in,
+                                    uint8_t *device_out, int width, int height, void *hip_stream);
+int tsdf_bilateral_filter_u16_device(const tsdf_bilateral *filter, const uint16_t *device_in,
+                                     uint16_t *device_out, int width, int height, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSDF_AMD_H */

@@ -49,6 +49,9 @@ def lib():
                                     fp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
         L.orc_raycast.argtypes = [fp, C.POINTER(Geom), fp, fp, C.c_uint32, C.c_uint32, fp, C.POINTER(C.c_int32),
                                   C.POINTER(C.c_uint8), C.POINTER(RayStats), C.c_int]
+        L.orc_raycast_rows.restype = C.c_int64
+        L.orc_raycast_rows.argtypes = [fp, C.POINTER(Geom), fp, fp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                       C.c_uint32, fp, C.c_int]
         L.orc_raycast_slab.argtypes = [fp, C.POINTER(Geom), fp, fp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                        C.c_uint32, fp, C.c_int]
         L.orc_normals.argtypes = [C.c_uint32, C.c_uint32, fp, fp]
@@ -234,6 +237,13 @@ class Volume:
         if stats:
             return V, N, {"samples": st.samples, "touched": st.touched, "hits": st.hits, "sample_count": sc}
         return V, N
+
+    def raycast_rows(self, width, height, pose, kinv, y_begin, y_end, y_step, nthreads=1):
+        """Bounded sample: only rows y_begin::y_step; returns (vertices with untouched rows = NaN, samples)."""
+        V = np.full(width * height * 3, np.nan, np.float32)
+        s = lib().orc_raycast_rows(_fp(self.dist), C.byref(self.g), _fp(_f32(pose, 16)), _fp(_f32(kinv, 9)), width,
+                                   height, y_begin, y_end, y_step, _fp(V), nthreads)
+        return V.reshape(-1, 3), int(s)
 
     def raycast_slab(self, width, height, pose, kinv, own, nthreads=1):
         hits = np.empty(width * height * 4, np.float32)

@@ -423,6 +423,36 @@ void orc_raycast(const float *dist, const orc_geom *g, const float pose[16], con
     }
 }
 
+/* Rows y_begin, y_begin+y_step, ... < y_end only (bounded CPU-baseline sample); other pixels untouched. */
+int64_t orc_raycast_rows(const float *dist, const orc_geom *g, const float pose[16], const float kinv[9],
+                         uint32_t width, uint32_t height, uint32_t y_begin, uint32_t y_end, uint32_t y_step,
+                         float *vertices, int nthreads) {
+    float origin[3], rot[9], smin[3], smax[3];
+    ray_setup(pose, g, origin, rot, smin, smax);
+    const uint32_t *dims = g->dims;
+    const float *vs = g->vs;
+    const float trunc = g->trunc;
+    int64_t total_samples = 0;
+    if (nthreads < 1) nthreads = 1;
+    if (y_step < 1) y_step = 1;
+    if (y_end > height) y_end = height;
+    int64_t nrows = (y_end > y_begin) ? ((int64_t)(y_end - y_begin) + y_step - 1) / y_step : 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads) reduction(+ : total_samples)
+    for (int64_t r = 0; r < nrows; r++) {
+        uint32_t imy = y_begin + (uint32_t)r * y_step;
+        for (uint32_t imx = 0; imx < width; imx++) {
+            float out[4];
+            total_samples += march_ray((int)imx, (int)imy, dist, dims, vs, smin, smax, trunc, origin, rot, kinv, 0,
+                                       NULL, 0, 0, 0, out);
+            size_t idx = (size_t)imy * width + imx;
+            vertices[idx * 3 + 0] = out[0];
+            vertices[idx * 3 + 1] = out[1];
+            vertices[idx * 3 + 2] = out[2];
+        }
+    }
+    return total_samples;
+}
+
 void orc_raycast_slab(const float *dist, const orc_geom *g, const float pose[16], const float kinv[9], uint32_t width,
                       uint32_t height, uint32_t z_store_begin, uint32_t z_own_begin,
                       uint32_t z_own_end, float *hits, int nthreads) {

@@ -87,6 +87,11 @@ void orc_raycast(const float *dist, const orc_geom *g, const float pose[16], con
                  uint32_t height, float *vertices, int32_t *sample_count, uint8_t *touched_map,
                  orc_ray_stats *stats, int nthreads);
 
+/* Rows y_begin, y_begin+y_step, ... < y_end only (bounded CPU-baseline sample); returns samples evaluated. */
+int64_t orc_raycast_rows(const float *dist, const orc_geom *g, const float pose[16], const float kinv[9],
+                         uint32_t width, uint32_t height, uint32_t y_begin, uint32_t y_end, uint32_t y_step,
+                         float *vertices, int nthreads);
+
 /*
  * Slab variant used to check the multi-GPU protocol: dist holds planes
  * [z_store_begin, ...) and only samples whose lower tap plane lies in [z_own_begin, z_own_end)

@@ -1,0 +1,266 @@
+"""Pins the CPU oracle before anything trusts it (no GPU needed).
+
+Sources of truth, in decreasing strength:
+  * the reference's own BilateralFilter compiled natively into oracle/_ref (bit-exact), and the
+    committed fixtures generated from it (tests/golden/bilateral_ref_*.npz);
+  * figures recorded in SURVEY.md 8c / BASELINE.md 2 from a run of the reference's device source in the
+    survey container (updated-voxel counts, sign change at the wall, centre vertex, mean hit depth);
+  * known answers of the reference's tests: Test_Camera.cpp, Test_TSDFMetrics.cpp and the ray/box and
+    wall-hit expectations kept (commented out) in Test_TSDF_RayCast.cpp.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+W, H = 640, 480
+
+
+def survey_camera(O):
+    """Camera of the survey probe: default depth camera at (1500,1500,-1000), identity rotation."""
+    k, kinv = O.camera_k()
+    pose = O.identity_pose((1500, 1500, -1000))
+    return k, kinv, pose, O.mat4_inverse(pose)
+
+
+# ----------------------------------------------------------------- survey-recorded reference outputs
+
+@pytest.mark.parametrize("n,expected_updates", [(128, 354056), (256, 2748639)])
+def test_integrate_updates_the_number_of_voxels_the_reference_source_did(oracle, n, expected_updates):
+    # wall at 2500 mm, 640x480, volume 3000 mm cube
+    k, kinv, pose, ip = survey_camera(oracle)
+    v = oracle.Volume((n, n, n), (3000, 3000, 3000))
+    depth = np.full(W * H, 2500, np.uint16)
+    assert v.integrate(depth, W, H, ip, k, kinv, nthreads=oracle.max_threads()) == expected_updates
+
+
+def test_integrate_sign_change_at_the_wall_matches_the_survey_probe(oracle):
+    # voxel (32,32,31)@64^3 = +23.4375, (32,32,32) = -23.4375
+    k, kinv, pose, ip = survey_camera(oracle)
+    v = oracle.Volume((64, 64, 64), (3000, 3000, 3000))
+    assert v.voxel_size()[0] == np.float32(46.875)
+    v.integrate(np.full(W * H, 2500, np.uint16), W, H, ip, k, kinv)
+    d = v.dist.reshape(64, 64, 64)
+    assert d[31, 32, 32] == np.float32(23.4375)
+    assert d[32, 32, 32] == np.float32(-23.4375)
+
+
+def test_truncation_distance_of_config1(oracle):
+    # 128^3 over 3000 mm -> vs 23.4375, trunc 44.6544
+    v = oracle.Volume((128, 128, 128), (3000, 3000, 3000))
+    assert v.voxel_size()[0] == np.float32(23.4375)
+    assert abs(v.truncation_distance() - 44.6544) < 1e-4
+
+
+def test_raycast_of_the_integrated_wall_matches_the_survey_probe(oracle):
+    # 307200 hits; centre-pixel vertex (1453.47, 1522.88, 1500.37); normal (0,0,-1);
+    # 8a-16: mean hit z 1502.4 mm at 64^3 for the wall at 1500 mm
+    k, kinv, pose, ip = survey_camera(oracle)
+    v = oracle.Volume((64, 64, 64), (3000, 3000, 3000))
+    v.integrate(np.full(W * H, 2500, np.uint16), W, H, ip, k, kinv)
+    V, N, st = v.raycast(W, H, pose, kinv, nthreads=oracle.max_threads(), stats=True)
+    assert st["hits"] == 307200
+    c = 240 * W + 320
+    assert np.allclose(V[c], [1453.47, 1522.88, 1500.37], atol=5e-3)
+    assert np.array_equal(N[c], np.array([0, 0, -1], np.float32))
+    assert abs(float(np.nanmean(V[:, 2])) - 1502.4) < 0.05
+    assert int(st["sample_count"].max()) <= 4402          # Q8
+
+
+# ----------------------------------------------------------------- reference test known answers
+
+WORLD = [(0, 0, 0), (100, 0, 0), (100, 100, 0), (0, 100, 0), (0, 100, 100), (0, 0, 100), (100, 0, 100), (100, 100, 100)]
+EPS = 1e-6
+
+
+def _w2c(O, pose, w):
+    return O.world_to_camera(O.mat4_inverse(pose), w)
+
+
+@pytest.mark.parametrize("target,expect", [
+    (None, lambda w: (w[0], w[1], w[2])),                 # Test_Camera.cpp:35-52
+    ((-1, 0, 0), lambda w: (w[2], w[1], -w[0])),          # :54-71
+    ((0, -1, 0), lambda w: (w[0], w[2], -w[1])),          # :73-89
+    ((0, 1, 0), lambda w: (w[0], -w[2], w[1])),           # :91-107
+    ((1, 0, 0), lambda w: (-w[2], w[1], w[0])),           # :109-125
+    ((0, 0, -1), lambda w: (-w[0], w[1], -w[2])),         # :127-143
+])
+def test_camera_world_to_camera_axis_aligned_look_at(oracle, target, expect):
+    pose = oracle.identity_pose()
+    if target is not None:
+        pose = oracle.look_at(pose, target)
+    for w in WORLD:
+        c = _w2c(oracle, pose, w)
+        assert np.allclose(c, expect(w), atol=EPS)
+
+
+@pytest.mark.parametrize("pos", [(100, 0, 0), (0, 100, 0), (0, 0, 100)])     # Test_Camera.cpp:146-197
+def test_camera_world_to_camera_translation_only(oracle, pos):
+    pose = oracle.identity_pose(pos)
+    for w in WORLD:
+        assert np.allclose(_w2c(oracle, pose, w), np.subtract(w, pos), atol=EPS)
+
+
+def test_camera_centre_pixel_maps_near_origin_and_corners_round_trip(oracle):
+    k, kinv = oracle.camera_k()
+    # Test_Camera.cpp:226-323 (tolerances are the reference's)
+    for px, ex, ey in [((0, 0), -0.5, -0.5), ((640, 0), 0.5, -0.5), ((0, 480), -0.5, 0.5), ((640, 480), 0.5, 0.5)]:
+        ip = oracle.pixel_to_image_plane(kinv, *px)
+        assert abs(ip[0] - ex) < 0.1 and abs(ip[1] - ey) < 0.11
+        assert oracle.image_plane_to_pixel(k, ip) == px
+
+
+def _y_rot(theta, pos):     # make_y_axis_rotation, TestHelpers.cpp:102-114
+    c, s = np.float32(math.cos(theta)), np.float32(math.sin(theta))
+    return [[c, 0, s, pos[0]], [0, 1, 0, pos[1]], [-s, 0, c, pos[2]], [0, 0, 0, 1]]
+
+
+def _x_rot(theta, pos):     # make_x_axis_rotation, TestHelpers.cpp:116-128
+    c, s = np.float32(math.cos(theta)), np.float32(math.sin(theta))
+    return [[1, 0, 0, pos[0]], [0, c, -s, pos[1]], [0, s, c, pos[2]], [0, 0, 0, 1]]
+
+
+@pytest.mark.parametrize("pos,expected", [
+    ((0, 0, 100), _y_rot(-math.pi, (0, 0, 100))),          # Test_Camera.cpp:355-374
+    ((100, 0, 0), _y_rot(-math.pi / 2, (100, 0, 0))),      # :377-396
+    ((-100, 0, 0), _y_rot(math.pi / 2, (-100, 0, 0))),     # :398-416
+    ((0, 0, -100), _y_rot(0, (0, 0, -100))),               # :418-436
+    ((0, 100, 0), _x_rot(math.pi / 2, (0, 100, 0))),       # :438-456
+    ((0, -100, 0), _x_rot(-math.pi / 2, (0, -100, 0))),    # :458-476
+])
+def test_camera_look_at_origin_pose(oracle, pos, expected):
+    pose = oracle.look_at(oracle.identity_pose(pos), (0, 0, 0))
+    assert np.allclose(pose, oracle.pose_from_rows(expected), atol=EPS)
+
+
+def test_voxel_geometry_known_answers(oracle):
+    # Test_TSDFMetrics.cpp:21-34 (voxel size), :97-200 (voxel centres, default and with offset)
+    v = oracle.Volume((9, 12, 15), (3000, 3000, 3000))
+    assert np.allclose(v.voxel_size(), [1000.0 / 3.0, 250.0, 200.0], atol=1e-4)
+    v = oracle.Volume((3, 4, 5), (3000, 3000, 3000))
+    assert np.allclose(v.voxel_centre(0, 0, 0), [500, 375, 300], atol=EPS)
+    assert np.allclose(v.voxel_centre(2, 0, 0), [2500, 375, 300], atol=EPS)
+    assert np.allclose(v.voxel_centre(0, 3, 0), [500, 2625, 300], atol=EPS)
+    assert np.allclose(v.voxel_centre(0, 0, 4), [500, 375, 2700], atol=EPS)
+    v = oracle.Volume((3, 4, 5), (3000, 3000, 3000))
+    v.offset(-1500.0, -2000.0, -2500.0)
+    v.g.offset_at_clear[:] = (0, 0, 0)     # offset applied once, as those tests assume
+    assert np.allclose(v.voxel_centre(0, 0, 0), [-1000, -1625, -2200], atol=1e-4)
+    assert np.allclose(v.voxel_centre(2, 0, 0), [1000, -1625, -2200], atol=1e-4)
+    assert np.allclose(v.voxel_centre(0, 3, 0), [-1000, 625, -2200], atol=1e-4)
+    assert np.allclose(v.voxel_centre(0, 0, 4), [-1000, -1625, 200], atol=1e-4)
+
+
+def test_ray_box_misses(oracle):
+    # Test_TSDF_RayCast.cpp:23-115: rays beside a 300 mm cube never intersect
+    lo, hi = (0, 0, 0), (300, 300, 300)
+    for origin, d in [((-10, 150, -150), (0, 0, 1)), ((310, 150, -150), (0, 0, 1)), ((150, 310, -150), (0, 0, 1)),
+                      ((150, -10, -150), (0, 0, 1)), ((150, 150, 310), (0, 1, 0)), ((150, 150, -10), (0, 1, 0))]:
+        assert oracle.ray_box(origin, d, lo, hi)[0] is False
+
+
+def test_ray_box_front_hits(oracle):
+    # Test_TSDF_RayCast.cpp:117-277: entry at t = 10 on the face the ray faces
+    lo, hi = (0, 0, 0), (300, 300, 300)
+    for a in range(10):
+        for b in range(10):
+            ga, gb = a * 30 + 15, b * 30 + 15
+            for origin, d in [((ga, gb, 310), (0, 0, -1)), ((ga, gb, -10), (0, 0, 1)), ((-10, ga, gb), (1, 0, 0)),
+                              ((310, ga, gb), (-1, 0, 0)), ((ga, 310, gb), (0, -1, 0)), ((ga, -10, gb), (0, 1, 0))]:
+                hit, near, far = oracle.ray_box(origin, d, lo, hi)
+                assert hit and abs(near - 10) < 1e-5 and abs(far - 310) < 1e-4
+
+
+def test_wall_tsdf_is_hit_near_z40_with_normal_minus_z(oracle):
+    # Test_TSDF_RayCast.cpp:307-342: create_wall_in_TSDF(volume, 40) on 64^3 / 300 mm, rays along +z from
+    # z=-150 hit with vertex.z within trunc of 40 and normal (0,0,-1); walking from behind finds nothing.
+    n = 64
+    v = oracle.Volume((n, n, n), (300, 300, 300))
+    vs, trunc = v.voxel_size(), np.float32(v.truncation_distance())
+    zc = (np.arange(n, dtype=np.float32) + np.float32(0.5)) * vs[2]      # create_wall_in_TSDF, TestHelpers.cpp:62-98
+    plane = np.minimum(np.maximum(np.float32(40) - zc, -trunc), trunc)
+    v.set_distance_data(np.repeat(plane, n * n))
+    k, kinv = oracle.camera_k(591.1, 590.1, 80.0, 60.0)
+    pose = oracle.identity_pose((150, 150, -150))
+    V, N = v.raycast(160, 120, pose, kinv, nthreads=oracle.max_threads())
+    hit = ~np.isnan(V[:, 0])
+    assert hit.sum() > 0.9 * hit.size
+    assert np.all(np.abs(V[hit, 2] - 40.0) < trunc)
+    inner = np.zeros((120, 160), bool)
+    inner[:-1, :-1] = True
+    ok = hit.reshape(120, 160) & np.roll(hit.reshape(120, 160), -1, 0) & np.roll(hit.reshape(120, 160), -1, 1) & inner
+    assert np.allclose(N.reshape(120, 160, 3)[ok], [0, 0, -1], atol=1e-3)
+    # from behind the wall (camera beyond the far face looking back): every sample is negative at entry ->
+    # the reference reports a vertex at the entry face, not a surface crossing at z=40
+    back = oracle.look_at(oracle.identity_pose((150, 150, 450)), (150, 150, 0))
+    Vb, _ = v.raycast(160, 120, back, kinv, nthreads=oracle.max_threads())
+    hb = ~np.isnan(Vb[:, 0])
+    assert np.all(Vb[hb, 2] > 250.0)
+
+
+# ----------------------------------------------------------------- bilateral: the real reference
+
+def _test_images():
+    rng = np.random.RandomState(7)
+    ramp = (np.arange(16)[None, :] * 12 + np.arange(8)[:, None] * 5).astype(np.uint8)
+    noisy = np.clip(np.tile(np.linspace(20, 230, 64), (48, 1)) + rng.randint(-12, 13, (48, 64)), 0, 255).astype(np.uint8)
+    step = np.full((33, 47), 40, np.uint8)
+    step[:, 20:] = 200
+    step[10:14, 5:9] = 255
+    return {"ramp16x8": ramp, "noisy64x48": noisy, "step47x33": step}
+
+
+@pytest.mark.parametrize("sigmas", [(3.0, 2.0), (30.0, 4.5), (12.5, 0.7)])
+def test_bilateral_u8_oracle_equals_the_reference_build(oracle, sigmas):
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref not built (reference tree not mounted)")
+    for name, img in _test_images().items():
+        h, w = img.shape
+        ref = oracle.ref_bilateral_u8(img, w, h, *sigmas)
+        got = oracle.bilateral_u8(img, w, h, *sigmas)
+        assert np.array_equal(ref, got), name
+
+
+def test_bilateral_u8_oracle_equals_committed_reference_fixtures(oracle):
+    f = np.load(os.path.join(GOLD, "bilateral_ref_u8.npz"))
+    n = int(f["count"])
+    assert n >= 6
+    for i in range(n):
+        img, out = f["in_%d" % i], f["out_%d" % i]
+        sc, ss = f["sigmas_%d" % i]
+        h, w = img.shape
+        assert np.array_equal(oracle.bilateral_u8(img, w, h, float(sc), float(ss)), out)
+
+
+def test_bilateral_tables_follow_the_constructor(oracle):
+    # src/BilateralFilter.cpp:17-41: r = ceil(1.5*sigma_space), kernel = exp(-d2/ss^2), similarity = exp(-i/sc^2)
+    r, kern, sim = oracle.bilateral_tables(30.0, 4.5)
+    assert r == 7 and kern.size == 225 and sim.size == 256
+    assert kern[112] == 1.0 and sim[0] == 1.0
+    assert abs(kern[0] - math.exp(-(49 + 49) / (4.5 * 4.5))) < 1e-7
+    assert abs(sim[255] - math.exp(-255 / 900.0)) < 1e-7
+
+
+def test_bilateral_u16_defined_semantics_agree_with_u8_on_small_values(oracle):
+    # the 16-bit semantics defined in DESIGN.md reduce to the reference's 8-bit behaviour when every
+    # pixel is < 256 (same tables, same accumulation)
+    img = _test_images()["noisy64x48"]
+    a = oracle.bilateral_u8(img, 64, 48, 30.0, 4.5)
+    b = oracle.bilateral_u16(img.astype(np.uint16), 64, 48, 30.0, 4.5)
+    assert np.array_equal(a.astype(np.uint16), b)
+
+
+# ----------------------------------------------------------------- oracle regression fixtures
+
+def test_oracle_matches_its_committed_golden_vectors(oracle):
+    """tests/golden/oracle_*.npz were generated by tests/golden/make_golden.py from this oracle; they pin it
+    against accidental edits and give the GPU tests expectations that do not need the oracle rebuilt."""
+    f = np.load(os.path.join(GOLD, "oracle_integrate_raycast.npz"))
+    from tests.golden.make_golden import integrate_raycast_case
+    for name in ("wall32", "rot32"):
+        got = integrate_raycast_case(oracle, name)
+        for key in ("dist", "weight", "vertices", "normals"):
+            a, b = got[key], f[name + "_" + key]
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (name, key)

@@ -1,0 +1,201 @@
+"""GPU parity: TSDFVolume.integrate (HIP, through the C ABI) against the CPU oracle, bit for bit.
+
+Run on the GPU box with `pytest -m gpu`.  The tolerance north_star allows is 1e-4 relative; because the HIP
+kernels keep the reference's operation order with fp contraction off, the assertion here is stronger: every
+distance and weight must be bit-identical to the oracle's.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import tsdf_amd
+from tests.helpers import H, W, assert_same_floats, camera_at, sphere_depth_map
+from tsdf_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def run_both(oracle, size, physical, frames, width=W, height=H, offset=None, offset_after_clear=None):
+    """Integrate `frames` = [(depth, camera)] on the GPU and in the oracle; return both volumes' arrays."""
+    gv = tsdf_amd.TSDFVolume(size, physical)
+    ov = oracle.Volume(size, physical)
+    if offset is not None:                    # offset known before clear(): baked into the grid (Q1)
+        gv.offset(*offset); gv.clear()
+        ov.offset(*offset); ov.clear()
+    if offset_after_clear is not None:        # offset changed after clear(): added on top (Q1)
+        gv.offset(*offset_after_clear)
+        ov.offset(*offset_after_clear)
+    gv.set_counting(True)
+    updates = []
+    for depth, cam in frames:
+        gv.integrate(depth, width, height, cam)
+        u = ov.integrate(depth, width, height, cam.inverse_pose(), cam.k(), cam.kinv(), nthreads=oracle.max_threads())
+        updates.append((gv.last_updated_voxels(), u))
+    return gv, ov, updates
+
+
+def check(gv, ov, updates, what):
+    assert_same_floats(gv.get_weight_data(), ov.weight, what + " weights")
+    assert_same_floats(gv.get_distance_data(), ov.dist, what + " distances")
+    for g, o in updates:
+        assert g == o, "%s: GPU counted %d updated voxels, oracle %d" % (what, g, o)
+
+
+def test_wall_frame_of_the_survey_probe(oracle):
+    cam = camera_at((1500, 1500, -1000))
+    gv, ov, up = run_both(oracle, (128, 128, 128), (3000, 3000, 3000), [(synth.wall_depth(2500), cam)])
+    check(gv, ov, up, "wall 128^3")
+    assert up[0][0] == 354056          # BASELINE.md section 2 (reference source run by the survey)
+
+
+def test_config1_frame_with_dropouts(oracle):
+    # BASELINE config 1: 128^3, single synthetic frame, ground-truth pose
+    cam = camera_at((1500, 1500, -1000))
+    gv, ov, up = run_both(oracle, (128, 128, 128), (3000, 3000, 3000), [(synth.config1_depth(), cam)])
+    check(gv, ov, up, "config1")
+
+
+def test_sphere_depth_map_like_the_reference_fixture(oracle):
+    depth = sphere_depth_map(W, H, 200, 1200, 2200)     # TestHelpers.cpp:144-183
+    cam = camera_at((1500, 1500, -500))
+    gv, ov, up = run_both(oracle, (64, 64, 64), (3000, 3000, 3000), [(depth, cam)])
+    check(gv, ov, up, "sphere depth")
+
+
+def test_rotated_poses_accumulate_over_several_frames(oracle):
+    frames = []
+    for i in range(5):
+        d, cam = synth.depth_frame(i, 5, seed=0x5EED0002)
+        frames.append((d, cam))
+    gv, ov, up = run_both(oracle, (96, 96, 96), (3000, 3000, 3000), frames)
+    check(gv, ov, up, "5 frames 96^3")
+    assert ov.weight.max() >= 4
+
+
+def test_general_rotation_and_camera_inside_the_volume(oracle):
+    # camera inside the grid: voxels behind the camera project too (Q2) and bricks straddle the camera plane
+    d, _ = synth.depth_frame(0, 7, seed=11)
+    cam = camera_at((1400, 1350, 600), yaw_pitch_roll=(0.35, -0.2, 0.15))
+    gv, ov, up = run_both(oracle, (80, 72, 64), (3000, 2700, 2400), [(d, cam)])
+    check(gv, ov, up, "camera inside")
+    assert up[0][1] > 0
+
+
+def test_odd_sizes_that_do_not_fill_the_tiles(oracle):
+    d, cam = synth.depth_frame(2, 9, seed=3)
+    gv, ov, up = run_both(oracle, (50, 37, 29), (2500, 1850, 1450), [(d, cam)])
+    check(gv, ov, up, "50x37x29")
+
+
+def test_small_image_and_tiny_volume(oracle):
+    cam = camera_at((150, 150, -300))
+    depth = np.full(32 * 24, 450, np.uint16)
+    k = cam.k().copy(); k[0] /= 20; k[4] /= 20; k[6] = 16; k[7] = 12
+    from tests.helpers import Cam
+    small = Cam(cam.pose(), cam.inverse_pose(), k, oracle.mat3_inverse(k))
+    gv, ov, up = run_both(oracle, (8, 8, 8), (300, 300, 300), [(depth, small)], width=32, height=24)
+    check(gv, ov, up, "8^3 / 32x24")
+    assert up[0][1] > 0
+
+
+def test_offset_baked_at_clear_and_offset_changed_afterwards(oracle):
+    d, cam = synth.depth_frame(1, 6, seed=5)
+    gv, ov, up = run_both(oracle, (64, 64, 64), (3000, 3000, 3000), [(d, cam)], offset=(100.0, -50.0, 25.0))
+    check(gv, ov, up, "offset at clear")
+    # Q1: setting the offset after construction adds it ON TOP of the grid built at clear() time
+    gv, ov, up = run_both(oracle, (64, 64, 64), (3000, 3000, 3000), [(d, cam)], offset_after_clear=(100.0, -50.0, 25.0))
+    check(gv, ov, up, "offset after clear")
+
+
+def test_all_invalid_depth_changes_nothing(oracle):
+    cam = camera_at((1500, 1500, -1000))
+    gv, ov, up = run_both(oracle, (32, 32, 32), (3000, 3000, 3000), [(np.zeros(W * H, np.uint16), cam)])
+    check(gv, ov, up, "all-zero depth")
+    assert up[0] == (0, 0)
+    assert np.all(gv.get_weight_data() == 0)
+    assert np.all(gv.get_distance_data() == np.float32(gv.truncation_distance()))
+
+
+def test_camera_looking_away_updates_nothing_in_front_but_matches_oracle(oracle):
+    cam = camera_at((1500, 1500, 4000), look_at=(1500, 1500, 9000))     # volume entirely behind the camera
+    gv, ov, up = run_both(oracle, (48, 48, 48), (3000, 3000, 3000), [(synth.wall_depth(1200), cam)])
+    check(gv, ov, up, "volume behind camera")
+
+
+def test_materialised_deformation_grid_gives_the_same_result_as_the_implicit_one(oracle):
+    d, cam = synth.depth_frame(0, 4, seed=9)
+    gv, ov, up = run_both(oracle, (40, 40, 40), (3000, 3000, 3000), [(d, cam)])
+    gv2 = tsdf_amd.TSDFVolume((40, 40, 40), (3000, 3000, 3000))
+    assert gv2.deformation() != 0                      # materialises the 24-byte nodes; DEFORM kernel path
+    assert gv2.info().deformation_materialised == 1
+    gv2.integrate(d, W, H, cam)
+    assert_same_floats(gv2.get_distance_data(), ov.dist, "materialised nodes")
+    assert_same_floats(gv2.get_weight_data(), ov.weight, "materialised nodes")
+
+
+def test_custom_deformation_nodes_move_the_voxel_centres(oracle):
+    n = 24
+    d, cam = synth.depth_frame(0, 4, seed=21)
+    ov = oracle.Volume((n, n, n), (3000, 3000, 3000))
+    vs = ov.voxel_size()
+    rng = np.random.RandomState(3)
+    zz, yy, xx = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
+    tr = np.stack([(xx + 0.5) * vs[0], (yy + 0.5) * vs[1], (zz + 0.5) * vs[2]], -1).astype(np.float32)
+    tr += rng.uniform(-40, 40, tr.shape).astype(np.float32)
+    ov.translation = np.ascontiguousarray(tr.reshape(-1))
+    ov.integrate(d, W, H, cam.inverse_pose(), cam.k(), cam.kinv())
+    gv = tsdf_amd.TSDFVolume((n, n, n), (3000, 3000, 3000))
+    nodes = np.concatenate([tr.reshape(-1, 3), np.zeros((n ** 3, 3), np.float32)], axis=1)
+    gv.set_deformation(nodes)
+    gv.integrate(d, W, H, cam)
+    assert_same_floats(gv.get_distance_data(), ov.dist, "custom nodes")
+    assert_same_floats(gv.get_weight_data(), ov.weight, "custom nodes")
+
+
+def test_clear_resets_and_set_get_round_trip(oracle):
+    gv = tsdf_amd.TSDFVolume((20, 21, 22), (2000, 2100, 2200))
+    ov = oracle.Volume((20, 21, 22), (2000, 2100, 2200))
+    assert gv.size() == (20, 21, 22)
+    assert np.array_equal(gv.voxel_size(), ov.voxel_size())
+    assert gv.truncation_distance() == ov.truncation_distance()
+    rng = np.random.RandomState(1)
+    a = rng.rand(20 * 21 * 22).astype(np.float32)
+    gv.set_distance_data(a)
+    gv.set_weight_data(a * 2)
+    assert np.array_equal(gv.get_distance_data(), a) and np.array_equal(gv.get_weight_data(), a * 2)
+    gv.clear()
+    assert np.all(gv.get_weight_data() == 0)
+    assert np.all(gv.get_distance_data() == np.float32(gv.truncation_distance()))
+
+
+def test_slab_volumes_integrate_their_planes_plus_one_halo_plane(oracle):
+    # multi-GPU sharding unit: two Z-slabs on one device equal the whole volume, plane for plane
+    n = 48
+    d, cam = synth.depth_frame(3, 8, seed=2)
+    ov = oracle.Volume((n, n, n), (3000, 3000, 3000))
+    ov.integrate(d, W, H, cam.inverse_pose(), cam.k(), cam.kinv())
+    full = ov.dist.reshape(n, n * n)
+    for zb, ze in ((0, 24), (24, 48), (10, 11)):
+        s = tsdf_amd.TSDFVolume((n, n, n), (3000, 3000, 3000), slab=(zb, ze))
+        lo, hi = s.resident_planes()
+        assert (lo, hi) == (zb, min(ze + 1, n))
+        s.integrate(d, W, H, cam)
+        assert_same_floats(s.get_distance_data(), full[lo:hi], "slab [%d,%d)" % (zb, ze))
+
+
+def test_committed_golden_vectors(oracle):
+    """tests/golden/oracle_integrate_raycast.npz (generated by tests/golden/make_golden.py)."""
+    from tests.helpers import Cam
+    f = np.load(os.path.join(GOLD, "oracle_integrate_raycast.npz"))
+    k2, kinv2 = oracle.camera_k(591.1 / 4, 590.1 / 4, 331.0 / 4, 234.6 / 4)
+    pose = oracle.identity_pose((1500, 1500, -1000))
+    cam = Cam(pose, oracle.mat4_inverse(pose), k2, kinv2)
+    gv = tsdf_amd.TSDFVolume((32, 32, 32), (3000, 3000, 3000))
+    gv.integrate(np.full(160 * 120, 2500, np.uint16), 160, 120, cam)
+    assert_same_floats(gv.get_distance_data(), f["wall32_dist"], "golden wall32 dist")
+    assert_same_floats(gv.get_weight_data(), f["wall32_weight"], "golden wall32 weight")
+    V, N = gv.raycast(160, 120, cam)
+    assert_same_floats(V, f["wall32_vertices"], "golden wall32 vertices")
+    assert_same_floats(N, f["wall32_normals"], "golden wall32 normals")

@@ -1,0 +1,129 @@
+"""ctypes binding of the C ABI declared in include/tsdf_amd.h (tsdf_amd/lib/libtsdf_hip.so).
+
+There is no fallback: if the HIP library is missing or fails to load, importing this module
+raises.  The CPU checker used by the tests lives outside this package and is never loaded from here.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtsdf_hip.so")
+
+TSDF_OK, TSDF_ERR_INVALID, TSDF_ERR_DEVICE, TSDF_ERR_NOMEM = 0, 1, 2, 3
+
+
+class TsdfError(RuntimeError):
+    """A C-ABI call failed with TSDF_ERR_DEVICE / TSDF_ERR_NOMEM."""
+
+
+class VolumeInfo(C.Structure):
+    """struct tsdf_volume_info (include/tsdf_amd.h)."""
+    _fields_ = [("size", C.c_uint32 * 3), ("z_begin", C.c_uint32), ("z_end", C.c_uint32),
+                ("z_store_begin", C.c_uint32), ("z_store_end", C.c_uint32),
+                ("physical_size", C.c_float * 3), ("voxel_size", C.c_float * 3), ("offset", C.c_float * 3),
+                ("offset_at_clear", C.c_float * 3), ("truncation_distance", C.c_float),
+                ("max_weight", C.c_float), ("global_translation", C.c_float * 3),
+                ("global_rotation", C.c_float * 3), ("deformation_materialised", C.c_int32)]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "tsdf_amd: %s is missing -- build it with `make hip` (or `python -c 'import __graft_entry__ as g; "
+            "g.build()'`). There is no CPU fallback." % LIB_PATH)
+    return C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+
+
+lib = _load()
+
+_vp, _fp = C.c_void_p, C.POINTER(C.c_float)
+_u32, _f, _i = C.c_uint32, C.c_float, C.c_int
+_SIGS = {
+    "tsdf_last_error": (C.c_char_p, []),
+    "tsdf_build_arch": (C.c_char_p, []),
+    "tsdf_device_count": (_i, [C.POINTER(_i)]),
+    "tsdf_set_device": (_i, [_i]),
+    "tsdf_get_device": (_i, [C.POINTER(_i)]),
+    "tsdf_volume_create": (_i, [_u32, _u32, _u32, _f, _f, _f, C.POINTER(_vp)]),
+    "tsdf_volume_create_slab": (_i, [_u32, _u32, _u32, _f, _f, _f, _u32, _u32, C.POINTER(_vp)]),
+    "tsdf_volume_destroy": (_i, [_vp]),
+    "tsdf_volume_set_stream": (_i, [_vp, _vp]),
+    "tsdf_volume_synchronize": (_i, [_vp]),
+    "tsdf_volume_clear": (_i, [_vp]),
+    "tsdf_volume_get_info": (_i, [_vp, C.POINTER(VolumeInfo)]),
+    "tsdf_volume_set_offset": (_i, [_vp, _f, _f, _f]),
+    "tsdf_volume_set_header": (_i, [_vp, _fp, _f, _f, _fp, _fp]),
+    "tsdf_volume_distances": (_i, [_vp, C.POINTER(_vp)]),
+    "tsdf_volume_weights": (_i, [_vp, C.POINTER(_vp)]),
+    "tsdf_volume_deformation": (_i, [_vp, C.POINTER(_vp)]),
+    "tsdf_volume_set_distance_data": (_i, [_vp, _vp]),
+    "tsdf_volume_set_weight_data": (_i, [_vp, _vp]),
+    "tsdf_volume_set_deformation": (_i, [_vp, _vp]),
+    "tsdf_volume_get_distance_data": (_i, [_vp, _vp]),
+    "tsdf_volume_get_weight_data": (_i, [_vp, _vp]),
+    "tsdf_integrate": (_i, [_vp, _vp, _u32, _u32, _fp, _fp, _fp, _fp]),
+    "tsdf_integrate_device": (_i, [_vp, _vp, _u32, _u32, _fp, _fp, _fp, _fp]),
+    "tsdf_volume_set_counting": (_i, [_vp, _i]),
+    "tsdf_volume_last_updated_voxels": (_i, [_vp, C.POINTER(C.c_uint64)]),
+    "tsdf_raycast": (_i, [_vp, _u32, _u32, _fp, _fp, _vp, _vp]),
+    "tsdf_raycast_device": (_i, [_vp, _u32, _u32, _fp, _fp, _vp, _vp]),
+    "tsdf_normals_device": (_i, [_u32, _u32, _vp, _vp, _vp]),
+    "tsdf_raycast_stats": (_i, [_vp, _u32, _u32, _fp, _fp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                C.POINTER(C.c_uint64)]),
+    "tsdf_raycast_slab_device": (_i, [_vp, _u32, _u32, _fp, _fp, _vp]),
+    "tsdf_merge_hits_device": (_i, [_vp, _u32, _u32, _u32, _vp, _vp]),
+    "tsdf_bilateral_create": (_i, [_f, _f, C.POINTER(_vp)]),
+    "tsdf_bilateral_destroy": (_i, [_vp]),
+    "tsdf_bilateral_filter_u8": (_i, [_vp, _vp, _i, _i]),
+    "tsdf_bilateral_filter_u16": (_i, [_vp, _vp, _i, _i]),
+    "tsdf_bilateral_filter_u8_device": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "tsdf_bilateral_filter_u16_device": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+}
+#: every symbol include/tsdf_amd.h declares
+EXPORTS = tuple(_SIGS)
+for _name, (_res, _args) in _SIGS.items():
+    _fn = getattr(lib, _name)   # AttributeError here = the library does not export a declared symbol
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def last_error():
+    return lib.tsdf_last_error().decode("utf-8", "replace")
+
+
+def check(rc):
+    """Map a C-ABI status to the reference's error behaviour: invalid argument -> ValueError
+    (std::invalid_argument in the C++ surface), anything else -> TsdfError."""
+    if rc == TSDF_OK:
+        return
+    msg = last_error()
+    if rc == TSDF_ERR_INVALID:
+        raise ValueError(msg)
+    if rc == TSDF_ERR_NOMEM:
+        raise MemoryError(msg)
+    raise TsdfError(msg)
+
+# ---- host library (C++ class surface; Camera is exposed to Python through it) ------------------
+HOST_LIB_PATH = os.path.join(_HERE, "lib", "libtsdf_host.so")
+if not os.path.exists(HOST_LIB_PATH):
+    raise ImportError("tsdf_amd: %s is missing -- build it with `make host`." % HOST_LIB_PATH)
+host = C.CDLL(HOST_LIB_PATH, mode=C.RTLD_GLOBAL)
+_ip = C.POINTER(C.c_int)
+_HOST_SIGS = {
+    "tsdf_camera_create": (_vp, [_f, _f, _f, _f]),
+    "tsdf_camera_destroy": (None, [_vp]),
+    "tsdf_camera_get": (None, [_vp, _fp, _fp, _fp, _fp]),
+    "tsdf_camera_set_pose": (None, [_vp, _fp]),
+    "tsdf_camera_set_pose_tum": (None, [_vp, _fp]),
+    "tsdf_camera_move_to": (None, [_vp, _f, _f, _f]),
+    "tsdf_camera_look_at": (None, [_vp, _f, _f, _f]),
+    "tsdf_camera_world_to_camera": (None, [_vp, _fp, _fp]),
+    "tsdf_camera_camera_to_world": (None, [_vp, _fp, _fp]),
+    "tsdf_camera_world_to_pixel": (None, [_vp, _fp, _ip]),
+    "tsdf_camera_pixel_to_image_plane": (None, [_vp, C.c_uint16, C.c_uint16, _fp]),
+    "tsdf_camera_image_plane_to_pixel": (None, [_vp, _fp, _ip]),
+}
+for _name, (_res, _args) in _HOST_SIGS.items():
+    _fn = getattr(host, _name)
+    _fn.restype = _res
+    _fn.argtypes = _args

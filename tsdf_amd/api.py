@@ -1,0 +1,345 @@
+"""Python mirror of the reference's class surface for the hot path, over the C ABI.
+
+Names, argument meaning and error behaviour follow src/include/TSDFVolume.hpp,
+GPURaycaster.hpp and BilateralFilter.hpp of the reference so that tests read like the
+reference's own.  Matrices are column-major float32 vectors (what Eigen's .data() yields).
+Every call runs the HIP kernels in tsdf_amd/lib/libtsdf_hip.so; there is no CPU path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import check, lib
+
+
+def _mat(a, n):
+    a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1)
+    if a.size != n:
+        raise ValueError("expected %d matrix elements, got %d" % (n, a.size))
+    return a
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _camera_matrices(camera):
+    """pose, inverse_pose, k, kinv of anything shaped like the reference's Camera (src/include/Camera.hpp)."""
+    return (_mat(camera.pose(), 16), _mat(camera.inverse_pose(), 16), _mat(camera.k(), 9), _mat(camera.kinv(), 9))
+
+
+class TSDFVolume:
+    """src/include/TSDFVolume.hpp:21-304.  `slab=(z_begin, z_end)` makes this object one Z-slab of the
+    grid (multi-GPU sharding); the default is the whole volume."""
+
+    def __init__(self, size=(64, 64, 64), physical_size=(3000.0, 3000.0, 3000.0), slab=None):
+        self._h = C.c_void_p()
+        sx, sy, sz = (int(s) for s in size)
+        if min(sx, sy, sz) < 0:
+            raise ValueError("Attempt to construct TSDFVolume with zero or negative size")
+        px, py, pz = (float(p) for p in physical_size)
+        if slab is None:
+            check(lib.tsdf_volume_create(sx, sy, sz, px, py, pz, C.byref(self._h)))
+        else:
+            check(lib.tsdf_volume_create_slab(sx, sy, sz, px, py, pz, int(slab[0]), int(slab[1]), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib.tsdf_volume_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    # ---- geometry accessors (TSDFVolume.hpp:120-153)
+    def info(self):
+        i = _capi.VolumeInfo()
+        check(lib.tsdf_volume_get_info(self._h, C.byref(i)))
+        return i
+
+    def size(self):
+        return tuple(self.info().size)
+
+    def voxel_size(self):
+        return np.array(self.info().voxel_size, np.float32)
+
+    def physical_size(self):
+        return np.array(self.info().physical_size, np.float32)
+
+    def truncation_distance(self):
+        return float(self.info().truncation_distance)
+
+    def offset(self, *o):
+        """offset() -> current offset; offset(ox, oy, oz) sets it (without re-initialising the deformation grid)."""
+        if o:
+            check(lib.tsdf_volume_set_offset(self._h, float(o[0]), float(o[1]), float(o[2])))
+            return None
+        return np.array(self.info().offset, np.float32)
+
+    def resident_planes(self):
+        i = self.info()
+        return int(i.z_store_begin), int(i.z_store_end)
+
+    def owned_planes(self):
+        i = self.info()
+        return int(i.z_begin), int(i.z_end)
+
+    def resident_voxels(self):
+        i = self.info()
+        return int(i.size[0]) * int(i.size[1]) * int(i.z_store_end - i.z_store_begin)
+
+    def index(self, x, y, z):
+        sx, sy, _ = self.size()
+        return x + y * sx + z * sx * sy
+
+    def clear(self):
+        check(lib.tsdf_volume_clear(self._h))
+        check(lib.tsdf_volume_synchronize(self._h))
+
+    def set_stream(self, hip_stream):
+        check(lib.tsdf_volume_set_stream(self._h, C.c_void_p(int(hip_stream) if hip_stream else 0)))
+
+    def synchronize(self):
+        check(lib.tsdf_volume_synchronize(self._h))
+
+    # ---- data access (TSDFVolume.hpp:165-203): device pointers, blocking uploads
+    def distance_data(self):
+        p = C.c_void_p()
+        check(lib.tsdf_volume_distances(self._h, C.byref(p)))
+        return p.value
+
+    def weight_data(self):
+        p = C.c_void_p()
+        check(lib.tsdf_volume_weights(self._h, C.byref(p)))
+        return p.value
+
+    def deformation(self):
+        p = C.c_void_p()
+        check(lib.tsdf_volume_deformation(self._h, C.byref(p)))
+        return p.value
+
+    def _host(self, a, per_voxel=1):
+        a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1)
+        if a.size != self.resident_voxels() * per_voxel:
+            raise ValueError("expected %d floats, got %d" % (self.resident_voxels() * per_voxel, a.size))
+        return a
+
+    def set_distance_data(self, distance_data):
+        a = self._host(distance_data)
+        check(lib.tsdf_volume_set_distance_data(self._h, a.ctypes.data))
+
+    def set_weight_data(self, weight_data):
+        a = self._host(weight_data)
+        check(lib.tsdf_volume_set_weight_data(self._h, a.ctypes.data))
+
+    def set_deformation(self, nodes):
+        """nodes: (voxels, 6) float32 = translation xyz + rotation xyz (DeformationNode, TSDFVolume.hpp:23-26)."""
+        a = self._host(nodes, 6)
+        check(lib.tsdf_volume_set_deformation(self._h, a.ctypes.data))
+
+    def get_distance_data(self):
+        a = np.empty(self.resident_voxels(), np.float32)
+        check(lib.tsdf_volume_get_distance_data(self._h, a.ctypes.data))
+        return a
+
+    def get_weight_data(self):
+        a = np.empty(self.resident_voxels(), np.float32)
+        check(lib.tsdf_volume_get_weight_data(self._h, a.ctypes.data))
+        return a
+
+    # ---- integrate (TSDFVolume.hpp:238-246)
+    def integrate(self, depth_map, width, height, camera):
+        """Blocking; depth_map is a host uint16 array of width*height mm values (0 = invalid)."""
+        if depth_map is None:
+            raise AssertionError("depth_map")        # the reference asserts (TSDFVolume.cu:862)
+        d = np.ascontiguousarray(depth_map, dtype=np.uint16).reshape(-1)
+        if d.size != width * height:
+            raise ValueError("depth map has %d pixels, expected %d" % (d.size, width * height))
+        pose, ipose, k, kinv = _camera_matrices(camera)
+        check(lib.tsdf_integrate(self._h, d.ctypes.data, width, height, _fp(pose), _fp(ipose), _fp(k), _fp(kinv)))
+
+    def integrate_device(self, depth_ptr, width, height, camera):
+        """Asynchronous on the volume's stream; depth_ptr is a device pointer to width*height uint16."""
+        pose, ipose, k, kinv = _camera_matrices(camera)
+        check(lib.tsdf_integrate_device(self._h, C.c_void_p(int(depth_ptr)), width, height, _fp(pose), _fp(ipose),
+                                        _fp(k), _fp(kinv)))
+
+    def set_counting(self, enabled):
+        check(lib.tsdf_volume_set_counting(self._h, 1 if enabled else 0))
+
+    def last_updated_voxels(self):
+        c = C.c_uint64()
+        check(lib.tsdf_volume_last_updated_voxels(self._h, C.byref(c)))
+        return int(c.value)
+
+    # ---- raycast (TSDFVolume.hpp:260): forwards to GPURaycaster like TSDFVolume.cu:1054-1058
+    def raycast(self, width, height, camera):
+        return GPURaycaster(width, height).raycast(self, camera)
+
+
+class GPURaycaster:
+    """src/include/GPURaycaster.hpp:19-41 (+ Raycaster.hpp:17-39)."""
+
+    def __init__(self, width=640, height=480):
+        self.m_width = int(width) & 0xFFFF    # uint16_t members in the reference
+        self.m_height = int(height) & 0xFFFF
+
+    def raycast(self, volume, camera):
+        """-> (vertices, normals), each (width*height, 3) float32; misses are NaN rows."""
+        pose, _, _, kinv = _camera_matrices(camera)
+        n = self.m_width * self.m_height
+        V = np.empty((n, 3), np.float32)
+        N = np.empty((n, 3), np.float32)
+        check(lib.tsdf_raycast(volume._h, self.m_width, self.m_height, _fp(pose), _fp(kinv), V.ctypes.data,
+                               N.ctypes.data))
+        return V, N
+
+    def get_vertices(self, volume, camera):
+        pose, _, _, kinv = _camera_matrices(camera)
+        V = np.empty((self.m_width * self.m_height, 3), np.float32)
+        check(lib.tsdf_raycast(volume._h, self.m_width, self.m_height, _fp(pose), _fp(kinv), V.ctypes.data, None))
+        return V
+
+    def raycast_device(self, volume, camera, vertices_ptr, normals_ptr=None):
+        pose, _, _, kinv = _camera_matrices(camera)
+        check(lib.tsdf_raycast_device(volume._h, self.m_width, self.m_height, _fp(pose), _fp(kinv),
+                                      C.c_void_p(int(vertices_ptr)),
+                                      C.c_void_p(int(normals_ptr)) if normals_ptr else None))
+
+    def raycast_slab_device(self, volume, camera, hits_ptr):
+        pose, _, _, kinv = _camera_matrices(camera)
+        check(lib.tsdf_raycast_slab_device(volume._h, self.m_width, self.m_height, _fp(pose), _fp(kinv),
+                                           C.c_void_p(int(hits_ptr))))
+
+    def stats(self, volume, camera):
+        """Roofline diagnostics of one raycast: samples S, distinct voxels touched T, hits."""
+        pose, _, _, kinv = _camera_matrices(camera)
+        s, t, h = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        check(lib.tsdf_raycast_stats(volume._h, self.m_width, self.m_height, _fp(pose), _fp(kinv), C.byref(s),
+                                     C.byref(t), C.byref(h)))
+        return {"samples": int(s.value), "touched": int(t.value), "hits": int(h.value)}
+
+
+def compute_normals_device(width, height, vertices_ptr, normals_ptr, stream=0):
+    check(lib.tsdf_normals_device(width, height, C.c_void_p(int(vertices_ptr)), C.c_void_p(int(normals_ptr)),
+                                  C.c_void_p(int(stream) if stream else 0)))
+
+
+def merge_hits_device(hits_all_ptr, n_slabs, width, height, vertices_ptr, stream=0):
+    check(lib.tsdf_merge_hits_device(C.c_void_p(int(hits_all_ptr)), n_slabs, width, height,
+                                     C.c_void_p(int(vertices_ptr)), C.c_void_p(int(stream) if stream else 0)))
+
+
+class BilateralFilter:
+    """src/include/BilateralFilter.hpp:12-35.  filter() works in place on a host image, as the reference does."""
+
+    def __init__(self, sigma_colour, sigma_space):
+        self._h = C.c_void_p()
+        check(lib.tsdf_bilateral_create(float(sigma_colour), float(sigma_space), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib.tsdf_bilateral_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def filter(self, image, width, height):
+        if not isinstance(image, np.ndarray) or image.dtype not in (np.uint8, np.uint16) or \
+                not image.flags["C_CONTIGUOUS"]:
+            raise ValueError("image must be a C-contiguous uint8 or uint16 numpy array")
+        if image.size != width * height:
+            raise ValueError("image has %d pixels, expected %d" % (image.size, width * height))
+        fn = lib.tsdf_bilateral_filter_u8 if image.dtype == np.uint8 else lib.tsdf_bilateral_filter_u16
+        check(fn(self._h, image.ctypes.data, width, height))
+
+    def filter_device(self, in_ptr, out_ptr, width, height, bits=16, stream=0):
+        fn = lib.tsdf_bilateral_filter_u8_device if bits == 8 else lib.tsdf_bilateral_filter_u16_device
+        check(fn(self._h, C.c_void_p(int(in_ptr)), C.c_void_p(int(out_ptr)), width, height,
+                 C.c_void_p(int(stream) if stream else 0)))
+
+
+class Camera:
+    """The C++ Camera of the host library (same surface as src/include/Camera.hpp of the reference).
+    Matrices come back as column-major float32 vectors, i.e. what Eigen's .data() yields."""
+
+    def __init__(self, focal_x, focal_y, centre_x, centre_y):
+        self._h = _capi.host.tsdf_camera_create(float(focal_x), float(focal_y), float(centre_x), float(centre_y))
+        self._refresh()
+
+    @staticmethod
+    def default_depth_camera():
+        return Camera(591.1, 590.1, 331.0, 234.6)   # Camera.hpp:41-44
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _capi.host.tsdf_camera_destroy(self._h)
+            self._h = None
+
+    def _refresh(self):
+        self._k, self._kinv = np.zeros(9, np.float32), np.zeros(9, np.float32)
+        self._pose, self._ipose = np.zeros(16, np.float32), np.zeros(16, np.float32)
+        _capi.host.tsdf_camera_get(self._h, _fp(self._k), _fp(self._kinv), _fp(self._pose), _fp(self._ipose))
+
+    def k(self):
+        return self._k
+
+    def kinv(self):
+        return self._kinv
+
+    def pose(self):
+        return self._pose
+
+    def inverse_pose(self):
+        return self._ipose
+
+    def set_pose(self, pose):
+        """pose: 16 floats column-major (or a 7-vector tx ty tz qx qy qz qw in TUM order)."""
+        p = np.ascontiguousarray(pose, dtype=np.float32).reshape(-1)
+        if p.size == 7:
+            _capi.host.tsdf_camera_set_pose_tum(self._h, _fp(p))
+        else:
+            _capi.host.tsdf_camera_set_pose(self._h, _fp(_mat(p, 16)))
+        self._refresh()
+
+    def set_pose_rows(self, rows):
+        """pose given as a 4x4 in the usual row-major maths notation."""
+        self.set_pose(np.ascontiguousarray(np.asarray(rows, np.float32).reshape(4, 4).T).reshape(-1))
+
+    def move_to(self, wx, wy, wz):
+        _capi.host.tsdf_camera_move_to(self._h, float(wx), float(wy), float(wz))
+        self._refresh()
+
+    def look_at(self, wx, wy, wz):
+        _capi.host.tsdf_camera_look_at(self._h, float(wx), float(wy), float(wz))
+        self._refresh()
+
+    def position(self):
+        return self._pose[12:15].copy()
+
+    def _v3(self, fn, w):
+        a = _mat(w, 3)
+        out = np.zeros(3, np.float32)
+        fn(self._h, _fp(a), _fp(out))
+        return out
+
+    def world_to_camera(self, w):
+        return self._v3(_capi.host.tsdf_camera_world_to_camera, w)
+
+    def camera_to_world(self, c):
+        return self._v3(_capi.host.tsdf_camera_camera_to_world, c)
+
+    def world_to_pixel(self, w):
+        out = (C.c_int * 2)()
+        _capi.host.tsdf_camera_world_to_pixel(self._h, _fp(_mat(w, 3)), out)
+        return int(out[0]), int(out[1])
+
+    def pixel_to_image_plane(self, x, y):
+        out = np.zeros(2, np.float32)
+        _capi.host.tsdf_camera_pixel_to_image_plane(self._h, int(x), int(y), _fp(out))
+        return out
+
+    def image_plane_to_pixel(self, p):
+        out = (C.c_int * 2)()
+        _capi.host.tsdf_camera_image_plane_to_pixel(self._h, _fp(_mat(p, 2)), out)
+        return int(out[0]), int(out[1])

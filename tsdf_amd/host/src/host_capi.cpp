@@ -1,0 +1,58 @@
+// C entry points of the host library for language bindings (the Python mirror in tsdf_amd/api.py):
+// they expose the C++ Camera so that Python uses the very same K^-1 / pose^-1 / look_at arithmetic
+// as C++ callers.  Matrices cross as column-major float arrays.
+#include <cstring>
+
+#include "Camera.hpp"
+
+extern "C" {
+
+typedef struct tsdf_camera tsdf_camera;
+
+tsdf_camera *tsdf_camera_create(float fx, float fy, float cx, float cy) {
+    return reinterpret_cast<tsdf_camera *>(new Camera(fx, fy, cx, cy));
+}
+void tsdf_camera_destroy(tsdf_camera *c) { delete reinterpret_cast<Camera *>(c); }
+
+void tsdf_camera_get(const tsdf_camera *c, float k[9], float kinv[9], float pose[16], float inv_pose[16]) {
+    const Camera *cam = reinterpret_cast<const Camera *>(c);
+    const Eigen::Matrix3f mk = cam->k(), mki = cam->kinv();
+    memcpy(k, mk.data(), 9 * sizeof(float));
+    memcpy(kinv, mki.data(), 9 * sizeof(float));
+    memcpy(pose, cam->pose().data(), 16 * sizeof(float));
+    memcpy(inv_pose, cam->inverse_pose().data(), 16 * sizeof(float));
+}
+void tsdf_camera_set_pose(tsdf_camera *c, const float pose[16]) {
+    Eigen::Matrix4f p;
+    memcpy(p.data(), pose, 16 * sizeof(float));
+    reinterpret_cast<Camera *>(c)->set_pose(p);
+}
+void tsdf_camera_set_pose_tum(tsdf_camera *c, const float vars[7]) {
+    float v[7];
+    memcpy(v, vars, sizeof(v));
+    reinterpret_cast<Camera *>(c)->set_pose(v);
+}
+void tsdf_camera_move_to(tsdf_camera *c, float x, float y, float z) { reinterpret_cast<Camera *>(c)->move_to(x, y, z); }
+void tsdf_camera_look_at(tsdf_camera *c, float x, float y, float z) { reinterpret_cast<Camera *>(c)->look_at(x, y, z); }
+void tsdf_camera_world_to_camera(const tsdf_camera *c, const float w[3], float out[3]) {
+    Eigen::Vector3f r = reinterpret_cast<const Camera *>(c)->world_to_camera(Eigen::Vector3f{w[0], w[1], w[2]});
+    out[0] = r[0]; out[1] = r[1]; out[2] = r[2];
+}
+void tsdf_camera_camera_to_world(const tsdf_camera *c, const float w[3], float out[3]) {
+    Eigen::Vector3f r = reinterpret_cast<const Camera *>(c)->camera_to_world(Eigen::Vector3f{w[0], w[1], w[2]});
+    out[0] = r[0]; out[1] = r[1]; out[2] = r[2];
+}
+void tsdf_camera_world_to_pixel(const tsdf_camera *c, const float w[3], int out[2]) {
+    Eigen::Vector2i r = reinterpret_cast<const Camera *>(c)->world_to_pixel(Eigen::Vector3f{w[0], w[1], w[2]});
+    out[0] = r[0]; out[1] = r[1];
+}
+void tsdf_camera_pixel_to_image_plane(const tsdf_camera *c, uint16_t x, uint16_t y, float out[2]) {
+    Eigen::Vector2f r = reinterpret_cast<const Camera *>(c)->pixel_to_image_plane(x, y);
+    out[0] = r[0]; out[1] = r[1];
+}
+void tsdf_camera_image_plane_to_pixel(const tsdf_camera *c, const float p[2], int out[2]) {
+    Eigen::Vector2i r = reinterpret_cast<const Camera *>(c)->image_plane_to_pixel(Eigen::Vector2f{p[0], p[1]});
+    out[0] = r[0]; out[1] = r[1];
+}
+
+}  // extern "C"
