@@ -101,8 +101,9 @@ def test_small_odd_image_sizes(oracle):
 
 
 def test_ray_timeout_cap_of_4402_samples(oracle):
-    # Q8: with an empty (all +trunc) fine grid every ray marches until the 4402-sample cap or the far face
-    n = 160
+    # Q8: with an empty (all +trunc) grid every ray marches until the far face or the 4402-sample cap; at
+    # 448^3 / 3000 mm the step is 0.638 mm, so the cap (2808 mm of camera-z) comes first
+    n = 448
     gv = tsdf_amd.TSDFVolume((n, n, n), (3000, 3000, 3000))
     ov = oracle.Volume((n, n, n), (3000, 3000, 3000))
     cam = camera_at((1500, 1500, -200))

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 output (the rocpd sqlite database of `rocprofv3 --kernel-trace [--stats] [--pmc X]`) into the
+small text summaries committed under profiles/.
+
+    python tools/rocprof_summary.py stats  gpurun_out/prof_stats/bench_results.db  > profiles/r01_kernel_stats.txt
+    python tools/rocprof_summary.py pmc    gpurun_out/prof_fetch/bench_results.db  > profiles/r01_pmc_FETCH_SIZE.txt
+    python tools/rocprof_summary.py traffic FETCH.db WRITE.db > profiles/traffic.json
+
+HBM traffic per launch follows MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE are reported in KiB-like
+units of 1024 B? -- no: rocprofv3 reports them in kilobytes (value * 1024 = bytes), and on gfx950 FETCH_SIZE
+counts 128-B read requests as 64 B, so the read side is doubled.  WRITE_SIZE is uncalibrated (taken as is).
+"""
+import json
+import sqlite3
+import sys
+
+
+def short(name):
+    name = name.split("(")[0]
+    for pre in ("void ", "tsdf::"):
+        name = name.replace(pre, "")
+    return name
+
+
+def kernel_stats(db):
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) "
+                       "from kernels group by name order by sum(duration) desc").fetchall()
+    total = sum(r[2] for r in rows) or 1
+    out = ["%-70s %6s %14s %12s %12s %12s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "min_ns", "max_ns", "pct")]
+    for name, calls, tot, avg, mn, mx in rows:
+        out.append("%-70s %6d %14d %12.0f %12d %12d %6.2f%%" % (short(name)[:70], calls, tot, avg, mn, mx, 100.0 * tot / total))
+    return "\n".join(out)
+
+
+def pmc_by_kernel(db):
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute("select kernel_name, counter_name, count(*), avg(value), min(value), max(value), avg(duration) "
+                       "from counters_collection group by kernel_name, counter_name order by avg(value) desc").fetchall()
+    return rows
+
+
+def pmc_text(db):
+    out = ["%-60s %-12s %6s %16s %16s %16s %12s" % ("kernel", "counter", "calls", "avg", "min", "max", "avg_ns")]
+    for k, c, n, a, mn, mx, d in pmc_by_kernel(db):
+        out.append("%-60s %-12s %6d %16.1f %16.1f %16.1f %12.0f" % (short(k)[:60], c, n, a, mn, mx, d or 0))
+    return "\n".join(out)
+
+
+def traffic(fetch_db, write_db):
+    res = {}
+    for db, cname, scale in ((fetch_db, "FETCH_SIZE", 2.0), (write_db, "WRITE_SIZE", 1.0)):
+        for k, c, n, a, mn, mx, d in pmc_by_kernel(db):
+            if c != cname:
+                continue
+            key = short(k).split("<")[0]
+            e = res.setdefault(key, {})
+            e[cname + "_avg_raw_kb"] = a
+            e[cname.lower().replace("_size", "") + "_bytes"] = a * 1024.0 * scale
+    out = {"note": "bytes per launch = FETCH_SIZE*1024*2 (gfx950 half-count correction, MI355X_MICROARCH.md HBM) + "
+                   "WRITE_SIZE*1024 (uncalibrated); separate --pmc passes of the bench command",
+           "bytes_per_launch": {}, "detail": res}
+    for k, e in res.items():
+        out["bytes_per_launch"][k] = int(e.get("fetch_bytes", 0) + e.get("write_bytes", 0))
+    return json.dumps(out, indent=1)
+
+
+if __name__ == "__main__":
+    mode = sys.argv[1]
+    if mode == "stats":
+        print(kernel_stats(sys.argv[2]))
+    elif mode == "pmc":
+        print(pmc_text(sys.argv[2]))
+    elif mode == "traffic":
+        print(traffic(sys.argv[2], sys.argv[3]))
