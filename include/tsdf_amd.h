@@ -56,6 +56,7 @@ typedef struct tsdf_volume_info {
     float global_translation[3]; /* m_global_translation                                       */
     float global_rotation[3];    /* m_global_rotation                                          */
     int32_t deformation_materialised; /* 0 while the 24-B/voxel node array is still implicit    */
+    int32_t fast_division_verified;   /* 1 = reciprocal division proven bit-equal to IEEE for this voxel size */
 } tsdf_volume_info;
 
 /* Layout of one deformation node, src/include/TSDFVolume.hpp:23-26 (2 x float3 = 24 bytes). */
@@ -112,6 +113,9 @@ int tsdf_volume_set_header(tsdf_volume *volume, const float offset[3], float tru
  * array on first use (until then integrate computes voxel centres analytically with the
  * same float expression as initialise_deformation, src/TSDF/TSDFVolume.cu:783-785). */
 int tsdf_volume_distances(const tsdf_volume *volume, float **device_ptr);
+/* Call after writing distances through the raw device pointer (the reference only ever reads through it):
+ * the ray caster's brick-occupancy summary is rebuilt before the next ray cast. */
+int tsdf_volume_mark_dirty(tsdf_volume *volume);
 int tsdf_volume_weights(const tsdf_volume *volume, float **device_ptr);
 int tsdf_volume_deformation(tsdf_volume *volume, tsdf_deformation_node **device_ptr);
 /* Replace set_distance_data/set_weight_data/set_deformation (src/TSDF/TSDFVolume.cu:731-757):
@@ -156,6 +160,13 @@ int tsdf_normals_device(uint32_t width, uint32_t height, const float *device_ver
  * touched by any tap, of one raycast with these arguments (runs an instrumented kernel). */
 int tsdf_raycast_stats(const tsdf_volume *volume, uint32_t width, uint32_t height, const float pose[16],
                        const float kinv[9], uint64_t *samples, uint64_t *touched_voxels, uint64_t *hits);
+
+/* Diagnostics: trilinear samples the production kernel actually evaluates (the rest of the reference's S
+ * samples are passed by exact empty-space skipping), and the state of the brick occupancy it skips on. */
+int tsdf_raycast_evaluated_samples(const tsdf_volume *volume, uint32_t width, uint32_t height,
+                                   const float pose[16], const float kinv[9], uint64_t *evaluated,
+                                   float *host_per_ray /* optional 3*W*H: samples, loop trips, count */);
+int tsdf_volume_occupancy(const tsdf_volume *volume, uint64_t *occupied_bricks, uint64_t *total_bricks);
 
 /* Multi-GPU raycast: a slab evaluates only the samples whose lower trilinear
  * tap plane it owns and writes one 16-byte record per pixel {k, x, y, z}: k = index of the

@@ -179,3 +179,97 @@ def test_slab_hit_records_merge_to_the_single_volume_result(oracle):
     torch.cuda.synchronize()
     assert_same_floats(V.cpu().numpy(), Vw, "merged vertices")
     assert_same_floats(Nn.cpu().numpy(), Nw, "merged normals")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Exact empty-space skipping (brick occupancy): adversarial volumes.  The ray caster may only skip samples
+# that the reference's march would have passed without a hit, so every case must stay bit-identical.
+
+def _speck_volume(oracle, n, rng, n_specks, values):
+    ov = oracle.Volume((n, n, n), (3000, 3000, 3000))
+    trunc = np.float32(ov.truncation_distance())
+    d = np.full((n, n, n), trunc, np.float32)
+    zs, ys, xs = (rng.randint(0, n, n_specks) for _ in range(3))
+    d[zs, ys, xs] = rng.choice(np.asarray(values, np.float32) * trunc, n_specks)
+    return d.reshape(-1)
+
+
+@pytest.mark.parametrize("values", [(-1.0, -0.5), (0.0,), (0.005, 0.0099, 1e-6), (0.0101, 0.02, 0.5)])
+def test_skipping_isolated_voxels_at_brick_corners_and_faces(oracle, values):
+    # single voxels that are negative / zero / barely positive / just above the occupancy threshold, placed at
+    # random (hence also on brick faces, edges and corners): neighbours within two voxels must not be skipped
+    n = 64
+    rng = np.random.RandomState(hash(values) & 0xFFFF)
+    dist = _speck_volume(oracle, n, rng, 400, values)
+    gv, ov = volumes_with(oracle, (n, n, n), (3000.0,) * 3, dist)
+    for cam in (camera_at((1500, 1500, -800)), camera_at((-700, 900, 500), look_at=(1500, 1500, 1500)),
+                camera_at((1400, 1600, 1450), yaw_pitch_roll=(1.1, 0.3, -0.2))):
+        compare(oracle, gv, ov, cam, what="specks %s" % (values,))
+
+
+def test_skipping_thin_oblique_sheet_and_noise(oracle):
+    n = 96
+    ov0 = oracle.Volume((n, n, n), (3000, 3000, 3000))
+    vs, trunc = ov0.voxel_size(), np.float32(ov0.truncation_distance())
+    c = (np.arange(n, dtype=np.float32) + 0.5) * vs[0]
+    zz, yy, xx = np.meshgrid(c, c, c, indexing="ij")
+    nrm = np.array([0.31, -0.22, 0.92], np.float32)
+    nrm /= np.linalg.norm(nrm)
+    sd = (xx * nrm[0] + yy * nrm[1] + zz * nrm[2]) - np.float32(1650.0)
+    rng = np.random.RandomState(12)
+    sd = -sd + rng.uniform(-0.2, 0.2, sd.shape).astype(np.float32) * trunc * (np.abs(sd) < 3 * trunc)
+    dist = np.clip(sd, -trunc, trunc).astype(np.float32)
+    dist[np.abs(sd) > 1.5 * trunc] = trunc          # a thin shell: free space on both sides
+    gv, ov = volumes_with(oracle, (n, n, n), (3000.0,) * 3, dist.reshape(-1))
+    for cam in (camera_at((1500, 1500, -900)), camera_at((2900, 200, 300), look_at=(1200, 1700, 1900))):
+        V, _ = compare(oracle, gv, ov, cam, what="oblique sheet")
+        assert (~np.isnan(V[:, 0])).sum() > 50000
+
+
+def test_skipping_fully_random_volume(oracle):
+    n = 48
+    rng = np.random.RandomState(99)
+    ov0 = oracle.Volume((n, n, n), (3000, 3000, 3000))
+    dist = rng.uniform(-1, 1, n ** 3).astype(np.float32) * np.float32(ov0.truncation_distance())
+    dist[rng.rand(n ** 3) < 0.9] = np.float32(ov0.truncation_distance())
+    gv, ov = volumes_with(oracle, (n, n, n), (3000.0,) * 3, dist)
+    compare(oracle, gv, ov, camera_at((300, 2500, -400), look_at=(1500, 1500, 1500)), what="random volume")
+
+
+def test_skipping_flags_follow_integrate_clear_and_upload(oracle):
+    n = 80
+    gv = tsdf_amd.TSDFVolume((n, n, n), (3000, 3000, 3000))
+    ov = oracle.Volume((n, n, n), (3000, 3000, 3000))
+    d0, cam0 = synth.depth_frame(0, 6, seed=41)
+    gv.integrate(d0, W, H, cam0)
+    ov.integrate(d0, W, H, cam0.inverse_pose(), cam0.k(), cam0.kinv(), nthreads=oracle.max_threads())
+    compare(oracle, gv, ov, cam0, what="after first integrate")
+    # clear, integrate a different frame from another pose: stale flags must not survive
+    gv.clear()
+    ov.clear()
+    d1, cam1 = synth.depth_frame(3, 6, seed=41)
+    gv.integrate(d1, W, H, cam1)
+    ov.integrate(d1, W, H, cam1.inverse_pose(), cam1.k(), cam1.kinv(), nthreads=oracle.max_threads())
+    compare(oracle, gv, ov, cam1, what="after clear + integrate")
+    # whole-array upload replaces everything
+    dist = sphere_tsdf(oracle, n, 3000.0, 500.0)
+    gv.set_distance_data(dist)
+    ov.set_distance_data(dist)
+    compare(oracle, gv, ov, cam0, what="after upload")
+    # and integrating on top of an uploaded volume keeps marking bricks
+    gv.integrate(d0, W, H, cam0)
+    ov.integrate(d0, W, H, cam0.inverse_pose(), cam0.k(), cam0.kinv(), nthreads=oracle.max_threads())
+    compare(oracle, gv, ov, cam1, what="upload + integrate")
+
+
+def test_skipping_anisotropic_voxels_disable_or_keep_exactness(oracle):
+    # step = 0.055*|voxel_size| can exceed a quarter of the smallest voxel edge: skipping must switch itself off
+    n = (96, 96, 24)
+    phys = (600.0, 600.0, 2400.0)
+    ov0 = oracle.Volume(n, phys)
+    trunc = np.float32(ov0.truncation_distance())
+    zz = (np.arange(n[2], dtype=np.float32) + 0.5)[:, None, None] * ov0.voxel_size()[2]
+    d = np.clip(np.float32(1300.0) - zz, -trunc, trunc) * np.ones((n[2], n[1], n[0]), np.float32)
+    gv, ov = volumes_with(oracle, n, phys, d.reshape(-1))
+    compare(oracle, gv, ov, camera_at((300, 300, -500)), what="anisotropic z-coarse")
+    compare(oracle, gv, ov, camera_at((-400, 300, 1200), look_at=(300, 300, 1250)), what="anisotropic side view")

@@ -1,0 +1,16 @@
+import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, tsdf_amd, time, torch
+from tsdf_amd import synth
+n=512
+v=tsdf_amd.TSDFVolume((n,n,n),(3000.,)*3)
+bil=tsdf_amd.BilateralFilter(30.0,4.5)
+rc=tsdf_amd.GPURaycaster(640,480)
+vert=torch.empty((640*480,3),dtype=torch.float32,device='cuda')
+s=torch.cuda.current_stream(); v.set_stream(s.cuda_stream)
+for i in range(0,8):
+    d,cam=synth.depth_frame(i,200,seed=0x5EED0003)
+    f=d.copy(); bil.filter(f,640,480)
+    v.integrate(f,640,480,cam)
+for r in range(5):
+    rc.raycast_device(v,cam,vert.data_ptr(),None)
+torch.cuda.synchronize()

@@ -23,7 +23,8 @@ class VolumeInfo(C.Structure):
                 ("physical_size", C.c_float * 3), ("voxel_size", C.c_float * 3), ("offset", C.c_float * 3),
                 ("offset_at_clear", C.c_float * 3), ("truncation_distance", C.c_float),
                 ("max_weight", C.c_float), ("global_translation", C.c_float * 3),
-                ("global_rotation", C.c_float * 3), ("deformation_materialised", C.c_int32)]
+                ("global_rotation", C.c_float * 3), ("deformation_materialised", C.c_int32),
+                ("fast_division_verified", C.c_int32)]
 
 
 def _load():
@@ -53,6 +54,7 @@ _SIGS = {
     "tsdf_volume_get_info": (_i, [_vp, C.POINTER(VolumeInfo)]),
     "tsdf_volume_set_offset": (_i, [_vp, _f, _f, _f]),
     "tsdf_volume_set_header": (_i, [_vp, _fp, _f, _f, _fp, _fp]),
+    "tsdf_volume_mark_dirty": (_i, [_vp]),
     "tsdf_volume_distances": (_i, [_vp, C.POINTER(_vp)]),
     "tsdf_volume_weights": (_i, [_vp, C.POINTER(_vp)]),
     "tsdf_volume_deformation": (_i, [_vp, C.POINTER(_vp)]),
@@ -70,6 +72,8 @@ _SIGS = {
     "tsdf_normals_device": (_i, [_u32, _u32, _vp, _vp, _vp]),
     "tsdf_raycast_stats": (_i, [_vp, _u32, _u32, _fp, _fp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                 C.POINTER(C.c_uint64)]),
+    "tsdf_raycast_evaluated_samples": (_i, [_vp, _u32, _u32, _fp, _fp, C.POINTER(C.c_uint64), _vp]),
+    "tsdf_volume_occupancy": (_i, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "tsdf_raycast_slab_device": (_i, [_vp, _u32, _u32, _fp, _fp, _vp]),
     "tsdf_merge_hits_device": (_i, [_vp, _u32, _u32, _u32, _vp, _vp]),
     "tsdf_bilateral_create": (_i, [_f, _f, C.POINTER(_vp)]),

@@ -164,6 +164,12 @@ class TSDFVolume:
         check(lib.tsdf_integrate_device(self._h, C.c_void_p(int(depth_ptr)), width, height, _fp(pose), _fp(ipose),
                                         _fp(k), _fp(kinv)))
 
+    def occupancy(self):
+        """(occupied, total) bricks of the ray caster's empty-space summary."""
+        o, t = C.c_uint64(), C.c_uint64()
+        check(lib.tsdf_volume_occupancy(self._h, C.byref(o), C.byref(t)))
+        return int(o.value), int(t.value)
+
     def set_counting(self, enabled):
         check(lib.tsdf_volume_set_counting(self._h, 1 if enabled else 0))
 
@@ -211,13 +217,20 @@ class GPURaycaster:
         check(lib.tsdf_raycast_slab_device(volume._h, self.m_width, self.m_height, _fp(pose), _fp(kinv),
                                            C.c_void_p(int(hits_ptr))))
 
-    def stats(self, volume, camera):
+    def stats(self, volume, camera, per_ray_work=False):
         """Roofline diagnostics of one raycast: samples S, distinct voxels touched T, hits."""
         pose, _, _, kinv = _camera_matrices(camera)
         s, t, h = C.c_uint64(), C.c_uint64(), C.c_uint64()
         check(lib.tsdf_raycast_stats(volume._h, self.m_width, self.m_height, _fp(pose), _fp(kinv), C.byref(s),
                                      C.byref(t), C.byref(h)))
-        return {"samples": int(s.value), "touched": int(t.value), "hits": int(h.value)}
+        e = C.c_uint64()
+        per_ray = np.empty((self.m_width * self.m_height, 3), np.float32) if per_ray_work else None
+        check(lib.tsdf_raycast_evaluated_samples(volume._h, self.m_width, self.m_height, _fp(pose), _fp(kinv), C.byref(e),
+                                                 per_ray.ctypes.data if per_ray is not None else None))
+        out = {"samples": int(s.value), "touched": int(t.value), "hits": int(h.value), "evaluated": int(e.value)}
+        if per_ray is not None:
+            out["per_ray"] = per_ray      # columns: samples evaluated, loop trips, reference sample count
+        return out
 
 
 def compute_normals_device(width, height, vertices_ptr, normals_ptr, stream=0):

@@ -13,11 +13,16 @@
 
 #include "tsdf_amd.h"
 
+struct tsdf_volume;
+
 namespace tsdf {
 
 // ---- error plumbing ----------------------------------------------------------------------
 void set_error(const char *fmt, ...);
 int hip_fail(hipError_t e, const char *what);
+int occupancy_rebuild(struct ::tsdf_volume *v);  // volume.hip
+int build_t_table(struct ::tsdf_volume *v);      // volume.hip
+int verify_fast_division(struct ::tsdf_volume *v);  // volume.hip
 
 #define TSDF_HIP(call, what)                                  \
     do {                                                      \
@@ -63,6 +68,21 @@ struct Geom {
     float trunc;
 };
 
+// Brick occupancy used by the ray caster for exact empty-space skipping (raycast.hip).  One byte per brick
+// of kBrick^3 voxels of the GLOBAL grid: 0 = every resident voxel within the brick grown by kBrickGrow
+// voxels on every side is > tau, i.e. no trilinear sample whose taps lie in the brick grown by one voxel can
+// be <= 0.  Flags are sticky: integrate only ever sets them, a rebuild (clear / whole-array upload) resets.
+// numerators with |a| < kFastDivMin (zero included) or non-finite take the IEEE division in raycast.hip
+constexpr float kFastDivMin = 1.0e-30f;
+constexpr int kBrick = 8;
+constexpr int kBrickShift = 3;
+constexpr int kBrickGrow = 2;
+struct OccGrid {
+    uint8_t *flags;
+    uint32_t nbx, nby, nbz;
+    float tau;  // "safely positive" threshold (a fraction of the truncation distance)
+};
+
 // float -> int with the reference target's semantics (CUDA cvt.rzi: saturating, NaN -> 0);
 // written out so the result does not depend on what an out-of-range fptosi lowers to.
 __host__ __device__ inline int f2i_sat(float f) {
@@ -92,6 +112,15 @@ struct tsdf_volume {
     float *vert_buf;
     float *norm_buf;
     size_t ray_cap;
+    // T[k]: the ray parameter of sample k, T[0] = 0, T[k+1] = T[k] + step in fp32 (raycast.hip)
+    float *t_table;
+    // 1 = dividing by each voxel edge via the 3-instruction reciprocal sequence was verified exhaustively
+    // against IEEE division for this volume's voxel size (volume.hip: verify_fast_division)
+    int fast_div;
+    unsigned long long fast_div_mismatches;
+    // brick occupancy (see OccGrid)
+    tsdf::OccGrid occ;
+    int occ_dirty;   // 1 = rebuild from the distance array before the next ray cast
     // diagnostics
     int counting;
     unsigned long long *counter_dev;  // [0] = updated voxels, [1] = samples, [2] = hits

@@ -93,6 +93,20 @@ __device__ inline bool brick_outside_image(uint32_t x0, uint32_t x1, uint32_t y0
     return false;
 }
 
+// A voxel whose new distance is not safely positive flags every brick whose grown region
+// (brick +- kBrickGrow voxels) contains it: the bricks holding voxel v-2 .. v+2 on each axis.
+__device__ inline void mark_occupied(const OccGrid &occ, uint32_t vx, uint32_t vy, uint32_t vz) {
+    const uint32_t bx0 = (max(vx, (uint32_t)kBrickGrow) - kBrickGrow) >> kBrickShift;
+    const uint32_t by0 = (max(vy, (uint32_t)kBrickGrow) - kBrickGrow) >> kBrickShift;
+    const uint32_t bz0 = (max(vz, (uint32_t)kBrickGrow) - kBrickGrow) >> kBrickShift;
+    const uint32_t bx1 = min((vx + kBrickGrow) >> kBrickShift, occ.nbx - 1);
+    const uint32_t by1 = min((vy + kBrickGrow) >> kBrickShift, occ.nby - 1);
+    const uint32_t bz1 = min((vz + kBrickGrow) >> kBrickShift, occ.nbz - 1);
+    for (uint32_t bz = bz0; bz <= bz1; bz++)
+        for (uint32_t by = by0; by <= by1; by++)
+            for (uint32_t bx = bx0; bx <= bx1; bx++) occ.flags[((size_t)bz * occ.nby + by) * occ.nbx + bx] = 1;
+}
+
 template <bool DEFORM, bool COUNT>
 __global__ __launch_bounds__(256) void integrate_kernel(float *__restrict__ dist, float *__restrict__ weight,
                                                         const tsdf_deformation_node *__restrict__ nodes,
@@ -100,7 +114,8 @@ __global__ __launch_bounds__(256) void integrate_kernel(float *__restrict__ dist
                                                         const Mat33 kinv, const uint32_t width,
                                                         const uint32_t height,
                                                         const uint16_t *__restrict__ depth,
-                                                        unsigned long long *__restrict__ counter) {
+                                                        unsigned long long *__restrict__ counter,
+                                                        const OccGrid occ) {
     const uint32_t x0 = blockIdx.x * kTileX;
     const uint32_t y0 = blockIdx.y * kTileY;
     const uint32_t z0 = g.z_store_begin + blockIdx.z * kChunkZ;
@@ -177,6 +192,7 @@ __global__ __launch_bounds__(256) void integrate_kernel(float *__restrict__ dist
                     float new_distance = ((prior_distance * prior_weight) + (tsdf * 1.0f)) / new_weight;
                     weight[idx] = new_weight;
                     dist[idx] = new_distance;
+                    if (!(new_distance > occ.tau)) mark_occupied(occ, vx, vy, vz);
                     did = true;
                 }
             }
@@ -204,7 +220,7 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
     if (v->counting) TSDF_HIP(hipMemsetAsync(v->counter_dev, 0, sizeof(unsigned long long), v->stream), "reset counter");
 #define LAUNCH(DEF, CNT)                                                                                     \
     hipLaunchKernelGGL((integrate_kernel<DEF, CNT>), grid, block, 0, v->stream, v->dist, v->weight, v->nodes, \
-                       g, ip, mk, mkinv, width, height, d_depth, v->counter_dev)
+                       g, ip, mk, mkinv, width, height, d_depth, v->counter_dev, v->occ)
     if (v->nodes) {
         if (v->counting) LAUNCH(true, true); else LAUNCH(true, false);
     } else {

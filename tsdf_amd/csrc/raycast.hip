@@ -1,13 +1,10 @@
 // TSDF ray casting + normals for gfx950 (wave64).  Replaces GPURaycaster::raycast, get_vertices /
 // process_ray and compute_normals of the reference (src/RayCaster/GPURaycaster.cu:14-547).
 //
-// One lane per pixel; a wave is an 8x8 pixel tile (coherent rays share cache lines of the
-// distance array), a 256-thread workgroup is a 16x16 tile, 1200 workgroups at 640x480.  The
-// march is the reference's, step for step, including its quirks (direction not normalised: Q6,
-// previous_tsdf == trunc: Q7, 4402-sample cap: Q8, t accumulated by repeated float adds: Q9,
-// unclamped point in the interpolation weights: Q10); fp contraction is off so every sample is
-// bit-identical.  Lanes leave the loop individually; the wave iterates while any lane is
-// still marching (ballot), so a tile costs as much as its longest ray.
+// The march is the reference's, sample for sample, including its quirks (direction not normalised: Q6,
+// previous_tsdf == trunc: Q7, 4402-sample cap: Q8, t accumulated by repeated float adds: Q9, unclamped
+// point in the interpolation weights: Q10); fp contraction is off so every evaluated sample is
+// bit-identical.  How the loop is reorganised for wave64 is described at process_ray_kernel below.
 #include <cmath>
 
 #include "common.hpp"
@@ -24,40 +21,70 @@ struct RayParams {
     uint32_t own_lo, own_hi;  // slab ownership (planes of the lower trilinear tap)
 };
 
-// tsdf_value_at (src/TSDF/TSDF_utilities.cu:29-37): uint16_t coordinates clamped to the grid.
-template <bool STATS>
-__device__ inline float tsdf_value_at(int xi, int yi, int zi, const float *__restrict__ dist, const Geom &g,
-                                      unsigned int *__restrict__ touched) {
-    uint32_t x = (uint16_t)xi, y = (uint16_t)yi, z = (uint16_t)zi;
-    x = min(x, g.X - 1);
-    y = min(y, g.Y - 1);
-    z = min(z, g.Z - 1);
-    if (STATS) {
-        size_t gi = (size_t)g.X * g.Y * z + (size_t)g.X * y + x;
-        atomicOr(&touched[gi >> 5], 1u << (gi & 31));
+// Division by a loop-invariant voxel edge.  The reference divides (IEEE, correctly rounded); when FASTDIV is
+// set the quotient is formed as q0 = a*y, r = fma(-b, q0, a), q = fma(r, y, q0) with y = RN(1/b).  That
+// sequence is used ONLY after volume.hip has checked it against the IEEE quotient for EVERY finite fp32
+// numerator with |a| >= kFastDivMin for this very b (verify_fast_division, ~2^32 cases per voxel
+// edge, a few ms once per volume), so on that domain it is the same function in three instructions instead
+// of the ~14 of a full fp32 division; numerators outside the domain take the IEEE division.
+struct InvDiv {
+    float b, y;
+};
+template <bool FASTDIV>
+__device__ inline float div_by(float a, const InvDiv &d) {
+    if (FASTDIV) {
+        const float mag = fabsf(a);
+        if (mag >= kFastDivMin && mag < INFINITY) {  // the verified domain
+            float q0 = a * d.y;
+            float r = __builtin_fmaf(-d.b, q0, a);
+            return __builtin_fmaf(r, d.y, q0);
+        }
     }
-    size_t idx = (size_t)g.X * g.Y * (z - g.z_store_begin) + (size_t)g.X * y + x;
-    return dist[idx];
+    return a / d.b;
 }
 
-// trilinearly_interpolate (src/RayCaster/GPURaycaster.cu:53-124).  For SLAB, samples whose lower
-// tap plane is not owned are not evaluated (owned=false, result NaN).
-template <bool SLAB, bool STATS>
+// Loop-invariant pieces of trilinearly_interpolate (:60-71) and of tsdf_value_at, same float expressions.
+struct TriConst {
+    float max_x, max_y, max_z;        // voxel_grid_size * voxel_size
+    float clamp_x, clamp_y, clamp_z;  // max - voxel_size / 10
+    InvDiv dx, dy, dz;
+    uint32_t row, plane;              // X, X*Y
+};
+__device__ inline TriConst make_tri_const(const Geom &g) {
+    TriConst c;
+    c.max_x = g.X * g.vs.x;
+    c.max_y = g.Y * g.vs.y;
+    c.max_z = g.Z * g.vs.z;
+    c.clamp_x = c.max_x - (g.vs.x / 10.0f);
+    c.clamp_y = c.max_y - (g.vs.y / 10.0f);
+    c.clamp_z = c.max_z - (g.vs.z / 10.0f);
+    c.dx = {g.vs.x, 1.0f / g.vs.x};
+    c.dy = {g.vs.y, 1.0f / g.vs.y};
+    c.dz = {g.vs.z, 1.0f / g.vs.z};
+    c.row = g.X;
+    c.plane = g.X * g.Y;  // X, Y <= 65535
+    return c;
+}
+
+// trilinearly_interpolate (src/RayCaster/GPURaycaster.cu:53-124) with voxel_for_point, centre_of_voxel_at and
+// tsdf_value_at (src/TSDF/TSDF_utilities.cu:10-53) inlined.  For SLAB, samples whose lower tap plane is not
+// owned are not evaluated (owned=false, result NaN).
+template <bool SLAB, bool STATS, bool FASTDIV>
 __device__ inline float trilinear(float px, float py, float pz, const float *__restrict__ dist, const Geom &g,
-                                  const RayParams &rp, bool &owned, unsigned int *__restrict__ touched) {
-    float max_x = g.X * g.vs.x, max_y = g.Y * g.vs.y, max_z = g.Z * g.vs.z;
+                                  const TriConst &tc, const RayParams &rp, bool &owned,
+                                  unsigned int *__restrict__ touched) {
     float ax = px, ay = py, az = pz;
-    if (px >= max_x) ax = max_x - (g.vs.x / 10.0f);
-    if (py >= max_y) ay = max_y - (g.vs.y / 10.0f);
-    if (pz >= max_z) az = max_z - (g.vs.z / 10.0f);
+    if (px >= tc.max_x) ax = tc.clamp_x;
+    if (py >= tc.max_y) ay = tc.clamp_y;
+    if (pz >= tc.max_z) az = tc.clamp_z;
     if (px < 0.0f) ax = 0.0f;
     if (py < 0.0f) ay = 0.0f;
     if (pz < 0.0f) az = 0.0f;
 
     // voxel_for_point (src/TSDF/TSDF_utilities.cu:45-53)
-    int vx = f2i_sat(floorf(ax / g.vs.x));
-    int vy = f2i_sat(floorf(ay / g.vs.y));
-    int vz = f2i_sat(floorf(az / g.vs.z));
+    int vx = f2i_sat(floorf(div_by<FASTDIV>(ax, tc.dx)));
+    int vy = f2i_sat(floorf(div_by<FASTDIV>(ay, tc.dy)));
+    int vz = f2i_sat(floorf(div_by<FASTDIV>(az, tc.dz)));
 
     owned = true;
     if (vx < 0 || vy < 0 || vz < 0 || (uint32_t)vx >= g.X || (uint32_t)vy >= g.Y || (uint32_t)vz >= g.Z) {
@@ -86,18 +113,32 @@ __device__ inline float trilinear(float px, float py, float pz, const float *__r
     float lcx = (lx + 0.5f) * g.vs.x + 0.0f;
     float lcy = (ly + 0.5f) * g.vs.y + 0.0f;
     float lcz = (lz + 0.5f) * g.vs.z + 0.0f;
-    float u = (px - lcx) / g.vs.x;
-    float v = (py - lcy) / g.vs.y;
-    float w = (pz - lcz) / g.vs.z;
+    float u = div_by<FASTDIV>(px - lcx, tc.dx);
+    float v = div_by<FASTDIV>(py - lcy, tc.dy);
+    float w = div_by<FASTDIV>(pz - lcz, tc.dz);
 
-    float c000 = tsdf_value_at<STATS>(lx + 0, ly + 0, lz + 0, dist, g, touched);
-    float c001 = tsdf_value_at<STATS>(lx + 0, ly + 0, lz + 1, dist, g, touched);
-    float c010 = tsdf_value_at<STATS>(lx + 0, ly + 1, lz + 0, dist, g, touched);
-    float c011 = tsdf_value_at<STATS>(lx + 0, ly + 1, lz + 1, dist, g, touched);
-    float c100 = tsdf_value_at<STATS>(lx + 1, ly + 0, lz + 0, dist, g, touched);
-    float c101 = tsdf_value_at<STATS>(lx + 1, ly + 0, lz + 1, dist, g, touched);
-    float c110 = tsdf_value_at<STATS>(lx + 1, ly + 1, lz + 0, dist, g, touched);
-    float c111 = tsdf_value_at<STATS>(lx + 1, ly + 1, lz + 1, dist, g, touched);
+    // tsdf_value_at clamps each tap to the grid (:31-33): lower is in range, so only lower+1 can be
+    // clamped, to lower itself (0 <= lower <= size-1 <= 65534: the uint16_t parameters never wrap).
+    const uint32_t ox = ((uint32_t)lx + 1 < g.X) ? 1u : 0u;
+    const uint32_t oy = ((uint32_t)ly + 1 < g.Y) ? tc.row : 0u;
+    const uint32_t oz = ((uint32_t)lz + 1 < g.Z) ? tc.plane : 0u;
+    const float *b000 = dist + ((size_t)tc.plane * ((uint32_t)lz - g.z_store_begin) + (size_t)tc.row * (uint32_t)ly + (uint32_t)lx);
+    if (STATS) {
+        const size_t gi = (size_t)tc.plane * (uint32_t)lz + (size_t)tc.row * (uint32_t)ly + (uint32_t)lx;
+        const uint32_t offs[8] = {0, oz, oy, oy + oz, ox, ox + oz, ox + oy, ox + oy + oz};
+        for (int i = 0; i < 8; i++) {
+            size_t q = gi + offs[i];
+            atomicOr(&touched[q >> 5], 1u << (q & 31));
+        }
+    }
+    float c000 = b000[0];
+    float c001 = b000[oz];
+    float c010 = b000[oy];
+    float c011 = b000[oy + oz];
+    float c100 = b000[ox];
+    float c101 = b000[ox + oz];
+    float c110 = b000[ox + oy];
+    float c111 = b000[ox + oy + oz];
 
     float interpolated = c000 * (1 - u) * (1 - v) * (1 - w) +
                          c001 * (1 - u) * (1 - v) * w +
@@ -160,14 +201,90 @@ __device__ inline bool compute_near_and_far_t(const F3 &o, const F3 &d, const F3
     return intersects;
 }
 
-// process_ray (src/RayCaster/GPURaycaster.cu:265-377).
+// ---- process_ray (src/RayCaster/GPURaycaster.cu:265-377) ---------------------------------------------------
+//
+// What the reference's loop does, restated so that it parallelises without changing a bit:
+//
+//  * Its parameter t only ever takes the values T[0] = 0, T[k+1] = T[k] + step (float additions), the same for
+//    every ray of a launch, until a sample is <= 0.  The host builds that table with the same additions
+//    (volume.hip: build_t_table) and the kernel stages it in LDS, so sample k of any ray is at T[k] without
+//    replaying k additions (Q9 is kept: the values ARE the repeated float sums).
+//  * Sample k is evaluated iff k < k_end, k_end = min(4402, first k >= 1 with T[k] >= max_t): that is the
+//    `t >= max_t` test and the `count++ > 4400` cap of the reference (Q8), hoisted out of the loop.
+//  * The first k with tsdf <= 0 ends the ray; t is refined from T[k] exactly as the reference does (Q7).
+//
+// Exact empty-space skipping (SKIP).  A sample whose 8 taps are all safely positive (> occ.tau) and whose
+// weights lie in [0,1] up to rounding cannot be <= 0, so the reference passes it doing nothing.  When sample k
+// lies in an interior brick whose occupancy flag is clear, k jumps to the brick's exit.  The flag covers the
+// brick grown by kBrickGrow = 2 voxels: one voxel for the reach of the taps, one for the slack of the
+// approximate arithmetic that locates the sample and counts the samples to the exit (errors of a few 1e-3
+// voxel; the jump may overshoot the face by < 1 step, i.e. < 0.25 voxel).  Bricks touching the grid boundary
+// are never skipped (there the weights can leave [0,1]: Q10).
+//
+// The same argument one level down, inside occupied interior bricks: the sample at p interpolates the 8 voxels
+// of its dual cell (lower = floor(p/vs - 1/2)).  If p is at least eps away from every face of that cell the
+// cheap arithmetic here and the reference's exact arithmetic agree on the cell; if its 8 values are all > tau
+// neither this sample nor the following ones that stay inside the cell shrunk by eps can be <= 0, so k jumps
+// to the cell's exit.  Otherwise the sample is interpolated exactly -- from the 8 values just gathered.
+//
+// Wave scheduling.  One lane per pixel, a wave is an 8x8 pixel tile of coherent rays.  Every pass of the loop
+// does the same straight-line work for all lanes (one brick flag, 8 gathers, a jump or one interpolation), so
+// lanes do not serialise on divergent code paths; the wave leaves when every lane is done (ballot).
 //   SLAB=false: out = packed float3 vertices.  SLAB=true: out = float4 records {k, x, y, z}.
-//   STATS: counters[1] += samples, counters[2] += hits, touched bitmap marked per tap.
-template <bool SLAB, bool STATS>
+//   STATS: counters[1] += samples evaluated, counters[2] += hits, touched bitmap marked per tap.  With
+//          SKIP=false the counts are those of the reference's march.
+constexpr int kMaxSamples = 4402;          // src/RayCaster/GPURaycaster.cu:369
+constexpr int kTableLen = kMaxSamples + 2;  // T[0..4402] is read
+constexpr int kDone = 0x7fffffff;
+
+struct SkipCtx {
+    float inv_vx, inv_vy, inv_vz;  // 1/voxel size (approximate on purpose)
+    float bsx, bsy, bsz;           // brick edge in mm
+    float inv_step;
+    float rdx, rdy, rdz;           // 1/dir (+-inf for a zero component)
+    int nfx, nfy, nfz;             // number of full bricks per axis
+    float eps;                     // cell_test: guard band at the cell faces, in voxels
+};
+
+// Locates the sample at p in the brick grid.  Returns true when the whole brick may be skipped (interior brick,
+// flag clear).  n = number of consecutive samples, starting with this one, that stay inside the brick (>= 1;
+// 1 for a position in the boundary shell, so the next sample is located again).  interior tells whether the
+// brick is one of those the skipping arguments apply to.
+__device__ inline bool locate(float px, float py, float pz, const F3 &dir, const SkipCtx &c, const OccGrid &occ, int &n,
+                              bool &interior) {
+    const int bx = (int)floorf(px * c.inv_vx) >> kBrickShift;
+    const int by = (int)floorf(py * c.inv_vy) >> kBrickShift;
+    const int bz = (int)floorf(pz * c.inv_vz) >> kBrickShift;
+    n = 1;
+    interior = bx >= 1 && by >= 1 && bz >= 1 && bx + 1 < c.nfx && by + 1 < c.nfy && bz + 1 < c.nfz;
+    if (!interior) return false;
+    // distance (in t) to the face through which the ray leaves the brick
+    float ex = ((dir.x > 0 ? (bx + 1) * c.bsx : bx * c.bsx) - px) * c.rdx;
+    float ey = ((dir.y > 0 ? (by + 1) * c.bsy : by * c.bsy) - py) * c.rdy;
+    float ez = ((dir.z > 0 ? (bz + 1) * c.bsz : bz * c.bsz) - pz) * c.rdz;
+    if (!(dir.x != 0)) ex = INFINITY;
+    if (!(dir.y != 0)) ey = INFINITY;
+    if (!(dir.z != 0)) ez = INFINITY;
+    float dt = fminf(ex, fminf(ey, ez));
+    n = (int)fminf(fmaxf(dt * c.inv_step, 1.0f), 8192.0f);
+    return occ.flags[((size_t)bz * occ.nby + by) * occ.nbx + bx] == 0;
+}
+
+__device__ inline int wave_min(int v) {
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return v;
+}
+
+template <bool SLAB, bool STATS, bool SKIP, bool FASTDIV>
 __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restrict__ dist, const Geom g,
                                                           const RayParams rp, float *__restrict__ out,
                                                           unsigned long long *__restrict__ counters,
-                                                          unsigned int *__restrict__ touched) {
+                                                          unsigned int *__restrict__ touched,
+                                                          const OccGrid occ, const float *__restrict__ t_table) {
+    __shared__ float T[kTableLen];
+    for (int i = threadIdx.x; i < kTableLen; i += 256) T[i] = t_table[i];
+    __syncthreads();
+
     // 16x16 pixel tile per workgroup, 8x8 per wave
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const int imx = blockIdx.x * 16 + (wave & 1u) * 8 + (lane & 7u);
@@ -196,41 +313,143 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
     const float sy = ((near_t * dir.y) + rp.origin.y) - rp.space_min.y;
     const float sz = ((near_t * dir.z) + rp.origin.z) - rp.space_min.z;
 
-    const float previous_tsdf = g.trunc;                      // Q7
-    const float step_size = (float)((double)g.trunc * 0.05);  // :324 (double literal)
+    const float previous_tsdf = g.trunc;  // Q7
+    const float step_size = T[1];         // = (float)((double)trunc * 0.05), :324
     const float max_t = far_t - near_t;
-    float t = 0;
-    int count = 0;
-    bool done = !intersects;
 
-    while (__ballot(!done) != 0ull) {
-        if (!done) {
-            float px = (t * dir.x) + sx;
-            float py = (t * dir.y) + sy;
-            float pz = (t * dir.z) + sz;
-            bool owned;
-            float tsdf = trilinear<SLAB, STATS>(px, py, pz, dist, g, rp, owned, touched);
-            if (STATS && owned) samples++;
-            if (tsdf <= 0) {
-                if (tsdf < 0) {
-                    t = t - step_size;
-                    t = t + (previous_tsdf / (previous_tsdf - tsdf)) * step_size;
+    // samples 0 .. k_end-1 are evaluated unless one of them is <= 0
+    int k_end = 0;
+    if (intersects) {
+        int lo = 1, hi = kMaxSamples;
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            if (T[mid] >= max_t) hi = mid; else lo = mid + 1;
+        }
+        k_end = lo;
+    }
+
+    const TriConst tc = make_tri_const(g);
+    SkipCtx sc;
+    sc.inv_vx = 1.0f / g.vs.x; sc.inv_vy = 1.0f / g.vs.y; sc.inv_vz = 1.0f / g.vs.z;
+    sc.bsx = kBrick * g.vs.x; sc.bsy = kBrick * g.vs.y; sc.bsz = kBrick * g.vs.z;
+    sc.inv_step = 1.0f / step_size;
+    sc.rdx = 1.0f / dir.x; sc.rdy = 1.0f / dir.y; sc.rdz = 1.0f / dir.z;
+    sc.nfx = (int)(g.X >> kBrickShift); sc.nfy = (int)(g.Y >> kBrickShift); sc.nfz = (int)(g.Z >> kBrickShift);
+    // one step must stay well inside the one-voxel slack on every axis
+    const bool skip_ok = SKIP && fabsf(dir.x) * step_size < 0.25f * g.vs.x && fabsf(dir.y) * step_size < 0.25f * g.vs.y &&
+                         fabsf(dir.z) * step_size < 0.25f * g.vs.z;
+
+    // guard band at the cell faces: the dual-cell index computed approximately below (coordinates up to
+    // max(X,Y,Z) voxels, a handful of roundings of 2^-24 relative each) must agree with the reference's exact one
+    sc.eps = fmaxf(1.0e-3f, 2.0e-6f * (float)max(g.X, max(g.Y, g.Z)));
+    const float cell_lo = sc.eps, cell_hi = 1.0f - sc.eps;
+
+    int k = (k_end == 0) ? kDone : 0;  // next sample of this lane (kDone when finished)
+    int k_brick_end = 0;               // the brick classification holds while k < k_brick_end
+    bool brick_interior = false;
+    uint32_t trips = 0, adv_iters = 0;  // diagnostics
+
+    // One pass of the loop handles one sample index per lane, the same straight-line work for every lane:
+    //   1. (when a brick boundary was crossed) read the brick flag; a clear interior brick is jumped over;
+    //   2. otherwise gather the 8 voxels of the sample's dual cell; if they are all
+    //      safely positive the samples up to the cell's (shrunk) exit are jumped over;
+    //   3. otherwise the sample is interpolated from those 8 values with the reference's arithmetic.
+    // Samples in the outer half-voxel shell of the grid, within eps of a cell face, or with skipping disabled
+    // take the reference's full trilinearly_interpolate instead (rare).
+    while (__ballot(k != kDone) != 0ull) {
+        if (STATS) trips++;
+        if (k != kDone) {
+            const float t = T[k];
+            const float px = (t * dir.x) + sx, py = (t * dir.y) + sy, pz = (t * dir.z) + sz;
+            float tsdf = 1.0f;      // value of sample k when it gets evaluated
+            bool evaluated = false;
+            int jump = 0;           // > 0: samples k .. k+jump-1 cannot hit
+            if (skip_ok) {
+                if (k >= k_brick_end) {
+                    int n;
+                    bool empty = locate(px, py, pz, dir, sc, occ, n, brick_interior);
+                    k_brick_end = k + n;
+                    if (empty) jump = n;
                 }
-                px = (t * dir.x) + sx;
-                py = (t * dir.y) + sy;
-                pz = (t * dir.z) + sz;
-                ix = px + rp.space_min.x;
-                iy = py + rp.space_min.y;
-                iz = pz + rp.space_min.z;
-                hit_k = (float)count;
-                done = true;
-            } else if (previous_tsdf < 0) {
-                done = true;
-            } else {
-                t = t + step_size;
-                if (t >= max_t) done = true;
+                if (jump == 0) {
+                    // dual cell of the sample: lower = floor(p/vs - 1/2), position inside it r in [0,1)
+                    const float cx = px * sc.inv_vx - 0.5f, cy = py * sc.inv_vy - 0.5f, cz = pz * sc.inv_vz - 0.5f;
+                    const float fx = floorf(cx), fy = floorf(cy), fz = floorf(cz);
+                    const float rx = cx - fx, ry = cy - fy, rz = cz - fz;
+                    // at least eps away from the cell faces, and all 8 voxels of the cell exist (then no tap is
+                    // clamped, the weights lie in [0,1], and p is inside the grid so nothing is clamped either;
+                    // the outer half-voxel shell of the grid, where the reference extrapolates (Q10), fails this)
+                    const bool safe = rx > cell_lo && rx < cell_hi && ry > cell_lo && ry < cell_hi && rz > cell_lo && rz < cell_hi &&
+                                      fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx + 1.0f < (float)g.X &&
+                                      fy + 1.0f < (float)g.Y && fz + 1.0f < (float)g.Z;
+                    if (safe) {
+                        // samples until the ray leaves the cell shrunk by eps
+                        float ex = (dir.x > 0 ? cell_hi - rx : rx - cell_lo) * fabsf(sc.rdx) * g.vs.x;
+                        float ey = (dir.y > 0 ? cell_hi - ry : ry - cell_lo) * fabsf(sc.rdy) * g.vs.y;
+                        float ez = (dir.z > 0 ? cell_hi - rz : rz - cell_lo) * fabsf(sc.rdz) * g.vs.z;
+                        if (!(dir.x != 0)) ex = INFINITY;
+                        if (!(dir.y != 0)) ey = INFINITY;
+                        if (!(dir.z != 0)) ez = INFINITY;
+                        const int n_cell = (int)fminf(fmaxf(fminf(ex, fminf(ey, ez)) * sc.inv_step, 1.0f), 8192.0f);
+                        const int lx = (int)fx, ly = (int)fy, lz = (int)fz;
+                        if (SLAB && !((uint32_t)lz >= rp.own_lo && (uint32_t)lz < rp.own_hi)) {
+                            jump = n_cell;  // not this rank's samples (and possibly not its planes): passed unevaluated
+                        } else {
+                            const float *b = dist + ((size_t)tc.plane * ((uint32_t)lz - g.z_store_begin) + (size_t)tc.row * (uint32_t)ly + (uint32_t)lx);
+                            const float c000 = b[0], c100 = b[1], c010 = b[tc.row], c110 = b[tc.row + 1];
+                            const float c001 = b[tc.plane], c101 = b[tc.plane + 1], c011 = b[tc.plane + tc.row],
+                                        c111 = b[tc.plane + tc.row + 1];
+                            const bool positive = c000 > occ.tau && c100 > occ.tau && c010 > occ.tau && c110 > occ.tau &&
+                                                  c001 > occ.tau && c101 > occ.tau && c011 > occ.tau && c111 > occ.tau;
+                            if (positive) {
+                                jump = n_cell;
+                            } else {
+                                // trilinearly_interpolate (:84-121) for lower = (lx,ly,lz), which is what the
+                                // reference derives for a sample this far from the cell faces
+                                const float lcx = (lx + 0.5f) * g.vs.x + 0.0f;
+                                const float lcy = (ly + 0.5f) * g.vs.y + 0.0f;
+                                const float lcz = (lz + 0.5f) * g.vs.z + 0.0f;
+                                const float u = div_by<FASTDIV>(px - lcx, tc.dx);
+                                const float v = div_by<FASTDIV>(py - lcy, tc.dy);
+                                const float w = div_by<FASTDIV>(pz - lcz, tc.dz);
+                                tsdf = c000 * (1 - u) * (1 - v) * (1 - w) +
+                                       c001 * (1 - u) * (1 - v) * w +
+                                       c010 * (1 - u) * v * (1 - w) +
+                                       c011 * (1 - u) * v * w +
+                                       c100 * u * (1 - v) * (1 - w) +
+                                       c101 * u * (1 - v) * w +
+                                       c110 * u * v * (1 - w) +
+                                       c111 * u * v * w;
+                                evaluated = true;
+                                if (STATS) samples++;
+                            }
+                        }
+                    }
+                }
             }
-            if (count++ > 4400) done = true;  // :369
+            if (jump == 0 && !evaluated) {
+                bool owned;
+                tsdf = trilinear<SLAB, STATS, FASTDIV>(px, py, pz, dist, g, tc, rp, owned, touched);
+                if (STATS && owned) samples++;
+                if (STATS) adv_iters++;
+            }
+            if (jump > 0) {
+                k += jump;
+            } else if (tsdf <= 0) {
+                float th = t;
+                if (tsdf < 0) {
+                    th = th - step_size;
+                    th = th + (previous_tsdf / (previous_tsdf - tsdf)) * step_size;
+                }
+                ix = ((th * dir.x) + sx) + rp.space_min.x;
+                iy = ((th * dir.y) + sy) + rp.space_min.y;
+                iz = ((th * dir.z) + sz) + rp.space_min.z;
+                hit_k = (float)k;
+                k = kDone;
+            } else {
+                k += 1;  // positive (or NaN) sample: the reference steps on; `previous_tsdf < 0` never holds (Q7)
+            }
+            if (k != kDone && k >= k_end) k = kDone;
         }
     }
 
@@ -238,6 +457,10 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
         size_t idx = (size_t)imy * rp.width + imx;
         if (SLAB) {
             reinterpret_cast<float4 *>(out)[idx] = make_float4(hit_k, ix, iy, iz);
+        } else if (STATS && SKIP) {  // diagnostics: per-ray work instead of the vertex
+            out[idx * 3 + 0] = (float)samples;
+            out[idx * 3 + 1] = (float)trips;
+            out[idx * 3 + 2] = (float)adv_iters;
         } else {
             out[idx * 3 + 0] = ix;
             out[idx * 3 + 1] = iy;
@@ -350,10 +573,18 @@ int tsdf_raycast_device(const tsdf_volume *v, uint32_t width, uint32_t height, c
     if (rc != TSDF_OK) return rc;
     TSDF_REQUIRE(device_vertices, "tsdf_raycast: null vertex buffer");
     TSDF_REQUIRE(v->z_begin == 0 && v->z_end == v->g.Z, "tsdf_raycast on a slab: use tsdf_raycast_slab_device");
+    if (v->occ_dirty) {
+        rc = occupancy_rebuild(const_cast<tsdf_volume *>(v));
+        if (rc != TSDF_OK) return rc;
+    }
     RayParams rp = make_params(v, width, height, pose, kinv);
     dim3 grid((width + 15) / 16, (height + 15) / 16);
-    hipLaunchKernelGGL((process_ray_kernel<false, false>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp,
-                       device_vertices, (unsigned long long *)nullptr, (unsigned int *)nullptr);
+    if (v->fast_div)
+        hipLaunchKernelGGL((process_ray_kernel<false, false, true, true>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp,
+                           device_vertices, (unsigned long long *)nullptr, (unsigned int *)nullptr, v->occ, v->t_table);
+    else
+        hipLaunchKernelGGL((process_ray_kernel<false, false, true, false>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp,
+                           device_vertices, (unsigned long long *)nullptr, (unsigned int *)nullptr, v->occ, v->t_table);
     TSDF_HIP(hipGetLastError(), "process_ray failed");
     if (device_normals) return launch_normals(width, height, device_vertices, device_normals, v->stream);
     return TSDF_OK;
@@ -409,8 +640,8 @@ int tsdf_raycast_stats(const tsdf_volume *v, uint32_t width, uint32_t height, co
     (void)hipMemsetAsync(bitmap, 0, words * sizeof(unsigned int), v->stream);
     (void)hipMemsetAsync(v->counter_dev, 0, 4 * sizeof(unsigned long long), v->stream);
     dim3 grid((width + 15) / 16, (height + 15) / 16);
-    hipLaunchKernelGGL((process_ray_kernel<false, true>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp, verts,
-                       v->counter_dev, bitmap);
+    hipLaunchKernelGGL((process_ray_kernel<false, true, false, false>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp, verts,
+                       v->counter_dev, bitmap, v->occ, v->t_table);
     hipLaunchKernelGGL(popcount_kernel, dim3(1024), dim3(256), 0, v->stream, bitmap, words, v->counter_dev + 3);
     unsigned long long c[4] = {0, 0, 0, 0};
     e = hipMemcpyAsync(c, v->counter_dev, sizeof(c), hipMemcpyDeviceToHost, v->stream);
@@ -424,15 +655,59 @@ int tsdf_raycast_stats(const tsdf_volume *v, uint32_t width, uint32_t height, co
     return TSDF_OK;
 }
 
+int tsdf_raycast_evaluated_samples(const tsdf_volume *v, uint32_t width, uint32_t height, const float pose[16],
+                                   const float kinv[9], uint64_t *evaluated, float *host_per_ray) {
+    int rc = check_ray_args(v, width, height, pose, kinv);
+    if (rc != TSDF_OK) return rc;
+    TSDF_REQUIRE(evaluated, "null argument");
+    TSDF_REQUIRE(v->z_begin == 0 && v->z_end == v->g.Z, "needs a whole volume");
+    if (v->occ_dirty) {
+        rc = occupancy_rebuild(const_cast<tsdf_volume *>(v));
+        if (rc != TSDF_OK) return rc;
+    }
+    RayParams rp = make_params(v, width, height, pose, kinv);
+    size_t words = ((size_t)v->g.X * v->g.Y * v->g.Z + 31) / 32;
+    unsigned int *bitmap = nullptr;
+    float *verts = nullptr;
+    TSDF_HIP(hipMalloc((void **)&bitmap, words * sizeof(unsigned int)), "stats bitmap alloc");
+    hipError_t e = hipMalloc((void **)&verts, (size_t)width * height * 3 * sizeof(float));
+    if (e != hipSuccess) {
+        (void)hipFree(bitmap);
+        return hip_fail(e, "stats vertex alloc");
+    }
+    (void)hipMemsetAsync(v->counter_dev, 0, 4 * sizeof(unsigned long long), v->stream);
+    dim3 grid((width + 15) / 16, (height + 15) / 16);
+    hipLaunchKernelGGL((process_ray_kernel<false, true, true, true>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp, verts,
+                       v->counter_dev, bitmap, v->occ, v->t_table);
+    unsigned long long c[4] = {0, 0, 0, 0};
+    e = hipMemcpyAsync(c, v->counter_dev, sizeof(c), hipMemcpyDeviceToHost, v->stream);
+    if (e == hipSuccess && host_per_ray)
+        e = hipMemcpyAsync(host_per_ray, verts, (size_t)width * height * 3 * sizeof(float), hipMemcpyDeviceToHost, v->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(v->stream);
+    (void)hipFree(bitmap);
+    (void)hipFree(verts);
+    if (e != hipSuccess) return hip_fail(e, "raycast stats");
+    *evaluated = c[1];
+    return TSDF_OK;
+}
+
 int tsdf_raycast_slab_device(const tsdf_volume *v, uint32_t width, uint32_t height, const float pose[16],
                              const float kinv[9], float *device_hits) {
     int rc = check_ray_args(v, width, height, pose, kinv);
     if (rc != TSDF_OK) return rc;
     TSDF_REQUIRE(device_hits, "tsdf_raycast_slab: null hit buffer");
+    if (v->occ_dirty) {
+        rc = occupancy_rebuild(const_cast<tsdf_volume *>(v));
+        if (rc != TSDF_OK) return rc;
+    }
     RayParams rp = make_params(v, width, height, pose, kinv);
     dim3 grid((width + 15) / 16, (height + 15) / 16);
-    hipLaunchKernelGGL((process_ray_kernel<true, false>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp,
-                       device_hits, (unsigned long long *)nullptr, (unsigned int *)nullptr);
+    if (v->fast_div)
+        hipLaunchKernelGGL((process_ray_kernel<true, false, true, true>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp,
+                           device_hits, (unsigned long long *)nullptr, (unsigned int *)nullptr, v->occ, v->t_table);
+    else
+        hipLaunchKernelGGL((process_ray_kernel<true, false, true, false>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp,
+                           device_hits, (unsigned long long *)nullptr, (unsigned int *)nullptr, v->occ, v->t_table);
     TSDF_HIP(hipGetLastError(), "process_ray (slab) failed");
     return TSDF_OK;
 }

@@ -5,8 +5,10 @@
 // asks for it and the colour array, which no kernel of the path touches, is
 // not allocated at all.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "common.hpp"
 
@@ -61,6 +63,94 @@ __global__ __launch_bounds__(256) void init_nodes_kernel(tsdf_deformation_node *
     nd.rotation[1] = 0.0f;
     nd.rotation[2] = 0.0f;
     nodes[idx] = nd;
+}
+
+// Rebuild of the brick occupancy from the distance array: one workgroup per brick scans the brick grown by
+// kBrickGrow voxels (clamped to the grid and to the resident planes) and flags it if any value is not
+// safely positive.  The overlap between neighbouring bricks is served by L2.
+__global__ __launch_bounds__(256) void occupancy_build_kernel(const float *__restrict__ dist, Geom g, OccGrid occ) {
+    const uint32_t bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    const int x0 = max((int)(bx * kBrick) - kBrickGrow, 0), x1 = min((int)(bx * kBrick) + kBrick + kBrickGrow, (int)g.X);
+    const int y0 = max((int)(by * kBrick) - kBrickGrow, 0), y1 = min((int)(by * kBrick) + kBrick + kBrickGrow, (int)g.Y);
+    const int z0 = max((int)(bz * kBrick) - kBrickGrow, (int)g.z_store_begin);
+    const int z1 = min((int)(bz * kBrick) + kBrick + kBrickGrow, (int)g.z_store_end);
+    const int nx = x1 - x0, ny = y1 - y0, nz = z1 - z0;
+    bool occupied = false;
+    if (nz > 0) {
+        const int n = nx * ny * nz;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            int x = x0 + i % nx, y = y0 + (i / nx) % ny, z = z0 + i / (nx * ny);
+            float d = dist[(size_t)g.X * g.Y * (z - g.z_store_begin) + (size_t)g.X * y + x];
+            occupied |= !(d > occ.tau);  // also true for NaN
+        }
+    }
+    int any = __syncthreads_or(occupied ? 1 : 0);
+    if (threadIdx.x == 0) occ.flags[((size_t)bz * occ.nby + by) * occ.nbx + bx] = any ? 1 : 0;
+}
+
+int occupancy_rebuild(tsdf_volume *v) {
+    dim3 grid(v->occ.nbx, v->occ.nby, v->occ.nbz);
+    hipLaunchKernelGGL(occupancy_build_kernel, grid, dim3(256), 0, v->stream, v->dist, v->g, v->occ);
+    TSDF_HIP(hipGetLastError(), "occupancy rebuild");
+    v->occ_dirty = 0;
+    return TSDF_OK;
+}
+
+// The ray caster's parameter table: the values t takes in the reference's loop (`t = t + step_size`,
+// src/RayCaster/GPURaycaster.cu:324,361), produced by the same fp32 additions on the host.
+int build_t_table(tsdf_volume *v) {
+    const int len = 4402 + 2;
+    std::vector<float> T(len);
+    const float step_size = (float)((double)v->g.trunc * 0.05);
+    volatile float t = 0.0f;  // volatile: one rounded fp32 addition per step, nothing folded
+    for (int k = 0; k < len; k++) {
+        T[k] = t;
+        t = t + step_size;
+    }
+    if (!v->t_table) TSDF_HIP(hipMalloc((void **)&v->t_table, len * sizeof(float)), "ray table alloc");
+    TSDF_HIP(hipMemcpy(v->t_table, T.data(), len * sizeof(float), hipMemcpyHostToDevice), "ray table upload");
+    return TSDF_OK;
+}
+
+// Exhaustive proof for one denominator b: over all finite fp32 numerators a with |a| >= kFastDivMin,
+// does the reciprocal sequence of raycast.hip (q0 = a*y, r = fma(-b,q0,a), q = fma(r,y,q0), y = RN(1/b))
+// return the bits of the IEEE quotient a / b?  (Numerators outside that set take the IEEE division there.)
+__global__ __launch_bounds__(256) void fastdiv_check_kernel(float b, unsigned long long *__restrict__ mismatches) {
+    const float y = 1.0f / b;
+    unsigned int bad = 0;
+    // 2^32 patterns = 65536 blocks x 256 threads x 256 iterations
+    const unsigned int base = (blockIdx.x * 256u + threadIdx.x) << 8;
+    for (unsigned int i = 0; i < 256u; i++) {
+        const float a = __uint_as_float(base + i);
+        const float mag = fabsf(a);
+        const bool in_domain = (mag < INFINITY) && (mag >= kFastDivMin);
+        const float ref = a / b;
+        const float q0 = a * y;
+        const float r = __builtin_fmaf(-b, q0, a);
+        const float q = __builtin_fmaf(r, y, q0);
+        if (in_domain && __float_as_uint(q) != __float_as_uint(ref)) bad++;
+    }
+    for (int o = 32; o > 0; o >>= 1) bad += __shfl_down(bad, o);
+    if ((threadIdx.x & 63u) == 0 && bad) atomicAdd(mismatches, (unsigned long long)bad);
+}
+
+int verify_fast_division(tsdf_volume *v) {
+    v->fast_div = 0;
+    const float b[3] = {v->g.vs.x, v->g.vs.y, v->g.vs.z};
+    TSDF_HIP(hipMemsetAsync(v->counter_dev + 3, 0, sizeof(unsigned long long), v->stream), "fastdiv counter");
+    for (int i = 0; i < 3; i++) {
+        if (i > 0 && b[i] == b[0]) continue;  // cubic voxels: one proof covers all axes
+        if (i == 2 && b[2] == b[1]) continue;
+        hipLaunchKernelGGL(fastdiv_check_kernel, dim3(65536), dim3(256), 0, v->stream, b[i], v->counter_dev + 3);
+    }
+    TSDF_HIP(hipGetLastError(), "fast division check");
+    unsigned long long bad = 1;
+    TSDF_HIP(hipMemcpyAsync(&bad, v->counter_dev + 3, sizeof(bad), hipMemcpyDeviceToHost, v->stream), "fast division check");
+    TSDF_HIP(hipStreamSynchronize(v->stream), "fast division check");
+    v->fast_div = (bad == 0) ? 1 : 0;
+    v->fast_div_mismatches = bad;
+    if (bad && getenv("TSDF_VERBOSE")) fprintf(stderr, "tsdf: fast division not verified (%llu mismatches)\n", bad);
+    return TSDF_OK;
 }
 
 static int init_nodes(tsdf_volume *v) {
@@ -132,7 +222,12 @@ int tsdf_volume_create_slab(uint32_t sx, uint32_t sy, uint32_t sz, float px, flo
     v->max_weight = 15.0f;                           // src/TSDF/TSDFVolume.cu:717
     v->stream = nullptr;
 
+    v->occ.nbx = (sx + kBrick - 1) / kBrick;
+    v->occ.nby = (sy + kBrick - 1) / kBrick;
+    v->occ.nbz = (sz + kBrick - 1) / kBrick;
+    v->occ.tau = 0.01f * g.trunc;
     hipError_t e = hipGetDevice(&v->device);
+    if (e == hipSuccess) e = hipMalloc((void **)&v->occ.flags, (size_t)v->occ.nbx * v->occ.nby * v->occ.nbz);
     size_t bytes = v->resident_voxels() * sizeof(float);
     if (e == hipSuccess) e = hipMalloc((void **)&v->dist, bytes);
     if (e == hipSuccess) e = hipMalloc((void **)&v->weight, bytes);
@@ -143,7 +238,9 @@ int tsdf_volume_create_slab(uint32_t sx, uint32_t sy, uint32_t sz, float px, flo
         tsdf_volume_destroy(v);
         return rc;
     }
-    int rc = tsdf_volume_clear(v);
+    int rc = build_t_table(v);
+    if (rc == TSDF_OK) rc = verify_fast_division(v);
+    if (rc == TSDF_OK) rc = tsdf_volume_clear(v);
     if (rc == TSDF_OK) rc = tsdf_volume_synchronize(v);
     if (rc != TSDF_OK) {
         tsdf_volume_destroy(v);
@@ -167,6 +264,8 @@ int tsdf_volume_destroy(tsdf_volume *v) {
     if (v->vert_buf) (void)hipFree(v->vert_buf);
     if (v->norm_buf) (void)hipFree(v->norm_buf);
     if (v->counter_dev) (void)hipFree(v->counter_dev);
+    if (v->occ.flags) (void)hipFree(v->occ.flags);
+    if (v->t_table) (void)hipFree(v->t_table);
     delete v;
     return TSDF_OK;
 }
@@ -188,6 +287,9 @@ int tsdf_volume_clear(tsdf_volume *v) {
     size_t n = v->resident_voxels();
     hipLaunchKernelGGL(fill2_kernel, dim3(2048), dim3(256), 0, v->stream, v->dist, v->weight, n, v->g.trunc, 0.0f);
     TSDF_HIP(hipGetLastError(), "Couldn't clear TSDF data");
+    // every distance is +trunc again: no brick can produce a hit
+    TSDF_HIP(hipMemsetAsync(v->occ.flags, 0, (size_t)v->occ.nbx * v->occ.nby * v->occ.nbz, v->stream), "clear occupancy");
+    v->occ_dirty = 0;
     // initialise_deformation bakes the CURRENT offset into the node translations (Q1)
     v->g.offset_clear = v->g.offset;
     if (v->nodes) return init_nodes(v);
@@ -212,6 +314,7 @@ int tsdf_volume_get_info(const tsdf_volume *v, tsdf_volume_info *info) {
         info->global_rotation[i] = v->global_rotation[i];
     }
     info->deformation_materialised = v->nodes ? 1 : 0;
+    info->fast_division_verified = v->fast_div;
     return TSDF_OK;
 }
 
@@ -226,11 +329,44 @@ int tsdf_volume_set_header(tsdf_volume *v, const float offset[3], float trunc, f
     TSDF_REQUIRE(v && offset && gt && gr, "null argument");
     v->g.offset = {offset[0], offset[1], offset[2]};
     v->g.trunc = trunc;
+    v->occ.tau = 0.01f * trunc;
+    v->occ_dirty = 1;
+    int rc = build_t_table(v);
+    if (rc != TSDF_OK) return rc;
     v->max_weight = max_weight;
     for (int i = 0; i < 3; i++) {
         v->global_translation[i] = gt[i];
         v->global_rotation[i] = gr[i];
     }
+    return TSDF_OK;
+}
+
+int tsdf_volume_occupancy(const tsdf_volume *v, uint64_t *occupied_bricks, uint64_t *total_bricks) {
+    TSDF_REQUIRE(v && occupied_bricks && total_bricks, "null argument");
+    if (v->occ_dirty) {
+        int rc = occupancy_rebuild(const_cast<tsdf_volume *>(v));
+        if (rc != TSDF_OK) return rc;
+    }
+    size_t n = (size_t)v->occ.nbx * v->occ.nby * v->occ.nbz;
+    uint8_t *h = new (std::nothrow) uint8_t[n];
+    if (!h) {
+        set_error("out of host memory");
+        return TSDF_ERR_NOMEM;
+    }
+    hipError_t e = hipMemcpyAsync(h, v->occ.flags, n, hipMemcpyDeviceToHost, v->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(v->stream);
+    uint64_t c = 0;
+    for (size_t i = 0; i < n; i++) c += h[i] ? 1 : 0;
+    delete[] h;
+    if (e != hipSuccess) return hip_fail(e, "read occupancy");
+    *occupied_bricks = c;
+    *total_bricks = n;
+    return TSDF_OK;
+}
+
+int tsdf_volume_mark_dirty(tsdf_volume *v) {
+    TSDF_REQUIRE(v, "null volume");
+    v->occ_dirty = 1;
     return TSDF_OK;
 }
 
@@ -272,6 +408,7 @@ static int copy_in(tsdf_volume *v, void *dst, const void *src, size_t bytes, con
 
 int tsdf_volume_set_distance_data(tsdf_volume *v, const float *host) {
     TSDF_REQUIRE(v, "null volume");
+    v->occ_dirty = 1;
     return copy_in(v, v->dist, host, v->resident_voxels() * sizeof(float), "Couldn't set distance data");
 }
 
