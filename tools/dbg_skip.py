@@ -19,6 +19,11 @@ st=rc.stats(v,cam,per_ray_work=True)
 pr=st["per_ray"].reshape(480,640,3)
 ev,it,adv=pr[...,0],pr[...,1],pr[...,2]
 print("fastdiv", v.info().fast_division_verified, "occ",v.occupancy(),"evaluated total",st["evaluated"], "S", st["samples"], "mean/ray", ev.mean(), "max", ev.max(), "p50,p90,p99", np.percentile(ev,[50,90,99]))
-print("general-path samples per ray: mean", adv.mean(), "max", adv.max(), "p50,p90,p99", np.percentile(adv,[50,90,99]))
+print("cell tests per ray: mean", adv.mean(), "max", adv.max(), "p50,p90,p99", np.percentile(adv,[50,90,99]))
 t_it=it.reshape(60,8,80,8).max(axis=(1,3)); t_ev=ev.reshape(60,8,80,8); t_adv=adv.reshape(60,8,80,8)
 print("per-wave trips: mean", t_it.mean(), "max", t_it.max(), " per-wave max adv iters mean", t_adv.max(axis=(1,3)).mean())
+np.set_printoptions(linewidth=250)
+print("per-wave trips map (/10), 60x80 waves -> 30x40 blocks max")
+print((t_it.reshape(30,2,40,2).max(axis=(1,3))/10).astype(int))
+print("cell tests per ray /10 (block mean)")
+print((adv.reshape(30,16,40,16).mean(axis=(1,3))/10).round(0).astype(int))

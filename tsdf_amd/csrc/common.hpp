@@ -68,19 +68,29 @@ struct Geom {
     float trunc;
 };
 
-// Brick occupancy used by the ray caster for exact empty-space skipping (raycast.hip).  One byte per brick
-// of kBrick^3 voxels of the GLOBAL grid: 0 = every resident voxel within the brick grown by kBrickGrow
-// voxels on every side is > tau, i.e. no trilinear sample whose taps lie in the brick grown by one voxel can
-// be <= 0.  Flags are sticky: integrate only ever sets them, a rebuild (clear / whole-array upload) resets.
+// Brick occupancy used by the ray caster for exact empty-space skipping (raycast.hip), two levels over the
+// GLOBAL grid: fine bricks of kBrick^3 voxels and coarse bricks of kCoarse^3 voxels (one byte each).
+//   fine[b] == 0  : every resident voxel within the brick grown by kBrickGrow voxels on every side is > tau,
+//                   i.e. no trilinear sample whose taps lie in the brick grown by one voxel can be <= 0;
+//   coarse[c] == 0: all INTERIOR fine bricks inside c are 0.
+// Fine bricks touching the grid boundary are set (non-zero) once and for all: there the reference extrapolates
+// (Q10) and the argument does not hold; coarse jumps are clipped to the interior instead.  Flags are sticky: integrate only ever sets them, a rebuild (clear /
+// whole-array upload) resets them.
 // numerators with |a| < kFastDivMin (zero included) or non-finite take the IEEE division in raycast.hip
 constexpr float kFastDivMin = 1.0e-30f;
-constexpr int kBrick = 8;
-constexpr int kBrickShift = 3;
+constexpr int kBrick = 4;
+constexpr int kBrickShift = 2;
 constexpr int kBrickGrow = 2;
+constexpr int kCoarse = 32;
+constexpr int kCoarseShift = 5;
 struct OccGrid {
-    uint8_t *flags;
-    uint32_t nbx, nby, nbz;
-    float tau;  // "safely positive" threshold (a fraction of the truncation distance)
+    uint8_t *fine;
+    uint8_t *coarse;
+    uint32_t nbx, nby, nbz;  // fine bricks per axis  = ceil(size / kBrick)
+    uint32_t ncx, ncy, ncz;  // coarse bricks per axis = ceil(size / kCoarse)
+    float tau;               // "safely positive" threshold (a fraction of the truncation distance)
+    __host__ __device__ size_t fine_count() const { return (size_t)nbx * nby * nbz; }
+    __host__ __device__ size_t coarse_count() const { return (size_t)ncx * ncy * ncz; }
 };
 
 // float -> int with the reference target's semantics (CUDA cvt.rzi: saturating, NaN -> 0);

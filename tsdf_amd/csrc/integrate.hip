@@ -104,7 +104,11 @@ __device__ inline void mark_occupied(const OccGrid &occ, uint32_t vx, uint32_t v
     const uint32_t bz1 = min((vz + kBrickGrow) >> kBrickShift, occ.nbz - 1);
     for (uint32_t bz = bz0; bz <= bz1; bz++)
         for (uint32_t by = by0; by <= by1; by++)
-            for (uint32_t bx = bx0; bx <= bx1; bx++) occ.flags[((size_t)bz * occ.nby + by) * occ.nbx + bx] = 1;
+            for (uint32_t bx = bx0; bx <= bx1; bx++) {
+                occ.fine[((size_t)bz * occ.nby + by) * occ.nbx + bx] = 1;
+                const uint32_t s = kCoarseShift - kBrickShift;
+                occ.coarse[((size_t)(bz >> s) * occ.ncy + (by >> s)) * occ.ncx + (bx >> s)] = 1;
+            }
 }
 
 template <bool DEFORM, bool COUNT>

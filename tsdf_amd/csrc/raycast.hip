@@ -239,35 +239,47 @@ constexpr int kDone = 0x7fffffff;
 
 struct SkipCtx {
     float inv_vx, inv_vy, inv_vz;  // 1/voxel size (approximate on purpose)
-    float bsx, bsy, bsz;           // brick edge in mm
     float inv_step;
     float rdx, rdy, rdz;           // 1/dir (+-inf for a zero component)
-    int nfx, nfy, nfz;             // number of full bricks per axis
-    float eps;                     // cell_test: guard band at the cell faces, in voxels
+    float eps;                     // guard band at the dual-cell faces, in voxels
 };
 
-// Locates the sample at p in the brick grid.  Returns true when the whole brick may be skipped (interior brick,
-// flag clear).  n = number of consecutive samples, starting with this one, that stay inside the brick (>= 1;
-// 1 for a position in the boundary shell, so the next sample is located again).  interior tells whether the
-// brick is one of those the skipping arguments apply to.
-__device__ inline bool locate(float px, float py, float pz, const F3 &dir, const SkipCtx &c, const OccGrid &occ, int &n,
-                              bool &interior) {
-    const int bx = (int)floorf(px * c.inv_vx) >> kBrickShift;
-    const int by = (int)floorf(py * c.inv_vy) >> kBrickShift;
-    const int bz = (int)floorf(pz * c.inv_vz) >> kBrickShift;
-    n = 1;
-    interior = bx >= 1 && by >= 1 && bz >= 1 && bx + 1 < c.nfx && by + 1 < c.nfy && bz + 1 < c.nfz;
-    if (!interior) return false;
-    // distance (in t) to the face through which the ray leaves the brick
-    float ex = ((dir.x > 0 ? (bx + 1) * c.bsx : bx * c.bsx) - px) * c.rdx;
-    float ey = ((dir.y > 0 ? (by + 1) * c.bsy : by * c.bsy) - py) * c.rdy;
-    float ez = ((dir.z > 0 ? (bz + 1) * c.bsz : bz * c.bsz) - pz) * c.rdz;
+// Samples (>= 1) from the one at p until the ray leaves the axis-aligned box [lo, hi) given in voxel units.
+__device__ inline int samples_to_exit(float px, float py, float pz, const F3 &dir, const SkipCtx &c, const Geom &g,
+                                      int lox, int loy, int loz, int hix, int hiy, int hiz) {
+    float ex = ((float)(dir.x > 0 ? hix : lox) * g.vs.x - px) * c.rdx;
+    float ey = ((float)(dir.y > 0 ? hiy : loy) * g.vs.y - py) * c.rdy;
+    float ez = ((float)(dir.z > 0 ? hiz : loz) * g.vs.z - pz) * c.rdz;
     if (!(dir.x != 0)) ex = INFINITY;
     if (!(dir.y != 0)) ey = INFINITY;
     if (!(dir.z != 0)) ez = INFINITY;
-    float dt = fminf(ex, fminf(ey, ez));
-    n = (int)fminf(fmaxf(dt * c.inv_step, 1.0f), 8192.0f);
-    return occ.flags[((size_t)bz * occ.nby + by) * occ.nbx + bx] == 0;
+    return (int)fminf(fmaxf(fminf(ex, fminf(ey, ez)) * c.inv_step, 1.0f), 8192.0f);
+}
+
+// Locates the sample at p in the two-level brick grid.  Returns true when the samples from this one up to the
+// exit of an empty region may be skipped; n = their number (>= 1).  The region is the coarse brick (clipped to
+// the interior of the grid, i.e. without the boundary fine bricks) when its flag is clear, else the fine brick.
+// When false (occupied or boundary brick, or a position off the grid) n = samples that stay inside the fine
+// brick.
+__device__ inline bool locate(float px, float py, float pz, const F3 &dir, const SkipCtx &c, const Geom &g,
+                              const OccGrid &occ, int &n) {
+    const int vx = (int)floorf(px * c.inv_vx), vy = (int)floorf(py * c.inv_vy), vz = (int)floorf(pz * c.inv_vz);
+    n = 1;
+    if (vx < 0 || vy < 0 || vz < 0 || vx >= (int)g.X || vy >= (int)g.Y || vz >= (int)g.Z) return false;
+    // interior of the grid in voxels: everything but the first and the last (possibly partial) fine brick
+    const int ix1 = (int)(occ.nbx - 1) << kBrickShift, iy1 = (int)(occ.nby - 1) << kBrickShift, iz1 = (int)(occ.nbz - 1) << kBrickShift;
+    const bool inner = vx >= kBrick && vy >= kBrick && vz >= kBrick && vx < ix1 && vy < iy1 && vz < iz1;
+    const int cx = vx >> kCoarseShift, cy = vy >> kCoarseShift, cz = vz >> kCoarseShift;
+    if (inner && occ.coarse[((size_t)cz * occ.ncy + cy) * occ.ncx + cx] == 0) {
+        n = samples_to_exit(px, py, pz, dir, c, g, max(cx << kCoarseShift, kBrick), max(cy << kCoarseShift, kBrick),
+                            max(cz << kCoarseShift, kBrick), min((cx + 1) << kCoarseShift, ix1),
+                            min((cy + 1) << kCoarseShift, iy1), min((cz + 1) << kCoarseShift, iz1));
+        return true;
+    }
+    const int bx = vx >> kBrickShift, by = vy >> kBrickShift, bz = vz >> kBrickShift;
+    n = samples_to_exit(px, py, pz, dir, c, g, bx << kBrickShift, by << kBrickShift, bz << kBrickShift,
+                        (bx + 1) << kBrickShift, (by + 1) << kBrickShift, (bz + 1) << kBrickShift);
+    return occ.fine[((size_t)bz * occ.nby + by) * occ.nbx + bx] == 0;
 }
 
 __device__ inline int wave_min(int v) {
@@ -331,10 +343,8 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
     const TriConst tc = make_tri_const(g);
     SkipCtx sc;
     sc.inv_vx = 1.0f / g.vs.x; sc.inv_vy = 1.0f / g.vs.y; sc.inv_vz = 1.0f / g.vs.z;
-    sc.bsx = kBrick * g.vs.x; sc.bsy = kBrick * g.vs.y; sc.bsz = kBrick * g.vs.z;
     sc.inv_step = 1.0f / step_size;
     sc.rdx = 1.0f / dir.x; sc.rdy = 1.0f / dir.y; sc.rdz = 1.0f / dir.z;
-    sc.nfx = (int)(g.X >> kBrickShift); sc.nfy = (int)(g.Y >> kBrickShift); sc.nfz = (int)(g.Z >> kBrickShift);
     // one step must stay well inside the one-voxel slack on every axis
     const bool skip_ok = SKIP && fabsf(dir.x) * step_size < 0.25f * g.vs.x && fabsf(dir.y) * step_size < 0.25f * g.vs.y &&
                          fabsf(dir.z) * step_size < 0.25f * g.vs.z;
@@ -346,7 +356,6 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
 
     int k = (k_end == 0) ? kDone : 0;  // next sample of this lane (kDone when finished)
     int k_brick_end = 0;               // the brick classification holds while k < k_brick_end
-    bool brick_interior = false;
     uint32_t trips = 0, adv_iters = 0;  // diagnostics
 
     // One pass of the loop handles one sample index per lane, the same straight-line work for every lane:
@@ -367,7 +376,7 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
             if (skip_ok) {
                 if (k >= k_brick_end) {
                     int n;
-                    bool empty = locate(px, py, pz, dir, sc, occ, n, brick_interior);
+                    bool empty = locate(px, py, pz, dir, sc, g, occ, n);
                     k_brick_end = k + n;
                     if (empty) jump = n;
                 }
@@ -383,6 +392,7 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
                                       fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx + 1.0f < (float)g.X &&
                                       fy + 1.0f < (float)g.Y && fz + 1.0f < (float)g.Z;
                     if (safe) {
+                        if (STATS) adv_iters++;  // diagnostics: cell tests
                         // samples until the ray leaves the cell shrunk by eps
                         float ex = (dir.x > 0 ? cell_hi - rx : rx - cell_lo) * fabsf(sc.rdx) * g.vs.x;
                         float ey = (dir.y > 0 ? cell_hi - ry : ry - cell_lo) * fabsf(sc.rdy) * g.vs.y;
@@ -431,7 +441,6 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
                 bool owned;
                 tsdf = trilinear<SLAB, STATS, FASTDIV>(px, py, pz, dist, g, tc, rp, owned, touched);
                 if (STATS && owned) samples++;
-                if (STATS) adv_iters++;
             }
             if (jump > 0) {
                 k += jump;

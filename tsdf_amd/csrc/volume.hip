@@ -65,10 +65,23 @@ __global__ __launch_bounds__(256) void init_nodes_kernel(tsdf_deformation_node *
     nodes[idx] = nd;
 }
 
-// Rebuild of the brick occupancy from the distance array: one workgroup per brick scans the brick grown by
-// kBrickGrow voxels (clamped to the grid and to the resident planes) and flags it if any value is not
-// safely positive.  The overlap between neighbouring bricks is served by L2.
-__global__ __launch_bounds__(256) void occupancy_build_kernel(const float *__restrict__ dist, Geom g, OccGrid occ) {
+// Occupancy with nothing but the permanent boundary marks: fine bricks touching the grid boundary (first / last
+// brick of an axis, the last one possibly partial).
+__global__ __launch_bounds__(256) void occupancy_init_kernel(OccGrid occ) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < occ.fine_count()) {
+        uint32_t bx = i % occ.nbx, by = (i / occ.nbx) % occ.nby, bz = i / ((size_t)occ.nbx * occ.nby);
+        bool boundary = bx == 0 || by == 0 || bz == 0 || bx + 1 == occ.nbx || by + 1 == occ.nby || bz + 1 == occ.nbz;
+        occ.fine[i] = boundary ? 1 : 0;
+    }
+    // coarse flags summarise the INTERIOR fine bricks only (the ray caster clips coarse jumps to the interior)
+    if (i < occ.coarse_count()) occ.coarse[i] = 0;
+}
+
+// Rebuild of the occupancy from the distance array: one wave per fine brick scans the brick grown by
+// kBrickGrow voxels (clamped to the grid and to the resident planes) and sets the brick and its coarse parent
+// if any value is not safely positive.  The overlap between neighbouring bricks is served by L2.
+__global__ __launch_bounds__(64) void occupancy_build_kernel(const float *__restrict__ dist, Geom g, OccGrid occ) {
     const uint32_t bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     const int x0 = max((int)(bx * kBrick) - kBrickGrow, 0), x1 = min((int)(bx * kBrick) + kBrick + kBrickGrow, (int)g.X);
     const int y0 = max((int)(by * kBrick) - kBrickGrow, 0), y1 = min((int)(by * kBrick) + kBrick + kBrickGrow, (int)g.Y);
@@ -78,19 +91,31 @@ __global__ __launch_bounds__(256) void occupancy_build_kernel(const float *__res
     bool occupied = false;
     if (nz > 0) {
         const int n = nx * ny * nz;
-        for (int i = threadIdx.x; i < n; i += 256) {
+        for (int i = threadIdx.x; i < n; i += 64) {
             int x = x0 + i % nx, y = y0 + (i / nx) % ny, z = z0 + i / (nx * ny);
             float d = dist[(size_t)g.X * g.Y * (z - g.z_store_begin) + (size_t)g.X * y + x];
             occupied |= !(d > occ.tau);  // also true for NaN
         }
     }
-    int any = __syncthreads_or(occupied ? 1 : 0);
-    if (threadIdx.x == 0) occ.flags[((size_t)bz * occ.nby + by) * occ.nbx + bx] = any ? 1 : 0;
+    if (__ballot(occupied) != 0ull && threadIdx.x == 0) {
+        occ.fine[((size_t)bz * occ.nby + by) * occ.nbx + bx] = 1;
+        const uint32_t s = kCoarseShift - kBrickShift;
+        occ.coarse[((size_t)(bz >> s) * occ.ncy + (by >> s)) * occ.ncx + (bx >> s)] = 1;
+    }
+}
+
+static int occupancy_reset(tsdf_volume *v) {
+    size_t n = v->occ.fine_count();
+    hipLaunchKernelGGL(occupancy_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, v->stream, v->occ);
+    TSDF_HIP(hipGetLastError(), "occupancy reset");
+    return TSDF_OK;
 }
 
 int occupancy_rebuild(tsdf_volume *v) {
+    int rc = occupancy_reset(v);
+    if (rc != TSDF_OK) return rc;
     dim3 grid(v->occ.nbx, v->occ.nby, v->occ.nbz);
-    hipLaunchKernelGGL(occupancy_build_kernel, grid, dim3(256), 0, v->stream, v->dist, v->g, v->occ);
+    hipLaunchKernelGGL(occupancy_build_kernel, grid, dim3(64), 0, v->stream, v->dist, v->g, v->occ);
     TSDF_HIP(hipGetLastError(), "occupancy rebuild");
     v->occ_dirty = 0;
     return TSDF_OK;
@@ -225,9 +250,13 @@ int tsdf_volume_create_slab(uint32_t sx, uint32_t sy, uint32_t sz, float px, flo
     v->occ.nbx = (sx + kBrick - 1) / kBrick;
     v->occ.nby = (sy + kBrick - 1) / kBrick;
     v->occ.nbz = (sz + kBrick - 1) / kBrick;
+    v->occ.ncx = (sx + kCoarse - 1) / kCoarse;
+    v->occ.ncy = (sy + kCoarse - 1) / kCoarse;
+    v->occ.ncz = (sz + kCoarse - 1) / kCoarse;
     v->occ.tau = 0.01f * g.trunc;
     hipError_t e = hipGetDevice(&v->device);
-    if (e == hipSuccess) e = hipMalloc((void **)&v->occ.flags, (size_t)v->occ.nbx * v->occ.nby * v->occ.nbz);
+    if (e == hipSuccess) e = hipMalloc((void **)&v->occ.fine, v->occ.fine_count());
+    if (e == hipSuccess) e = hipMalloc((void **)&v->occ.coarse, v->occ.coarse_count());
     size_t bytes = v->resident_voxels() * sizeof(float);
     if (e == hipSuccess) e = hipMalloc((void **)&v->dist, bytes);
     if (e == hipSuccess) e = hipMalloc((void **)&v->weight, bytes);
@@ -264,7 +293,8 @@ int tsdf_volume_destroy(tsdf_volume *v) {
     if (v->vert_buf) (void)hipFree(v->vert_buf);
     if (v->norm_buf) (void)hipFree(v->norm_buf);
     if (v->counter_dev) (void)hipFree(v->counter_dev);
-    if (v->occ.flags) (void)hipFree(v->occ.flags);
+    if (v->occ.fine) (void)hipFree(v->occ.fine);
+    if (v->occ.coarse) (void)hipFree(v->occ.coarse);
     if (v->t_table) (void)hipFree(v->t_table);
     delete v;
     return TSDF_OK;
@@ -287,8 +317,9 @@ int tsdf_volume_clear(tsdf_volume *v) {
     size_t n = v->resident_voxels();
     hipLaunchKernelGGL(fill2_kernel, dim3(2048), dim3(256), 0, v->stream, v->dist, v->weight, n, v->g.trunc, 0.0f);
     TSDF_HIP(hipGetLastError(), "Couldn't clear TSDF data");
-    // every distance is +trunc again: no brick can produce a hit
-    TSDF_HIP(hipMemsetAsync(v->occ.flags, 0, (size_t)v->occ.nbx * v->occ.nby * v->occ.nbz, v->stream), "clear occupancy");
+    // every distance is +trunc again: only the permanent boundary marks remain
+    int rc0 = occupancy_reset(v);
+    if (rc0 != TSDF_OK) return rc0;
     v->occ_dirty = 0;
     // initialise_deformation bakes the CURRENT offset into the node translations (Q1)
     v->g.offset_clear = v->g.offset;
@@ -347,13 +378,13 @@ int tsdf_volume_occupancy(const tsdf_volume *v, uint64_t *occupied_bricks, uint6
         int rc = occupancy_rebuild(const_cast<tsdf_volume *>(v));
         if (rc != TSDF_OK) return rc;
     }
-    size_t n = (size_t)v->occ.nbx * v->occ.nby * v->occ.nbz;
+    size_t n = v->occ.fine_count();
     uint8_t *h = new (std::nothrow) uint8_t[n];
     if (!h) {
         set_error("out of host memory");
         return TSDF_ERR_NOMEM;
     }
-    hipError_t e = hipMemcpyAsync(h, v->occ.flags, n, hipMemcpyDeviceToHost, v->stream);
+    hipError_t e = hipMemcpyAsync(h, v->occ.fine, n, hipMemcpyDeviceToHost, v->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(v->stream);
     uint64_t c = 0;
     for (size_t i = 0; i < n; i++) c += h[i] ? 1 : 0;
