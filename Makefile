@@ -23,7 +23,7 @@ HOSTFLAGS = -std=c++11 -O2 -ffp-contract=off -fPIC -Wall -Iinclude -I$(HOSTDIR)/
 HOST_SRCS = $(wildcard $(HOSTDIR)/src/*.cpp)
 HOST_OBJS = $(HOST_SRCS:.cpp=.o)
 
-all: hip host oracle
+all: hip host oracle cpptest
 
 host: $(LIBDIR)/libtsdf_host.so
 
@@ -45,8 +45,15 @@ $(LIBDIR)/libtsdf_hip.so: $(HIP_OBJS)
 oracle:
 	$(MAKE) -C oracle -s all
 
+# C++ test program of the class surface (run by tests/test_cpp_surface.py on the GPU box)
+cpptest: build/test_surface
+
+build/test_surface: tests/cpp/test_surface.cpp $(LIBDIR)/libtsdf_host.so
+	@mkdir -p build
+	$(CXX) $(HOSTFLAGS) -o $@ tests/cpp/test_surface.cpp -L$(LIBDIR) -ltsdf_host -ltsdf_hip -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)'
+
 clean:
 	rm -f $(HIP_OBJS) $(HOST_OBJS) $(LIBDIR)/*.so
 	$(MAKE) -C oracle clean
 
-.PHONY: all hip host oracle clean
+.PHONY: all hip host oracle cpptest clean

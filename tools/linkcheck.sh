@@ -1,0 +1,26 @@
+#!/bin/bash
+# Drop-in check of the C++ class surface: compile the REFERENCE's unchanged src/Tools/kinfu.cpp against this
+# repo's headers (tsdf_amd/host/include) and link it with libtsdf_host.so / libtsdf_hip.so.
+#
+# kinfu.cpp includes "../include/<Name>.hpp", resolved relative to the including file, so a scratch tree is
+# built where src/Tools/kinfu.cpp is a symlink to the reference file and src/include a symlink to our headers.
+# The reference source is never copied into the repo.  Runs only where /root/reference is mounted.
+set -euo pipefail
+ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
+REF="${REF:-/root/reference}"
+SRC="$REF/src/Tools/kinfu.cpp"
+if [ ! -f "$SRC" ]; then echo "linkcheck: $SRC not present, skipped"; exit 0; fi
+W="$ROOT/build/linkcheck"
+OUT="$ROOT/oracle/_ref"   # reference-derived build outputs live only here (git-ignored, travels to the GPU box)
+rm -rf "$W"; mkdir -p "$W/src/Tools"
+ln -s "$SRC" "$W/src/Tools/kinfu.cpp"
+ln -s "$ROOT/tsdf_amd/host/include" "$W/src/include"
+EIGEN=""
+for d in /usr/include/eigen3 /usr/local/include/eigen3; do [ -f "$d/Eigen/Core" ] && EIGEN="-I$d" && break; done
+[ -z "$EIGEN" ] && EIGEN="-I$ROOT/tsdf_amd/host/eigen_compat"
+g++ -std=c++11 -O1 -w $EIGEN -I"$ROOT/include" -c "$W/src/Tools/kinfu.cpp" -o "$W/kinfu.o"
+mkdir -p "$OUT"
+g++ -o "$OUT/kinfu" "$W/kinfu.o" -L"$ROOT/tsdf_amd/lib" -ltsdf_host -ltsdf_hip -Wl,-rpath,'$ORIGIN/../../tsdf_amd/lib'
+echo "linkcheck: reference kinfu.cpp compiled unchanged and linked -> $OUT/kinfu"
+# usage line only (no GPU needed): the binary must start and reject a bad command line like the reference
+"$OUT/kinfu" 2>&1 | head -2 || true

@@ -1,0 +1,13 @@
+// Small file helpers.  Same functions as the reference's src/include/FileUtilities.hpp (those the path uses).
+#ifndef FILE_UTLITIES_HPP
+#define FILE_UTLITIES_HPP
+
+#include <functional>
+#include <string>
+#include <vector>
+
+bool process_file_by_lines(const std::string &file_name, std::function<void(const std::string &)> processor);
+bool file_exists(const std::string &file_name, bool &is_directory);
+void files_in_directory(const std::string &directory, std::vector<std::string> &files, std::function<bool(const char *)> filter);
+
+#endif

@@ -1,0 +1,14 @@
+// Iso-surface extraction from a TSDFVolume (zero level set of the distance field), on the HOST.
+// Same entry point as the reference's extract_surface (src/include/MarkAndSweepMC.hpp:8).  The reference runs
+// marching cubes on the GPU; here the distance array is copied to the host and triangulated there
+// (BASELINE north_star: "src/MarchingCubes stays host-side").
+#ifndef MarkAndSweepMC_hpp
+#define MarkAndSweepMC_hpp
+
+#include <vector>
+
+#include "TSDFVolume.hpp"
+
+void extract_surface(const TSDFVolume *volume, std::vector<float3> &vertices, std::vector<int3> &triangles);
+
+#endif

@@ -122,3 +122,48 @@ def config1_depth(seed=1, width=WIDTH, height=HEIGHT):
     h = splitmix64((np.arange(width * height, dtype=np.uint64).reshape(height, width)) ^ np.uint64(seed))
     d = np.where(h % np.uint64(50) == 0, 0.0, d)
     return np.rint(d).astype(np.uint16).reshape(-1)
+
+
+def _write_png16(path, image):
+    """16-bit greyscale PNG (big-endian samples, filter 0), enough for TUM-style depth maps."""
+    import struct
+    import zlib
+    h, w = image.shape
+    raw = b"".join(b"\x00" + image[y].astype(">u2").tobytes() for y in range(h))
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n")
+        f.write(chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 16, 0, 0, 0, 0)))
+        f.write(chunk(b"IDAT", zlib.compress(raw, 6)))
+        f.write(chunk(b"IEND", b""))
+
+
+def write_tum_directory(directory, n_frames, seed, stream_frames=None, width=WIDTH, height=HEIGHT):
+    """Writes the layout the reference's TUMDataLoader expects (src/DataLoader/TUMDataLoader.cpp:20,111-128):
+    <dir>/depth/<stem>.png (uint16, 5 units per mm) and <dir>/ground_truth.txt with lines
+    '<stem> tx ty tz qx qy qz qw' (metres, TUM quaternion order).  Returns the per-frame (depth_mm, pose16)."""
+    import os
+    os.makedirs(os.path.join(directory, "depth"), exist_ok=True)
+    frames = []
+    lines = ["# synthetic TUM surrogate (tsdf_amd.synth), seed 0x%X" % seed]
+    total = stream_frames or n_frames
+    for i in range(n_frames):
+        depth, cam = depth_frame(i, total, seed, width, height)
+        stem = "%010.6f" % (1305031102.0 + i / 30.0)
+        _write_png16(os.path.join(directory, "depth", stem + ".png"), (depth.astype(np.uint32) * 5).clip(0, 65535)
+                     .astype(np.uint16).reshape(height, width))
+        P = cam.pose().astype(np.float64).reshape(4, 4).T
+        R, t = P[:3, :3], P[:3, 3] / 1000.0
+        # rotation -> quaternion (w largest-branch free form is enough for these small rotations)
+        qw = math.sqrt(max(0.0, 1.0 + R[0, 0] + R[1, 1] + R[2, 2])) / 2.0
+        qx = (R[2, 1] - R[1, 2]) / (4.0 * qw)
+        qy = (R[0, 2] - R[2, 0]) / (4.0 * qw)
+        qz = (R[1, 0] - R[0, 1]) / (4.0 * qw)
+        lines.append("%s %.9f %.9f %.9f %.9f %.9f %.9f %.9f" % (stem, t[0], t[1], t[2], qx, qy, qz, qw))
+        frames.append((depth, cam.pose().copy()))
+    with open(os.path.join(directory, "ground_truth.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    return frames
