@@ -15,6 +15,7 @@ CPU baseline (the oracle, timed here on the host cores on a bounded sample) ride
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -189,6 +190,7 @@ def main():
                     "unit": "GB/s", "frac": round(ray_gbs / HBM_PEAK_GBS, 5), "traffic": traffic.get("process_ray_kernel"),
                     "algorithmic_bytes": ray_bytes, "avg_launch_ms": round(stage_ms["raycast"], 4),
                     "T_voxels_touched": st["touched"], "S_samples": st["samples"],
+                    "samples_evaluated_after_exact_skipping": st["evaluated"],
                     "msamples_per_s": round(st["samples"] / (stage_ms["raycast"] * 1e-3) / 1e6, 1),
                     "l2_level_gbs": round(32 * st["samples"] / (stage_ms["raycast"] * 1e-3) / 1e9, 1)}
         roof_int = {"kernel": "integrate_kernel", "bound": "hbm", "achieved": round(int_gbs, 2), "peak": HBM_PEAK_GBS,
@@ -278,7 +280,12 @@ def cpu_baseline(vol, depth, cam, n, physical, budget_s):
     t = time.perf_counter()
     ov.integrate(f, W, H, cam.inverse_pose(), cam.k(), cam.kinv(), z_range=(n // 2, n // 2 + zs), nthreads=1)
     t_int1 = (time.perf_counter() - t) * (n / zs)
-    row_step = 16
+    # probe with every 64th row, then size the sample to the remaining CPU budget (at least every 16th row)
+    t = time.perf_counter()
+    ov.raycast_rows(W, H, cam.pose(), cam.kinv(), 0, H, 64, nthreads=cores)
+    probe = time.perf_counter() - t
+    remaining = max(1.0, budget_s - (t_bil + t_int + t_int1 * zs / n + probe))
+    row_step = int(min(16, max(1, math.ceil(64 * probe / remaining))))
     t = time.perf_counter()
     Vs, samples = ov.raycast_rows(W, H, cam.pose(), cam.kinv(), 0, H, row_step, nthreads=cores)
     t_ray = time.perf_counter() - t
@@ -292,7 +299,9 @@ def cpu_baseline(vol, depth, cam, n, physical, budget_s):
             "integrate_mvoxels_per_s": round(n ** 3 / t_int / 1e6, 2),
             "integrate_mvoxels_per_s_1thread": round(n ** 3 / t_int1 / 1e6, 2),
             "raycast_mrays_per_s": round(rays / t_ray / 1e6, 4),
-            "bilateral_ms": round(t_bil * 1e3, 2), "seconds_spent": round(t_bil + t_int + t_int1 * zs / n + t_ray, 2)}
+            "bilateral_ms": round(t_bil * 1e3, 2),
+            "wall_seconds_spent": round(t_bil + t_int + t_int1 * zs / n + probe + t_ray, 2),
+            "cpu_seconds_spent": round((t_bil + t_int + probe + t_ray) * cores + t_int1 * zs / n, 1)}
 
 
 if __name__ == "__main__":

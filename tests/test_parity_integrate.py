@@ -199,3 +199,24 @@ def test_committed_golden_vectors(oracle):
     V, N = gv.raycast(160, 120, cam)
     assert_same_floats(V, f["wall32_vertices"], "golden wall32 vertices")
     assert_same_floats(N, f["wall32_normals"], "golden wall32 normals")
+
+
+def test_non_standard_intrinsics_and_projective_pose_take_the_general_path(oracle):
+    # skewed K (k12 != 0) and an inverse pose whose last row is not (0,0,0,1): the standard-camera shortcuts of
+    # the kernel (image.z == cam.z, w == 1, surface z == depth) must not be taken
+    from tests.helpers import Cam
+    d, cam = synth.depth_frame(1, 5, seed=17)
+    k = cam.k().copy()
+    k[3] = 3.5                      # K(0,1): skew
+    kinv = oracle.mat3_inverse(k)
+    skew = Cam(cam.pose(), cam.inverse_pose(), k, kinv)
+    gv, ov, up = run_both(oracle, (64, 64, 64), (3000, 3000, 3000), [(d, skew)])
+    check(gv, ov, up, "skewed intrinsics")
+    assert up[0][1] > 0
+    ip = cam.inverse_pose().copy()
+    ip[3] = 1.0e-5                  # inv_pose(3,0): w = 1 + 1e-5 * x
+    ip[15] = 0.98
+    proj = Cam(cam.pose(), ip, cam.k(), cam.kinv())
+    gv, ov, up = run_both(oracle, (64, 64, 64), (3000, 3000, 3000), [(d, proj)])
+    check(gv, ov, up, "projective inverse pose")
+    assert up[0][1] > 0

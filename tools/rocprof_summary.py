@@ -6,9 +6,9 @@ small text summaries committed under profiles/.
     python tools/rocprof_summary.py pmc    gpurun_out/prof_fetch/bench_results.db  > profiles/r01_pmc_FETCH_SIZE.txt
     python tools/rocprof_summary.py traffic FETCH.db WRITE.db > profiles/traffic.json
 
-HBM traffic per launch follows MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE are reported in KiB-like
-units of 1024 B? -- no: rocprofv3 reports them in kilobytes (value * 1024 = bytes), and on gfx950 FETCH_SIZE
-counts 128-B read requests as 64 B, so the read side is doubled.  WRITE_SIZE is uncalibrated (taken as is).
+HBM traffic per launch follows MI355X_MICROARCH.md "HBM": rocprofv3 reports FETCH_SIZE / WRITE_SIZE in kilobytes
+(value * 1024 = bytes); on gfx950 FETCH_SIZE counts 128-B read requests as 64 B, so the read side is doubled.
+WRITE_SIZE was calibrated on this repo's fill2_kernel (2 x 512 MiB written -> 1048576.0 reported): taken as is.
 """
 import json
 import sqlite3
@@ -49,13 +49,19 @@ def pmc_text(db):
 
 def traffic(fetch_db, write_db):
     res = {}
+    calls = {}
     for db, cname, scale in ((fetch_db, "FETCH_SIZE", 2.0), (write_db, "WRITE_SIZE", 1.0)):
         for k, c, n, a, mn, mx, d in pmc_by_kernel(db):
             if c != cname:
                 continue
             key = short(k).split("<")[0]
+            # several template variants share a name: keep the one launched most often (the production variant)
+            if calls.get((key, cname), 0) >= n:
+                continue
+            calls[(key, cname)] = n
             e = res.setdefault(key, {})
             e[cname + "_avg_raw_kb"] = a
+            e[cname + "_variant"] = short(k)
             e[cname.lower().replace("_size", "") + "_bytes"] = a * 1024.0 * scale
     out = {"note": "bytes per launch = FETCH_SIZE*1024*2 (gfx950 half-count correction, MI355X_MICROARCH.md HBM) + "
                    "WRITE_SIZE*1024 (uncalibrated); separate --pmc passes of the bench command",

@@ -131,6 +131,11 @@ struct tsdf_volume {
     // brick occupancy (see OccGrid)
     tsdf::OccGrid occ;
     int occ_dirty;   // 1 = rebuild from the distance array before the next ray cast
+    // integrate scratch: compact list of bricks a frame can touch (+ its counter), depth tile maxima
+    uint32_t *brick_list;
+    size_t brick_list_cap;
+    uint16_t *tile_max;
+    size_t tile_max_cap;
     // diagnostics
     int counting;
     unsigned long long *counter_dev;  // [0] = updated voxels, [1] = samples, [2] = hits

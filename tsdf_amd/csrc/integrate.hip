@@ -4,22 +4,29 @@
 // Mapping (the reference runs one thread per (y,z) with a serial x loop, so neighbouring
 // lanes are 4*X bytes apart): here lane <-> x, so one wave touches 64 consecutive voxels
 // = 256 contiguous bytes of the distance array and of the weight array; a 256-thread
-// workgroup owns a brick of 64(x) x 4(y) x ZC(z) voxels and walks it plane by plane.
+// workgroup owns a brick of 64(x) x 4(y) x 16(z) voxels and walks it plane by plane.
 //
-//   1. Brick culling (exact): lanes 0..7 project the 8 corner voxel centres of the brick.
-//      A projective map sends the convex brick into the convex hull of the projected corners
-//      as long as the homogeneous divisor keeps one sign over the brick, so if all corners
-//      fall off the same side of the depth image (with a margin covering rounding) no voxel
-//      of the brick can pass the reference's frustum test and the workgroup exits without
-//      touching memory.  Bricks that straddle the camera plane are never culled (the
-//      reference projects voxels behind the camera too: Q2).
-//   2. Per voxel, the reference's arithmetic in its operation order (fp contraction is off):
-//      world_to_pixel -> depth gather -> pixel_to_camera.z -> world_to_camera.z -> sdf ->
-//      running weighted mean.  Distance and weight are loaded only under the update
-//      predicate and stored with the same mask, so the algorithmic traffic is
-//      16 B per updated voxel + the depth pixels gathered (L2 resident: 614 KB).
-//   3. Camera matrices, intrinsics and grid geometry are kernel arguments: they are
-//      wave-uniform and live in SGPRs.
+// Three launches per frame:
+//   1. depth_tile_max_kernel: max depth of every 16x16 pixel tile (1200 tiles at 640x480).
+//   2. brick_cull_kernel (one thread per brick): exact, conservative culling.  The 8 corner voxel centres are
+//      projected with running error bounds.  A projective map sends the convex brick into the convex hull of
+//      the projected corners as long as the homogeneous divisor keeps one sign over the brick, so
+//        (a) if all corners fall off the same side of the depth image no voxel passes the reference's
+//            frustum test (bricks that straddle the camera plane are never culled: the reference projects
+//            voxels behind the camera too, Q2);
+//        (b) if every depth tile the hull can touch is all-invalid, no voxel finds a depth > 0;
+//        (c) for rigid poses / standard intrinsics (surface z == depth, w == 1 exactly): if the nearest corner
+//            lies more than trunc behind the largest depth of those tiles, every sdf is < -trunc.
+//      Surviving bricks are appended to a compact list.
+//   3. integrate_kernel: a persistent grid walks the list.  Per voxel, the reference's arithmetic in its
+//      operation order (fp contraction is off): world_to_pixel -> depth gather -> pixel_to_camera.z ->
+//      world_to_camera.z -> sdf -> running weighted mean.  Distance and weight are loaded only under the
+//      update predicate and stored with the same mask, so the algorithmic traffic is 16 B per updated voxel +
+//      the depth pixels gathered (L2 resident: 614 KB).  Camera matrices, intrinsics and grid geometry are
+//      kernel arguments: wave-uniform, they live in SGPRs.
+#include <algorithm>
+#include <cmath>
+
 #include "common.hpp"
 
 namespace tsdf {
@@ -27,10 +34,12 @@ namespace tsdf {
 constexpr int kTileX = 64;  // one wave along x
 constexpr int kTileY = 4;   // waves per workgroup
 constexpr int kChunkZ = 16; // planes walked by one workgroup
+constexpr int kBatchZ = 4;  // planes whose loads are issued together
 
 struct Projected {
     float ix, iy, iz;  // K * cam
     float cam_z;       // row 3 of inv_pose applied to the point
+    float ecz;         // absolute error bound of cam_z
     float ex, ey, ez;  // absolute error bounds of ix, iy, iz
 };
 
@@ -45,6 +54,7 @@ __device__ inline Projected project_with_bounds(float px, float py, float pz, co
     float ecz = u * (fabsf(ip.m31 * px) + fabsf(ip.m32 * py) + fabsf(ip.m33 * pz) + fabsf(ip.m34));
     Projected r;
     r.cam_z = cz;
+    r.ecz = ecz;
     r.ix = k.m11 * cx + k.m12 * cy + k.m13 * cz;
     r.iy = k.m21 * cx + k.m22 * cy + k.m23 * cz;
     r.iz = k.m31 * cx + k.m32 * cy + k.m33 * cz;
@@ -52,45 +62,6 @@ __device__ inline Projected project_with_bounds(float px, float py, float pz, co
     r.ey = u * (fabsf(k.m21 * cx) + fabsf(k.m22 * cy) + fabsf(k.m23 * cz)) + fabsf(k.m21) * ecx + fabsf(k.m22) * ecy + fabsf(k.m23) * ecz;
     r.ez = u * (fabsf(k.m31 * cx) + fabsf(k.m32 * cy) + fabsf(k.m33 * cz)) + fabsf(k.m31) * ecx + fabsf(k.m32) * ecy + fabsf(k.m33) * ecz;
     return r;
-}
-
-// Returns true when no voxel centre of the brick [x0,x1]x[y0,y1]x[z0,z1] (inclusive voxel
-// indices) can project inside the image.  Wave-uniform result.
-__device__ inline bool brick_outside_image(uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1, uint32_t z0,
-                                           uint32_t z1, const Geom &g, const Mat44 &ip, const Mat33 &k,
-                                           uint32_t width, uint32_t height) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t c = lane & 7u;
-    uint32_t vx = (c & 1u) ? x1 : x0;
-    uint32_t vy = (c & 2u) ? y1 : y0;
-    uint32_t vz = (c & 4u) ? z1 : z0;
-    float px = ((((int)vx + 0.5f) * g.vs.x) + g.offset_clear.x) + g.offset.x;
-    float py = ((((int)vy + 0.5f) * g.vs.y) + g.offset_clear.y) + g.offset.y;
-    float pz = ((((int)vz + 0.5f) * g.vs.z) + g.offset_clear.z) + g.offset.z;
-    // voxel centres inside the brick deviate from the exact lattice spanned by the corners by
-    // a few ulps of the coordinate; folded into the error bounds below.
-    Projected p = project_with_bounds(px, py, pz, ip, k);
-    float aiz = fabsf(p.iz);
-    bool sign_ok = aiz > 8.0f * p.ez + 1.0e-3f;  // divisor reliably away from zero
-    float qx = p.ix / p.iz;
-    float qy = p.iy / p.iz;
-    // error of the quotient (first order, doubled)
-    float mqx = 2.0f * (p.ex + fabsf(qx) * p.ez) / aiz + 1.0e-3f;
-    float mqy = 2.0f * (p.ey + fabsf(qy) * p.ez) / aiz + 1.0e-3f;
-    // a voxel passes the frustum test iff round(q) in [0, W-1]  <=>  q in [-0.5, W-0.5)
-    bool left = qx + mqx < -1.0f;
-    bool right = qx - mqx > (float)width;
-    bool top = qy + mqy < -1.0f;
-    bool bottom = qy - mqy > (float)height;
-    const unsigned long long m8 = 0xFFull;
-    unsigned long long pos = __ballot(sign_ok && p.iz > 0.0f) & m8;
-    unsigned long long neg = __ballot(sign_ok && p.iz < 0.0f) & m8;
-    if (pos != m8 && neg != m8) return false;
-    if ((__ballot(left) & m8) == m8) return true;
-    if ((__ballot(right) & m8) == m8) return true;
-    if ((__ballot(top) & m8) == m8) return true;
-    if ((__ballot(bottom) & m8) == m8) return true;
-    return false;
 }
 
 // A voxel whose new distance is not safely positive flags every brick whose grown region
@@ -111,97 +82,239 @@ __device__ inline void mark_occupied(const OccGrid &occ, uint32_t vx, uint32_t v
             }
 }
 
-template <bool DEFORM, bool COUNT>
+constexpr int kDepthTile = 16;  // pixels per side of a depth tile
+
+// Max depth per 16x16 pixel tile (0 = the tile holds no valid depth).  One wave per tile.
+__global__ __launch_bounds__(64) void depth_tile_max_kernel(const uint16_t *__restrict__ depth, uint32_t width,
+                                                            uint32_t height, uint32_t tiles_x,
+                                                            uint16_t *__restrict__ tile_max) {
+    const uint32_t tx = blockIdx.x, ty = blockIdx.y;
+    uint32_t m = 0;
+    for (uint32_t i = threadIdx.x; i < kDepthTile * kDepthTile; i += 64) {
+        uint32_t x = tx * kDepthTile + (i & (kDepthTile - 1)), y = ty * kDepthTile + (i / kDepthTile);
+        if (x < width && y < height) m = max(m, (uint32_t)depth[(size_t)y * width + x]);
+    }
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_down(m, o));
+    if (threadIdx.x == 0) tile_max[ty * tiles_x + tx] = (uint16_t)m;
+}
+
+struct BrickGrid {
+    uint32_t nx, ny, nz;  // bricks per axis over the resident planes
+};
+
+// One thread per 64x4x16 brick: decide whether any voxel of it can be updated by this frame (see the header).
+__global__ __launch_bounds__(256) void brick_cull_kernel(const Geom g, const BrickGrid bg, const Mat44 ip, const Mat33 k,
+                                                         const uint32_t width, const uint32_t height,
+                                                         const uint16_t *__restrict__ tile_max, const uint32_t tiles_x,
+                                                         const int depth_test, uint32_t *__restrict__ list,
+                                                         uint32_t *__restrict__ count) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= bg.nx * bg.ny * bg.nz) return;
+    const uint32_t bx = b % bg.nx, by = (b / bg.nx) % bg.ny, bz = b / (bg.nx * bg.ny);
+    const uint32_t x0 = bx * kTileX, x1 = min(x0 + kTileX, g.X) - 1;
+    const uint32_t y0 = by * kTileY, y1 = min(y0 + kTileY, g.Y) - 1;
+    const uint32_t z0 = g.z_store_begin + bz * kChunkZ, z1 = min(z0 + kChunkZ, g.z_store_end) - 1;
+
+    bool all_pos = true, all_neg = true;
+    bool left = true, right = true, top = true, bottom = true;
+    float qx_lo = INFINITY, qx_hi = -INFINITY, qy_lo = INFINITY, qy_hi = -INFINITY;
+    float camz_lo = INFINITY, ecz_max = 0.0f;
+    for (int c = 0; c < 8; c++) {
+        const uint32_t vx = (c & 1) ? x1 : x0, vy = (c & 2) ? y1 : y0, vz = (c & 4) ? z1 : z0;
+        const float px = ((((int)vx + 0.5f) * g.vs.x) + g.offset_clear.x) + g.offset.x;
+        const float py = ((((int)vy + 0.5f) * g.vs.y) + g.offset_clear.y) + g.offset.y;
+        const float pz = ((((int)vz + 0.5f) * g.vs.z) + g.offset_clear.z) + g.offset.z;
+        // voxel centres inside the brick deviate from the exact lattice spanned by the corners by a few ulps of
+        // the coordinate; that is folded into the error bounds
+        const Projected p = project_with_bounds(px, py, pz, ip, k);
+        const float aiz = fabsf(p.iz);
+        const bool sign_ok = aiz > 8.0f * p.ez + 1.0e-3f;  // divisor reliably away from zero
+        all_pos = all_pos && sign_ok && p.iz > 0.0f;
+        all_neg = all_neg && sign_ok && p.iz < 0.0f;
+        const float qx = p.ix / p.iz, qy = p.iy / p.iz;
+        // error of the quotient (first order, doubled)
+        const float mqx = 2.0f * (p.ex + fabsf(qx) * p.ez) / aiz + 1.0e-3f;
+        const float mqy = 2.0f * (p.ey + fabsf(qy) * p.ez) / aiz + 1.0e-3f;
+        // a voxel passes the frustum test iff round(q) in [0, W-1]  <=>  q in [-0.5, W-0.5)
+        left = left && (qx + mqx < -1.0f);
+        right = right && (qx - mqx > (float)width);
+        top = top && (qy + mqy < -1.0f);
+        bottom = bottom && (qy - mqy > (float)height);
+        qx_lo = fminf(qx_lo, qx - mqx); qx_hi = fmaxf(qx_hi, qx + mqx);
+        qy_lo = fminf(qy_lo, qy - mqy); qy_hi = fmaxf(qy_hi, qy + mqy);
+        camz_lo = fminf(camz_lo, p.cam_z - p.ecz);
+        ecz_max = fmaxf(ecz_max, p.ecz);
+    }
+    bool keep = true;
+    if (all_pos || all_neg) {
+        if (left || right || top || bottom) keep = false;
+        if (keep && depth_test) {
+            // pixels any voxel of the brick can round to: the hull's bounding box grown by 1 px
+            const float fx0 = fmaxf(qx_lo - 1.0f, 0.0f), fx1 = fminf(qx_hi + 1.0f, (float)(width - 1));
+            const float fy0 = fmaxf(qy_lo - 1.0f, 0.0f), fy1 = fminf(qy_hi + 1.0f, (float)(height - 1));
+            if (fx0 <= fx1 && fy0 <= fy1) {  // (false for NaN: keep)
+                const uint32_t tx0 = (uint32_t)fx0 / kDepthTile, tx1 = (uint32_t)fx1 / kDepthTile;
+                const uint32_t ty0 = (uint32_t)fy0 / kDepthTile, ty1 = (uint32_t)fy1 / kDepthTile;
+                if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) <= 256u) {
+                    uint32_t dmax = 0;
+                    for (uint32_t ty = ty0; ty <= ty1; ty++)
+                        for (uint32_t tx = tx0; tx <= tx1; tx++) dmax = max(dmax, (uint32_t)tile_max[ty * tiles_x + tx]);
+                    // (b) nothing but invalid depth in reach; (c) the whole brick lies more than trunc behind the
+                    // farthest surface in reach: sdf = depth - cam_z < -trunc for every voxel
+                    if (dmax == 0) keep = false;
+                    // (a voxel's own cam_z carries the same kind of rounding error as a corner's: 2 * ecz_max more)
+                    else if (camz_lo - (float)dmax > g.trunc * 1.0001f + 1.0e-3f + 1.0e-5f * fabsf(camz_lo) + 2.0f * ecz_max)
+                        keep = false;
+                }
+            }
+        }
+    }
+    if (keep) list[atomicAdd(count, 1u)] = b;
+}
+
+// STD: the camera has the standard shape -- K = [fx 0 cx; 0 fy cy; 0 0 1], K^-1 with last row (0,0,1), inverse
+// pose with last row (0,0,0,1), all entries finite (checked on the host).  Then, for the finite voxel centres of
+// a grid, the reference's terms `0 * x` are +-0 and drop out of its sums without changing a bit that matters:
+// image.z == cam.z, surface z == depth, w == 1 (adding -0 is the identity, adding +0 only turns a -0 into +0, and
+// a zero's sign reaches neither the rounded pixel nor the sdf).  The kernel then skips those multiplications and
+// the divisions by 1.
+template <bool DEFORM, bool COUNT, bool STD>
 __global__ __launch_bounds__(256) void integrate_kernel(float *__restrict__ dist, float *__restrict__ weight,
                                                         const tsdf_deformation_node *__restrict__ nodes,
-                                                        const Geom g, const Mat44 ip, const Mat33 k,
+                                                        const Geom g, const BrickGrid bg, const Mat44 ip, const Mat33 k,
                                                         const Mat33 kinv, const uint32_t width,
                                                         const uint32_t height,
                                                         const uint16_t *__restrict__ depth,
                                                         unsigned long long *__restrict__ counter,
-                                                        const OccGrid occ) {
-    const uint32_t x0 = blockIdx.x * kTileX;
-    const uint32_t y0 = blockIdx.y * kTileY;
-    const uint32_t z0 = g.z_store_begin + blockIdx.z * kChunkZ;
-    const uint32_t z1 = min(z0 + kChunkZ, g.z_store_end);  // exclusive
-    const uint32_t vx = x0 + threadIdx.x;
-    const uint32_t vy = y0 + threadIdx.y;
-
-    if (!DEFORM) {
-        uint32_t bx1 = min(x0 + kTileX, g.X) - 1, by1 = min(y0 + kTileY, g.Y) - 1;
-        if (brick_outside_image(x0, bx1, y0, by1, z0, z1 - 1, g, ip, k, width, height)) return;
-    }
-    if (vx >= g.X || vy >= g.Y) return;
-
+                                                        const OccGrid occ, const uint32_t *__restrict__ list,
+                                                        const uint32_t *__restrict__ count) {
+    const uint32_t n_active = DEFORM ? bg.nx * bg.ny * bg.nz : *count;  // custom nodes: every brick
     const size_t plane = (size_t)g.X * g.Y;
-    size_t idx = plane * (z0 - g.z_store_begin) + (size_t)g.X * vy + vx;
-
-    // voxel centre, x and y parts: initialise_deformation (src/TSDF/TSDFVolume.cu:783-784) then
-    // integrate_kernel's offset + translation (:343)
-    float cx = 0.f, cy = 0.f;
-    // partial row sums of inv_pose * (c,1): the reference evaluates ((m_i1*x + m_i2*y) + m_i3*z) + m_i4
-    float r1 = 0.f, r2 = 0.f, r3 = 0.f, r4 = 0.f;
-    if (!DEFORM) {
-        cx = ((((int)vx + 0.5f) * g.vs.x) + g.offset_clear.x) + g.offset.x;
-        cy = ((((int)vy + 0.5f) * g.vs.y) + g.offset_clear.y) + g.offset.y;
-        r1 = ip.m11 * cx + ip.m12 * cy;
-        r2 = ip.m21 * cx + ip.m22 * cy;
-        r3 = ip.m31 * cx + ip.m32 * cy;
-        r4 = ip.m41 * cx + ip.m42 * cy;
-    }
     const float neg_trunc = -g.trunc;
+    const float fwidth = (float)width, fheight = (float)height;
     uint32_t updated = 0;
 
-    for (uint32_t vz = z0; vz < z1; ++vz, idx += plane) {
-        float cz;
-        if (DEFORM) {
-            const tsdf_deformation_node &nd = nodes[idx];
-            cx = nd.translation[0] + g.offset.x;
-            cy = nd.translation[1] + g.offset.y;
-            cz = nd.translation[2] + g.offset.z;
+    for (uint32_t i = blockIdx.x; i < n_active; i += gridDim.x) {
+        const uint32_t b = DEFORM ? i : list[i];
+        const uint32_t bx = b % bg.nx, by = (b / bg.nx) % bg.ny, bz = b / (bg.nx * bg.ny);
+        const uint32_t vx = bx * kTileX + threadIdx.x;
+        const uint32_t vy = by * kTileY + threadIdx.y;
+        const uint32_t z0 = g.z_store_begin + bz * kChunkZ;
+        const uint32_t z1 = min(z0 + kChunkZ, g.z_store_end);  // exclusive
+        if (vx >= g.X || vy >= g.Y) continue;
+
+        size_t idx = plane * (z0 - g.z_store_begin) + (size_t)g.X * vy + vx;
+
+        // voxel centre, x and y parts: initialise_deformation (src/TSDF/TSDFVolume.cu:783-784) then
+        // integrate_kernel's offset + translation (:343)
+        float cx = 0.f, cy = 0.f;
+        // partial row sums of inv_pose * (c,1): the reference evaluates ((m_i1*x + m_i2*y) + m_i3*z) + m_i4
+        float r1 = 0.f, r2 = 0.f, r3 = 0.f, r4 = 0.f;
+        float r4_[kBatchZ] = {};
+        if (!DEFORM) {
+            cx = ((((int)vx + 0.5f) * g.vs.x) + g.offset_clear.x) + g.offset.x;
+            cy = ((((int)vy + 0.5f) * g.vs.y) + g.offset_clear.y) + g.offset.y;
             r1 = ip.m11 * cx + ip.m12 * cy;
             r2 = ip.m21 * cx + ip.m22 * cy;
             r3 = ip.m31 * cx + ip.m32 * cy;
             r4 = ip.m41 * cx + ip.m42 * cy;
-        } else {
-            cz = ((((int)vz + 0.5f) * g.vs.z) + g.offset_clear.z) + g.offset.z;
         }
-        // world_to_pixel (src/Utilities/cuda_coordinate_transforms.cu:10-30)
-        float camx = (r1 + ip.m13 * cz) + ip.m14;
-        float camy = (r2 + ip.m23 * cz) + ip.m24;
-        float camz = (r3 + ip.m33 * cz) + ip.m34;
-        float imx = k.m11 * camx + k.m12 * camy + k.m13 * camz;
-        float imy = k.m21 * camx + k.m22 * camy + k.m23 * camz;
-        float imz = k.m31 * camx + k.m32 * camy + k.m33 * camz;
-        int px = f2i_sat(roundf(imx / imz));
-        int py = f2i_sat(roundf(imy / imz));
-        bool did = false;
-        // frustum test (src/TSDF/TSDFVolume.cu:349)
-        if (px >= 0 && (uint32_t)px < width && py >= 0 && (uint32_t)py < height) {
-            uint16_t d = depth[(uint32_t)py * width + (uint32_t)px];
-            if (d > 0) {
-                // pixel_to_camera(...).z (cuda_coordinate_transforms.cu:132-146)
-                float ipz = kinv.m31 * px + kinv.m32 * py + kinv.m33;
-                float scale = (float)d / ipz;
-                float surf_z = ipz * scale;
-                // world_to_camera(...).z (cuda_coordinate_transforms.cu:108-121): same numerator as camz
-                float w = (r4 + ip.m43 * cz) + ip.m44;
-                float voxel_cam_z = camz / w;
-                float sdf = surf_z - voxel_cam_z;
-                if (sdf >= neg_trunc) {
-                    float tsdf = (sdf > 0) ? fminf(sdf, g.trunc) : sdf;
-                    float prior_weight = weight[idx];
-                    float prior_distance = dist[idx];
-                    float new_weight = prior_weight + 1.0f;
-                    float new_distance = ((prior_distance * prior_weight) + (tsdf * 1.0f)) / new_weight;
-                    weight[idx] = new_weight;
-                    dist[idx] = new_distance;
-                    if (!(new_distance > occ.tau)) mark_occupied(occ, vx, vy, vz);
-                    did = true;
+
+        // The planes of the brick are processed kBatchZ at a time in three passes -- project + gather depth,
+        // decide + load distance/weight, blend + store -- so that the depth gathers of a batch, and then its
+        // HBM loads, are all in flight together instead of one dependent chain per plane.
+        for (uint32_t zb = z0; zb < z1; zb += kBatchZ, idx += plane * kBatchZ) {
+            float camz_[kBatchZ], cz_[kBatchZ];
+            int px_[kBatchZ], py_[kBatchZ];
+            uint16_t d_[kBatchZ];
+            bool act[kBatchZ];
+#pragma unroll
+            for (int j = 0; j < kBatchZ; j++) {
+                const uint32_t vz = zb + j;
+                act[j] = vz < z1;
+                d_[j] = 0;
+                px_[j] = py_[j] = 0;
+                float cz;
+                if (DEFORM) {
+                    // (custom nodes: x/y parts differ per voxel)
+                    cz = 0.f;
+                    if (act[j]) {
+                        const tsdf_deformation_node &nd = nodes[idx + plane * j];
+                        cx = nd.translation[0] + g.offset.x;
+                        cy = nd.translation[1] + g.offset.y;
+                        cz = nd.translation[2] + g.offset.z;
+                    }
+                    r1 = ip.m11 * cx + ip.m12 * cy;
+                    r2 = ip.m21 * cx + ip.m22 * cy;
+                    r3 = ip.m31 * cx + ip.m32 * cy;
+                    r4 = ip.m41 * cx + ip.m42 * cy;
+                } else {
+                    cz = ((((int)vz + 0.5f) * g.vs.z) + g.offset_clear.z) + g.offset.z;
+                }
+                cz_[j] = cz;
+                // world_to_pixel (src/Utilities/cuda_coordinate_transforms.cu:10-30)
+                const float camx = (r1 + ip.m13 * cz) + ip.m14;
+                const float camy = (r2 + ip.m23 * cz) + ip.m24;
+                const float camz = (r3 + ip.m33 * cz) + ip.m34;
+                camz_[j] = camz;
+                const float imx = STD ? k.m11 * camx + k.m13 * camz : k.m11 * camx + k.m12 * camy + k.m13 * camz;
+                const float imy = STD ? k.m22 * camy + k.m23 * camz : k.m21 * camx + k.m22 * camy + k.m23 * camz;
+                const float imz = STD ? camz : k.m31 * camx + k.m32 * camy + k.m33 * camz;
+                // pixel = (int)round(q) with the target's conversion (NaN -> 0, saturating: f2i_sat); the
+                // frustum test (:349) is done on the rounded floats, which order exactly like the saturated ints
+                float rx = roundf(imx / imz), ry = roundf(imy / imz);
+                if (rx != rx) rx = 0.0f;
+                if (ry != ry) ry = 0.0f;
+                if (act[j] && rx >= 0.0f && rx < fwidth && ry >= 0.0f && ry < fheight) {
+                    px_[j] = (int)rx;
+                    py_[j] = (int)ry;
+                    d_[j] = depth[(uint32_t)py_[j] * width + (uint32_t)px_[j]];
+                }
+                if (DEFORM) {  // keep the per-voxel row sums for pass 2
+                    r4_[j] = r4;
+                }
+            }
+            float tsdf_[kBatchZ], pw_[kBatchZ], pd_[kBatchZ];
+            bool upd[kBatchZ];
+#pragma unroll
+            for (int j = 0; j < kBatchZ; j++) {
+                upd[j] = false;
+                tsdf_[j] = pw_[j] = pd_[j] = 0.f;
+                if (d_[j] > 0) {  // (:355) also false for planes past the brick and pixels off the image
+                    // pixel_to_camera(...).z (cuda_coordinate_transforms.cu:132-146)
+                    float surf_z, voxel_cam_z;
+                    if (STD) {
+                        surf_z = (float)d_[j];
+                        voxel_cam_z = camz_[j];
+                    } else {
+                        const float ipz = kinv.m31 * px_[j] + kinv.m32 * py_[j] + kinv.m33;
+                        const float scale = (float)d_[j] / ipz;
+                        surf_z = ipz * scale;
+                        // world_to_camera(...).z (cuda_coordinate_transforms.cu:108-121): same numerator as camz
+                        const float w = ((DEFORM ? r4_[j] : r4) + ip.m43 * cz_[j]) + ip.m44;
+                        voxel_cam_z = camz_[j] / w;
+                    }
+                    const float sdf = surf_z - voxel_cam_z;
+                    if (sdf >= neg_trunc) {
+                        tsdf_[j] = (sdf > 0) ? fminf(sdf, g.trunc) : sdf;
+                        pw_[j] = weight[idx + plane * j];
+                        pd_[j] = dist[idx + plane * j];
+                        upd[j] = true;
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kBatchZ; j++) {
+                if (upd[j]) {
+                    const float new_weight = pw_[j] + 1.0f;
+                    const float new_distance = ((pd_[j] * pw_[j]) + (tsdf_[j] * 1.0f)) / new_weight;
+                    weight[idx + plane * j] = new_weight;
+                    dist[idx + plane * j] = new_distance;
+                    if (!(new_distance > occ.tau)) mark_occupied(occ, vx, vy, zb + j);
+                    if (COUNT) updated++;
                 }
             }
         }
-        if (COUNT) updated += did ? 1u : 0u;
     }
     if (COUNT) {
         // wave reduction then one atomic per wave
@@ -218,17 +331,59 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
     memcpy(&mk, k, sizeof(mk));
     memcpy(&mkinv, kinv, sizeof(mkinv));
     const Geom &g = v->g;
-    dim3 block(kTileX, kTileY, 1);
-    dim3 grid((g.X + kTileX - 1) / kTileX, (g.Y + kTileY - 1) / kTileY,
-              (g.z_store_end - g.z_store_begin + kChunkZ - 1) / kChunkZ);
+    BrickGrid bg;
+    bg.nx = (g.X + kTileX - 1) / kTileX;
+    bg.ny = (g.Y + kTileY - 1) / kTileY;
+    bg.nz = (g.z_store_end - g.z_store_begin + kChunkZ - 1) / kChunkZ;
+    const size_t n_bricks = (size_t)bg.nx * bg.ny * bg.nz;
+    TSDF_REQUIRE(n_bricks < 0xFFFFFFFFull, "volume too large for the brick list");
+
+    // scratch: brick list + counter, depth tile maxima
+    const uint32_t tiles_x = (width + kDepthTile - 1) / kDepthTile, tiles_y = (height + kDepthTile - 1) / kDepthTile;
+    if (v->brick_list_cap < n_bricks + 1) {
+        if (v->brick_list) (void)hipFree(v->brick_list);
+        v->brick_list = nullptr;
+        v->brick_list_cap = 0;
+        TSDF_HIP(hipMalloc((void **)&v->brick_list, (n_bricks + 1) * sizeof(uint32_t)), "brick list alloc");
+        v->brick_list_cap = n_bricks + 1;
+    }
+    if (v->tile_max_cap < (size_t)tiles_x * tiles_y) {
+        if (v->tile_max) (void)hipFree(v->tile_max);
+        v->tile_max = nullptr;
+        v->tile_max_cap = 0;
+        TSDF_HIP(hipMalloc((void **)&v->tile_max, (size_t)tiles_x * tiles_y * sizeof(uint16_t)), "depth tile alloc");
+        v->tile_max_cap = (size_t)tiles_x * tiles_y;
+    }
+    uint32_t *count = v->brick_list + n_bricks;  // last slot
+
     if (v->counting) TSDF_HIP(hipMemsetAsync(v->counter_dev, 0, sizeof(unsigned long long), v->stream), "reset counter");
-#define LAUNCH(DEF, CNT)                                                                                     \
-    hipLaunchKernelGGL((integrate_kernel<DEF, CNT>), grid, block, 0, v->stream, v->dist, v->weight, v->nodes, \
-                       g, ip, mk, mkinv, width, height, d_depth, v->counter_dev, v->occ)
+    if (!v->nodes) {
+        // the depth tests need surface z == depth and w == 1 exactly (rigid pose, standard intrinsics)
+        const int depth_test = (ip.m41 == 0.0f && ip.m42 == 0.0f && ip.m43 == 0.0f && ip.m44 == 1.0f &&
+                                mkinv.m31 == 0.0f && mkinv.m32 == 0.0f && mkinv.m33 == 1.0f) ? 1 : 0;
+        TSDF_HIP(hipMemsetAsync(count, 0, sizeof(uint32_t), v->stream), "reset brick count");
+        hipLaunchKernelGGL(depth_tile_max_kernel, dim3(tiles_x, tiles_y), dim3(64), 0, v->stream, d_depth, width, height,
+                           tiles_x, v->tile_max);
+        hipLaunchKernelGGL(brick_cull_kernel, dim3((unsigned)((n_bricks + 255) / 256)), dim3(256), 0, v->stream, g, bg, ip, mk,
+                           width, height, v->tile_max, tiles_x, depth_test, v->brick_list, count);
+    }
+    dim3 block(kTileX, kTileY, 1);
+    dim3 grid((unsigned)std::min<size_t>(n_bricks, 256 * 6));  // resident at once (SGPR-limited to 6-7 blocks per CU)
+    bool finite = true;
+    for (int i = 0; i < 16; i++) finite = finite && std::isfinite(inv_pose[i]);
+    for (int i = 0; i < 9; i++) finite = finite && std::isfinite(k[i]) && std::isfinite(kinv[i]);
+    const bool std_camera = finite && ip.m41 == 0.0f && ip.m42 == 0.0f && ip.m43 == 0.0f && ip.m44 == 1.0f &&
+                            mk.m21 == 0.0f && mk.m31 == 0.0f && mk.m12 == 0.0f && mk.m32 == 0.0f && mk.m33 == 1.0f &&
+                            mkinv.m31 == 0.0f && mkinv.m32 == 0.0f && mkinv.m33 == 1.0f;
+#define LAUNCH(DEF, CNT, STDC)                                                                                       \
+    hipLaunchKernelGGL((integrate_kernel<DEF, CNT, STDC>), grid, block, 0, v->stream, v->dist, v->weight, v->nodes, \
+                       g, bg, ip, mk, mkinv, width, height, d_depth, v->counter_dev, v->occ, v->brick_list, count)
     if (v->nodes) {
-        if (v->counting) LAUNCH(true, true); else LAUNCH(true, false);
+        if (v->counting) LAUNCH(true, true, false); else LAUNCH(true, false, false);
+    } else if (std_camera) {
+        if (v->counting) LAUNCH(false, true, true); else LAUNCH(false, false, true);
     } else {
-        if (v->counting) LAUNCH(false, true); else LAUNCH(false, false);
+        if (v->counting) LAUNCH(false, true, false); else LAUNCH(false, false, false);
     }
 #undef LAUNCH
     TSDF_HIP(hipGetLastError(), "Integrate kernel failed");
