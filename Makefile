@@ -27,7 +27,7 @@ all: hip host oracle cpptest
 
 host: $(LIBDIR)/libtsdf_host.so
 
-$(HOSTDIR)/src/%.o: $(HOSTDIR)/src/%.cpp $(wildcard $(HOSTDIR)/include/*.hpp) $(wildcard $(HOSTDIR)/src/*.hpp) include/tsdf_amd.h
+$(HOSTDIR)/src/%.o: $(HOSTDIR)/src/%.cpp $(wildcard $(HOSTDIR)/include/*.hpp) $(wildcard $(HOSTDIR)/src/*.hpp) $(wildcard $(HOSTDIR)/eigen_compat/Eigen/*) include/tsdf_amd.h
 	$(CXX) $(HOSTFLAGS) -c $< -o $@
 
 $(LIBDIR)/libtsdf_host.so: $(HOST_OBJS) $(LIBDIR)/libtsdf_hip.so

@@ -57,10 +57,18 @@ def main():
         # launched without torchrun for N>1 is a usage error; N=1 runs standalone
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run" % args.gpus)
+    # Debug aid for a 1-GPU box: TSDF_BENCH_SHARE_GPU=1 puts every rank on device 0 and uses gloo for the
+    # collective, so the N>1 code path can be exercised (the numbers mean nothing then).
+    share = os.environ.get("TSDF_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import tsdf_amd
     from tsdf_amd import synth
@@ -97,11 +105,11 @@ def main():
     bil = tsdf_amd.BilateralFilter(30.0, 4.5)
     rc = tsdf_amd.GPURaycaster(W, H)
 
-    stage_names = ["bilateral", "integrate", "raycast", "normals"]
+    stage_names = ["bilateral", "integrate", "raycast", "exchange", "normals"]
     ev = {s: [] for s in stage_names}
 
     def step(i, timed):
-        e = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if timed else None
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(6)] if timed else None
         cam = cams[i]
         if timed: e[0].record(stream)
         bil.filter_device(depth_dev[i].data_ptr(), filt_dev.data_ptr(), W, H, bits=16, stream=stream.cuda_stream)
@@ -114,11 +122,17 @@ def main():
         else:
             rc.raycast_slab_device(vol, cam, hits_mine.data_ptr())
             if timed: e[3].record(stream)
-            dist.all_gather_into_tensor(hits_all.view(-1), hits_mine.view(-1))
+            if share:   # gloo: stage through the host
+                h_all = torch.empty(hits_all.shape, dtype=hits_all.dtype)
+                dist.all_gather_into_tensor(h_all.view(-1), hits_mine.cpu().view(-1))
+                hits_all.copy_(h_all)
+            else:
+                dist.all_gather_into_tensor(hits_all.view(-1), hits_mine.view(-1))
             tsdf_amd.merge_hits_device(hits_all.data_ptr(), world, W, H, vert_dev.data_ptr(), stream.cuda_stream)
+        if timed: e[4].record(stream)
         tsdf_amd.compute_normals_device(W, H, vert_dev.data_ptr(), norm_dev.data_ptr(), stream.cuda_stream)
         if timed:
-            e[4].record(stream)
+            e[5].record(stream)
             for j, s in enumerate(stage_names):
                 ev[s].append((e[j], e[j + 1]))
 
@@ -167,7 +181,7 @@ def main():
                                "raycast + normals per frame" % (n, args.physical, args.stream_frames, SEED),
                    "grid": [n, n, n], "image": [W, H], "parallelism": "zslab%d" % world},
         "integrate_mvoxels_per_s": round(N_vox / (stage_ms["integrate"] * 1e-3) / 1e6, 1),
-        "raycast_mrays_per_s": round(W * H / ((stage_ms["raycast"] + stage_ms["normals"]) * 1e-3) / 1e6, 2),
+        "raycast_mrays_per_s": round(W * H / ((stage_ms["raycast"] + stage_ms["exchange"] + stage_ms["normals"]) * 1e-3) / 1e6, 2),
         "stage_ms": {s: round(v, 4) for s, v in stage_ms.items()},
     }
 

@@ -620,7 +620,11 @@ void orc_mat4_inverse(const float m[16], float out[16]) {
     float c2 = A(2, 0) * A(3, 3) - A(3, 0) * A(2, 3);
     float c1 = A(2, 0) * A(3, 2) - A(3, 0) * A(2, 2);
     float c0 = A(2, 0) * A(3, 1) - A(3, 0) * A(2, 1);
-    float det = s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
+    /* summed so that, for a pose with last row (0,0,0,1), det is bit-identical to the numerator of O(3,3)
+     * below: the inverse's last row is then exactly (0,0,0,1) */
+    float det = A(2, 0) * s3 - A(2, 1) * s1 + A(2, 2) * s0;
+    if (!(A(3, 0) == 0.0f && A(3, 1) == 0.0f && A(3, 2) == 0.0f && A(3, 3) == 1.0f))
+        det = s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
 #define O(r, c) out[(c) * 4 + (r)]
     O(0, 0) = (A(1, 1) * c5 - A(1, 2) * c4 + A(1, 3) * c3) / det;
     O(0, 1) = (-A(0, 1) * c5 + A(0, 2) * c4 - A(0, 3) * c3) / det;
