@@ -122,6 +122,9 @@ struct tsdf_volume {
     float *vert_buf;
     float *norm_buf;
     size_t ray_cap;
+    // per-range hit records of the segmented ray march (kRaySegments x W*H float4), raycast.hip
+    float *seg_hits;
+    size_t seg_cap;
     // T[k]: the ray parameter of sample k, T[0] = 0, T[k+1] = T[k] + step in fp32 (raycast.hip)
     float *t_table;
     // 1 = dividing by each voxel edge via the 3-instruction reciprocal sequence was verified exhaustively

@@ -6,6 +6,7 @@
 // point in the interpolation weights: Q10); fp contraction is off so every evaluated sample is
 // bit-identical.  How the loop is reorganised for wave64 is described at process_ray_kernel below.
 #include <cmath>
+#include <cstdlib>
 
 #include "common.hpp"
 
@@ -19,6 +20,7 @@ struct RayParams {
     F3 space_max;
     uint32_t width, height;
     uint32_t own_lo, own_hi;  // slab ownership (planes of the lower trilinear tap)
+    uint32_t seg_len;         // > 0: blockIdx.z handles samples [z*seg_len, (z+1)*seg_len) and writes records
 };
 
 // Division by a loop-invariant voxel edge.  The reference divides (IEEE, correctly rounded); when FASTDIV is
@@ -230,55 +232,67 @@ __device__ inline bool compute_near_and_far_t(const F3 &o, const F3 &d, const F3
 // Wave scheduling.  One lane per pixel, a wave is an 8x8 pixel tile of coherent rays.  Every pass of the loop
 // does the same straight-line work for all lanes (one brick flag, 8 gathers, a jump or one interpolation), so
 // lanes do not serialise on divergent code paths; the wave leaves when every lane is done (ballot).
-//   SLAB=false: out = packed float3 vertices.  SLAB=true: out = float4 records {k, x, y, z}.
+//   SLAB / SEG: out = float4 records {k, x, y, z} (per slab, or per sample range); otherwise packed float3 vertices.
 //   STATS: counters[1] += samples evaluated, counters[2] += hits, touched bitmap marked per tap.  With
 //          SKIP=false the counts are those of the reference's march.
 constexpr int kMaxSamples = 4402;          // src/RayCaster/GPURaycaster.cu:369
 constexpr int kTableLen = kMaxSamples + 2;  // T[0..4402] is read
 constexpr int kDone = 0x7fffffff;
+constexpr int kRaySegmentsDefault = 16;     // sample ranges a ray's march is split into (single-GPU path)
+static int ray_segments() {
+    static const int n = [] {
+        const char *e = getenv("TSDF_RAY_SEGMENTS");  // tuning aid
+        int v = e ? atoi(e) : kRaySegmentsDefault;
+        return v < 1 ? 1 : (v > 64 ? 64 : v);
+    }();
+    return n;
+}
 
+// Per-ray constants of the skipping arithmetic.  Everything here is APPROXIMATE on purpose (hardware
+// reciprocals, no care for rounding): it only decides how far k may jump, and the slack of the occupancy
+// argument (one voxel at brick level, eps at cell level) covers its error.
 struct SkipCtx {
-    float inv_vx, inv_vy, inv_vz;  // 1/voxel size (approximate on purpose)
-    float inv_step;
-    float rdx, rdy, rdz;           // 1/dir (+-inf for a zero component)
+    float inv_vx, inv_vy, inv_vz;  // ~ 1 / voxel size
+    float inv_step;                // ~ 1 / step
+    float tx, ty, tz;              // ~ |voxel size / dir| : t needed to cross one voxel (inf for a zero component)
+    bool px_, py_, pz_;            // dir component > 0
     float eps;                     // guard band at the dual-cell faces, in voxels
 };
 
-// Samples (>= 1) from the one at p until the ray leaves the axis-aligned box [lo, hi) given in voxel units.
-__device__ inline int samples_to_exit(float px, float py, float pz, const F3 &dir, const SkipCtx &c, const Geom &g,
-                                      int lox, int loy, int loz, int hix, int hiy, int hiz) {
-    float ex = ((float)(dir.x > 0 ? hix : lox) * g.vs.x - px) * c.rdx;
-    float ey = ((float)(dir.y > 0 ? hiy : loy) * g.vs.y - py) * c.rdy;
-    float ez = ((float)(dir.z > 0 ? hiz : loz) * g.vs.z - pz) * c.rdz;
-    if (!(dir.x != 0)) ex = INFINITY;
-    if (!(dir.y != 0)) ey = INFINITY;
-    if (!(dir.z != 0)) ez = INFINITY;
+// Samples (>= 1) from the one at voxel coordinate (fx,fy,fz) until the ray leaves the axis-aligned box
+// [lo, hi) given in voxel units.
+__device__ inline int samples_to_exit(float fx, float fy, float fz, const SkipCtx &c, float lox, float loy, float loz,
+                                      float hix, float hiy, float hiz) {
+    const float ex = (c.px_ ? hix - fx : fx - lox) * c.tx;
+    const float ey = (c.py_ ? hiy - fy : fy - loy) * c.ty;
+    const float ez = (c.pz_ ? hiz - fz : fz - loz) * c.tz;
+    // fminf ignores a NaN (0 * inf when the ray runs inside a face of the box)
     return (int)fminf(fmaxf(fminf(ex, fminf(ey, ez)) * c.inv_step, 1.0f), 8192.0f);
 }
 
-// Locates the sample at p in the two-level brick grid.  Returns true when the samples from this one up to the
-// exit of an empty region may be skipped; n = their number (>= 1).  The region is the coarse brick (clipped to
-// the interior of the grid, i.e. without the boundary fine bricks) when its flag is clear, else the fine brick.
-// When false (occupied or boundary brick, or a position off the grid) n = samples that stay inside the fine
-// brick.
-__device__ inline bool locate(float px, float py, float pz, const F3 &dir, const SkipCtx &c, const Geom &g,
-                              const OccGrid &occ, int &n) {
-    const int vx = (int)floorf(px * c.inv_vx), vy = (int)floorf(py * c.inv_vy), vz = (int)floorf(pz * c.inv_vz);
+// Locates the sample at voxel coordinate f = p / vs in the two-level brick grid.  Returns true when the samples
+// from this one up to the exit of an empty region may be skipped; n = their number (>= 1).  The region is the
+// coarse brick (clipped to the interior of the grid, i.e. without the boundary fine bricks) when its flag is
+// clear, else the fine brick.  When false (occupied or boundary brick, or a position off the grid) n = samples
+// that stay inside the fine brick.
+__device__ inline bool locate(float fx, float fy, float fz, const SkipCtx &c, const Geom &g, const OccGrid &occ, int &n) {
+    const int vx = (int)floorf(fx), vy = (int)floorf(fy), vz = (int)floorf(fz);
     n = 1;
-    if (vx < 0 || vy < 0 || vz < 0 || vx >= (int)g.X || vy >= (int)g.Y || vz >= (int)g.Z) return false;
+    if ((uint32_t)vx >= g.X || (uint32_t)vy >= g.Y || (uint32_t)vz >= g.Z) return false;
     // interior of the grid in voxels: everything but the first and the last (possibly partial) fine brick
     const int ix1 = (int)(occ.nbx - 1) << kBrickShift, iy1 = (int)(occ.nby - 1) << kBrickShift, iz1 = (int)(occ.nbz - 1) << kBrickShift;
-    const bool inner = vx >= kBrick && vy >= kBrick && vz >= kBrick && vx < ix1 && vy < iy1 && vz < iz1;
+    const bool inner = (uint32_t)(vx - kBrick) < (uint32_t)(ix1 - kBrick) && (uint32_t)(vy - kBrick) < (uint32_t)(iy1 - kBrick) &&
+                       (uint32_t)(vz - kBrick) < (uint32_t)(iz1 - kBrick);
     const int cx = vx >> kCoarseShift, cy = vy >> kCoarseShift, cz = vz >> kCoarseShift;
     if (inner && occ.coarse[((size_t)cz * occ.ncy + cy) * occ.ncx + cx] == 0) {
-        n = samples_to_exit(px, py, pz, dir, c, g, max(cx << kCoarseShift, kBrick), max(cy << kCoarseShift, kBrick),
-                            max(cz << kCoarseShift, kBrick), min((cx + 1) << kCoarseShift, ix1),
-                            min((cy + 1) << kCoarseShift, iy1), min((cz + 1) << kCoarseShift, iz1));
+        n = samples_to_exit(fx, fy, fz, c, (float)max(cx << kCoarseShift, kBrick), (float)max(cy << kCoarseShift, kBrick),
+                            (float)max(cz << kCoarseShift, kBrick), (float)min((cx + 1) << kCoarseShift, ix1),
+                            (float)min((cy + 1) << kCoarseShift, iy1), (float)min((cz + 1) << kCoarseShift, iz1));
         return true;
     }
     const int bx = vx >> kBrickShift, by = vy >> kBrickShift, bz = vz >> kBrickShift;
-    n = samples_to_exit(px, py, pz, dir, c, g, bx << kBrickShift, by << kBrickShift, bz << kBrickShift,
-                        (bx + 1) << kBrickShift, (by + 1) << kBrickShift, (bz + 1) << kBrickShift);
+    n = samples_to_exit(fx, fy, fz, c, (float)(bx << kBrickShift), (float)(by << kBrickShift), (float)(bz << kBrickShift),
+                        (float)((bx + 1) << kBrickShift), (float)((by + 1) << kBrickShift), (float)((bz + 1) << kBrickShift));
     return occ.fine[((size_t)bz * occ.nby + by) * occ.nbx + bx] == 0;
 }
 
@@ -287,14 +301,21 @@ __device__ inline int wave_min(int v) {
     return v;
 }
 
-template <bool SLAB, bool STATS, bool SKIP, bool FASTDIV>
+template <bool SLAB, bool STATS, bool SKIP, bool FASTDIV, bool SEG>
 __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restrict__ dist, const Geom g,
                                                           const RayParams rp, float *__restrict__ out,
                                                           unsigned long long *__restrict__ counters,
                                                           unsigned int *__restrict__ touched,
                                                           const OccGrid occ, const float *__restrict__ t_table) {
+    // Sample-range splitting: with rp.seg_len > 0 the z index of the workgroup selects a contiguous range of
+    // sample indices; every range is marched independently (first owned sample <= 0 -> record {k,x,y,z}) and a
+    // min-k merge picks the ray's first hit, exactly as for Z-slabs.  Long rays thus become several short waves.
+    const int k_lo = (int)(blockIdx.z * rp.seg_len);
+    const int k_hi = rp.seg_len ? min(kMaxSamples, k_lo + (int)rp.seg_len) : kMaxSamples;
     __shared__ float T[kTableLen];
-    for (int i = threadIdx.x; i < kTableLen; i += 256) T[i] = t_table[i];
+    // T[1] (the step) plus the part of the table this range reads: T[k_lo .. k_hi]
+    for (int i = k_lo + (int)threadIdx.x; i <= k_hi; i += 256) T[i] = t_table[i];
+    if (threadIdx.x < 2) T[threadIdx.x] = t_table[threadIdx.x];
     __syncthreads();
 
     // 16x16 pixel tile per workgroup, 8x8 per wave
@@ -332,19 +353,26 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
     // samples 0 .. k_end-1 are evaluated unless one of them is <= 0
     int k_end = 0;
     if (intersects) {
-        int lo = 1, hi = kMaxSamples;
+        // smallest k in [max(k_lo,1), k_hi] with T[k] >= max_t (k_hi when there is none): only this range's
+        // part of the table is staged, and only this range's samples are marched
+        int lo = max(k_lo, 1), hi = k_hi;
         while (lo < hi) {
             int mid = (lo + hi) >> 1;
             if (T[mid] >= max_t) hi = mid; else lo = mid + 1;
         }
         k_end = lo;
+        // the range starts beyond the ray's last sample (k_lo >= 1 and T[k_lo] >= max_t): nothing to do
+        if (k_lo >= 1 && T[k_lo] >= max_t) k_end = 0;
     }
 
     const TriConst tc = make_tri_const(g);
     SkipCtx sc;
-    sc.inv_vx = 1.0f / g.vs.x; sc.inv_vy = 1.0f / g.vs.y; sc.inv_vz = 1.0f / g.vs.z;
-    sc.inv_step = 1.0f / step_size;
-    sc.rdx = 1.0f / dir.x; sc.rdy = 1.0f / dir.y; sc.rdz = 1.0f / dir.z;
+    sc.inv_vx = __builtin_amdgcn_rcpf(g.vs.x); sc.inv_vy = __builtin_amdgcn_rcpf(g.vs.y); sc.inv_vz = __builtin_amdgcn_rcpf(g.vs.z);
+    sc.inv_step = __builtin_amdgcn_rcpf(step_size);
+    sc.tx = dir.x != 0 ? fabsf(g.vs.x * __builtin_amdgcn_rcpf(dir.x)) : INFINITY;
+    sc.ty = dir.y != 0 ? fabsf(g.vs.y * __builtin_amdgcn_rcpf(dir.y)) : INFINITY;
+    sc.tz = dir.z != 0 ? fabsf(g.vs.z * __builtin_amdgcn_rcpf(dir.z)) : INFINITY;
+    sc.px_ = dir.x > 0; sc.py_ = dir.y > 0; sc.pz_ = dir.z > 0;
     // one step must stay well inside the one-voxel slack on every axis
     const bool skip_ok = SKIP && fabsf(dir.x) * step_size < 0.25f * g.vs.x && fabsf(dir.y) * step_size < 0.25f * g.vs.y &&
                          fabsf(dir.z) * step_size < 0.25f * g.vs.z;
@@ -352,9 +380,9 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
     // guard band at the cell faces: the dual-cell index computed approximately below (coordinates up to
     // max(X,Y,Z) voxels, a handful of roundings of 2^-24 relative each) must agree with the reference's exact one
     sc.eps = fmaxf(1.0e-3f, 2.0e-6f * (float)max(g.X, max(g.Y, g.Z)));
-    const float cell_lo = sc.eps, cell_hi = 1.0f - sc.eps;
+    const float cell_lo = sc.eps, cell_hi = 1.0f - sc.eps, cell_half = 0.5f - sc.eps;
 
-    int k = (k_end == 0) ? kDone : 0;  // next sample of this lane (kDone when finished)
+    int k = (k_end <= k_lo) ? kDone : k_lo;  // next sample of this lane (kDone when finished)
     int k_brick_end = 0;               // the brick classification holds while k < k_brick_end
     uint32_t trips = 0, adv_iters = 0;  // diagnostics
 
@@ -374,34 +402,29 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
             bool evaluated = false;
             int jump = 0;           // > 0: samples k .. k+jump-1 cannot hit
             if (skip_ok) {
+                // position in voxel units (approximate)
+                const float fx = px * sc.inv_vx, fy = py * sc.inv_vy, fz = pz * sc.inv_vz;
                 if (k >= k_brick_end) {
                     int n;
-                    bool empty = locate(px, py, pz, dir, sc, g, occ, n);
+                    bool empty = locate(fx, fy, fz, sc, g, occ, n);
                     k_brick_end = k + n;
                     if (empty) jump = n;
                 }
                 if (jump == 0) {
                     // dual cell of the sample: lower = floor(p/vs - 1/2), position inside it r in [0,1)
-                    const float cx = px * sc.inv_vx - 0.5f, cy = py * sc.inv_vy - 0.5f, cz = pz * sc.inv_vz - 0.5f;
-                    const float fx = floorf(cx), fy = floorf(cy), fz = floorf(cz);
-                    const float rx = cx - fx, ry = cy - fy, rz = cz - fz;
+                    const float cx = fx - 0.5f, cy = fy - 0.5f, cz = fz - 0.5f;
+                    const float lfx = floorf(cx), lfy = floorf(cy), lfz = floorf(cz);
+                    const float rx = cx - lfx, ry = cy - lfy, rz = cz - lfz;
+                    const int lx = (int)lfx, ly = (int)lfy, lz = (int)lfz;
                     // at least eps away from the cell faces, and all 8 voxels of the cell exist (then no tap is
                     // clamped, the weights lie in [0,1], and p is inside the grid so nothing is clamped either;
                     // the outer half-voxel shell of the grid, where the reference extrapolates (Q10), fails this)
-                    const bool safe = rx > cell_lo && rx < cell_hi && ry > cell_lo && ry < cell_hi && rz > cell_lo && rz < cell_hi &&
-                                      fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx + 1.0f < (float)g.X &&
-                                      fy + 1.0f < (float)g.Y && fz + 1.0f < (float)g.Z;
+                    const bool safe = fabsf(rx - 0.5f) < cell_half && fabsf(ry - 0.5f) < cell_half && fabsf(rz - 0.5f) < cell_half &&
+                                      (uint32_t)lx < g.X - 1 && (uint32_t)ly < g.Y - 1 && (uint32_t)lz < g.Z - 1;
                     if (safe) {
                         if (STATS) adv_iters++;  // diagnostics: cell tests
                         // samples until the ray leaves the cell shrunk by eps
-                        float ex = (dir.x > 0 ? cell_hi - rx : rx - cell_lo) * fabsf(sc.rdx) * g.vs.x;
-                        float ey = (dir.y > 0 ? cell_hi - ry : ry - cell_lo) * fabsf(sc.rdy) * g.vs.y;
-                        float ez = (dir.z > 0 ? cell_hi - rz : rz - cell_lo) * fabsf(sc.rdz) * g.vs.z;
-                        if (!(dir.x != 0)) ex = INFINITY;
-                        if (!(dir.y != 0)) ey = INFINITY;
-                        if (!(dir.z != 0)) ez = INFINITY;
-                        const int n_cell = (int)fminf(fmaxf(fminf(ex, fminf(ey, ez)) * sc.inv_step, 1.0f), 8192.0f);
-                        const int lx = (int)fx, ly = (int)fy, lz = (int)fz;
+                        const int n_cell = samples_to_exit(rx, ry, rz, sc, cell_lo, cell_lo, cell_lo, cell_hi, cell_hi, cell_hi);
                         if (SLAB && !((uint32_t)lz >= rp.own_lo && (uint32_t)lz < rp.own_hi)) {
                             jump = n_cell;  // not this rank's samples (and possibly not its planes): passed unevaluated
                         } else {
@@ -464,8 +487,9 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
 
     if (in_image) {
         size_t idx = (size_t)imy * rp.width + imx;
-        if (SLAB) {
-            reinterpret_cast<float4 *>(out)[idx] = make_float4(hit_k, ix, iy, iz);
+        if (SLAB || SEG) {
+            const size_t rec = SEG ? (size_t)blockIdx.z * rp.width * rp.height + idx : idx;
+            reinterpret_cast<float4 *>(out)[rec] = make_float4(hit_k, ix, iy, iz);
         } else if (STATS && SKIP) {  // diagnostics: per-ray work instead of the vertex
             out[idx * 3 + 0] = (float)samples;
             out[idx * 3 + 1] = (float)trips;
@@ -553,6 +577,7 @@ static RayParams make_params(const tsdf_volume *v, uint32_t width, uint32_t heig
     rp.height = height;
     rp.own_lo = v->z_begin;
     rp.own_hi = v->z_end;
+    rp.seg_len = 0;
     return rp;
 }
 
@@ -587,14 +612,30 @@ int tsdf_raycast_device(const tsdf_volume *v, uint32_t width, uint32_t height, c
         if (rc != TSDF_OK) return rc;
     }
     RayParams rp = make_params(v, width, height, pose, kinv);
-    dim3 grid((width + 15) / 16, (height + 15) / 16);
+    // the march is split into kRaySegments sample ranges per ray (short waves, 8x the parallelism); their
+    // records are merged by the same min-k select the multi-GPU path uses
+    const size_t n_pix = (size_t)width * height;
+    const int kRaySegments = ray_segments();
+    tsdf_volume *mv = const_cast<tsdf_volume *>(v);
+    if (mv->seg_cap < n_pix * kRaySegments) {
+        if (mv->seg_hits) (void)hipFree(mv->seg_hits);
+        mv->seg_hits = nullptr;
+        mv->seg_cap = 0;
+        TSDF_HIP(hipMalloc((void **)&mv->seg_hits, n_pix * kRaySegments * 4 * sizeof(float)), "ray segment records alloc");
+        mv->seg_cap = n_pix * kRaySegments;
+    }
+    rp.seg_len = (kMaxSamples + kRaySegments - 1) / kRaySegments;
+    dim3 grid((width + 15) / 16, (height + 15) / 16, kRaySegments);
     if (v->fast_div)
-        hipLaunchKernelGGL((process_ray_kernel<false, false, true, true>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp,
-                           device_vertices, (unsigned long long *)nullptr, (unsigned int *)nullptr, v->occ, v->t_table);
+        hipLaunchKernelGGL((process_ray_kernel<false, false, true, true, true>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp,
+                           mv->seg_hits, (unsigned long long *)nullptr, (unsigned int *)nullptr, v->occ, v->t_table);
     else
-        hipLaunchKernelGGL((process_ray_kernel<false, false, true, false>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp,
-                           device_vertices, (unsigned long long *)nullptr, (unsigned int *)nullptr, v->occ, v->t_table);
+        hipLaunchKernelGGL((process_ray_kernel<false, false, true, false, true>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp,
+                           mv->seg_hits, (unsigned long long *)nullptr, (unsigned int *)nullptr, v->occ, v->t_table);
     TSDF_HIP(hipGetLastError(), "process_ray failed");
+    hipLaunchKernelGGL(merge_hits_kernel, dim3((unsigned)((n_pix + 255) / 256)), dim3(256), 0, v->stream,
+                       reinterpret_cast<const float4 *>(mv->seg_hits), (uint32_t)kRaySegments, (uint32_t)n_pix, device_vertices);
+    TSDF_HIP(hipGetLastError(), "merge ray segments failed");
     if (device_normals) return launch_normals(width, height, device_vertices, device_normals, v->stream);
     return TSDF_OK;
 }
@@ -649,7 +690,7 @@ int tsdf_raycast_stats(const tsdf_volume *v, uint32_t width, uint32_t height, co
     (void)hipMemsetAsync(bitmap, 0, words * sizeof(unsigned int), v->stream);
     (void)hipMemsetAsync(v->counter_dev, 0, 4 * sizeof(unsigned long long), v->stream);
     dim3 grid((width + 15) / 16, (height + 15) / 16);
-    hipLaunchKernelGGL((process_ray_kernel<false, true, false, false>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp, verts,
+    hipLaunchKernelGGL((process_ray_kernel<false, true, false, false, false>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp, verts,
                        v->counter_dev, bitmap, v->occ, v->t_table);
     hipLaunchKernelGGL(popcount_kernel, dim3(1024), dim3(256), 0, v->stream, bitmap, words, v->counter_dev + 3);
     unsigned long long c[4] = {0, 0, 0, 0};
@@ -686,7 +727,7 @@ int tsdf_raycast_evaluated_samples(const tsdf_volume *v, uint32_t width, uint32_
     }
     (void)hipMemsetAsync(v->counter_dev, 0, 4 * sizeof(unsigned long long), v->stream);
     dim3 grid((width + 15) / 16, (height + 15) / 16);
-    hipLaunchKernelGGL((process_ray_kernel<false, true, true, true>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp, verts,
+    hipLaunchKernelGGL((process_ray_kernel<false, true, true, true, false>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp, verts,
                        v->counter_dev, bitmap, v->occ, v->t_table);
     unsigned long long c[4] = {0, 0, 0, 0};
     e = hipMemcpyAsync(c, v->counter_dev, sizeof(c), hipMemcpyDeviceToHost, v->stream);
@@ -712,10 +753,10 @@ int tsdf_raycast_slab_device(const tsdf_volume *v, uint32_t width, uint32_t heig
     RayParams rp = make_params(v, width, height, pose, kinv);
     dim3 grid((width + 15) / 16, (height + 15) / 16);
     if (v->fast_div)
-        hipLaunchKernelGGL((process_ray_kernel<true, false, true, true>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp,
+        hipLaunchKernelGGL((process_ray_kernel<true, false, true, true, false>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp,
                            device_hits, (unsigned long long *)nullptr, (unsigned int *)nullptr, v->occ, v->t_table);
     else
-        hipLaunchKernelGGL((process_ray_kernel<true, false, true, false>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp,
+        hipLaunchKernelGGL((process_ray_kernel<true, false, true, false, false>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp,
                            device_hits, (unsigned long long *)nullptr, (unsigned int *)nullptr, v->occ, v->t_table);
     TSDF_HIP(hipGetLastError(), "process_ray (slab) failed");
     return TSDF_OK;

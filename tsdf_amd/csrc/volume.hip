@@ -296,6 +296,7 @@ int tsdf_volume_destroy(tsdf_volume *v) {
     if (v->occ.fine) (void)hipFree(v->occ.fine);
     if (v->occ.coarse) (void)hipFree(v->occ.coarse);
     if (v->t_table) (void)hipFree(v->t_table);
+    if (v->seg_hits) (void)hipFree(v->seg_hits);
     if (v->brick_list) (void)hipFree(v->brick_list);
     if (v->tile_max) (void)hipFree(v->tile_max);
     delete v;
