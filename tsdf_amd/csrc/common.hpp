@@ -137,6 +137,8 @@ struct tsdf_volume {
     // integrate scratch: compact list of bricks a frame can touch (+ its counter), depth tile maxima
     uint32_t *brick_list;
     size_t brick_list_cap;
+    uint32_t *brick_boxes;   // uint4 per active brick: pixel box of the brick's projection
+    size_t brick_box_cap;
     uint16_t *tile_max;
     size_t tile_max_cap;
     // diagnostics

@@ -35,6 +35,7 @@ constexpr int kTileX = 64;  // one wave along x
 constexpr int kTileY = 4;   // waves per workgroup
 constexpr int kChunkZ = 16; // planes walked by one workgroup
 constexpr int kBatchZ = 4;  // planes whose loads are issued together
+constexpr int kTilePixels = 8192;  // LDS depth tile of a brick: 16 KiB
 
 struct Projected {
     float ix, iy, iz;  // K * cam
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void brick_cull_kernel(const Geom g, const Bri
                                                          const uint32_t width, const uint32_t height,
                                                          const uint16_t *__restrict__ tile_max, const uint32_t tiles_x,
                                                          const int depth_test, uint32_t *__restrict__ list,
-                                                         uint32_t *__restrict__ count) {
+                                                         uint4 *__restrict__ boxes, uint32_t *__restrict__ count) {
     const uint32_t b = blockIdx.x * 256 + threadIdx.x;
     if (b >= bg.nx * bg.ny * bg.nz) return;
     const uint32_t bx = b % bg.nx, by = (b / bg.nx) % bg.ny, bz = b / (bg.nx * bg.ny);
@@ -146,13 +147,16 @@ __global__ __launch_bounds__(256) void brick_cull_kernel(const Geom g, const Bri
         ecz_max = fmaxf(ecz_max, p.ecz);
     }
     bool keep = true;
+    // pixel box that contains the pixel of every voxel of the brick that passes the frustum test; 0 x 0 = unknown
+    uint4 box = make_uint4(0, 0, 0, 0);  // x0, y0, width, height
     if (all_pos || all_neg) {
         if (left || right || top || bottom) keep = false;
-        if (keep && depth_test) {
-            // pixels any voxel of the brick can round to: the hull's bounding box grown by 1 px
-            const float fx0 = fmaxf(qx_lo - 1.0f, 0.0f), fx1 = fminf(qx_hi + 1.0f, (float)(width - 1));
-            const float fy0 = fmaxf(qy_lo - 1.0f, 0.0f), fy1 = fminf(qy_hi + 1.0f, (float)(height - 1));
-            if (fx0 <= fx1 && fy0 <= fy1) {  // (false for NaN: keep)
+        // pixels any voxel of the brick can round to: the hull's bounding box grown by 1 px
+        const float fx0 = fmaxf(qx_lo - 1.0f, 0.0f), fx1 = fminf(qx_hi + 1.0f, (float)(width - 1));
+        const float fy0 = fmaxf(qy_lo - 1.0f, 0.0f), fy1 = fminf(qy_hi + 1.0f, (float)(height - 1));
+        if (keep && fx0 <= fx1 && fy0 <= fy1) {  // (false for NaN: box stays unknown)
+            box = make_uint4((uint32_t)fx0, (uint32_t)fy0, (uint32_t)fx1 - (uint32_t)fx0 + 1, (uint32_t)fy1 - (uint32_t)fy0 + 1);
+            if (depth_test) {
                 const uint32_t tx0 = (uint32_t)fx0 / kDepthTile, tx1 = (uint32_t)fx1 / kDepthTile;
                 const uint32_t ty0 = (uint32_t)fy0 / kDepthTile, ty1 = (uint32_t)fy1 / kDepthTile;
                 if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) <= 256u) {
@@ -169,7 +173,11 @@ __global__ __launch_bounds__(256) void brick_cull_kernel(const Geom g, const Bri
             }
         }
     }
-    if (keep) list[atomicAdd(count, 1u)] = b;
+    if (keep) {
+        const uint32_t slot = atomicAdd(count, 1u);
+        list[slot] = b;
+        boxes[slot] = box;
+    }
 }
 
 // STD: the camera has the standard shape -- K = [fx 0 cx; 0 fy cy; 0 0 1], K^-1 with last row (0,0,1), inverse
@@ -178,6 +186,33 @@ __global__ __launch_bounds__(256) void brick_cull_kernel(const Geom g, const Bri
 // image.z == cam.z, surface z == depth, w == 1 (adding -0 is the identity, adding +0 only turns a -0 into +0, and
 // a zero's sign reaches neither the rounded pixel nor the sdf).  The kernel then skips those multiplications and
 // the divisions by 1.
+// roundf(x): half away from zero, written out (trunc + compare) so that the distance to the rounding boundary
+// is available to round_quotients below.  Identical to roundf for every input (NaN and infinities included).
+__device__ inline float round_half_away(float q, float &dist_to_half) {
+    const float t = truncf(q);
+    const float d = fabsf(q - t);
+    dist_to_half = fabsf(d - 0.5f);
+    return (d >= 0.5f) ? t + copysignf(1.0f, q) : t;
+}
+
+// rx = roundf(a1 / b), ry = roundf(a2 / b) exactly as the reference's IEEE divisions + round() give them
+// (src/Utilities/cuda_coordinate_transforms.cu:25-26), at a fraction of the cost: the quotients are first formed
+// with the hardware reciprocal (relative error < 2.4e-7 against the correctly rounded quotient); unless such a
+// quotient lies within 4e-7*|q| of a rounding boundary (x.5) both round to the same integer.  The rare lanes that
+// are that close to a boundary, or whose divisor is tiny, redo the IEEE division.
+__device__ inline void round_quotients(float a1, float a2, float b, float &rx, float &ry) {
+    const float rc = __builtin_amdgcn_rcpf(b);
+    const float q1 = a1 * rc, q2 = a2 * rc;
+    float h1, h2;
+    rx = round_half_away(q1, h1);
+    ry = round_half_away(q2, h2);
+    const bool unsure = !(h1 > 4.0e-7f * fabsf(q1)) || !(h2 > 4.0e-7f * fabsf(q2)) || !(fabsf(b) >= 1.0e-30f);
+    if (unsure) {  // (also taken for NaN / infinite quotients)
+        rx = roundf(a1 / b);
+        ry = roundf(a2 / b);
+    }
+}
+
 template <bool DEFORM, bool COUNT, bool STD>
 __global__ __launch_bounds__(256) void integrate_kernel(float *__restrict__ dist, float *__restrict__ weight,
                                                         const tsdf_deformation_node *__restrict__ nodes,
@@ -187,7 +222,12 @@ __global__ __launch_bounds__(256) void integrate_kernel(float *__restrict__ dist
                                                         const uint16_t *__restrict__ depth,
                                                         unsigned long long *__restrict__ counter,
                                                         const OccGrid occ, const uint32_t *__restrict__ list,
+                                                        const uint4 *__restrict__ boxes,
                                                         const uint32_t *__restrict__ count) {
+    // Depth tile of the current brick: the pixel box the cull kernel derived for it, staged once per brick with
+    // coalesced row loads; the per-voxel depth look-ups then read LDS instead of gathering from L2.
+    __shared__ uint16_t tile[kTilePixels];
+    const uint32_t tid = threadIdx.y * kTileX + threadIdx.x;
     const uint32_t n_active = DEFORM ? bg.nx * bg.ny * bg.nz : *count;  // custom nodes: every brick
     const size_t plane = (size_t)g.X * g.Y;
     const float neg_trunc = -g.trunc;
@@ -201,6 +241,19 @@ __global__ __launch_bounds__(256) void integrate_kernel(float *__restrict__ dist
         const uint32_t vy = by * kTileY + threadIdx.y;
         const uint32_t z0 = g.z_store_begin + bz * kChunkZ;
         const uint32_t z1 = min(z0 + kChunkZ, g.z_store_end);  // exclusive
+        // stage the brick's pixel box (whole workgroup; falls back to global gathers when it is unknown or too big)
+        uint4 box = make_uint4(0, 0, 0, 0);
+        if (!DEFORM) box = boxes[i];
+        const uint32_t pitch = (box.z + 1u) & ~1u;  // even, so a row starts on a 4-byte boundary
+        const bool staged = box.z != 0 && pitch * box.w <= (uint32_t)kTilePixels;
+        __syncthreads();  // the previous brick's look-ups are done
+        if (staged) {
+            for (uint32_t p = tid; p < pitch * box.w; p += kTileX * kTileY) {
+                const uint32_t ty = p / pitch, tx = p - ty * pitch;
+                tile[p] = (tx < box.z) ? depth[(size_t)(box.y + ty) * width + (box.x + tx)] : (uint16_t)0;
+            }
+        }
+        __syncthreads();
         if (vx >= g.X || vy >= g.Y) continue;
 
         size_t idx = plane * (z0 - g.z_store_begin) + (size_t)g.X * vy + vx;
@@ -262,13 +315,18 @@ __global__ __launch_bounds__(256) void integrate_kernel(float *__restrict__ dist
                 const float imz = STD ? camz : k.m31 * camx + k.m32 * camy + k.m33 * camz;
                 // pixel = (int)round(q) with the target's conversion (NaN -> 0, saturating: f2i_sat); the
                 // frustum test (:349) is done on the rounded floats, which order exactly like the saturated ints
-                float rx = roundf(imx / imz), ry = roundf(imy / imz);
+                float rx, ry;
+                round_quotients(imx, imy, imz, rx, ry);
                 if (rx != rx) rx = 0.0f;
                 if (ry != ry) ry = 0.0f;
                 if (act[j] && rx >= 0.0f && rx < fwidth && ry >= 0.0f && ry < fheight) {
                     px_[j] = (int)rx;
                     py_[j] = (int)ry;
-                    d_[j] = depth[(uint32_t)py_[j] * width + (uint32_t)px_[j]];
+                    // the box contains every pixel a voxel of this brick can map to (cull kernel); the range
+                    // check only guards the LDS bounds should that ever be violated
+                    const uint32_t tx = (uint32_t)px_[j] - box.x, ty = (uint32_t)py_[j] - box.y;
+                    if (staged && tx < box.z && ty < box.w) d_[j] = tile[ty * pitch + tx];
+                    else d_[j] = depth[(uint32_t)py_[j] * width + (uint32_t)px_[j]];
                 }
                 if (DEFORM) {  // keep the per-voxel row sums for pass 2
                     r4_[j] = r4;
@@ -355,6 +413,14 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
         v->tile_max_cap = (size_t)tiles_x * tiles_y;
     }
     uint32_t *count = v->brick_list + n_bricks;  // last slot
+    if (v->brick_box_cap < n_bricks) {
+        if (v->brick_boxes) (void)hipFree(v->brick_boxes);
+        v->brick_boxes = nullptr;
+        v->brick_box_cap = 0;
+        TSDF_HIP(hipMalloc((void **)&v->brick_boxes, n_bricks * 4 * sizeof(uint32_t)), "brick box alloc");
+        v->brick_box_cap = n_bricks;
+    }
+    uint4 *boxes = reinterpret_cast<uint4 *>(v->brick_boxes);
 
     if (v->counting) TSDF_HIP(hipMemsetAsync(v->counter_dev, 0, sizeof(unsigned long long), v->stream), "reset counter");
     if (!v->nodes) {
@@ -365,7 +431,7 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
         hipLaunchKernelGGL(depth_tile_max_kernel, dim3(tiles_x, tiles_y), dim3(64), 0, v->stream, d_depth, width, height,
                            tiles_x, v->tile_max);
         hipLaunchKernelGGL(brick_cull_kernel, dim3((unsigned)((n_bricks + 255) / 256)), dim3(256), 0, v->stream, g, bg, ip, mk,
-                           width, height, v->tile_max, tiles_x, depth_test, v->brick_list, count);
+                           width, height, v->tile_max, tiles_x, depth_test, v->brick_list, boxes, count);
     }
     dim3 block(kTileX, kTileY, 1);
     dim3 grid((unsigned)std::min<size_t>(n_bricks, 256 * 6));  // resident at once (SGPR-limited to 6-7 blocks per CU)
@@ -377,7 +443,7 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
                             mkinv.m31 == 0.0f && mkinv.m32 == 0.0f && mkinv.m33 == 1.0f;
 #define LAUNCH(DEF, CNT, STDC)                                                                                       \
     hipLaunchKernelGGL((integrate_kernel<DEF, CNT, STDC>), grid, block, 0, v->stream, v->dist, v->weight, v->nodes, \
-                       g, bg, ip, mk, mkinv, width, height, d_depth, v->counter_dev, v->occ, v->brick_list, count)
+                       g, bg, ip, mk, mkinv, width, height, d_depth, v->counter_dev, v->occ, v->brick_list, boxes, count)
     if (v->nodes) {
         if (v->counting) LAUNCH(true, true, false); else LAUNCH(true, false, false);
     } else if (std_camera) {

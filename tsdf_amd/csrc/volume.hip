@@ -298,6 +298,7 @@ int tsdf_volume_destroy(tsdf_volume *v) {
     if (v->t_table) (void)hipFree(v->t_table);
     if (v->seg_hits) (void)hipFree(v->seg_hits);
     if (v->brick_list) (void)hipFree(v->brick_list);
+    if (v->brick_boxes) (void)hipFree(v->brick_boxes);
     if (v->tile_max) (void)hipFree(v->tile_max);
     delete v;
     return TSDF_OK;
