@@ -275,10 +275,31 @@ __device__ inline int samples_to_exit(float fx, float fy, float fz, const SkipCt
 // coarse brick (clipped to the interior of the grid, i.e. without the boundary fine bricks) when its flag is
 // clear, else the fine brick.  When false (occupied or boundary brick, or a position off the grid) n = samples
 // that stay inside the fine brick.
-__device__ inline bool locate(float fx, float fy, float fz, const SkipCtx &c, const Geom &g, const OccGrid &occ, int &n) {
+template <bool SLAB>
+__device__ inline bool locate(float fx, float fy, float fz, const SkipCtx &c, const Geom &g, const OccGrid &occ,
+                              const RayParams &rp, int &n) {
     const int vx = (int)floorf(fx), vy = (int)floorf(fy), vz = (int)floorf(fz);
     n = 1;
     if ((uint32_t)vx >= g.X || (uint32_t)vy >= g.Y || (uint32_t)vz >= g.Z) return false;
+    if (SLAB) {
+        // A slab evaluates only samples whose lower tap plane lz (= voxel z or voxel z - 1) it owns.  Samples
+        // located (to within one voxel) in z planes [z0, z1) have lz in [z0 - 2, z1]; if that misses the owned
+        // range entirely the whole run is passed unevaluated, like an empty region -- the coarse brick if possible.
+        const int own_lo = (int)rp.own_lo, own_hi = (int)rp.own_hi;
+        const int cz0 = (vz >> kCoarseShift) << kCoarseShift, bz0 = (vz >> kBrickShift) << kBrickShift;
+        if (cz0 + kCoarse < own_lo || cz0 - 2 >= own_hi) {
+            const int cx0 = (vx >> kCoarseShift) << kCoarseShift, cy0 = (vy >> kCoarseShift) << kCoarseShift;
+            n = samples_to_exit(fx, fy, fz, c, (float)cx0, (float)cy0, (float)cz0, (float)(cx0 + kCoarse), (float)(cy0 + kCoarse),
+                                (float)(cz0 + kCoarse));
+            return true;
+        }
+        if (bz0 + kBrick < own_lo || bz0 - 2 >= own_hi) {
+            const int bx0 = (vx >> kBrickShift) << kBrickShift, by0 = (vy >> kBrickShift) << kBrickShift;
+            n = samples_to_exit(fx, fy, fz, c, (float)bx0, (float)by0, (float)bz0, (float)(bx0 + kBrick), (float)(by0 + kBrick),
+                                (float)(bz0 + kBrick));
+            return true;
+        }
+    }
     // interior of the grid in voxels: everything but the first and the last (possibly partial) fine brick
     const int ix1 = (int)(occ.nbx - 1) << kBrickShift, iy1 = (int)(occ.nby - 1) << kBrickShift, iz1 = (int)(occ.nbz - 1) << kBrickShift;
     const bool inner = (uint32_t)(vx - kBrick) < (uint32_t)(ix1 - kBrick) && (uint32_t)(vy - kBrick) < (uint32_t)(iy1 - kBrick) &&
@@ -365,6 +386,25 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
         if (k_lo >= 1 && T[k_lo] >= max_t) k_end = 0;
     }
 
+    // A slab only ever evaluates samples whose lower tap plane it owns; along a ray those occupy one interval
+    // of sample indices (z is linear in t).  Clip the lane's range to a conservative superset of that interval
+    // -- two voxels and three samples of slack -- instead of hopping through the rest of the volume.
+    int k_first = k_lo;
+    if (SLAB && k_end > 0) {
+        const float za = ((float)rp.own_lo - 2.0f) * g.vs.z, zb = ((float)rp.own_hi + 2.0f) * g.vs.z;  // grid mm
+        if (dir.z != 0.0f) {
+            const float r = __builtin_amdgcn_rcpf(dir.z);
+            const float t0 = (za - sz) * r, t1 = (zb - sz) * r;
+            const float ta = fminf(t0, t1), tb = fmaxf(t0, t1);
+            const float ka = floorf(ta * __builtin_amdgcn_rcpf(step_size)) - 3.0f;
+            const float kb = ceilf(tb * __builtin_amdgcn_rcpf(step_size)) + 3.0f;
+            if (ka > (float)k_first) k_first = (int)fminf(ka, (float)kMaxSamples);
+            if (kb < (float)k_end) k_end = (int)fmaxf(kb, 0.0f);
+        } else if (sz < za || sz > zb) {
+            k_end = 0;  // the ray runs parallel to the slab, outside it
+        }
+    }
+
     const TriConst tc = make_tri_const(g);
     SkipCtx sc;
     sc.inv_vx = __builtin_amdgcn_rcpf(g.vs.x); sc.inv_vy = __builtin_amdgcn_rcpf(g.vs.y); sc.inv_vz = __builtin_amdgcn_rcpf(g.vs.z);
@@ -382,7 +422,7 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
     sc.eps = fmaxf(1.0e-3f, 2.0e-6f * (float)max(g.X, max(g.Y, g.Z)));
     const float cell_lo = sc.eps, cell_hi = 1.0f - sc.eps, cell_half = 0.5f - sc.eps;
 
-    int k = (k_end <= k_lo) ? kDone : k_lo;  // next sample of this lane (kDone when finished)
+    int k = (k_end <= k_first) ? kDone : k_first;  // next sample of this lane (kDone when finished)
     int k_brick_end = 0;               // the brick classification holds while k < k_brick_end
     uint32_t trips = 0, adv_iters = 0;  // diagnostics
 
@@ -406,7 +446,7 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
                 const float fx = px * sc.inv_vx, fy = py * sc.inv_vy, fz = pz * sc.inv_vz;
                 if (k >= k_brick_end) {
                     int n;
-                    bool empty = locate(fx, fy, fz, sc, g, occ, n);
+                    bool empty = locate<SLAB>(fx, fy, fz, sc, g, occ, rp, n);
                     k_brick_end = k + n;
                     if (empty) jump = n;
                 }
@@ -552,6 +592,19 @@ __global__ __launch_bounds__(256) void merge_hits_kernel(const float4 *__restric
     V[(size_t)i * 3 + 0] = best.y;
     V[(size_t)i * 3 + 1] = best.z;
     V[(size_t)i * 3 + 2] = best.w;
+}
+
+// Same min-k select, keeping the winning record (used to fold a slab's sample ranges into its one record).
+__global__ __launch_bounds__(256) void merge_records_kernel(const float4 *__restrict__ hits, uint32_t n_sets,
+                                                            uint32_t n_pixels, float4 *__restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels) return;
+    float4 best = hits[i];
+    for (uint32_t s = 1; s < n_sets; s++) {
+        float4 h = hits[(size_t)s * n_pixels + i];
+        if (h.x < best.x) best = h;
+    }
+    out[i] = best;
 }
 
 __global__ __launch_bounds__(256) void popcount_kernel(const unsigned int *__restrict__ words, size_t n,
@@ -751,13 +804,29 @@ int tsdf_raycast_slab_device(const tsdf_volume *v, uint32_t width, uint32_t heig
         if (rc != TSDF_OK) return rc;
     }
     RayParams rp = make_params(v, width, height, pose, kinv);
-    dim3 grid((width + 15) / 16, (height + 15) / 16);
+    // as on a single GPU the march is split into sample ranges; the ranges' records are folded into the slab's
+    // one record per pixel before it leaves this rank
+    const size_t n_pix = (size_t)width * height;
+    const int kRaySegments = ray_segments();
+    tsdf_volume *mv = const_cast<tsdf_volume *>(v);
+    if (mv->seg_cap < n_pix * kRaySegments) {
+        if (mv->seg_hits) (void)hipFree(mv->seg_hits);
+        mv->seg_hits = nullptr;
+        mv->seg_cap = 0;
+        TSDF_HIP(hipMalloc((void **)&mv->seg_hits, n_pix * kRaySegments * 4 * sizeof(float)), "ray segment records alloc");
+        mv->seg_cap = n_pix * kRaySegments;
+    }
+    rp.seg_len = (kMaxSamples + kRaySegments - 1) / kRaySegments;
+    dim3 grid((width + 15) / 16, (height + 15) / 16, kRaySegments);
     if (v->fast_div)
-        hipLaunchKernelGGL((process_ray_kernel<true, false, true, true, false>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp,
-                           device_hits, (unsigned long long *)nullptr, (unsigned int *)nullptr, v->occ, v->t_table);
+        hipLaunchKernelGGL((process_ray_kernel<true, false, true, true, true>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp,
+                           mv->seg_hits, (unsigned long long *)nullptr, (unsigned int *)nullptr, v->occ, v->t_table);
     else
-        hipLaunchKernelGGL((process_ray_kernel<true, false, true, false, false>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp,
-                           device_hits, (unsigned long long *)nullptr, (unsigned int *)nullptr, v->occ, v->t_table);
+        hipLaunchKernelGGL((process_ray_kernel<true, false, true, false, true>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp,
+                           mv->seg_hits, (unsigned long long *)nullptr, (unsigned int *)nullptr, v->occ, v->t_table);
+    hipLaunchKernelGGL(merge_records_kernel, dim3((unsigned)((n_pix + 255) / 256)), dim3(256), 0, v->stream,
+                       reinterpret_cast<const float4 *>(mv->seg_hits), (uint32_t)kRaySegments, (uint32_t)n_pix,
+                       reinterpret_cast<float4 *>(device_hits));
     TSDF_HIP(hipGetLastError(), "process_ray (slab) failed");
     return TSDF_OK;
 }
