@@ -50,12 +50,36 @@ def integrate_raycast_case(O, name):
             depth = (2200 + 150 * np.sin(xx / 17.0 + i) + 120 * np.cos(yy / 11.0)).astype(np.uint16)
             depth[rng.rand(H, W) < 0.02] = 0
             frames.append((depth.reshape(-1), pose))
+    elif name == "spheredepth32":
+        # hemispherical bulge in front of the camera, like make_sphere_depth_map (TestHelpers.cpp:144-183)
+        pose = O.identity_pose((1500, 1500, -500))
+        yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+        r2 = (W / 2.0 - xx) ** 2 + (H / 2.0 - yy) ** 2
+        depth = np.where(r2 < 50.0 ** 2, np.clip(1700.0 - np.sqrt(np.maximum(50.0 ** 2 - r2, 0)) * 8, 1200, 2200), 0)
+        frames = [(depth.astype(np.uint16).reshape(-1), pose)]
     else:
         raise KeyError(name)
     for depth, pose in frames:
         v.integrate(depth, W, H, O.mat4_inverse(pose), k2, kinv2)
     V, N = v.raycast(W, H, frames[0][1], kinv2, nthreads=O.max_threads())
     return {"dist": v.dist.copy(), "weight": v.weight.copy(), "vertices": V, "normals": N}
+
+
+def sphere_raycast_case(O, cam_pos):
+    """Analytic sphere TSDF (create_sphere_in_TSDF, TestHelpers.cpp:17-60) in a 256 mm cube of 64^3 voxels, ray cast at
+    160x120 from one of the two poses of Test_TSDF_RayCast.cpp:430-431 / :580-581."""
+    n, phys, radius = 64, 256.0, 80.0
+    v = O.Volume((n, n, n), (phys,) * 3)
+    vs, trunc = v.voxel_size(), np.float32(v.truncation_distance())
+    c = (np.arange(n, dtype=np.float32) + np.float32(0.5)) * vs[0]
+    centre = np.float32(phys) / np.float32(2.0)
+    dx, dy, dz = (centre - c)[None, None, :], (centre - c)[None, :, None], (centre - c)[:, None, None]
+    d = np.sqrt(dx * dx + dy * dy + dz * dz).astype(np.float32) - np.float32(radius)
+    v.set_distance_data(np.minimum(np.maximum(d, -trunc), trunc))
+    k2, kinv2 = O.camera_k(591.1 / 4, 590.1 / 4, 331.0 / 4, 234.6 / 4)
+    pose = O.look_at(O.identity_pose(cam_pos), (128, 128, 128))
+    V, N = v.raycast(160, 120, pose, kinv2, nthreads=O.max_threads())
+    return {"dist": v.dist.copy(), "pose": pose, "kinv": kinv2, "vertices": V, "normals": N}
 
 
 def main():
@@ -73,10 +97,15 @@ def main():
     np.savez_compressed(os.path.join(HERE, "bilateral_ref_u8.npz"), **out)
 
     out = {}
-    for name in ("wall32", "rot32"):
+    for name in ("wall32", "rot32", "spheredepth32"):
         for key, val in integrate_raycast_case(O, name).items():
             out[name + "_" + key] = val
     np.savez_compressed(os.path.join(HERE, "oracle_integrate_raycast.npz"), **out)
+    out = {}
+    for tag, pos in (("a", (450, 150, 150)), ("b", (-150, 150, 450))):
+        for key, val in sphere_raycast_case(O, pos).items():
+            out[tag + "_" + key] = val
+    np.savez_compressed(os.path.join(HERE, "oracle_sphere_raycast.npz"), **out)
     print("wrote fixtures to", HERE)
 
 

@@ -259,8 +259,22 @@ def test_oracle_matches_its_committed_golden_vectors(oracle):
     against accidental edits and give the GPU tests expectations that do not need the oracle rebuilt."""
     f = np.load(os.path.join(GOLD, "oracle_integrate_raycast.npz"))
     from tests.golden.make_golden import integrate_raycast_case
-    for name in ("wall32", "rot32"):
+    for name in ("wall32", "rot32", "spheredepth32"):
         got = integrate_raycast_case(oracle, name)
         for key in ("dist", "weight", "vertices", "normals"):
             a, b = got[key], f[name + "_" + key]
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (name, key)
+
+
+def test_sphere_raycast_golden_vectors_lie_on_the_sphere(oracle):
+    """tests/golden/oracle_sphere_raycast.npz: the analytic sphere of the reference's ray-cast tests."""
+    from tests.golden.make_golden import sphere_raycast_case
+    f = np.load(os.path.join(GOLD, "oracle_sphere_raycast.npz"))
+    for tag, pos in (("a", (450, 150, 150)), ("b", (-150, 150, 450))):
+        got = sphere_raycast_case(oracle, pos)
+        assert np.array_equal(got["vertices"].view(np.uint32), f[tag + "_vertices"].view(np.uint32))
+        V = f[tag + "_vertices"]
+        hit = ~np.isnan(V[:, 0])
+        assert hit.sum() > 500
+        r = np.linalg.norm(V[hit].astype(np.float64) - 128.0, axis=1)
+        assert np.all(np.abs(r - 80.0) < 8.0)          # within the truncation band of the radius-80 sphere

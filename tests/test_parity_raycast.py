@@ -273,3 +273,18 @@ def test_skipping_anisotropic_voxels_disable_or_keep_exactness(oracle):
     gv, ov = volumes_with(oracle, n, phys, d.reshape(-1))
     compare(oracle, gv, ov, camera_at((300, 300, -500)), what="anisotropic z-coarse")
     compare(oracle, gv, ov, camera_at((-400, 300, 1200), look_at=(300, 300, 1250)), what="anisotropic side view")
+
+
+def test_sphere_golden_vectors(oracle):
+    """tests/golden/oracle_sphere_raycast.npz (generated by tests/golden/make_golden.py): stored inputs -> stored outputs."""
+    import os
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_sphere_raycast.npz"))
+    for tag in ("a", "b"):
+        gv = tsdf_amd.TSDFVolume((64, 64, 64), (256.0, 256.0, 256.0))
+        gv.set_distance_data(f[tag + "_dist"])
+        pose = f[tag + "_pose"]
+        k, _ = oracle.camera_k(591.1 / 4, 590.1 / 4, 331.0 / 4, 234.6 / 4)
+        cam = Cam(pose, oracle.mat4_inverse(pose), k, f[tag + "_kinv"])
+        V, N = gv.raycast(160, 120, cam)
+        assert_same_floats(V, f[tag + "_vertices"], "golden sphere vertices " + tag)
+        assert_same_floats(N, f[tag + "_normals"], "golden sphere normals " + tag)
