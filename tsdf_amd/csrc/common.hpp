@@ -21,6 +21,7 @@ namespace tsdf {
 void set_error(const char *fmt, ...);
 int hip_fail(hipError_t e, const char *what);
 int occupancy_rebuild(struct ::tsdf_volume *v);  // volume.hip
+int occupancy_refresh(struct ::tsdf_volume *v);  // volume.hip: bring fine + reach up to date
 int build_t_table(struct ::tsdf_volume *v);      // volume.hip
 int verify_fast_division(struct ::tsdf_volume *v);  // volume.hip
 
@@ -68,29 +69,30 @@ struct Geom {
     float trunc;
 };
 
-// Brick occupancy used by the ray caster for exact empty-space skipping (raycast.hip), two levels over the
-// GLOBAL grid: fine bricks of kBrick^3 voxels and coarse bricks of kCoarse^3 voxels (one byte each).
-//   fine[b] == 0  : every resident voxel within the brick grown by kBrickGrow voxels on every side is > tau,
-//                   i.e. no trilinear sample whose taps lie in the brick grown by one voxel can be <= 0;
-//   coarse[c] == 0: all INTERIOR fine bricks inside c are 0.
-// Fine bricks touching the grid boundary are set (non-zero) once and for all: there the reference extrapolates
-// (Q10) and the argument does not hold; coarse jumps are clipped to the interior instead.  Flags are sticky: integrate only ever sets them, a rebuild (clear /
-// whole-array upload) resets them.
+// Brick occupancy used by the ray caster for exact empty-space skipping (raycast.hip), over the GLOBAL grid in
+// bricks of kBrick^3 voxels:
+//   fine[b] == 0 : every resident voxel within the brick grown by kBrickGrow voxels on every side is > tau,
+//                  i.e. no trilinear sample whose taps lie in the brick grown by one voxel can be <= 0.
+//                  Bricks touching the grid boundary are set once and for all (there the reference extrapolates,
+//                  Q10, and the argument does not hold).  Sticky: integrate only ever sets flags, a rebuild
+//                  (clear / whole-array upload) resets them.
+//   reach[b]     : size class of the largest clear ALIGNED block of bricks containing b (0 = b is set; l >= 1 = the
+//                  aligned block of 2^(l-1) bricks per side is clear, up to kReachLevels).  A ray inside b may jump
+//                  to the faces of that block.  Recomputed from `fine` before a ray cast when stale (volume.hip).
 // numerators with |a| < kFastDivMin (zero included) or non-finite take the IEEE division in raycast.hip
 constexpr float kFastDivMin = 1.0e-30f;
 constexpr int kBrick = 4;
 constexpr int kBrickShift = 2;
 constexpr int kBrickGrow = 2;
-constexpr int kCoarse = 32;
-constexpr int kCoarseShift = 5;
+constexpr int kReachLevels = 5;     // largest block: 2^(5-1) = 16 bricks = 64 voxels per side
+constexpr int kSlabSkip = 32;       // voxels: granularity at which a slab passes regions it cannot own
+constexpr int kSlabSkipShift = 5;
 struct OccGrid {
     uint8_t *fine;
-    uint8_t *coarse;
-    uint32_t nbx, nby, nbz;  // fine bricks per axis  = ceil(size / kBrick)
-    uint32_t ncx, ncy, ncz;  // coarse bricks per axis = ceil(size / kCoarse)
+    uint8_t *reach;
+    uint32_t nbx, nby, nbz;  // bricks per axis = ceil(size / kBrick)
     float tau;               // "safely positive" threshold (a fraction of the truncation distance)
     __host__ __device__ size_t fine_count() const { return (size_t)nbx * nby * nbz; }
-    __host__ __device__ size_t coarse_count() const { return (size_t)ncx * ncy * ncz; }
 };
 
 // float -> int with the reference target's semantics (CUDA cvt.rzi: saturating, NaN -> 0);
@@ -134,6 +136,7 @@ struct tsdf_volume {
     // brick occupancy (see OccGrid)
     tsdf::OccGrid occ;
     int occ_dirty;   // 1 = rebuild from the distance array before the next ray cast
+    int reach_dirty; // 1 = `fine` changed since `reach` was computed
     // integrate scratch: compact list of bricks a frame can touch (+ its counter), depth tile maxima
     uint32_t *brick_list;
     size_t brick_list_cap;

@@ -76,11 +76,7 @@ __device__ inline void mark_occupied(const OccGrid &occ, uint32_t vx, uint32_t v
     const uint32_t bz1 = min((vz + kBrickGrow) >> kBrickShift, occ.nbz - 1);
     for (uint32_t bz = bz0; bz <= bz1; bz++)
         for (uint32_t by = by0; by <= by1; by++)
-            for (uint32_t bx = bx0; bx <= bx1; bx++) {
-                occ.fine[((size_t)bz * occ.nby + by) * occ.nbx + bx] = 1;
-                const uint32_t s = kCoarseShift - kBrickShift;
-                occ.coarse[((size_t)(bz >> s) * occ.ncy + (by >> s)) * occ.ncx + (bx >> s)] = 1;
-            }
+            for (uint32_t bx = bx0; bx <= bx1; bx++) occ.fine[((size_t)bz * occ.nby + by) * occ.nbx + bx] = 1;
 }
 
 constexpr int kDepthTile = 16;  // pixels per side of a depth tile
@@ -453,6 +449,7 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
     }
 #undef LAUNCH
     TSDF_HIP(hipGetLastError(), "Integrate kernel failed");
+    v->reach_dirty = 1;  // bricks may have been flagged
     return TSDF_OK;
 }
 

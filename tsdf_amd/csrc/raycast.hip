@@ -270,11 +270,10 @@ __device__ inline int samples_to_exit(float fx, float fy, float fz, const SkipCt
     return (int)fminf(fmaxf(fminf(ex, fminf(ey, ez)) * c.inv_step, 1.0f), 8192.0f);
 }
 
-// Locates the sample at voxel coordinate f = p / vs in the two-level brick grid.  Returns true when the samples
-// from this one up to the exit of an empty region may be skipped; n = their number (>= 1).  The region is the
-// coarse brick (clipped to the interior of the grid, i.e. without the boundary fine bricks) when its flag is
-// clear, else the fine brick.  When false (occupied or boundary brick, or a position off the grid) n = samples
-// that stay inside the fine brick.
+// Locates the sample at voxel coordinate f = p / vs in the brick grid.  Returns true when the samples from this
+// one up to the exit of an empty region may be skipped; n = their number (>= 1).  The region is the largest clear
+// aligned block of bricks around the sample (reach[]).  When false (flagged or boundary brick, or a position off
+// the grid) n = samples that stay inside the brick.
 template <bool SLAB>
 __device__ inline bool locate(float fx, float fy, float fz, const SkipCtx &c, const Geom &g, const OccGrid &occ,
                               const RayParams &rp, int &n) {
@@ -284,13 +283,13 @@ __device__ inline bool locate(float fx, float fy, float fz, const SkipCtx &c, co
     if (SLAB) {
         // A slab evaluates only samples whose lower tap plane lz (= voxel z or voxel z - 1) it owns.  Samples
         // located (to within one voxel) in z planes [z0, z1) have lz in [z0 - 2, z1]; if that misses the owned
-        // range entirely the whole run is passed unevaluated, like an empty region -- the coarse brick if possible.
+        // range entirely the whole run is passed unevaluated, like an empty region -- 32 voxels at a time if possible.
         const int own_lo = (int)rp.own_lo, own_hi = (int)rp.own_hi;
-        const int cz0 = (vz >> kCoarseShift) << kCoarseShift, bz0 = (vz >> kBrickShift) << kBrickShift;
-        if (cz0 + kCoarse < own_lo || cz0 - 2 >= own_hi) {
-            const int cx0 = (vx >> kCoarseShift) << kCoarseShift, cy0 = (vy >> kCoarseShift) << kCoarseShift;
-            n = samples_to_exit(fx, fy, fz, c, (float)cx0, (float)cy0, (float)cz0, (float)(cx0 + kCoarse), (float)(cy0 + kCoarse),
-                                (float)(cz0 + kCoarse));
+        const int cz0 = (vz >> kSlabSkipShift) << kSlabSkipShift, bz0 = (vz >> kBrickShift) << kBrickShift;
+        if (cz0 + kSlabSkip < own_lo || cz0 - 2 >= own_hi) {
+            const int cx0 = (vx >> kSlabSkipShift) << kSlabSkipShift, cy0 = (vy >> kSlabSkipShift) << kSlabSkipShift;
+            n = samples_to_exit(fx, fy, fz, c, (float)cx0, (float)cy0, (float)cz0, (float)(cx0 + kSlabSkip),
+                                (float)(cy0 + kSlabSkip), (float)(cz0 + kSlabSkip));
             return true;
         }
         if (bz0 + kBrick < own_lo || bz0 - 2 >= own_hi) {
@@ -300,21 +299,13 @@ __device__ inline bool locate(float fx, float fy, float fz, const SkipCtx &c, co
             return true;
         }
     }
-    // interior of the grid in voxels: everything but the first and the last (possibly partial) fine brick
-    const int ix1 = (int)(occ.nbx - 1) << kBrickShift, iy1 = (int)(occ.nby - 1) << kBrickShift, iz1 = (int)(occ.nbz - 1) << kBrickShift;
-    const bool inner = (uint32_t)(vx - kBrick) < (uint32_t)(ix1 - kBrick) && (uint32_t)(vy - kBrick) < (uint32_t)(iy1 - kBrick) &&
-                       (uint32_t)(vz - kBrick) < (uint32_t)(iz1 - kBrick);
-    const int cx = vx >> kCoarseShift, cy = vy >> kCoarseShift, cz = vz >> kCoarseShift;
-    if (inner && occ.coarse[((size_t)cz * occ.ncy + cy) * occ.ncx + cx] == 0) {
-        n = samples_to_exit(fx, fy, fz, c, (float)max(cx << kCoarseShift, kBrick), (float)max(cy << kCoarseShift, kBrick),
-                            (float)max(cz << kCoarseShift, kBrick), (float)min((cx + 1) << kCoarseShift, ix1),
-                            (float)min((cy + 1) << kCoarseShift, iy1), (float)min((cz + 1) << kCoarseShift, iz1));
-        return true;
-    }
     const int bx = vx >> kBrickShift, by = vy >> kBrickShift, bz = vz >> kBrickShift;
-    n = samples_to_exit(fx, fy, fz, c, (float)(bx << kBrickShift), (float)(by << kBrickShift), (float)(bz << kBrickShift),
-                        (float)((bx + 1) << kBrickShift), (float)((by + 1) << kBrickShift), (float)((bz + 1) << kBrickShift));
-    return occ.fine[((size_t)bz * occ.nby + by) * occ.nbx + bx] == 0;
+    const int reach = occ.reach[((size_t)bz * occ.nby + by) * occ.nbx + bx];
+    // aligned block of 4 * 2^(reach-1) voxels per side (the brick itself when reach is 0)
+    const int shift = kBrickShift + max(reach, 1) - 1, size = 1 << shift;
+    const int x0 = (vx >> shift) << shift, y0 = (vy >> shift) << shift, z0 = (vz >> shift) << shift;
+    n = samples_to_exit(fx, fy, fz, c, (float)x0, (float)y0, (float)z0, (float)(x0 + size), (float)(y0 + size), (float)(z0 + size));
+    return reach != 0;
 }
 
 __device__ inline int wave_min(int v) {
@@ -424,7 +415,7 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
 
     int k = (k_end <= k_first) ? kDone : k_first;  // next sample of this lane (kDone when finished)
     int k_brick_end = 0;               // the brick classification holds while k < k_brick_end
-    uint32_t trips = 0, adv_iters = 0;  // diagnostics
+    uint32_t trips = 0, adv_iters = 0, hop_count = 0;  // diagnostics
 
     // One pass of the loop handles one sample index per lane, the same straight-line work for every lane:
     //   1. (when a brick boundary was crossed) read the brick flag; a clear interior brick is jumped over;
@@ -449,6 +440,7 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
                     bool empty = locate<SLAB>(fx, fy, fz, sc, g, occ, rp, n);
                     k_brick_end = k + n;
                     if (empty) jump = n;
+                    if (STATS) hop_count += empty ? 1u : 0u;
                 }
                 if (jump == 0) {
                     // dual cell of the sample: lower = floor(p/vs - 1/2), position inside it r in [0,1)
@@ -532,7 +524,7 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
             reinterpret_cast<float4 *>(out)[rec] = make_float4(hit_k, ix, iy, iz);
         } else if (STATS && SKIP) {  // diagnostics: per-ray work instead of the vertex
             out[idx * 3 + 0] = (float)samples;
-            out[idx * 3 + 1] = (float)trips;
+            out[idx * 3 + 1] = (float)hop_count;
             out[idx * 3 + 2] = (float)adv_iters;
         } else {
             out[idx * 3 + 0] = ix;
@@ -660,10 +652,8 @@ int tsdf_raycast_device(const tsdf_volume *v, uint32_t width, uint32_t height, c
     if (rc != TSDF_OK) return rc;
     TSDF_REQUIRE(device_vertices, "tsdf_raycast: null vertex buffer");
     TSDF_REQUIRE(v->z_begin == 0 && v->z_end == v->g.Z, "tsdf_raycast on a slab: use tsdf_raycast_slab_device");
-    if (v->occ_dirty) {
-        rc = occupancy_rebuild(const_cast<tsdf_volume *>(v));
-        if (rc != TSDF_OK) return rc;
-    }
+    rc = occupancy_refresh(const_cast<tsdf_volume *>(v));
+    if (rc != TSDF_OK) return rc;
     RayParams rp = make_params(v, width, height, pose, kinv);
     // the march is split into kRaySegments sample ranges per ray (short waves, 8x the parallelism); their
     // records are merged by the same min-k select the multi-GPU path uses
@@ -764,10 +754,8 @@ int tsdf_raycast_evaluated_samples(const tsdf_volume *v, uint32_t width, uint32_
     if (rc != TSDF_OK) return rc;
     TSDF_REQUIRE(evaluated, "null argument");
     TSDF_REQUIRE(v->z_begin == 0 && v->z_end == v->g.Z, "needs a whole volume");
-    if (v->occ_dirty) {
-        rc = occupancy_rebuild(const_cast<tsdf_volume *>(v));
-        if (rc != TSDF_OK) return rc;
-    }
+    rc = occupancy_refresh(const_cast<tsdf_volume *>(v));
+    if (rc != TSDF_OK) return rc;
     RayParams rp = make_params(v, width, height, pose, kinv);
     size_t words = ((size_t)v->g.X * v->g.Y * v->g.Z + 31) / 32;
     unsigned int *bitmap = nullptr;
@@ -799,10 +787,8 @@ int tsdf_raycast_slab_device(const tsdf_volume *v, uint32_t width, uint32_t heig
     int rc = check_ray_args(v, width, height, pose, kinv);
     if (rc != TSDF_OK) return rc;
     TSDF_REQUIRE(device_hits, "tsdf_raycast_slab: null hit buffer");
-    if (v->occ_dirty) {
-        rc = occupancy_rebuild(const_cast<tsdf_volume *>(v));
-        if (rc != TSDF_OK) return rc;
-    }
+    rc = occupancy_refresh(const_cast<tsdf_volume *>(v));
+    if (rc != TSDF_OK) return rc;
     RayParams rp = make_params(v, width, height, pose, kinv);
     // as on a single GPU the march is split into sample ranges; the ranges' records are folded into the slab's
     // one record per pixel before it leaves this rank

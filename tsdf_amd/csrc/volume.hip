@@ -74,13 +74,11 @@ __global__ __launch_bounds__(256) void occupancy_init_kernel(OccGrid occ) {
         bool boundary = bx == 0 || by == 0 || bz == 0 || bx + 1 == occ.nbx || by + 1 == occ.nby || bz + 1 == occ.nbz;
         occ.fine[i] = boundary ? 1 : 0;
     }
-    // coarse flags summarise the INTERIOR fine bricks only (the ray caster clips coarse jumps to the interior)
-    if (i < occ.coarse_count()) occ.coarse[i] = 0;
 }
 
 // Rebuild of the occupancy from the distance array: one wave per fine brick scans the brick grown by
-// kBrickGrow voxels (clamped to the grid and to the resident planes) and sets the brick and its coarse parent
-// if any value is not safely positive.  The overlap between neighbouring bricks is served by L2.
+// kBrickGrow voxels (clamped to the grid and to the resident planes) and sets the brick if any value is not
+// safely positive.  The overlap between neighbouring bricks is served by L2.
 __global__ __launch_bounds__(64) void occupancy_build_kernel(const float *__restrict__ dist, Geom g, OccGrid occ) {
     const uint32_t bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     const int x0 = max((int)(bx * kBrick) - kBrickGrow, 0), x1 = min((int)(bx * kBrick) + kBrick + kBrickGrow, (int)g.X);
@@ -97,10 +95,67 @@ __global__ __launch_bounds__(64) void occupancy_build_kernel(const float *__rest
             occupied |= !(d > occ.tau);  // also true for NaN
         }
     }
-    if (__ballot(occupied) != 0ull && threadIdx.x == 0) {
-        occ.fine[((size_t)bz * occ.nby + by) * occ.nbx + bx] = 1;
-        const uint32_t s = kCoarseShift - kBrickShift;
-        occ.coarse[((size_t)(bz >> s) * occ.ncy + (by >> s)) * occ.ncx + (bx >> s)] = 1;
+    if (__ballot(occupied) != 0ull && threadIdx.x == 0) occ.fine[((size_t)bz * occ.nby + by) * occ.nbx + bx] = 1;
+}
+
+// ---- reach[b]: size class of the largest EMPTY aligned block of bricks that contains brick b:
+//   0 = b itself is flagged; l >= 1 = the aligned block of 2^(l-1) bricks per side (4 * 2^(l-1) voxels) is clear,
+// up to l = kReachLevels (64 voxels).  One workgroup per 16^3-brick super block: OR-reduce in LDS, then every
+// brick looks up its ancestors.  Bricks outside the grid count as flagged, so blocks that stick out are never
+// reported empty.  O(1) work per brick, ~2 x 2 MiB of traffic at 512^3.
+constexpr int kSuper = 16;  // bricks per side of a super block = 2^(kReachLevels - 1)
+__global__ __launch_bounds__(256) void reach_mip_kernel(OccGrid occ) {
+    __shared__ unsigned char f[kSuper * kSuper * kSuper];  // 4096
+    __shared__ unsigned char l1[8 * 8 * 8], l2[4 * 4 * 4], l3[2 * 2 * 2], l4[1];
+    const uint32_t ox = blockIdx.x * kSuper, oy = blockIdx.y * kSuper, oz = blockIdx.z * kSuper;
+    for (uint32_t i = threadIdx.x; i < kSuper * kSuper * kSuper; i += 256) {
+        const uint32_t x = ox + (i & 15), y = oy + ((i >> 4) & 15), z = oz + (i >> 8);
+        f[i] = (x < occ.nbx && y < occ.nby && z < occ.nbz) ? occ.fine[((size_t)z * occ.nby + y) * occ.nbx + x] : (unsigned char)1;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 512; i += 256) {
+        const uint32_t x = (i & 7) * 2, y = ((i >> 3) & 7) * 2, z = (i >> 6) * 2;
+        unsigned char o = 0;
+        for (int c = 0; c < 8; c++) o |= f[((z + (c >> 2)) << 8) | ((y + ((c >> 1) & 1)) << 4) | (x + (c & 1))];
+        l1[i] = o;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const uint32_t i = threadIdx.x, x = (i & 3) * 2, y = ((i >> 2) & 3) * 2, z = (i >> 4) * 2;
+        unsigned char o = 0;
+        for (int c = 0; c < 8; c++) o |= l1[((z + (c >> 2)) << 6) | ((y + ((c >> 1) & 1)) << 3) | (x + (c & 1))];
+        l2[i] = o;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const uint32_t i = threadIdx.x, x = (i & 1) * 2, y = ((i >> 1) & 1) * 2, z = (i >> 2) * 2;
+        unsigned char o = 0;
+        for (int c = 0; c < 8; c++) o |= l2[((z + (c >> 2)) << 4) | ((y + ((c >> 1) & 1)) << 2) | (x + (c & 1))];
+        l3[i] = o;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned char o = 0;
+        for (int c = 0; c < 8; c++) o |= l3[c];
+        l4[0] = o;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < kSuper * kSuper * kSuper; i += 256) {
+        const uint32_t lx = i & 15, ly = (i >> 4) & 15, lz = i >> 8;
+        const uint32_t x = ox + lx, y = oy + ly, z = oz + lz;
+        if (x >= occ.nbx || y >= occ.nby || z >= occ.nbz) continue;
+        unsigned char level = 0;
+        if (!f[i]) {
+            level = 1;
+            if (!l1[((lz >> 1) << 6) | ((ly >> 1) << 3) | (lx >> 1)]) {
+                level = 2;
+                if (!l2[((lz >> 2) << 4) | ((ly >> 2) << 2) | (lx >> 2)]) {
+                    level = 3;
+                    if (!l3[((lz >> 3) << 2) | ((ly >> 3) << 1) | (lx >> 3)]) level = l4[0] ? 4 : 5;
+                }
+            }
+        }
+        occ.reach[((size_t)z * occ.nby + y) * occ.nbx + x] = level;
     }
 }
 
@@ -108,6 +163,7 @@ static int occupancy_reset(tsdf_volume *v) {
     size_t n = v->occ.fine_count();
     hipLaunchKernelGGL(occupancy_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, v->stream, v->occ);
     TSDF_HIP(hipGetLastError(), "occupancy reset");
+    v->reach_dirty = 1;
     return TSDF_OK;
 }
 
@@ -118,6 +174,21 @@ int occupancy_rebuild(tsdf_volume *v) {
     hipLaunchKernelGGL(occupancy_build_kernel, grid, dim3(64), 0, v->stream, v->dist, v->g, v->occ);
     TSDF_HIP(hipGetLastError(), "occupancy rebuild");
     v->occ_dirty = 0;
+    v->reach_dirty = 1;
+    return TSDF_OK;
+}
+
+int occupancy_refresh(tsdf_volume *v) {
+    if (v->occ_dirty) {
+        int rc = occupancy_rebuild(v);
+        if (rc != TSDF_OK) return rc;
+    }
+    if (v->reach_dirty) {
+        dim3 grid((v->occ.nbx + kSuper - 1) / kSuper, (v->occ.nby + kSuper - 1) / kSuper, (v->occ.nbz + kSuper - 1) / kSuper);
+        hipLaunchKernelGGL(reach_mip_kernel, grid, dim3(256), 0, v->stream, v->occ);
+        TSDF_HIP(hipGetLastError(), "occupancy summary");
+        v->reach_dirty = 0;
+    }
     return TSDF_OK;
 }
 
@@ -250,13 +321,10 @@ int tsdf_volume_create_slab(uint32_t sx, uint32_t sy, uint32_t sz, float px, flo
     v->occ.nbx = (sx + kBrick - 1) / kBrick;
     v->occ.nby = (sy + kBrick - 1) / kBrick;
     v->occ.nbz = (sz + kBrick - 1) / kBrick;
-    v->occ.ncx = (sx + kCoarse - 1) / kCoarse;
-    v->occ.ncy = (sy + kCoarse - 1) / kCoarse;
-    v->occ.ncz = (sz + kCoarse - 1) / kCoarse;
     v->occ.tau = 0.01f * g.trunc;
     hipError_t e = hipGetDevice(&v->device);
     if (e == hipSuccess) e = hipMalloc((void **)&v->occ.fine, v->occ.fine_count());
-    if (e == hipSuccess) e = hipMalloc((void **)&v->occ.coarse, v->occ.coarse_count());
+    if (e == hipSuccess) e = hipMalloc((void **)&v->occ.reach, v->occ.fine_count());
     size_t bytes = v->resident_voxels() * sizeof(float);
     if (e == hipSuccess) e = hipMalloc((void **)&v->dist, bytes);
     if (e == hipSuccess) e = hipMalloc((void **)&v->weight, bytes);
@@ -294,7 +362,7 @@ int tsdf_volume_destroy(tsdf_volume *v) {
     if (v->norm_buf) (void)hipFree(v->norm_buf);
     if (v->counter_dev) (void)hipFree(v->counter_dev);
     if (v->occ.fine) (void)hipFree(v->occ.fine);
-    if (v->occ.coarse) (void)hipFree(v->occ.coarse);
+    if (v->occ.reach) (void)hipFree(v->occ.reach);
     if (v->t_table) (void)hipFree(v->t_table);
     if (v->seg_hits) (void)hipFree(v->seg_hits);
     if (v->brick_list) (void)hipFree(v->brick_list);
@@ -378,8 +446,8 @@ int tsdf_volume_set_header(tsdf_volume *v, const float offset[3], float trunc, f
 
 int tsdf_volume_occupancy(const tsdf_volume *v, uint64_t *occupied_bricks, uint64_t *total_bricks) {
     TSDF_REQUIRE(v && occupied_bricks && total_bricks, "null argument");
-    if (v->occ_dirty) {
-        int rc = occupancy_rebuild(const_cast<tsdf_volume *>(v));
+    {
+        int rc = occupancy_refresh(const_cast<tsdf_volume *>(v));
         if (rc != TSDF_OK) return rc;
     }
     size_t n = v->occ.fine_count();
