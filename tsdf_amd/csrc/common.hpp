@@ -76,6 +76,11 @@ struct Geom {
 //                  Bricks touching the grid boundary are set once and for all (there the reference extrapolates,
 //                  Q10, and the argument does not hold).  Sticky: integrate only ever sets flags, a rebuild
 //                  (clear / whole-array upload) resets them.
+//   cell[b] == 0 : every resident voxel in [4b, 4b+4] on every axis is > tau, i.e. all 8 taps of every dual cell
+//                  (lower corner) in [4b, 4b+4) are safely positive: a sample whose cell is KNOWN to lie in that
+//                  "cell brick" cannot be <= 0.  Tighter than `fine` (no slack for approximate location: the ray
+//                  caster uses it only for samples at least eps away from the cell faces).  Cell bricks that
+//                  contain cells beyond the grid are set for good.  Sticky like `fine`.
 //   reach[b]     : size class of the largest clear ALIGNED block of bricks containing b (0 = b is set; l >= 1 = the
 //                  aligned block of 2^(l-1) bricks per side is clear, up to kReachLevels).  A ray inside b may jump
 //                  to the faces of that block.  Recomputed from `fine` before a ray cast when stale (volume.hip).
@@ -89,6 +94,7 @@ constexpr int kSlabSkip = 32;       // voxels: granularity at which a slab passe
 constexpr int kSlabSkipShift = 5;
 struct OccGrid {
     uint8_t *fine;
+    uint8_t *cell;
     uint8_t *reach;
     uint32_t nbx, nby, nbz;  // bricks per axis = ceil(size / kBrick)
     float tau;               // "safely positive" threshold (a fraction of the truncation distance)

@@ -77,6 +77,14 @@ __device__ inline void mark_occupied(const OccGrid &occ, uint32_t vx, uint32_t v
     for (uint32_t bz = bz0; bz <= bz1; bz++)
         for (uint32_t by = by0; by <= by1; by++)
             for (uint32_t bx = bx0; bx <= bx1; bx++) occ.fine[((size_t)bz * occ.nby + by) * occ.nbx + bx] = 1;
+    // cell bricks whose voxel range [4b, 4b+4] contains the voxel: b = v/4, and b-1 when v is a multiple of 4
+    const uint32_t cx1 = vx >> kBrickShift, cy1 = vy >> kBrickShift, cz1 = vz >> kBrickShift;
+    const uint32_t cx0 = ((vx & (kBrick - 1)) == 0 && cx1 > 0) ? cx1 - 1 : cx1;
+    const uint32_t cy0 = ((vy & (kBrick - 1)) == 0 && cy1 > 0) ? cy1 - 1 : cy1;
+    const uint32_t cz0 = ((vz & (kBrick - 1)) == 0 && cz1 > 0) ? cz1 - 1 : cz1;
+    for (uint32_t bz = cz0; bz <= cz1; bz++)
+        for (uint32_t by = cy0; by <= cy1; by++)
+            for (uint32_t bx = cx0; bx <= cx1; bx++) occ.cell[((size_t)bz * occ.nby + by) * occ.nbx + bx] = 1;
 }
 
 constexpr int kDepthTile = 16;  // pixels per side of a depth tile

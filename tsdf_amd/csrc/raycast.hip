@@ -415,6 +415,8 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
 
     int k = (k_end <= k_first) ? kDone : k_first;  // next sample of this lane (kDone when finished)
     int k_brick_end = 0;               // the brick classification holds while k < k_brick_end
+    int k_cellbrick_end = 0;           // ... and the cell-brick classification while k < k_cellbrick_end
+    bool cellbrick_clear = false;
     uint32_t trips = 0, adv_iters = 0, hop_count = 0;  // diagnostics
 
     // One pass of the loop handles one sample index per lane, the same straight-line work for every lane:
@@ -453,7 +455,20 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
                     // the outer half-voxel shell of the grid, where the reference extrapolates (Q10), fails this)
                     const bool safe = fabsf(rx - 0.5f) < cell_half && fabsf(ry - 0.5f) < cell_half && fabsf(rz - 0.5f) < cell_half &&
                                       (uint32_t)lx < g.X - 1 && (uint32_t)ly < g.Y - 1 && (uint32_t)lz < g.Z - 1;
-                    if (safe) {
+                    if (safe && k >= k_cellbrick_end) {
+                        // the sample's cell is known exactly: is its whole cell brick (4^3 cells) clear?  If so the
+                        // samples up to the exit of that brick (shrunk by eps, in cell coordinates) cannot hit.
+                        const int qx = lx >> kBrickShift, qy = ly >> kBrickShift, qz = lz >> kBrickShift;
+                        const float e = sc.eps;
+                        const int n_cb = samples_to_exit(cx, cy, cz, sc, (float)(qx << kBrickShift) + e, (float)(qy << kBrickShift) + e,
+                                                         (float)(qz << kBrickShift) + e, (float)((qx + 1) << kBrickShift) - e,
+                                                         (float)((qy + 1) << kBrickShift) - e, (float)((qz + 1) << kBrickShift) - e);
+                        k_cellbrick_end = k + n_cb;
+                        cellbrick_clear = occ.cell[((size_t)qz * occ.nby + qy) * occ.nbx + qx] == 0;
+                    }
+                    if (safe && cellbrick_clear && k < k_cellbrick_end) {
+                        jump = k_cellbrick_end - k;
+                    } else if (safe) {
                         if (STATS) adv_iters++;  // diagnostics: cell tests
                         // samples until the ray leaves the cell shrunk by eps
                         const int n_cell = samples_to_exit(rx, ry, rz, sc, cell_lo, cell_lo, cell_lo, cell_hi, cell_hi, cell_hi);

@@ -67,12 +67,15 @@ __global__ __launch_bounds__(256) void init_nodes_kernel(tsdf_deformation_node *
 
 // Occupancy with nothing but the permanent boundary marks: fine bricks touching the grid boundary (first / last
 // brick of an axis, the last one possibly partial).
-__global__ __launch_bounds__(256) void occupancy_init_kernel(OccGrid occ) {
+__global__ __launch_bounds__(256) void occupancy_init_kernel(OccGrid occ, uint32_t size_x, uint32_t size_y, uint32_t size_z) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < occ.fine_count()) {
         uint32_t bx = i % occ.nbx, by = (i / occ.nbx) % occ.nby, bz = i / ((size_t)occ.nbx * occ.nby);
         bool boundary = bx == 0 || by == 0 || bz == 0 || bx + 1 == occ.nbx || by + 1 == occ.nby || bz + 1 == occ.nbz;
         occ.fine[i] = boundary ? 1 : 0;
+        // cell brick b holds dual cells 4b .. 4b+3; cells exist for lower corners 0 .. size-2
+        bool partial = bx * kBrick + kBrick > size_x - 1 || by * kBrick + kBrick > size_y - 1 || bz * kBrick + kBrick > size_z - 1;
+        occ.cell[i] = partial ? 1 : 0;
     }
 }
 
@@ -86,16 +89,23 @@ __global__ __launch_bounds__(64) void occupancy_build_kernel(const float *__rest
     const int z0 = max((int)(bz * kBrick) - kBrickGrow, (int)g.z_store_begin);
     const int z1 = min((int)(bz * kBrick) + kBrick + kBrickGrow, (int)g.z_store_end);
     const int nx = x1 - x0, ny = y1 - y0, nz = z1 - z0;
-    bool occupied = false;
+    bool occupied = false, cell_occupied = false;
+    // the cell brick's voxels [4b, 4b+4] are a subset of the grown region scanned for `fine`
+    const int cx0 = bx * kBrick, cx1 = bx * kBrick + kBrick, cy0 = by * kBrick, cy1 = by * kBrick + kBrick;
+    const int cz0 = bz * kBrick, cz1 = bz * kBrick + kBrick;
     if (nz > 0) {
         const int n = nx * ny * nz;
         for (int i = threadIdx.x; i < n; i += 64) {
             int x = x0 + i % nx, y = y0 + (i / nx) % ny, z = z0 + i / (nx * ny);
             float d = dist[(size_t)g.X * g.Y * (z - g.z_store_begin) + (size_t)g.X * y + x];
-            occupied |= !(d > occ.tau);  // also true for NaN
+            const bool bad = !(d > occ.tau);  // also true for NaN
+            occupied |= bad;
+            cell_occupied |= bad && x >= cx0 && x <= cx1 && y >= cy0 && y <= cy1 && z >= cz0 && z <= cz1;
         }
     }
-    if (__ballot(occupied) != 0ull && threadIdx.x == 0) occ.fine[((size_t)bz * occ.nby + by) * occ.nbx + bx] = 1;
+    const size_t b = ((size_t)bz * occ.nby + by) * occ.nbx + bx;
+    if (__ballot(occupied) != 0ull && threadIdx.x == 0) occ.fine[b] = 1;
+    if (__ballot(cell_occupied) != 0ull && threadIdx.x == 0) occ.cell[b] = 1;
 }
 
 // ---- reach[b]: size class of the largest EMPTY aligned block of bricks that contains brick b:
@@ -161,7 +171,7 @@ __global__ __launch_bounds__(256) void reach_mip_kernel(OccGrid occ) {
 
 static int occupancy_reset(tsdf_volume *v) {
     size_t n = v->occ.fine_count();
-    hipLaunchKernelGGL(occupancy_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, v->stream, v->occ);
+    hipLaunchKernelGGL(occupancy_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, v->stream, v->occ, v->g.X, v->g.Y, v->g.Z);
     TSDF_HIP(hipGetLastError(), "occupancy reset");
     v->reach_dirty = 1;
     return TSDF_OK;
@@ -324,6 +334,7 @@ int tsdf_volume_create_slab(uint32_t sx, uint32_t sy, uint32_t sz, float px, flo
     v->occ.tau = 0.01f * g.trunc;
     hipError_t e = hipGetDevice(&v->device);
     if (e == hipSuccess) e = hipMalloc((void **)&v->occ.fine, v->occ.fine_count());
+    if (e == hipSuccess) e = hipMalloc((void **)&v->occ.cell, v->occ.fine_count());
     if (e == hipSuccess) e = hipMalloc((void **)&v->occ.reach, v->occ.fine_count());
     size_t bytes = v->resident_voxels() * sizeof(float);
     if (e == hipSuccess) e = hipMalloc((void **)&v->dist, bytes);
@@ -362,6 +373,7 @@ int tsdf_volume_destroy(tsdf_volume *v) {
     if (v->norm_buf) (void)hipFree(v->norm_buf);
     if (v->counter_dev) (void)hipFree(v->counter_dev);
     if (v->occ.fine) (void)hipFree(v->occ.fine);
+    if (v->occ.cell) (void)hipFree(v->occ.cell);
     if (v->occ.reach) (void)hipFree(v->occ.reach);
     if (v->t_table) (void)hipFree(v->t_table);
     if (v->seg_hits) (void)hipFree(v->seg_hits);
