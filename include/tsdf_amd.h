@@ -136,6 +136,13 @@ int tsdf_integrate(tsdf_volume *volume, const uint16_t *host_depth, uint32_t wid
 int tsdf_integrate_device(tsdf_volume *volume, const uint16_t *device_depth, uint32_t width,
                           uint32_t height, const float pose[16], const float inv_pose[16],
                           const float k[9], const float kinv[9]);
+/* Optional kernel timing for roofline reports: when enabled, every launch of integrate_kernel (which = 0) and of
+ * process_ray_kernel (which = 1) is bracketed by HIP events on the volume's stream; tsdf_volume_kernel_time
+ * synchronises the stream and returns the number of launches and their average duration since timing was
+ * (re-)enabled.  Off by default (two event records per launch). */
+int tsdf_volume_set_timing(tsdf_volume *volume, int enabled);
+int tsdf_volume_kernel_time(tsdf_volume *volume, int which, uint32_t *launches, float *average_ms);
+
 /* Diagnostics: when enabled, integrate also counts the voxels whose weight changed (U in the
  * roofline model).  Costs one atomic per wave; leave off when timing. */
 int tsdf_volume_set_counting(tsdf_volume *volume, int enabled);

@@ -65,6 +65,8 @@ _SIGS = {
     "tsdf_volume_get_weight_data": (_i, [_vp, _vp]),
     "tsdf_integrate": (_i, [_vp, _vp, _u32, _u32, _fp, _fp, _fp, _fp]),
     "tsdf_integrate_device": (_i, [_vp, _vp, _u32, _u32, _fp, _fp, _fp, _fp]),
+    "tsdf_volume_set_timing": (_i, [_vp, _i]),
+    "tsdf_volume_kernel_time": (_i, [_vp, _i, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]),
     "tsdf_volume_set_counting": (_i, [_vp, _i]),
     "tsdf_volume_last_updated_voxels": (_i, [_vp, C.POINTER(C.c_uint64)]),
     "tsdf_raycast": (_i, [_vp, _u32, _u32, _fp, _fp, _vp, _vp]),

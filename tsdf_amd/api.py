@@ -170,6 +170,16 @@ class TSDFVolume:
         check(lib.tsdf_volume_occupancy(self._h, C.byref(o), C.byref(t)))
         return int(o.value), int(t.value)
 
+    def set_timing(self, enabled):
+        """HIP-event timing of integrate_kernel / process_ray_kernel launches on the volume's stream."""
+        check(lib.tsdf_volume_set_timing(self._h, 1 if enabled else 0))
+
+    def kernel_time(self, which):
+        """(launches, average ms) of which = 'integrate' | 'raycast' since set_timing(True)."""
+        n, ms = C.c_uint32(), C.c_float()
+        check(lib.tsdf_volume_kernel_time(self._h, {"integrate": 0, "raycast": 1}[which], C.byref(n), C.byref(ms)))
+        return int(n.value), float(ms.value)
+
     def set_counting(self, enabled):
         check(lib.tsdf_volume_set_counting(self._h, 1 if enabled else 0))
 

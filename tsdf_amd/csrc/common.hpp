@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <vector>
 
 #include "tsdf_amd.h"
 
@@ -23,6 +24,9 @@ int hip_fail(hipError_t e, const char *what);
 int occupancy_rebuild(struct ::tsdf_volume *v);  // volume.hip
 int occupancy_refresh(struct ::tsdf_volume *v);  // volume.hip: bring fine + reach up to date
 int build_t_table(struct ::tsdf_volume *v);      // volume.hip
+// timing helpers (volume.hip): bracket one launch of kernel `which` with events when timing is on
+void timing_begin(struct ::tsdf_volume *v, int which);
+void timing_end(struct ::tsdf_volume *v, int which);
 int verify_fast_division(struct ::tsdf_volume *v);  // volume.hip
 
 #define TSDF_HIP(call, what)                                  \
@@ -150,6 +154,9 @@ struct tsdf_volume {
     size_t brick_box_cap;
     uint16_t *tile_max;
     size_t tile_max_cap;
+    // optional HIP-event timing of the two dominant kernels on the volume's stream (tsdf_volume_set_timing)
+    int timing;
+    std::vector<hipEvent_t> *tev[2];  // [0] integrate_kernel, [1] process_ray_kernel: start/stop pairs
     // diagnostics
     int counting;
     unsigned long long *counter_dev;  // [0] = updated voxels, [1] = samples, [2] = hits

@@ -448,6 +448,7 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
 #define LAUNCH(DEF, CNT, STDC)                                                                                       \
     hipLaunchKernelGGL((integrate_kernel<DEF, CNT, STDC>), grid, block, 0, v->stream, v->dist, v->weight, v->nodes, \
                        g, bg, ip, mk, mkinv, width, height, d_depth, v->counter_dev, v->occ, v->brick_list, boxes, count)
+    timing_begin(v, 0);
     if (v->nodes) {
         if (v->counting) LAUNCH(true, true, false); else LAUNCH(true, false, false);
     } else if (std_camera) {
@@ -456,6 +457,7 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
         if (v->counting) LAUNCH(false, true, false); else LAUNCH(false, false, false);
     }
 #undef LAUNCH
+    timing_end(v, 0);
     TSDF_HIP(hipGetLastError(), "Integrate kernel failed");
     v->reach_dirty = 1;  // bricks may have been flagged
     return TSDF_OK;

@@ -684,12 +684,14 @@ int tsdf_raycast_device(const tsdf_volume *v, uint32_t width, uint32_t height, c
     }
     rp.seg_len = (kMaxSamples + kRaySegments - 1) / kRaySegments;
     dim3 grid((width + 15) / 16, (height + 15) / 16, kRaySegments);
+    timing_begin(mv, 1);
     if (v->fast_div)
         hipLaunchKernelGGL((process_ray_kernel<false, false, true, true, true>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp,
                            mv->seg_hits, (unsigned long long *)nullptr, (unsigned int *)nullptr, v->occ, v->t_table);
     else
         hipLaunchKernelGGL((process_ray_kernel<false, false, true, false, true>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp,
                            mv->seg_hits, (unsigned long long *)nullptr, (unsigned int *)nullptr, v->occ, v->t_table);
+    timing_end(mv, 1);
     TSDF_HIP(hipGetLastError(), "process_ray failed");
     hipLaunchKernelGGL(merge_hits_kernel, dim3((unsigned)((n_pix + 255) / 256)), dim3(256), 0, v->stream,
                        reinterpret_cast<const float4 *>(mv->seg_hits), (uint32_t)kRaySegments, (uint32_t)n_pix, device_vertices);

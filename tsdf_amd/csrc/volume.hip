@@ -259,6 +259,27 @@ int verify_fast_division(tsdf_volume *v) {
     return TSDF_OK;
 }
 
+void timing_begin(tsdf_volume *v, int which) {
+    if (!v->timing) return;
+    if (!v->tev[which]) v->tev[which] = new std::vector<hipEvent_t>();
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, v->stream);
+    v->tev[which]->push_back(e);
+}
+
+void timing_end(tsdf_volume *v, int which) {
+    if (!v->timing || !v->tev[which] || (v->tev[which]->size() & 1) == 0) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) {
+        (void)hipEventDestroy(v->tev[which]->back());
+        v->tev[which]->pop_back();
+        return;
+    }
+    (void)hipEventRecord(e, v->stream);
+    v->tev[which]->push_back(e);
+}
+
 static int init_nodes(tsdf_volume *v) {
     dim3 block(256, 1, 1);
     dim3 grid((v->g.X + 255) / 256, v->g.Y, v->g.z_store_end - v->g.z_store_begin);
@@ -377,6 +398,11 @@ int tsdf_volume_destroy(tsdf_volume *v) {
     if (v->occ.reach) (void)hipFree(v->occ.reach);
     if (v->t_table) (void)hipFree(v->t_table);
     if (v->seg_hits) (void)hipFree(v->seg_hits);
+    for (int w = 0; w < 2; w++)
+        if (v->tev[w]) {
+            for (hipEvent_t e : *v->tev[w]) (void)hipEventDestroy(e);
+            delete v->tev[w];
+        }
     if (v->brick_list) (void)hipFree(v->brick_list);
     if (v->brick_boxes) (void)hipFree(v->brick_boxes);
     if (v->tile_max) (void)hipFree(v->tile_max);
@@ -555,6 +581,37 @@ int tsdf_volume_get_distance_data(const tsdf_volume *v, float *host) {
 int tsdf_volume_get_weight_data(const tsdf_volume *v, float *host) {
     TSDF_REQUIRE(v, "null volume");
     return copy_out(v, host, v->weight, v->resident_voxels() * sizeof(float), "Couldn't read weight data");
+}
+
+int tsdf_volume_set_timing(tsdf_volume *v, int enabled) {
+    TSDF_REQUIRE(v, "null volume");
+    v->timing = enabled ? 1 : 0;
+    for (int w = 0; w < 2; w++)
+        if (v->tev[w]) {
+            for (hipEvent_t e : *v->tev[w]) (void)hipEventDestroy(e);
+            v->tev[w]->clear();
+        }
+    return TSDF_OK;
+}
+
+int tsdf_volume_kernel_time(tsdf_volume *v, int which, uint32_t *launches, float *average_ms) {
+    TSDF_REQUIRE(v && launches && average_ms && (which == 0 || which == 1), "bad argument");
+    *launches = 0;
+    *average_ms = 0.0f;
+    if (!v->tev[which] || v->tev[which]->size() < 2) return TSDF_OK;
+    TSDF_HIP(hipStreamSynchronize(v->stream), "kernel timing");
+    double total = 0.0;
+    uint32_t n = 0;
+    for (size_t i = 0; i + 1 < v->tev[which]->size(); i += 2) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, (*v->tev[which])[i], (*v->tev[which])[i + 1]) == hipSuccess) {
+            total += ms;
+            n++;
+        }
+    }
+    *launches = n;
+    *average_ms = n ? (float)(total / n) : 0.0f;
+    return TSDF_OK;
 }
 
 int tsdf_volume_set_counting(tsdf_volume *v, int enabled) {
