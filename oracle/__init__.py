@@ -307,7 +307,7 @@ def have_ref():
 
 def ref_bilateral_u8(image, width, height, sigma_colour, sigma_space):
     """The reference's own BilateralFilter (oracle/_ref, built from /root/reference/src/BilateralFilter.cpp)."""
-    L = C.CDLL(_REF)
+    L = C.CDLL(_REF, mode=getattr(os, "RTLD_LOCAL", 0) | getattr(os, "RTLD_DEEPBIND", 0))
     L.ref_bilateral_u8.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_float, C.c_float]
     img = np.ascontiguousarray(image, np.uint8).reshape(-1).copy()
     L.ref_bilateral_u8(img.ctypes.data_as(C.POINTER(C.c_uint8)), width, height, sigma_colour, sigma_space)

@@ -32,7 +32,7 @@ def _load():
         raise ImportError(
             "tsdf_amd: %s is missing -- build it with `make hip` (or `python -c 'import __graft_entry__ as g; "
             "g.build()'`). There is no CPU fallback." % LIB_PATH)
-    return C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    return C.CDLL(LIB_PATH)      # RTLD_LOCAL: the class names of the host library must not leak into other .so files
 
 
 lib = _load()
@@ -113,7 +113,7 @@ def check(rc):
 HOST_LIB_PATH = os.path.join(_HERE, "lib", "libtsdf_host.so")
 if not os.path.exists(HOST_LIB_PATH):
     raise ImportError("tsdf_amd: %s is missing -- build it with `make host`." % HOST_LIB_PATH)
-host = C.CDLL(HOST_LIB_PATH, mode=C.RTLD_GLOBAL)
+host = C.CDLL(HOST_LIB_PATH)
 _ip = C.POINTER(C.c_int)
 _HOST_SIGS = {
     "tsdf_camera_create": (_vp, [_f, _f, _f, _f]),
