@@ -32,7 +32,10 @@ def _load():
         raise ImportError(
             "tsdf_amd: %s is missing -- build it with `make hip` (or `python -c 'import __graft_entry__ as g; "
             "g.build()'`). There is no CPU fallback." % LIB_PATH)
-    return C.CDLL(LIB_PATH)      # RTLD_LOCAL: the class names of the host library must not leak into other .so files
+    # RTLD_GLOBAL on purpose: torch ships its own libamdhip64 under a different NEEDED name, so a process can hold
+    # two HIP runtimes; with the first-loaded one in the global scope everything binds to that single runtime
+    # whichever of torch / this library is imported first.  (Only tsdf_* and tsdf:: symbols are exported here.)
+    return C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
 
 
 lib = _load()
@@ -113,6 +116,8 @@ def check(rc):
 HOST_LIB_PATH = os.path.join(_HERE, "lib", "libtsdf_host.so")
 if not os.path.exists(HOST_LIB_PATH):
     raise ImportError("tsdf_amd: %s is missing -- build it with `make host`." % HOST_LIB_PATH)
+# RTLD_LOCAL: this library defines the reference's class names (BilateralFilter, Camera, ...); they must not
+# interpose the same names inside other shared objects (e.g. the reference build the tests compare against).
 host = C.CDLL(HOST_LIB_PATH)
 _ip = C.POINTER(C.c_int)
 _HOST_SIGS = {
