@@ -174,6 +174,10 @@ int tsdf_raycast_evaluated_samples(const tsdf_volume *volume, uint32_t width, ui
                                    const float pose[16], const float kinv[9], uint64_t *evaluated,
                                    float *host_per_ray /* optional 3*W*H: samples, loop trips, count */);
 int tsdf_volume_occupancy(const tsdf_volume *volume, uint64_t *occupied_bricks, uint64_t *total_bricks);
+/* Diagnostics / tests: the per-brick bytes themselves (ceil(X/4) * ceil(Y/4) * ceil(Z/4) each, x fastest; any pointer
+ * may be NULL).  force_rebuild != 0 recomputes the flags from the distance array first. */
+int tsdf_volume_get_occupancy_data(const tsdf_volume *volume, int force_rebuild, uint8_t *host_fine, uint8_t *host_cell,
+                                   uint8_t *host_reach);
 
 /* Multi-GPU raycast: a slab evaluates only the samples whose lower trilinear
  * tap plane it owns and writes one 16-byte record per pixel {k, x, y, z}: k = index of the

@@ -1,0 +1,90 @@
+"""The brick flags the ray caster skips on (tsdf_amd/csrc/volume.hip: occupancy_rebuild, reach_mip_kernel) against
+a direct numpy evaluation of their definition.  They are an internal acceleration structure -- every parity test of
+the ray caster depends on them being conservative -- so they are pinned separately here: exact equality after a
+rebuild, and 'never less than exact' for the marks integrate leaves between rebuilds."""
+import numpy as np
+import pytest
+
+import tsdf_amd
+from tsdf_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _expected(D, dims, tau, planes=None):
+    X, Y, Z = dims
+    low = ~(D.reshape(Z, Y, X) > tau)                       # also NaN
+    if planes is not None:                                   # slab: only resident planes are scanned
+        keep = np.zeros(Z, bool)
+        keep[planes[0]:planes[1]] = True
+        low &= keep[:, None, None]
+    nbx, nby, nbz = (X + 3) // 4, (Y + 3) // 4, (Z + 3) // 4
+    fine = np.zeros((nbz, nby, nbx), np.uint8)
+    cell = np.zeros((nbz, nby, nbx), np.uint8)
+    for bz in range(nbz):
+        for by in range(nby):
+            for bx in range(nbx):
+                g = low[max(4 * bz - 2, 0):4 * bz + 6, max(4 * by - 2, 0):4 * by + 6, max(4 * bx - 2, 0):4 * bx + 6]
+                boundary = bx == 0 or by == 0 or bz == 0 or bx == nbx - 1 or by == nby - 1 or bz == nbz - 1
+                fine[bz, by, bx] = 1 if (boundary or g.any()) else 0
+                c = low[4 * bz:4 * bz + 5, 4 * by:4 * by + 5, 4 * bx:4 * bx + 5]
+                partial = 4 * bx + 4 > X - 1 or 4 * by + 4 > Y - 1 or 4 * bz + 4 > Z - 1
+                cell[bz, by, bx] = 1 if (partial or c.any()) else 0
+    return fine, cell
+
+
+def _expected_reach(fine):
+    nbz, nby, nbx = fine.shape
+    reach = np.zeros_like(fine)
+    for bz in range(nbz):
+        for by in range(nby):
+            for bx in range(nbx):
+                level = 0
+                for l in range(1, 6):
+                    s = 1 << (l - 1)
+                    z0, y0, x0 = (bz // s) * s, (by // s) * s, (bx // s) * s
+                    if z0 + s > nbz or y0 + s > nby or x0 + s > nbx:
+                        break                                 # blocks sticking out of the grid are never empty
+                    if fine[z0:z0 + s, y0:y0 + s, x0:x0 + s].any():
+                        break
+                    level = l
+                reach[bz, by, bx] = level
+    return reach
+
+
+@pytest.mark.parametrize("dims", [(48, 40, 44), (37, 30, 41), (72, 72, 72)])
+def test_rebuilt_flags_equal_their_definition(dims):
+    X, Y, Z = dims
+    rng = np.random.default_rng(X * 1000 + Y)
+    v = tsdf_amd.TSDFVolume(dims, (X * 10.0, Y * 10.0, Z * 10.0))
+    trunc = v.truncation_distance()
+    tau = np.float32(0.01) * np.float32(trunc)
+    D = np.full(X * Y * Z, trunc, np.float32)
+    # a sprinkle of isolated low voxels, values straddling tau, one NaN, and a small solid block
+    idx = rng.choice(D.size, size=max(6, D.size // 4000), replace=False)
+    D[idx] = rng.choice(np.array([-trunc, 0.0, tau, np.nextafter(tau, np.float32(1e9)), 0.5 * tau], np.float32), idx.size)
+    D[idx[0]] = np.nan
+    Dv = D.reshape(Z, Y, X)
+    Dv[Z // 2:Z // 2 + 3, Y // 2:Y // 2 + 5, X // 2:X // 2 + 4] = -1.0
+    v.set_distance_data(D)
+    fine, cell, reach = v.occupancy_data(force_rebuild=True)
+    ef, ec = _expected(D, dims, tau)
+    assert np.array_equal(fine, ef)
+    assert np.array_equal(cell, ec)
+    assert np.array_equal(reach, _expected_reach(ef))
+
+
+def test_marks_left_by_integrate_cover_the_exact_flags_and_rebuild_tightens_them():
+    n = 96
+    v = tsdf_amd.TSDFVolume((n, n, n), (3000.0,) * 3)
+    tau = np.float32(0.01) * np.float32(v.truncation_distance())
+    for i in range(3):
+        d, cam = synth.depth_frame(i * 5, 200, seed=0x5EED0003)
+        v.integrate(d, synth.WIDTH, synth.HEIGHT, cam)
+    sticky_fine, sticky_cell, _ = v.occupancy_data()
+    D = v.get_distance_data()
+    ef, ec = _expected(D, (n, n, n), tau)
+    assert np.all(sticky_fine >= ef) and np.all(sticky_cell >= ec)
+    fine, cell, _ = v.occupancy_data(force_rebuild=True)
+    assert np.array_equal(fine, ef) and np.array_equal(cell, ec)
+    assert fine.sum() <= sticky_fine.sum()

@@ -1,16 +1,25 @@
+"""Times the ray cast alone (kernel-only HIP events) on the bench scene: python tools/dbg_ray_only.py [frames]"""
 import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, tsdf_amd, time, torch
 from tsdf_amd import synth
 n=512
+frames=int(sys.argv[1]) if len(sys.argv)>1 else 8
 v=tsdf_amd.TSDFVolume((n,n,n),(3000.,)*3)
 bil=tsdf_amd.BilateralFilter(30.0,4.5)
 rc=tsdf_amd.GPURaycaster(640,480)
 vert=torch.empty((640*480,3),dtype=torch.float32,device='cuda')
 s=torch.cuda.current_stream(); v.set_stream(s.cuda_stream)
-for i in range(0,8):
+for i in range(0,frames):
     d,cam=synth.depth_frame(i,200,seed=0x5EED0003)
     f=d.copy(); bil.filter(f,640,480)
     v.integrate(f,640,480,cam)
-for r in range(5):
+for r in range(3):
     rc.raycast_device(v,cam,vert.data_ptr(),None)
 torch.cuda.synchronize()
+v.set_timing(True)
+t=time.time()
+for r in range(20):
+    rc.raycast_device(v,cam,vert.data_ptr(),None)
+torch.cuda.synchronize()
+wall=(time.time()-t)/20*1e3
+print("segments", os.environ.get("TSDF_RAY_SEGMENTS","default"), "kernel ms", v.kernel_time("raycast"), "wall ms per raycast", round(wall,4))

@@ -15,3 +15,5 @@ ev,hops,cells=pr[...,0],pr[...,1],pr[...,2]
 print("per ray: exact", ev.mean(), "hops", hops.mean(), np.percentile(hops,[50,90,99]), "cell tests", cells.mean(), np.percentile(cells,[50,90,99]))
 tot=ev+hops+cells
 print("lane trips mean", tot.mean(), "per-wave max mean", tot.reshape(60,8,80,8).max(axis=(1,3)).mean())
+os.makedirs("gpurun_out", exist_ok=True)
+np.savez_compressed("gpurun_out/per_ray.npz", ev=ev.astype(np.uint16), hops=hops.astype(np.uint16), cells=cells.astype(np.uint16))

@@ -170,6 +170,14 @@ class TSDFVolume:
         check(lib.tsdf_volume_occupancy(self._h, C.byref(o), C.byref(t)))
         return int(o.value), int(t.value)
 
+    def occupancy_data(self, force_rebuild=False):
+        """(fine, cell, reach) uint8 arrays of shape (nbz, nby, nbx): the ray caster's brick flags (diagnostics)."""
+        X, Y, Z = self.size()
+        shape = ((Z + 3) // 4, (Y + 3) // 4, (X + 3) // 4)
+        out = [np.empty(shape, np.uint8) for _ in range(3)]
+        check(lib.tsdf_volume_get_occupancy_data(self._h, 1 if force_rebuild else 0, *[a.ctypes.data for a in out]))
+        return tuple(out)
+
     def set_timing(self, enabled):
         """HIP-event timing of integrate_kernel / process_ray_kernel launches on the volume's stream."""
         check(lib.tsdf_volume_set_timing(self._h, 1 if enabled else 0))

@@ -147,6 +147,11 @@ struct tsdf_volume {
     tsdf::OccGrid occ;
     int occ_dirty;   // 1 = rebuild from the distance array before the next ray cast
     int reach_dirty; // 1 = `fine` changed since `reach` was computed
+    uint16_t *occ_bits;              // scratch of the rebuild: 16 summary bits per brick (volume.hip)
+    // integrate only ever SETS flags (a voxel that stops being low is not noticed), so the flags are refreshed from
+    // the distance array after 2, 4, 8, 16 integrations and then every kOccRebuildPeriod (integrate.hip)
+    uint32_t integrations_since_rebuild;
+    uint32_t integrations_total;
     // integrate scratch: compact list of bricks a frame can touch (+ its counter), depth tile maxima
     uint32_t *brick_list;
     size_t brick_list_cap;

@@ -27,6 +27,8 @@
 #include <algorithm>
 #include <cmath>
 
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace tsdf {
@@ -88,6 +90,15 @@ __device__ inline void mark_occupied(const OccGrid &occ, uint32_t vx, uint32_t v
 }
 
 constexpr int kDepthTile = 16;  // pixels per side of a depth tile
+
+static uint32_t occupancy_rebuild_period() {
+    static const uint32_t n = [] {
+        const char *e = getenv("TSDF_OCC_REBUILD_PERIOD");  // tuning aid; 0 = never
+        int v = e ? atoi(e) : 16;
+        return (uint32_t)(v < 0 ? 0 : v);
+    }();
+    return n;
+}
 
 // Max depth per 16x16 pixel tile (0 = the tile holds no valid depth).  One wave per tile.
 __global__ __launch_bounds__(64) void depth_tile_max_kernel(const uint16_t *__restrict__ depth, uint32_t width,
@@ -460,6 +471,17 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
     timing_end(v, 0);
     TSDF_HIP(hipGetLastError(), "Integrate kernel failed");
     v->reach_dirty = 1;  // bricks may have been flagged
+    // The kernel only sets occupancy flags.  A voxel that was low when first seen (sensor dropouts smeared by the
+    // bilateral filter put phantom surfaces into free space) and has since been averaged back up keeps its bricks
+    // flagged, which fragments the empty regions the ray caster jumps over; so the flags are recomputed from the
+    // distances (volume.hip: occupancy_rebuild, one streaming read) after 2, 4, 8, 16 frames, then every period.
+    v->integrations_total++;
+    v->integrations_since_rebuild++;
+    const uint32_t period = occupancy_rebuild_period();
+    if (period && (v->integrations_since_rebuild >= period ||
+                   (v->integrations_total <= period && (v->integrations_total & (v->integrations_total - 1)) == 0 &&
+                    v->integrations_total >= 2)))
+        v->occ_dirty = 1;
     return TSDF_OK;
 }
 

@@ -260,14 +260,19 @@ struct SkipCtx {
 };
 
 // Samples (>= 1) from the one at voxel coordinate (fx,fy,fz) until the ray leaves the axis-aligned box
-// [lo, hi) given in voxel units.
+// [lo, hi) given in voxel units.  x = (exit parameter) / step: samples k .. k + ceil(x) - 1 are inside the box,
+// sample k + ceil(x) is the first one beyond it.  ALL = true returns ceil(x) (every inside sample; the estimate of x is
+// good to ~1e-2 voxel, which the one-voxel slack of the brick-level flags absorbs), ALL = false returns floor(x) and so
+// keeps up to one step of margin (cell-level boxes, whose only slack is eps).
+template <bool ALL>
 __device__ inline int samples_to_exit(float fx, float fy, float fz, const SkipCtx &c, float lox, float loy, float loz,
                                       float hix, float hiy, float hiz) {
     const float ex = (c.px_ ? hix - fx : fx - lox) * c.tx;
     const float ey = (c.py_ ? hiy - fy : fy - loy) * c.ty;
     const float ez = (c.pz_ ? hiz - fz : fz - loz) * c.tz;
     // fminf ignores a NaN (0 * inf when the ray runs inside a face of the box)
-    return (int)fminf(fmaxf(fminf(ex, fminf(ey, ez)) * c.inv_step, 1.0f), 8192.0f);
+    const float x = fminf(ex, fminf(ey, ez)) * c.inv_step;
+    return (int)fminf(fmaxf(ALL ? ceilf(x) : x, 1.0f), 8192.0f);
 }
 
 // Locates the sample at voxel coordinate f = p / vs in the brick grid.  Returns true when the samples from this
@@ -288,13 +293,13 @@ __device__ inline bool locate(float fx, float fy, float fz, const SkipCtx &c, co
         const int cz0 = (vz >> kSlabSkipShift) << kSlabSkipShift, bz0 = (vz >> kBrickShift) << kBrickShift;
         if (cz0 + kSlabSkip < own_lo || cz0 - 2 >= own_hi) {
             const int cx0 = (vx >> kSlabSkipShift) << kSlabSkipShift, cy0 = (vy >> kSlabSkipShift) << kSlabSkipShift;
-            n = samples_to_exit(fx, fy, fz, c, (float)cx0, (float)cy0, (float)cz0, (float)(cx0 + kSlabSkip),
+            n = samples_to_exit<true>(fx, fy, fz, c, (float)cx0, (float)cy0, (float)cz0, (float)(cx0 + kSlabSkip),
                                 (float)(cy0 + kSlabSkip), (float)(cz0 + kSlabSkip));
             return true;
         }
         if (bz0 + kBrick < own_lo || bz0 - 2 >= own_hi) {
             const int bx0 = (vx >> kBrickShift) << kBrickShift, by0 = (vy >> kBrickShift) << kBrickShift;
-            n = samples_to_exit(fx, fy, fz, c, (float)bx0, (float)by0, (float)bz0, (float)(bx0 + kBrick), (float)(by0 + kBrick),
+            n = samples_to_exit<true>(fx, fy, fz, c, (float)bx0, (float)by0, (float)bz0, (float)(bx0 + kBrick), (float)(by0 + kBrick),
                                 (float)(bz0 + kBrick));
             return true;
         }
@@ -304,7 +309,7 @@ __device__ inline bool locate(float fx, float fy, float fz, const SkipCtx &c, co
     // aligned block of 4 * 2^(reach-1) voxels per side (the brick itself when reach is 0)
     const int shift = kBrickShift + max(reach, 1) - 1, size = 1 << shift;
     const int x0 = (vx >> shift) << shift, y0 = (vy >> shift) << shift, z0 = (vz >> shift) << shift;
-    n = samples_to_exit(fx, fy, fz, c, (float)x0, (float)y0, (float)z0, (float)(x0 + size), (float)(y0 + size), (float)(z0 + size));
+    n = samples_to_exit<true>(fx, fy, fz, c, (float)x0, (float)y0, (float)z0, (float)(x0 + size), (float)(y0 + size), (float)(z0 + size));
     return reach != 0;
 }
 
@@ -460,7 +465,7 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
                         // samples up to the exit of that brick (shrunk by eps, in cell coordinates) cannot hit.
                         const int qx = lx >> kBrickShift, qy = ly >> kBrickShift, qz = lz >> kBrickShift;
                         const float e = sc.eps;
-                        const int n_cb = samples_to_exit(cx, cy, cz, sc, (float)(qx << kBrickShift) + e, (float)(qy << kBrickShift) + e,
+                        const int n_cb = samples_to_exit<false>(cx, cy, cz, sc, (float)(qx << kBrickShift) + e, (float)(qy << kBrickShift) + e,
                                                          (float)(qz << kBrickShift) + e, (float)((qx + 1) << kBrickShift) - e,
                                                          (float)((qy + 1) << kBrickShift) - e, (float)((qz + 1) << kBrickShift) - e);
                         k_cellbrick_end = k + n_cb;
@@ -471,7 +476,7 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
                     } else if (safe) {
                         if (STATS) adv_iters++;  // diagnostics: cell tests
                         // samples until the ray leaves the cell shrunk by eps
-                        const int n_cell = samples_to_exit(rx, ry, rz, sc, cell_lo, cell_lo, cell_lo, cell_hi, cell_hi, cell_hi);
+                        const int n_cell = samples_to_exit<false>(rx, ry, rz, sc, cell_lo, cell_lo, cell_lo, cell_hi, cell_hi, cell_hi);
                         if (SLAB && !((uint32_t)lz >= rp.own_lo && (uint32_t)lz < rp.own_hi)) {
                             jump = n_cell;  // not this rank's samples (and possibly not its planes): passed unevaluated
                         } else {

@@ -79,33 +79,88 @@ __global__ __launch_bounds__(256) void occupancy_init_kernel(OccGrid occ, uint32
     }
 }
 
-// Rebuild of the occupancy from the distance array: one wave per fine brick scans the brick grown by
-// kBrickGrow voxels (clamped to the grid and to the resident planes) and sets the brick if any value is not
-// safely positive.  The overlap between neighbouring bricks is served by L2.
-__global__ __launch_bounds__(64) void occupancy_build_kernel(const float *__restrict__ dist, Geom g, OccGrid occ) {
-    const uint32_t bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    const int x0 = max((int)(bx * kBrick) - kBrickGrow, 0), x1 = min((int)(bx * kBrick) + kBrick + kBrickGrow, (int)g.X);
-    const int y0 = max((int)(by * kBrick) - kBrickGrow, 0), y1 = min((int)(by * kBrick) + kBrick + kBrickGrow, (int)g.Y);
-    const int z0 = max((int)(bz * kBrick) - kBrickGrow, (int)g.z_store_begin);
-    const int z1 = min((int)(bz * kBrick) + kBrick + kBrickGrow, (int)g.z_store_end);
-    const int nx = x1 - x0, ny = y1 - y0, nz = z1 - z0;
-    bool occupied = false, cell_occupied = false;
-    // the cell brick's voxels [4b, 4b+4] are a subset of the grown region scanned for `fine`
-    const int cx0 = bx * kBrick, cx1 = bx * kBrick + kBrick, cy0 = by * kBrick, cy1 = by * kBrick + kBrick;
-    const int cz0 = bz * kBrick, cz1 = bz * kBrick + kBrick;
-    if (nz > 0) {
-        const int n = nx * ny * nz;
-        for (int i = threadIdx.x; i < n; i += 64) {
-            int x = x0 + i % nx, y = y0 + (i / nx) % ny, z = z0 + i / (nx * ny);
-            float d = dist[(size_t)g.X * g.Y * (z - g.z_store_begin) + (size_t)g.X * y + x];
-            const bool bad = !(d > occ.tau);  // also true for NaN
-            occupied |= bad;
-            cell_occupied |= bad && x >= cx0 && x <= cx1 && y >= cy0 && y <= cy1 && z >= cz0 && z <= cz1;
+// Rebuild of the occupancy from the distance array, in two steps.
+//
+// 1. occupancy_scan_kernel streams the resident planes once (float4 per lane, coalesced) and leaves 16 bits per
+//    4^3 brick: bits 0-7 = which of the brick's eight 2^3-voxel octants hold a value that is not safely positive
+//    (octant index xo + 2 yo + 4 zo); bits 8-15 = the same question for the whole brick (A), its x = 0, y = 0, z = 0
+//    voxel layers (Fx, Fy, Fz), the three edges shared by two of those layers (Exy, Exz, Eyz) and the corner voxel (C).
+// 2. occupancy_flags_kernel combines the 27 neighbours: `fine[b]` = some octant inside the brick grown by kBrickGrow = 2
+//    voxels (= one octant) is marked; `cell[b]` = some voxel in [4b, 4b+4]^3 is marked, i.e. the brick itself plus the
+//    x/y/z = 0 layers, edges and corner of the bricks on its + side.  Boundary / partial bricks keep their permanent marks.
+// Workgroup of scan: 64 bricks along x (lane) x the 4 voxel rows of one brick row (wave); loops over the brick's 4 planes.
+__global__ __launch_bounds__(256) void occupancy_scan_kernel(const float *__restrict__ dist, Geom g, OccGrid occ,
+                                                             uint16_t *__restrict__ bits) {
+    __shared__ uint32_t acc[64];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t bx = blockIdx.x * 64 + lane, by = blockIdx.y, bz = blockIdx.z;
+    const uint32_t y = by * kBrick + wave;
+    if (threadIdx.x < 64) acc[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t oct = 0, low = 0;
+    if (bx < occ.nbx && y < g.Y) {
+        const uint32_t x0 = bx * kBrick;
+        const bool vec = (g.X & 3u) == 0;  // rows are 16-byte aligned and a brick never straddles the row end
+        const uint32_t y0f = wave == 0 ? 1u : 0u, yo = wave >> 1;
+        for (uint32_t j = 0; j < (uint32_t)kBrick; j++) {
+            const uint32_t z = bz * kBrick + j;
+            if (z < g.z_store_begin || z >= g.z_store_end) continue;  // not resident (or beyond the grid)
+            const float *row = dist + ((size_t)g.X * g.Y * (z - g.z_store_begin) + (size_t)g.X * y + x0);
+            uint32_t m = 0;  // bit i: voxel x0 + i is not safely positive (also true for NaN)
+            if (vec) {
+                const float4 d = *reinterpret_cast<const float4 *>(row);
+                m = (!(d.x > occ.tau) ? 1u : 0u) | (!(d.y > occ.tau) ? 2u : 0u) | (!(d.z > occ.tau) ? 4u : 0u) | (!(d.w > occ.tau) ? 8u : 0u);
+            } else {
+                for (uint32_t i = 0; i < (uint32_t)kBrick; i++)
+                    if (x0 + i < g.X && !(row[i] > occ.tau)) m |= 1u << i;
+            }
+            if (m) {
+                const uint32_t zo = j >> 1, z0f = j == 0 ? 1u : 0u, fx = m & 1u;
+                if (m & 3u) oct |= 1u << (0 + 2 * yo + 4 * zo);
+                if (m & 12u) oct |= 1u << (1 + 2 * yo + 4 * zo);
+                low |= 1u | (fx << 1) | (y0f << 2) | (z0f << 3) | ((fx & y0f) << 4) | ((fx & z0f) << 5) | ((y0f & z0f) << 6) |
+                       ((fx & y0f & z0f) << 7);
+            }
         }
     }
-    const size_t b = ((size_t)bz * occ.nby + by) * occ.nbx + bx;
-    if (__ballot(occupied) != 0ull && threadIdx.x == 0) occ.fine[b] = 1;
-    if (__ballot(cell_occupied) != 0ull && threadIdx.x == 0) occ.cell[b] = 1;
+    const uint32_t both = oct | (low << 8);
+    if (both) atomicOr(&acc[lane], both);
+    __syncthreads();
+    if (threadIdx.x < 64 && bx < occ.nbx) bits[((size_t)bz * occ.nby + by) * occ.nbx + bx] = (uint16_t)acc[lane];
+}
+
+__global__ __launch_bounds__(256) void occupancy_flags_kernel(const uint16_t *__restrict__ bits, OccGrid occ, uint32_t size_x,
+                                                              uint32_t size_y, uint32_t size_z) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= occ.fine_count()) return;
+    const int bx = (int)(i % occ.nbx), by = (int)((i / occ.nbx) % occ.nby), bz = (int)(i / ((size_t)occ.nbx * occ.nby));
+    // the permanent marks of occupancy_init_kernel
+    bool fine = bx == 0 || by == 0 || bz == 0 || bx + 1 == (int)occ.nbx || by + 1 == (int)occ.nby || bz + 1 == (int)occ.nbz;
+    bool cell = bx * kBrick + kBrick > (int)size_x - 1 || by * kBrick + kBrick > (int)size_y - 1 || bz * kBrick + kBrick > (int)size_z - 1;
+    // octants of a neighbour at offset d that lie within 2 voxels of this brick: all (d = 0), the high half (d = -1),
+    // the low half (d = +1); per axis, as masks over the octant index xo + 2 yo + 4 zo
+    const uint32_t mx[3] = {0xAAu, 0xFFu, 0x55u}, my[3] = {0xCCu, 0xFFu, 0x33u}, mz[3] = {0xF0u, 0xFFu, 0x0Fu};
+    for (int dz = -1; dz <= 1; dz++) {
+        const int z = bz + dz;
+        if (z < 0 || z >= (int)occ.nbz) continue;
+        for (int dy = -1; dy <= 1; dy++) {
+            const int y = by + dy;
+            if (y < 0 || y >= (int)occ.nby) continue;
+            for (int dx = -1; dx <= 1; dx++) {
+                const int x = bx + dx;
+                if (x < 0 || x >= (int)occ.nbx) continue;
+                const uint32_t w = bits[((size_t)z * occ.nby + y) * occ.nbx + x];
+                if (w & mx[dx + 1] & my[dy + 1] & mz[dz + 1]) fine = true;
+                if (dx >= 0 && dy >= 0 && dz >= 0) {
+                    // which summary of the + side neighbour touches [4b, 4b+4]^3: A, Fx, Fy, Exy, Fz, Exz, Eyz, C
+                    const uint32_t sel[8] = {1u << 8, 1u << 9, 1u << 10, 1u << 12, 1u << 11, 1u << 13, 1u << 14, 1u << 15};
+                    if (w & sel[dx + 2 * dy + 4 * dz]) cell = true;
+                }
+            }
+        }
+    }
+    occ.fine[i] = fine ? 1 : 0;
+    occ.cell[i] = cell ? 1 : 0;
 }
 
 // ---- reach[b]: size class of the largest EMPTY aligned block of bricks that contains brick b:
@@ -178,13 +233,17 @@ static int occupancy_reset(tsdf_volume *v) {
 }
 
 int occupancy_rebuild(tsdf_volume *v) {
-    int rc = occupancy_reset(v);
-    if (rc != TSDF_OK) return rc;
-    dim3 grid(v->occ.nbx, v->occ.nby, v->occ.nbz);
-    hipLaunchKernelGGL(occupancy_build_kernel, grid, dim3(64), 0, v->stream, v->dist, v->g, v->occ);
+    const size_t n = v->occ.fine_count();
+    if (!v->occ_bits) TSDF_HIP(hipMalloc((void **)&v->occ_bits, n * sizeof(uint16_t)), "occupancy scratch alloc");
+    dim3 grid((v->occ.nbx + 63) / 64, v->occ.nby, v->occ.nbz);
+    hipLaunchKernelGGL(occupancy_scan_kernel, grid, dim3(256), 0, v->stream, v->dist, v->g, v->occ, v->occ_bits);
+    TSDF_HIP(hipGetLastError(), "occupancy scan");
+    hipLaunchKernelGGL(occupancy_flags_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, v->stream, v->occ_bits, v->occ,
+                       v->g.X, v->g.Y, v->g.Z);
     TSDF_HIP(hipGetLastError(), "occupancy rebuild");
     v->occ_dirty = 0;
     v->reach_dirty = 1;
+    v->integrations_since_rebuild = 0;
     return TSDF_OK;
 }
 
@@ -396,6 +455,7 @@ int tsdf_volume_destroy(tsdf_volume *v) {
     if (v->occ.fine) (void)hipFree(v->occ.fine);
     if (v->occ.cell) (void)hipFree(v->occ.cell);
     if (v->occ.reach) (void)hipFree(v->occ.reach);
+    if (v->occ_bits) (void)hipFree(v->occ_bits);
     if (v->t_table) (void)hipFree(v->t_table);
     if (v->seg_hits) (void)hipFree(v->seg_hits);
     for (int w = 0; w < 2; w++)
@@ -431,6 +491,7 @@ int tsdf_volume_clear(tsdf_volume *v) {
     int rc0 = occupancy_reset(v);
     if (rc0 != TSDF_OK) return rc0;
     v->occ_dirty = 0;
+    v->integrations_since_rebuild = v->integrations_total = 0;
     // initialise_deformation bakes the CURRENT offset into the node translations (Q1)
     v->g.offset_clear = v->g.offset;
     if (v->nodes) return init_nodes(v);
@@ -502,6 +563,23 @@ int tsdf_volume_occupancy(const tsdf_volume *v, uint64_t *occupied_bricks, uint6
     if (e != hipSuccess) return hip_fail(e, "read occupancy");
     *occupied_bricks = c;
     *total_bricks = n;
+    return TSDF_OK;
+}
+
+int tsdf_volume_get_occupancy_data(const tsdf_volume *cv, int force_rebuild, uint8_t *host_fine, uint8_t *host_cell,
+                                   uint8_t *host_reach) {
+    TSDF_REQUIRE(cv, "null volume");
+    tsdf_volume *v = const_cast<tsdf_volume *>(cv);
+    if (force_rebuild) v->occ_dirty = 1;
+    int rc = occupancy_refresh(v);
+    if (rc != TSDF_OK) return rc;
+    const size_t n = v->occ.fine_count();
+    hipError_t e = hipSuccess;
+    if (host_fine) e = hipMemcpyAsync(host_fine, v->occ.fine, n, hipMemcpyDeviceToHost, v->stream);
+    if (e == hipSuccess && host_cell) e = hipMemcpyAsync(host_cell, v->occ.cell, n, hipMemcpyDeviceToHost, v->stream);
+    if (e == hipSuccess && host_reach) e = hipMemcpyAsync(host_reach, v->occ.reach, n, hipMemcpyDeviceToHost, v->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(v->stream);
+    if (e != hipSuccess) return hip_fail(e, "read occupancy");
     return TSDF_OK;
 }
 
