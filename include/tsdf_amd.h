@@ -137,7 +137,7 @@ int tsdf_integrate_device(tsdf_volume *volume, const uint16_t *device_depth, uin
                           uint32_t height, const float pose[16], const float inv_pose[16],
                           const float k[9], const float kinv[9]);
 /* Optional kernel timing for roofline reports: when enabled, every launch of integrate_kernel (which = 0) and of
- * process_ray_kernel (which = 1) is bracketed by HIP events on the volume's stream; tsdf_volume_kernel_time
+ * process_ray_kernel (which = 1) and process_ray_tail_kernel (which = 2) is bracketed by HIP events on the volume's stream; tsdf_volume_kernel_time
  * synchronises the stream and returns the number of launches and their average duration since timing was
  * (re-)enabled.  Off by default (two event records per launch). */
 int tsdf_volume_set_timing(tsdf_volume *volume, int enabled);

@@ -22,4 +22,4 @@ for r in range(20):
     rc.raycast_device(v,cam,vert.data_ptr(),None)
 torch.cuda.synchronize()
 wall=(time.time()-t)/20*1e3
-print("segments", os.environ.get("TSDF_RAY_SEGMENTS","default"), "kernel ms", v.kernel_time("raycast"), "wall ms per raycast", round(wall,4))
+print("segments", os.environ.get("TSDF_RAY_SEGMENTS","default"), "budget", os.environ.get("TSDF_RAY_TRIP_BUDGET","default"), "kernel ms %.4f tail ms %.4f" % (v.kernel_time("raycast")[1], v.kernel_time("raycast_tail")[1]), "wall ms per raycast", round(wall,4))

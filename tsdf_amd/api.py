@@ -183,9 +183,9 @@ class TSDFVolume:
         check(lib.tsdf_volume_set_timing(self._h, 1 if enabled else 0))
 
     def kernel_time(self, which):
-        """(launches, average ms) of which = 'integrate' | 'raycast' since set_timing(True)."""
+        """(launches, average ms) of which = 'integrate' | 'raycast' | 'raycast_tail' since set_timing(True)."""
         n, ms = C.c_uint32(), C.c_float()
-        check(lib.tsdf_volume_kernel_time(self._h, {"integrate": 0, "raycast": 1}[which], C.byref(n), C.byref(ms)))
+        check(lib.tsdf_volume_kernel_time(self._h, {"integrate": 0, "raycast": 1, "raycast_tail": 2}[which], C.byref(n), C.byref(ms)))
         return int(n.value), float(ms.value)
 
     def set_counting(self, enabled):

@@ -137,6 +137,10 @@ struct tsdf_volume {
     // per-range hit records of the segmented ray march (kRaySegments x W*H float4), raycast.hip
     float *seg_hits;
     size_t seg_cap;
+    // rays the first ray-cast kernel hands to the tail kernel: uint2 per (pixel, sample range) + {appended, taken}
+    void *tail_entries;
+    uint32_t *tail_count;
+    size_t tail_cap;
     // T[k]: the ray parameter of sample k, T[0] = 0, T[k+1] = T[k] + step in fp32 (raycast.hip)
     float *t_table;
     // 1 = dividing by each voxel edge via the 3-instruction reciprocal sequence was verified exhaustively
@@ -161,7 +165,7 @@ struct tsdf_volume {
     size_t tile_max_cap;
     // optional HIP-event timing of the two dominant kernels on the volume's stream (tsdf_volume_set_timing)
     int timing;
-    std::vector<hipEvent_t> *tev[2];  // [0] integrate_kernel, [1] process_ray_kernel: start/stop pairs
+    std::vector<hipEvent_t> *tev[3];  // [0] integrate_kernel, [1] process_ray_kernel, [2] process_ray_tail_kernel: start/stop pairs
     // diagnostics
     int counting;
     unsigned long long *counter_dev;  // [0] = updated voxels, [1] = samples, [2] = hits

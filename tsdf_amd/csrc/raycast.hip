@@ -229,21 +229,42 @@ __device__ inline bool compute_near_and_far_t(const F3 &o, const F3 &d, const F3
 // neither this sample nor the following ones that stay inside the cell shrunk by eps can be <= 0, so k jumps
 // to the cell's exit.  Otherwise the sample is interpolated exactly -- from the 8 values just gathered.
 //
-// Wave scheduling.  One lane per pixel, a wave is an 8x8 pixel tile of coherent rays.  Every pass of the loop
-// does the same straight-line work for all lanes (one brick flag, 8 gathers, a jump or one interpolation), so
-// lanes do not serialise on divergent code paths; the wave leaves when every lane is done (ballot).
-//   SLAB / SEG: out = float4 records {k, x, y, z} (per slab, or per sample range); otherwise packed float3 vertices.
-//   STATS: counters[1] += samples evaluated, counters[2] += hits, touched bitmap marked per tap.  With
-//          SKIP=false the counts are those of the reference's march.
+// How the march is scheduled on the machine is described at process_ray_kernel / process_ray_tail_kernel below.
 constexpr int kMaxSamples = 4402;          // src/RayCaster/GPURaycaster.cu:369
 constexpr int kTableLen = kMaxSamples + 2;  // T[0..4402] is read
 constexpr int kDone = 0x7fffffff;
-constexpr int kRaySegmentsDefault = 16;     // sample ranges a ray's march is split into (single-GPU path)
+constexpr int kRaySegmentsDefault = 8;      // sample ranges a ray's march is split into
+constexpr int kTailGridDefault = 256 * 10;   // workgroups of the tail kernel (5 fit a CU at 86 VGPRs: two rounds)
+constexpr int kTripBudgetDefault = 24;      // passes of the first kernel's loop before unfinished rays go to the tail kernel
 static int ray_segments() {
     static const int n = [] {
         const char *e = getenv("TSDF_RAY_SEGMENTS");  // tuning aid
         int v = e ? atoi(e) : kRaySegmentsDefault;
         return v < 1 ? 1 : (v > 64 ? 64 : v);
+    }();
+    return n;
+}
+static int tail_lanes() {
+    static const int n = [] {
+        const char *e = getenv("TSDF_RAY_TAIL_LANES");  // tuning aid: 4, 8, 16, 32 or 64
+        int v = e ? atoi(e) : 16;
+        return (v == 4 || v == 8 || v == 32 || v == 64) ? v : 16;
+    }();
+    return n;
+}
+static int tail_grid() {
+    static const int n = [] {
+        const char *e = getenv("TSDF_RAY_TAIL_GRID");  // tuning aid
+        int v = e ? atoi(e) : kTailGridDefault;
+        return v < 1 ? 1 : v;
+    }();
+    return n;
+}
+static int trip_budget() {
+    static const int n = [] {
+        const char *e = getenv("TSDF_RAY_TRIP_BUDGET");  // tuning aid
+        int v = e ? atoi(e) : kTripBudgetDefault;
+        return v < 1 ? 1 : v;
     }();
     return n;
 }
@@ -257,6 +278,7 @@ struct SkipCtx {
     float tx, ty, tz;              // ~ |voxel size / dir| : t needed to cross one voxel (inf for a zero component)
     bool px_, py_, pz_;            // dir component > 0
     float eps;                     // guard band at the dual-cell faces, in voxels
+    bool skip_ok;                  // skipping allowed for this ray (short enough steps)
 };
 
 // Samples (>= 1) from the one at voxel coordinate (fx,fy,fz) until the ray leaves the axis-aligned box
@@ -318,33 +340,217 @@ __device__ inline int wave_min(int v) {
     return v;
 }
 
-template <bool SLAB, bool STATS, bool SKIP, bool FASTDIV, bool SEG>
-__global__ __launch_bounds__(256) void process_ray_kernel(const float *__restrict__ dist, const Geom g,
-                                                          const RayParams rp, float *__restrict__ out,
-                                                          unsigned long long *__restrict__ counters,
-                                                          unsigned int *__restrict__ touched,
-                                                          const OccGrid occ, const float *__restrict__ t_table) {
-    // Sample-range splitting: with rp.seg_len > 0 the z index of the workgroup selects a contiguous range of
-    // sample indices; every range is marched independently (first owned sample <= 0 -> record {k,x,y,z}) and a
-    // min-k merge picks the ray's first hit, exactly as for Z-slabs.  Long rays thus become several short waves.
-    const int k_lo = (int)(blockIdx.z * rp.seg_len);
-    const int k_hi = rp.seg_len ? min(kMaxSamples, k_lo + (int)rp.seg_len) : kMaxSamples;
-    __shared__ float T[kTableLen];
-    // T[1] (the step) plus the part of the table this range reads: T[k_lo .. k_hi]
-    for (int i = k_lo + (int)threadIdx.x; i <= k_hi; i += 256) T[i] = t_table[i];
-    if (threadIdx.x < 2) T[threadIdx.x] = t_table[threadIdx.x];
-    __syncthreads();
+// ---- one sample of one ray ------------------------------------------------------------------------------------
+struct RayState {
+    float dx, dy, dz;  // direction (not normalised: Q6)
+    float sx, sy, sz;  // start point in grid coordinates (:306)
+};
+// Classification that stays valid while the ray remains in the same brick / cell brick (single-ray marching only).
+struct BrickCache {
+    int k_brick_end;      // the brick classification holds while k < k_brick_end
+    int k_cellbrick_end;  // ... and the cell-brick classification while k < k_cellbrick_end
+    bool cellbrick_clear;
+};
+struct SampleWork {  // diagnostics (STATS)
+    uint32_t samples, hops, cell_tests, trips;
+};
 
-    // 16x16 pixel tile per workgroup, 8x8 per wave
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const int imx = blockIdx.x * 16 + (wave & 1u) * 8 + (lane & 7u);
-    const int imy = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
-    const bool in_image = imx < (int)rp.width && imy < (int)rp.height;
+// The per-ray part of the skipping arithmetic.
+template <bool SKIP>
+__device__ inline void set_ray(SkipCtx &sc, const RayState &r, float step_size, const Geom &g) {
+    sc.tx = r.dx != 0 ? fabsf(g.vs.x * __builtin_amdgcn_rcpf(r.dx)) : INFINITY;
+    sc.ty = r.dy != 0 ? fabsf(g.vs.y * __builtin_amdgcn_rcpf(r.dy)) : INFINITY;
+    sc.tz = r.dz != 0 ? fabsf(g.vs.z * __builtin_amdgcn_rcpf(r.dz)) : INFINITY;
+    sc.px_ = r.dx > 0; sc.py_ = r.dy > 0; sc.pz_ = r.dz > 0;
+    // one step must stay well inside the one-voxel slack on every axis
+    sc.skip_ok = SKIP && fabsf(r.dx) * step_size < 0.25f * g.vs.x && fabsf(r.dy) * step_size < 0.25f * g.vs.y &&
+                 fabsf(r.dz) * step_size < 0.25f * g.vs.z;
+}
 
-    float ix = NAN, iy = NAN, iz = NAN;
-    float hit_k = INFINITY;
-    uint32_t samples = 0;
+// The hit point for a sample with tsdf <= 0 at parameter t (:336-350), previous_tsdf == trunc (Q7).
+__device__ inline void refine_hit(float t, float tsdf, float previous_tsdf, float step_size, const RayState &r,
+                                  const RayParams &rp, float &ix, float &iy, float &iz) {
+    float th = t;
+    if (tsdf < 0) {
+        th = th - step_size;
+        th = th + (previous_tsdf / (previous_tsdf - tsdf)) * step_size;
+    }
+    ix = ((th * r.dx) + r.sx) + rp.space_min.x;
+    iy = ((th * r.dy) + r.sy) + rp.space_min.y;
+    iz = ((th * r.dz) + r.sz) + rp.space_min.z;
+}
 
+// Sample k of ray r, at parameter t = T[k].  Either proves that samples k .. k+jump-1 cannot be <= 0 (jump > 0),
+// or returns the sample's value, computed with the reference's arithmetic (jump == 0; NaN for a sample another slab owns):
+//   1. (when a brick boundary was crossed) read the brick's reach; a clear interior region is jumped over;
+//   2. otherwise gather the 8 voxels of the sample's dual cell; if they are all safely positive the samples up to the
+//      cell's (shrunk) exit are jumped over;
+//   3. otherwise the sample is interpolated from those 8 values.
+// Samples in the outer half-voxel shell of the grid, within eps of a cell face, or with skipping disabled take the
+// reference's full trilinearly_interpolate instead (rare).
+template <bool SLAB, bool STATS, bool FASTDIV>
+__device__ inline float process_sample(float t, int k, const RayState &r, const SkipCtx &sc, BrickCache &bc,
+                                       const float *__restrict__ dist, const Geom &g, const TriConst &tc, const RayParams &rp,
+                                       const OccGrid &occ, unsigned int *__restrict__ touched, SampleWork &work, int &jump) {
+    const float px = (t * r.dx) + r.sx, py = (t * r.dy) + r.sy, pz = (t * r.dz) + r.sz;
+    const float cell_lo = sc.eps, cell_hi = 1.0f - sc.eps, cell_half = 0.5f - sc.eps;
+    jump = 0;
+    if (sc.skip_ok) {
+        // position in voxel units (approximate)
+        const float fx = px * sc.inv_vx, fy = py * sc.inv_vy, fz = pz * sc.inv_vz;
+        if (k >= bc.k_brick_end) {
+            int n;
+            const bool empty = locate<SLAB>(fx, fy, fz, sc, g, occ, rp, n);
+            bc.k_brick_end = k + n;
+            if (empty) {
+                if (STATS) work.hops++;
+                jump = n;
+                return 1.0f;
+            }
+        }
+        // dual cell of the sample: lower = floor(p/vs - 1/2), position inside it in [0,1)
+        const float cx = fx - 0.5f, cy = fy - 0.5f, cz = fz - 0.5f;
+        const float lfx = floorf(cx), lfy = floorf(cy), lfz = floorf(cz);
+        const float rx = cx - lfx, ry = cy - lfy, rz = cz - lfz;
+        const int lx = (int)lfx, ly = (int)lfy, lz = (int)lfz;
+        // at least eps away from the cell faces, and all 8 voxels of the cell exist (then no tap is clamped, the
+        // weights lie in [0,1], and p is inside the grid so nothing is clamped either; the outer half-voxel shell of
+        // the grid, where the reference extrapolates (Q10), fails this)
+        const bool safe = fabsf(rx - 0.5f) < cell_half && fabsf(ry - 0.5f) < cell_half && fabsf(rz - 0.5f) < cell_half &&
+                          (uint32_t)lx < g.X - 1 && (uint32_t)ly < g.Y - 1 && (uint32_t)lz < g.Z - 1;
+        if (safe) {
+            if (k >= bc.k_cellbrick_end) {
+                // the sample's cell is known exactly: is its whole cell brick (4^3 cells) clear?  If so the samples
+                // up to the exit of that brick (shrunk by eps, in cell coordinates) cannot hit.
+                const int qx = lx >> kBrickShift, qy = ly >> kBrickShift, qz = lz >> kBrickShift;
+                const float e = sc.eps;
+                const int n_cb = samples_to_exit<false>(cx, cy, cz, sc, (float)(qx << kBrickShift) + e, (float)(qy << kBrickShift) + e,
+                                                        (float)(qz << kBrickShift) + e, (float)((qx + 1) << kBrickShift) - e,
+                                                        (float)((qy + 1) << kBrickShift) - e, (float)((qz + 1) << kBrickShift) - e);
+                bc.k_cellbrick_end = k + n_cb;
+                bc.cellbrick_clear = occ.cell[((size_t)qz * occ.nby + qy) * occ.nbx + qx] == 0;
+            }
+            if (bc.cellbrick_clear && k < bc.k_cellbrick_end) {
+                jump = bc.k_cellbrick_end - k;
+                return 1.0f;
+            }
+            if (STATS) work.cell_tests++;
+            // samples until the ray leaves the cell shrunk by eps
+            const int n_cell = samples_to_exit<false>(rx, ry, rz, sc, cell_lo, cell_lo, cell_lo, cell_hi, cell_hi, cell_hi);
+            if (SLAB && !((uint32_t)lz >= rp.own_lo && (uint32_t)lz < rp.own_hi)) {
+                jump = n_cell;  // not this rank's samples (and possibly not its planes): passed unevaluated
+                return 1.0f;
+            }
+            const float *b = dist + ((size_t)tc.plane * ((uint32_t)lz - g.z_store_begin) + (size_t)tc.row * (uint32_t)ly + (uint32_t)lx);
+            const float c000 = b[0], c100 = b[1], c010 = b[tc.row], c110 = b[tc.row + 1];
+            const float c001 = b[tc.plane], c101 = b[tc.plane + 1], c011 = b[tc.plane + tc.row], c111 = b[tc.plane + tc.row + 1];
+            const bool positive = c000 > occ.tau && c100 > occ.tau && c010 > occ.tau && c110 > occ.tau &&
+                                  c001 > occ.tau && c101 > occ.tau && c011 > occ.tau && c111 > occ.tau;
+            if (positive) {
+                jump = n_cell;
+                return 1.0f;
+            }
+            // trilinearly_interpolate (:84-121) for lower = (lx,ly,lz), which is what the reference derives for a
+            // sample this far from the cell faces
+            const float lcx = (lx + 0.5f) * g.vs.x + 0.0f;
+            const float lcy = (ly + 0.5f) * g.vs.y + 0.0f;
+            const float lcz = (lz + 0.5f) * g.vs.z + 0.0f;
+            const float u = div_by<FASTDIV>(px - lcx, tc.dx);
+            const float v = div_by<FASTDIV>(py - lcy, tc.dy);
+            const float w = div_by<FASTDIV>(pz - lcz, tc.dz);
+            if (STATS) work.samples++;
+            return c000 * (1 - u) * (1 - v) * (1 - w) +
+                   c001 * (1 - u) * (1 - v) * w +
+                   c010 * (1 - u) * v * (1 - w) +
+                   c011 * (1 - u) * v * w +
+                   c100 * u * (1 - v) * (1 - w) +
+                   c101 * u * (1 - v) * w +
+                   c110 * u * v * (1 - w) +
+                   c111 * u * v * w;
+        }
+    }
+    bool owned;
+    const float tsdf = trilinear<SLAB, STATS, FASTDIV>(px, py, pz, dist, g, tc, rp, owned, touched);
+    if (STATS && owned) work.samples++;
+    return tsdf;
+}
+
+// process_sample for the tail kernel: the same decisions in the same order, but without the per-brick memory (a lane
+// takes a different ray's sample every time) and with every load issued before the first decision -- the brick's reach,
+// the cell brick's flag and the 8 voxels have addresses that depend only on the sample position, so one memory round
+// trip serves all three instead of three dependent ones.  (Only worth it where rays are few: the speculative gathers
+// cost bandwidth in the bulk kernel.)
+template <bool SLAB, bool FASTDIV>
+__device__ inline float process_sample_eager(float t, const RayState &r, const SkipCtx &sc, const float *__restrict__ dist,
+                                             const Geom &g, const TriConst &tc, const RayParams &rp, const OccGrid &occ, int &jump) {
+    const float px = (t * r.dx) + r.sx, py = (t * r.dy) + r.sy, pz = (t * r.dz) + r.sz;
+    const float cell_lo = sc.eps, cell_hi = 1.0f - sc.eps, cell_half = 0.5f - sc.eps;
+    jump = 0;
+    if (sc.skip_ok) {
+        const float fx = px * sc.inv_vx, fy = py * sc.inv_vy, fz = pz * sc.inv_vz;
+        int n_brick;
+        const bool empty = locate<SLAB>(fx, fy, fz, sc, g, occ, rp, n_brick);
+        const float cx = fx - 0.5f, cy = fy - 0.5f, cz = fz - 0.5f;
+        const float lfx = floorf(cx), lfy = floorf(cy), lfz = floorf(cz);
+        const float rx = cx - lfx, ry = cy - lfy, rz = cz - lfz;
+        const int lx = (int)lfx, ly = (int)lfy, lz = (int)lfz;
+        const bool safe = fabsf(rx - 0.5f) < cell_half && fabsf(ry - 0.5f) < cell_half && fabsf(rz - 0.5f) < cell_half &&
+                          (uint32_t)lx < g.X - 1 && (uint32_t)ly < g.Y - 1 && (uint32_t)lz < g.Z - 1;
+        const int qx = lx >> kBrickShift, qy = ly >> kBrickShift, qz = lz >> kBrickShift;
+        const float e = sc.eps;
+        const int n_cb = samples_to_exit<false>(cx, cy, cz, sc, (float)(qx << kBrickShift) + e, (float)(qy << kBrickShift) + e,
+                                                (float)(qz << kBrickShift) + e, (float)((qx + 1) << kBrickShift) - e,
+                                                (float)((qy + 1) << kBrickShift) - e, (float)((qz + 1) << kBrickShift) - e);
+        const int n_cell = samples_to_exit<false>(rx, ry, rz, sc, cell_lo, cell_lo, cell_lo, cell_hi, cell_hi, cell_hi);
+        const bool owned = !SLAB || ((uint32_t)lz >= rp.own_lo && (uint32_t)lz < rp.own_hi);
+        unsigned char cell_flag = 1;
+        float c000 = 0, c100 = 0, c010 = 0, c110 = 0, c001 = 0, c101 = 0, c011 = 0, c111 = 0;
+        if (safe) {
+            cell_flag = occ.cell[((size_t)qz * occ.nby + qy) * occ.nbx + qx];
+            if (owned) {  // (a slab holds the planes of the samples it owns, and only those for certain)
+                const float *b = dist + ((size_t)tc.plane * ((uint32_t)lz - g.z_store_begin) + (size_t)tc.row * (uint32_t)ly + (uint32_t)lx);
+                c000 = b[0]; c100 = b[1]; c010 = b[tc.row]; c110 = b[tc.row + 1];
+                c001 = b[tc.plane]; c101 = b[tc.plane + 1]; c011 = b[tc.plane + tc.row]; c111 = b[tc.plane + tc.row + 1];
+            }
+        }
+        if (empty) {
+            jump = n_brick;
+            return 1.0f;
+        }
+        if (safe) {
+            if (cell_flag == 0) {
+                jump = n_cb;
+                return 1.0f;
+            }
+            const bool positive = c000 > occ.tau && c100 > occ.tau && c010 > occ.tau && c110 > occ.tau &&
+                                  c001 > occ.tau && c101 > occ.tau && c011 > occ.tau && c111 > occ.tau;
+            if (!owned || positive) {
+                jump = n_cell;
+                return 1.0f;
+            }
+            const float lcx = (lx + 0.5f) * g.vs.x + 0.0f;
+            const float lcy = (ly + 0.5f) * g.vs.y + 0.0f;
+            const float lcz = (lz + 0.5f) * g.vs.z + 0.0f;
+            const float u = div_by<FASTDIV>(px - lcx, tc.dx);
+            const float v = div_by<FASTDIV>(py - lcy, tc.dy);
+            const float w = div_by<FASTDIV>(pz - lcz, tc.dz);
+            return c000 * (1 - u) * (1 - v) * (1 - w) +
+                   c001 * (1 - u) * (1 - v) * w +
+                   c010 * (1 - u) * v * (1 - w) +
+                   c011 * (1 - u) * v * w +
+                   c100 * u * (1 - v) * (1 - w) +
+                   c101 * u * (1 - v) * w +
+                   c110 * u * v * (1 - w) +
+                   c111 * u * v * w;
+        }
+    }
+    bool owned;
+    return trilinear<SLAB, false, FASTDIV>(px, py, pz, dist, g, tc, rp, owned, nullptr);
+}
+
+// Ray set-up: direction and start point (ray_geometry), and the range of sample indices [k_first, k_end) of the
+// sample range [k_lo, k_hi] that the reference's loop evaluates unless it hits earlier (setup_ray).  T = the staged table.
+__device__ inline bool ray_geometry(int imx, int imy, bool in_image, const RayParams &rp, RayState &ray, float &max_t) {
     // compute_ray_direction_at_pixel (:24-44); f3_normalise is a no-op (by-value argument): Q6
     uint16_t pix_x = (uint16_t)imx, pix_y = (uint16_t)imy;
     float rcx = pix_x * rp.kinv.m11 + pix_y * rp.kinv.m12 + rp.kinv.m13;
@@ -362,13 +568,21 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
     const float sx = ((near_t * dir.x) + rp.origin.x) - rp.space_min.x;
     const float sy = ((near_t * dir.y) + rp.origin.y) - rp.space_min.y;
     const float sz = ((near_t * dir.z) + rp.origin.z) - rp.space_min.z;
+    ray = {dir.x, dir.y, dir.z, sx, sy, sz};
+    max_t = far_t - near_t;
+    return intersects;
+}
 
-    const float previous_tsdf = g.trunc;  // Q7
-    const float step_size = T[1];         // = (float)((double)trunc * 0.05), :324
-    const float max_t = far_t - near_t;
+template <bool SLAB>
+__device__ inline void setup_ray(int imx, int imy, bool in_image, int k_lo, int k_hi, const float *T, const RayParams &rp,
+                                 const Geom &g, float step_size, RayState &ray, int &k_first, int &k_end) {
+    float max_t;
+    const bool intersects = ray_geometry(imx, imy, in_image, rp, ray, max_t);
+    const float sz = ray.sz;
+    const F3 dir = {ray.dx, ray.dy, ray.dz};
 
     // samples 0 .. k_end-1 are evaluated unless one of them is <= 0
-    int k_end = 0;
+    k_end = 0;
     if (intersects) {
         // smallest k in [max(k_lo,1), k_hi] with T[k] >= max_t (k_hi when there is none): only this range's
         // part of the table is staged, and only this range's samples are marched
@@ -383,9 +597,9 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
     }
 
     // A slab only ever evaluates samples whose lower tap plane it owns; along a ray those occupy one interval
-    // of sample indices (z is linear in t).  Clip the lane's range to a conservative superset of that interval
+    // of sample indices (z is linear in t).  Clip the range to a conservative superset of that interval
     // -- two voxels and three samples of slack -- instead of hopping through the rest of the volume.
-    int k_first = k_lo;
+    k_first = k_lo;
     if (SLAB && k_end > 0) {
         const float za = ((float)rp.own_lo - 2.0f) * g.vs.z, zb = ((float)rp.own_hi + 2.0f) * g.vs.z;  // grid mm
         if (dir.z != 0.0f) {
@@ -400,134 +614,87 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
             k_end = 0;  // the ray runs parallel to the slab, outside it
         }
     }
+}
 
-    const TriConst tc = make_tri_const(g);
+__device__ inline SkipCtx make_skip_ctx(const Geom &g, float step_size) {
     SkipCtx sc;
     sc.inv_vx = __builtin_amdgcn_rcpf(g.vs.x); sc.inv_vy = __builtin_amdgcn_rcpf(g.vs.y); sc.inv_vz = __builtin_amdgcn_rcpf(g.vs.z);
     sc.inv_step = __builtin_amdgcn_rcpf(step_size);
-    sc.tx = dir.x != 0 ? fabsf(g.vs.x * __builtin_amdgcn_rcpf(dir.x)) : INFINITY;
-    sc.ty = dir.y != 0 ? fabsf(g.vs.y * __builtin_amdgcn_rcpf(dir.y)) : INFINITY;
-    sc.tz = dir.z != 0 ? fabsf(g.vs.z * __builtin_amdgcn_rcpf(dir.z)) : INFINITY;
-    sc.px_ = dir.x > 0; sc.py_ = dir.y > 0; sc.pz_ = dir.z > 0;
-    // one step must stay well inside the one-voxel slack on every axis
-    const bool skip_ok = SKIP && fabsf(dir.x) * step_size < 0.25f * g.vs.x && fabsf(dir.y) * step_size < 0.25f * g.vs.y &&
-                         fabsf(dir.z) * step_size < 0.25f * g.vs.z;
-
-    // guard band at the cell faces: the dual-cell index computed approximately below (coordinates up to
-    // max(X,Y,Z) voxels, a handful of roundings of 2^-24 relative each) must agree with the reference's exact one
+    // guard band at the cell faces: the dual-cell index computed approximately (coordinates up to max(X,Y,Z) voxels, a
+    // handful of roundings of 2^-24 relative each) must agree with the reference's exact one
     sc.eps = fmaxf(1.0e-3f, 2.0e-6f * (float)max(g.X, max(g.Y, g.Z)));
-    const float cell_lo = sc.eps, cell_hi = 1.0f - sc.eps, cell_half = 0.5f - sc.eps;
+    sc.tx = sc.ty = sc.tz = INFINITY;
+    sc.px_ = sc.py_ = sc.pz_ = false;
+    sc.skip_ok = false;
+    return sc;
+}
 
-    int k = (k_end <= k_first) ? kDone : k_first;  // next sample of this lane (kDone when finished)
-    int k_brick_end = 0;               // the brick classification holds while k < k_brick_end
-    int k_cellbrick_end = 0;           // ... and the cell-brick classification while k < k_cellbrick_end
-    bool cellbrick_clear = false;
-    uint32_t trips = 0, adv_iters = 0, hop_count = 0;  // diagnostics
+// Unfinished rays handed from process_ray_kernel to process_ray_tail_kernel.
+struct TailQueue {
+    uint2 *entries;        // {pixel index, sample range << 26 | k_end << 13 | next sample k}
+    uint32_t *count;       // [0] entries appended
+    uint32_t trip_budget;  // passes of the marching loop before a wave hands its unfinished rays over
+    uint32_t lanes;        // lanes per ray in the tail kernel (power of two, 4..64)
+};
 
-    // One pass of the loop handles one sample index per lane, the same straight-line work for every lane:
-    //   1. (when a brick boundary was crossed) read the brick flag; a clear interior brick is jumped over;
-    //   2. otherwise gather the 8 voxels of the sample's dual cell; if they are all
-    //      safely positive the samples up to the cell's (shrunk) exit are jumped over;
-    //   3. otherwise the sample is interpolated from those 8 values with the reference's arithmetic.
-    // Samples in the outer half-voxel shell of the grid, within eps of a cell face, or with skipping disabled
-    // take the reference's full trilinearly_interpolate instead (rare).
-    while (__ballot(k != kDone) != 0ull) {
-        if (STATS) trips++;
+// One lane per pixel, a wave is an 8x8 pixel tile of coherent rays, a workgroup a 16x16 tile.  Every pass of the loop
+// does the same straight-line work for all lanes (process_sample), so lanes do not serialise on divergent code paths.
+// Sample-range splitting: with rp.seg_len > 0 the z index of the workgroup selects a contiguous range of sample
+// indices; every range is marched independently (first owned sample <= 0 -> record {k,x,y,z}) and a min-k merge picks
+// the ray's first hit, exactly as for Z-slabs.
+// TAIL: most rays finish within a few dozen passes, a few (those grazing a surface, e.g. the skirts the bilateral filter
+// leaves at depth discontinuities) need hundreds of evaluated samples.  After tail.trip_budget passes a wave appends its
+// unfinished rays to a queue and leaves; process_ray_tail_kernel finishes them with 16 lanes per ray.
+//   SLAB / SEG: out = float4 records {k, x, y, z} (per slab, or per sample range); otherwise packed float3 vertices.
+//   STATS: counters[1] += samples evaluated, counters[2] += hits, touched bitmap marked per tap.  With
+//          SKIP=false the counts are those of the reference's march.
+template <bool SLAB, bool STATS, bool SKIP, bool FASTDIV, bool SEG, bool TAIL>
+__global__ __launch_bounds__(256) void process_ray_kernel(const float *__restrict__ dist, const Geom g,
+                                                          const RayParams rp, float *__restrict__ out,
+                                                          unsigned long long *__restrict__ counters,
+                                                          unsigned int *__restrict__ touched,
+                                                          const OccGrid occ, const float *__restrict__ t_table,
+                                                          const TailQueue tail) {
+    const int k_lo = (int)(blockIdx.z * rp.seg_len);
+    const int k_hi = rp.seg_len ? min(kMaxSamples, k_lo + (int)rp.seg_len) : kMaxSamples;
+    __shared__ float T[kTableLen];
+    // T[1] (the step) plus the part of the table this range reads: T[k_lo .. k_hi]
+    for (int i = k_lo + (int)threadIdx.x; i <= k_hi; i += 256) T[i] = t_table[i];
+    if (threadIdx.x < 2) T[threadIdx.x] = t_table[threadIdx.x];
+    __syncthreads();
+
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const int imx = blockIdx.x * 16 + (wave & 1u) * 8 + (lane & 7u);
+    const int imy = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const bool in_image = imx < (int)rp.width && imy < (int)rp.height;
+
+    float ix = NAN, iy = NAN, iz = NAN;
+    float hit_k = INFINITY;
+    const float previous_tsdf = g.trunc;  // Q7
+    const float step_size = T[1];         // = (float)((double)trunc * 0.05), :324
+
+    RayState ray;
+    int k_first, k_end;
+    setup_ray<SLAB>(imx, imy, in_image, k_lo, k_hi, T, rp, g, step_size, ray, k_first, k_end);
+    const TriConst tc = make_tri_const(g);
+    SkipCtx sc = make_skip_ctx(g, step_size);
+    set_ray<SKIP>(sc, ray, step_size, g);
+
+    int k = (k_end <= k_first) ? kDone : k_first;  // next sample of this lane's ray (kDone when finished)
+    BrickCache bc = {0, 0, false};
+    SampleWork work = {0, 0, 0, 0};
+
+    for (uint32_t trip = 0; __ballot(k != kDone) != 0ull; trip++) {
+        if (TAIL && trip >= tail.trip_budget) break;
+        if (STATS) work.trips++;
         if (k != kDone) {
             const float t = T[k];
-            const float px = (t * dir.x) + sx, py = (t * dir.y) + sy, pz = (t * dir.z) + sz;
-            float tsdf = 1.0f;      // value of sample k when it gets evaluated
-            bool evaluated = false;
-            int jump = 0;           // > 0: samples k .. k+jump-1 cannot hit
-            if (skip_ok) {
-                // position in voxel units (approximate)
-                const float fx = px * sc.inv_vx, fy = py * sc.inv_vy, fz = pz * sc.inv_vz;
-                if (k >= k_brick_end) {
-                    int n;
-                    bool empty = locate<SLAB>(fx, fy, fz, sc, g, occ, rp, n);
-                    k_brick_end = k + n;
-                    if (empty) jump = n;
-                    if (STATS) hop_count += empty ? 1u : 0u;
-                }
-                if (jump == 0) {
-                    // dual cell of the sample: lower = floor(p/vs - 1/2), position inside it r in [0,1)
-                    const float cx = fx - 0.5f, cy = fy - 0.5f, cz = fz - 0.5f;
-                    const float lfx = floorf(cx), lfy = floorf(cy), lfz = floorf(cz);
-                    const float rx = cx - lfx, ry = cy - lfy, rz = cz - lfz;
-                    const int lx = (int)lfx, ly = (int)lfy, lz = (int)lfz;
-                    // at least eps away from the cell faces, and all 8 voxels of the cell exist (then no tap is
-                    // clamped, the weights lie in [0,1], and p is inside the grid so nothing is clamped either;
-                    // the outer half-voxel shell of the grid, where the reference extrapolates (Q10), fails this)
-                    const bool safe = fabsf(rx - 0.5f) < cell_half && fabsf(ry - 0.5f) < cell_half && fabsf(rz - 0.5f) < cell_half &&
-                                      (uint32_t)lx < g.X - 1 && (uint32_t)ly < g.Y - 1 && (uint32_t)lz < g.Z - 1;
-                    if (safe && k >= k_cellbrick_end) {
-                        // the sample's cell is known exactly: is its whole cell brick (4^3 cells) clear?  If so the
-                        // samples up to the exit of that brick (shrunk by eps, in cell coordinates) cannot hit.
-                        const int qx = lx >> kBrickShift, qy = ly >> kBrickShift, qz = lz >> kBrickShift;
-                        const float e = sc.eps;
-                        const int n_cb = samples_to_exit<false>(cx, cy, cz, sc, (float)(qx << kBrickShift) + e, (float)(qy << kBrickShift) + e,
-                                                         (float)(qz << kBrickShift) + e, (float)((qx + 1) << kBrickShift) - e,
-                                                         (float)((qy + 1) << kBrickShift) - e, (float)((qz + 1) << kBrickShift) - e);
-                        k_cellbrick_end = k + n_cb;
-                        cellbrick_clear = occ.cell[((size_t)qz * occ.nby + qy) * occ.nbx + qx] == 0;
-                    }
-                    if (safe && cellbrick_clear && k < k_cellbrick_end) {
-                        jump = k_cellbrick_end - k;
-                    } else if (safe) {
-                        if (STATS) adv_iters++;  // diagnostics: cell tests
-                        // samples until the ray leaves the cell shrunk by eps
-                        const int n_cell = samples_to_exit<false>(rx, ry, rz, sc, cell_lo, cell_lo, cell_lo, cell_hi, cell_hi, cell_hi);
-                        if (SLAB && !((uint32_t)lz >= rp.own_lo && (uint32_t)lz < rp.own_hi)) {
-                            jump = n_cell;  // not this rank's samples (and possibly not its planes): passed unevaluated
-                        } else {
-                            const float *b = dist + ((size_t)tc.plane * ((uint32_t)lz - g.z_store_begin) + (size_t)tc.row * (uint32_t)ly + (uint32_t)lx);
-                            const float c000 = b[0], c100 = b[1], c010 = b[tc.row], c110 = b[tc.row + 1];
-                            const float c001 = b[tc.plane], c101 = b[tc.plane + 1], c011 = b[tc.plane + tc.row],
-                                        c111 = b[tc.plane + tc.row + 1];
-                            const bool positive = c000 > occ.tau && c100 > occ.tau && c010 > occ.tau && c110 > occ.tau &&
-                                                  c001 > occ.tau && c101 > occ.tau && c011 > occ.tau && c111 > occ.tau;
-                            if (positive) {
-                                jump = n_cell;
-                            } else {
-                                // trilinearly_interpolate (:84-121) for lower = (lx,ly,lz), which is what the
-                                // reference derives for a sample this far from the cell faces
-                                const float lcx = (lx + 0.5f) * g.vs.x + 0.0f;
-                                const float lcy = (ly + 0.5f) * g.vs.y + 0.0f;
-                                const float lcz = (lz + 0.5f) * g.vs.z + 0.0f;
-                                const float u = div_by<FASTDIV>(px - lcx, tc.dx);
-                                const float v = div_by<FASTDIV>(py - lcy, tc.dy);
-                                const float w = div_by<FASTDIV>(pz - lcz, tc.dz);
-                                tsdf = c000 * (1 - u) * (1 - v) * (1 - w) +
-                                       c001 * (1 - u) * (1 - v) * w +
-                                       c010 * (1 - u) * v * (1 - w) +
-                                       c011 * (1 - u) * v * w +
-                                       c100 * u * (1 - v) * (1 - w) +
-                                       c101 * u * (1 - v) * w +
-                                       c110 * u * v * (1 - w) +
-                                       c111 * u * v * w;
-                                evaluated = true;
-                                if (STATS) samples++;
-                            }
-                        }
-                    }
-                }
-            }
-            if (jump == 0 && !evaluated) {
-                bool owned;
-                tsdf = trilinear<SLAB, STATS, FASTDIV>(px, py, pz, dist, g, tc, rp, owned, touched);
-                if (STATS && owned) samples++;
-            }
+            int jump;
+            const float tsdf = process_sample<SLAB, STATS, FASTDIV>(t, k, ray, sc, bc, dist, g, tc, rp, occ, touched, work, jump);
             if (jump > 0) {
                 k += jump;
             } else if (tsdf <= 0) {
-                float th = t;
-                if (tsdf < 0) {
-                    th = th - step_size;
-                    th = th + (previous_tsdf / (previous_tsdf - tsdf)) * step_size;
-                }
-                ix = ((th * dir.x) + sx) + rp.space_min.x;
-                iy = ((th * dir.y) + sy) + rp.space_min.y;
-                iz = ((th * dir.z) + sz) + rp.space_min.z;
+                refine_hit(t, tsdf, previous_tsdf, step_size, ray, rp, ix, iy, iz);
                 hit_k = (float)k;
                 k = kDone;
             } else {
@@ -537,15 +704,26 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
         }
     }
 
-    if (in_image) {
-        size_t idx = (size_t)imy * rp.width + imx;
+    const size_t idx = (size_t)imy * rp.width + imx;
+    if (TAIL) {
+        // hand the unfinished rays over (one atomic per wave); their records are written by the tail kernel
+        const unsigned long long unfinished = __ballot(k != kDone);
+        if (unfinished != 0ull) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&tail.count[0], (uint32_t)__popcll(unfinished));
+            base = __shfl(base, 0);
+            if (k != kDone)
+                tail.entries[base + __popcll(unfinished & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)idx, (blockIdx.z << 26) | ((uint32_t)k_end << 13) | (uint32_t)k);
+        }
+    }
+    if (in_image && !(TAIL && k != kDone)) {
         if (SLAB || SEG) {
             const size_t rec = SEG ? (size_t)blockIdx.z * rp.width * rp.height + idx : idx;
             reinterpret_cast<float4 *>(out)[rec] = make_float4(hit_k, ix, iy, iz);
         } else if (STATS && SKIP) {  // diagnostics: per-ray work instead of the vertex
-            out[idx * 3 + 0] = (float)samples;
-            out[idx * 3 + 1] = (float)hop_count;
-            out[idx * 3 + 2] = (float)adv_iters;
+            out[idx * 3 + 0] = (float)work.samples;
+            out[idx * 3 + 1] = (float)work.hops;
+            out[idx * 3 + 2] = (float)work.cell_tests;
         } else {
             out[idx * 3 + 0] = ix;
             out[idx * 3 + 1] = iy;
@@ -554,6 +732,7 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
     }
     if (STATS) {
         uint32_t h = (in_image && ix == ix) ? 1u : 0u;
+        uint32_t samples = work.samples;
         for (int o = 32; o > 0; o >>= 1) {
             samples += __shfl_down(samples, o);
             h += __shfl_down(h, o);
@@ -562,6 +741,83 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
             atomicAdd(&counters[1], (unsigned long long)samples);
             atomicAdd(&counters[2], (unsigned long long)h);
         }
+    }
+}
+
+// The rays process_ray_kernel did not finish.  lanes_per_ray lanes per ray: the group's lanes take the ray's next samples
+// k .. k+15, each classifying / evaluating its own (process_sample without the per-brick memory).  The first lane of
+// the group with a value <= 0 is the ray's hit -- everything before it was evaluated positive or proven positive --
+// otherwise the ray advances past everything the group has dealt with.  Sample k of a ray is computed by the same
+// expressions whichever lane does it, so the result does not depend on the schedule.  Groups take queue entries round
+// robin until none is left (persistent workgroups); every pass of the loop is uniform across the wave.
+template <bool SLAB, bool FASTDIV>
+__global__ __launch_bounds__(256) void process_ray_tail_kernel(const float *__restrict__ dist, const Geom g, const RayParams rp,
+                                                               float *__restrict__ out, const OccGrid occ,
+                                                               const float *__restrict__ t_table, const TailQueue tail) {
+    __shared__ float T[kTableLen];
+    for (int i = (int)threadIdx.x; i < kTableLen; i += 256) T[i] = t_table[i];
+    __syncthreads();
+    const uint32_t n_entries = tail.count[0];
+    const uint32_t lane = threadIdx.x & 63u, lanes_per_ray = tail.lanes;
+    const int j = (int)(lane & (lanes_per_ray - 1)), leader = (int)(lane & ~(uint32_t)(lanes_per_ray - 1));
+    const float previous_tsdf = g.trunc, step_size = T[1];
+    const TriConst tc = make_tri_const(g);
+    SkipCtx sc = make_skip_ctx(g, step_size);
+    // A wave takes as many consecutive queue entries as it has groups (they are rays of one tile and one sample range,
+    // alike in length), works on them until all are finished, then takes the next batch: waves round robin.
+    const uint32_t groups_per_wave = 64 / lanes_per_ray;
+    const uint32_t n_waves = gridDim.x * 4, wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (uint32_t batch = wave_id * groups_per_wave; batch < n_entries; batch += n_waves * groups_per_wave) {
+    RayState ray = {0, 0, 0, 0, 0, 0};
+    int k = kDone, k_end = 0;   // the group's ray (all its lanes hold the same values); kDone: none
+    size_t rec = 0;
+    const uint32_t e = batch + (lane / lanes_per_ray);
+    if (e < n_entries) {
+        const uint2 q = tail.entries[e];
+        const uint32_t seg = q.y >> 26;
+        float max_t;
+        (void)ray_geometry((int)(q.x % rp.width), (int)(q.x / rp.width), true, rp, ray, max_t);
+        set_ray<true>(sc, ray, step_size, g);
+        k = (int)(q.y & 0x1fffu);
+        k_end = (int)((q.y >> 13) & 0x1fffu);
+        rec = (size_t)seg * rp.width * rp.height + q.x;
+    }
+    while (true) {
+        if (__ballot(k != kDone) == 0ull) break;
+        const int kk = k + j;
+        float cx = NAN, cy = NAN, cz = NAN;
+        int adv = 0;
+        bool hit = false;
+        if (k != kDone && kk < k_end) {
+            const float t = T[kk];
+            int jump;
+            const float tsdf = process_sample_eager<SLAB, FASTDIV>(t, ray, sc, dist, g, tc, rp, occ, jump);
+            if (jump > 0) {
+                adv = j + jump;
+            } else if (tsdf <= 0) {
+                refine_hit(t, tsdf, previous_tsdf, step_size, ray, rp, cx, cy, cz);
+                hit = true;
+            } else {
+                adv = j + 1;
+            }
+        }
+        // furthest sample (relative to k) the group has dealt with
+        for (int o = 1; o < (int)lanes_per_ray; o <<= 1) adv = max(adv, __shfl_xor(adv, o));
+        const unsigned long long hits = __ballot(hit);
+        const unsigned long long mine = (hits >> leader) & (lanes_per_ray == 64 ? ~0ull : ((1ull << lanes_per_ray) - 1ull));
+        if (k != kDone) {
+            if (mine) {
+                if (j == __builtin_ctzll(mine)) reinterpret_cast<float4 *>(out)[rec] = make_float4((float)kk, cx, cy, cz);
+                k = kDone;
+            } else {
+                k += adv;
+                if (k >= k_end) {
+                    if (j == 0) reinterpret_cast<float4 *>(out)[rec] = make_float4(INFINITY, NAN, NAN, NAN);
+                    k = kDone;
+                }
+            }
+        }
+    }
     }
 }
 
@@ -660,6 +916,53 @@ static int check_ray_args(const tsdf_volume *v, uint32_t width, uint32_t height,
     return TSDF_OK;
 }
 
+// The production march: process_ray_kernel over kRaySegments sample ranges per ray with a pass budget, then
+// process_ray_tail_kernel for the rays it handed over.  Leaves one {k,x,y,z} record per (range, pixel) in v->seg_hits.
+template <bool SLAB>
+static int march_segments(tsdf_volume *v, RayParams &rp, size_t n_pix, int &n_segments) {
+    n_segments = ray_segments();
+    const size_t n_rec = n_pix * n_segments;
+    if (v->seg_cap < n_rec) {
+        if (v->seg_hits) (void)hipFree(v->seg_hits);
+        v->seg_hits = nullptr;
+        v->seg_cap = 0;
+        TSDF_HIP(hipMalloc((void **)&v->seg_hits, n_rec * 4 * sizeof(float)), "ray segment records alloc");
+        v->seg_cap = n_rec;
+    }
+    if (v->tail_cap < n_rec) {
+        if (v->tail_entries) (void)hipFree(v->tail_entries);
+        v->tail_entries = nullptr;
+        v->tail_cap = 0;
+        TSDF_HIP(hipMalloc(&v->tail_entries, n_rec * sizeof(uint2)), "ray tail queue alloc");
+        v->tail_cap = n_rec;
+    }
+    if (!v->tail_count) TSDF_HIP(hipMalloc((void **)&v->tail_count, 2 * sizeof(uint32_t)), "ray tail counter alloc");
+    TSDF_HIP(hipMemsetAsync(v->tail_count, 0, 2 * sizeof(uint32_t), v->stream), "ray tail counter reset");
+    TailQueue tail = {reinterpret_cast<uint2 *>(v->tail_entries), v->tail_count, (uint32_t)trip_budget(), (uint32_t)tail_lanes()};
+    rp.seg_len = (kMaxSamples + n_segments - 1) / n_segments;
+    dim3 grid((rp.width + 15) / 16, (rp.height + 15) / 16, n_segments);
+    timing_begin(v, 1);
+    if (v->fast_div)
+        hipLaunchKernelGGL((process_ray_kernel<SLAB, false, true, true, true, true>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp,
+                           v->seg_hits, (unsigned long long *)nullptr, (unsigned int *)nullptr, v->occ, v->t_table, tail);
+    else
+        hipLaunchKernelGGL((process_ray_kernel<SLAB, false, true, false, true, true>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp,
+                           v->seg_hits, (unsigned long long *)nullptr, (unsigned int *)nullptr, v->occ, v->t_table, tail);
+    timing_end(v, 1);
+    TSDF_HIP(hipGetLastError(), "process_ray failed");
+    // persistent workgroups: 16 groups of 16 lanes each, fetching rays until the queue is empty
+    timing_begin(v, 2);
+    if (v->fast_div)
+        hipLaunchKernelGGL((process_ray_tail_kernel<SLAB, true>), dim3(tail_grid()), dim3(256), 0, v->stream, v->dist, v->g, rp, v->seg_hits,
+                           v->occ, v->t_table, tail);
+    else
+        hipLaunchKernelGGL((process_ray_tail_kernel<SLAB, false>), dim3(tail_grid()), dim3(256), 0, v->stream, v->dist, v->g, rp, v->seg_hits,
+                           v->occ, v->t_table, tail);
+    timing_end(v, 2);
+    TSDF_HIP(hipGetLastError(), "process_ray (tail) failed");
+    return TSDF_OK;
+}
+
 }  // namespace tsdf
 
 using namespace tsdf;
@@ -675,29 +978,11 @@ int tsdf_raycast_device(const tsdf_volume *v, uint32_t width, uint32_t height, c
     rc = occupancy_refresh(const_cast<tsdf_volume *>(v));
     if (rc != TSDF_OK) return rc;
     RayParams rp = make_params(v, width, height, pose, kinv);
-    // the march is split into kRaySegments sample ranges per ray (short waves, 8x the parallelism); their
-    // records are merged by the same min-k select the multi-GPU path uses
     const size_t n_pix = (size_t)width * height;
-    const int kRaySegments = ray_segments();
     tsdf_volume *mv = const_cast<tsdf_volume *>(v);
-    if (mv->seg_cap < n_pix * kRaySegments) {
-        if (mv->seg_hits) (void)hipFree(mv->seg_hits);
-        mv->seg_hits = nullptr;
-        mv->seg_cap = 0;
-        TSDF_HIP(hipMalloc((void **)&mv->seg_hits, n_pix * kRaySegments * 4 * sizeof(float)), "ray segment records alloc");
-        mv->seg_cap = n_pix * kRaySegments;
-    }
-    rp.seg_len = (kMaxSamples + kRaySegments - 1) / kRaySegments;
-    dim3 grid((width + 15) / 16, (height + 15) / 16, kRaySegments);
-    timing_begin(mv, 1);
-    if (v->fast_div)
-        hipLaunchKernelGGL((process_ray_kernel<false, false, true, true, true>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp,
-                           mv->seg_hits, (unsigned long long *)nullptr, (unsigned int *)nullptr, v->occ, v->t_table);
-    else
-        hipLaunchKernelGGL((process_ray_kernel<false, false, true, false, true>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp,
-                           mv->seg_hits, (unsigned long long *)nullptr, (unsigned int *)nullptr, v->occ, v->t_table);
-    timing_end(mv, 1);
-    TSDF_HIP(hipGetLastError(), "process_ray failed");
+    int kRaySegments = 0;
+    rc = march_segments<false>(mv, rp, n_pix, kRaySegments);
+    if (rc != TSDF_OK) return rc;
     hipLaunchKernelGGL(merge_hits_kernel, dim3((unsigned)((n_pix + 255) / 256)), dim3(256), 0, v->stream,
                        reinterpret_cast<const float4 *>(mv->seg_hits), (uint32_t)kRaySegments, (uint32_t)n_pix, device_vertices);
     TSDF_HIP(hipGetLastError(), "merge ray segments failed");
@@ -755,8 +1040,8 @@ int tsdf_raycast_stats(const tsdf_volume *v, uint32_t width, uint32_t height, co
     (void)hipMemsetAsync(bitmap, 0, words * sizeof(unsigned int), v->stream);
     (void)hipMemsetAsync(v->counter_dev, 0, 4 * sizeof(unsigned long long), v->stream);
     dim3 grid((width + 15) / 16, (height + 15) / 16);
-    hipLaunchKernelGGL((process_ray_kernel<false, true, false, false, false>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp, verts,
-                       v->counter_dev, bitmap, v->occ, v->t_table);
+    hipLaunchKernelGGL((process_ray_kernel<false, true, false, false, false, false>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp, verts,
+                       v->counter_dev, bitmap, v->occ, v->t_table, TailQueue{nullptr, nullptr, 0, 0});
     hipLaunchKernelGGL(popcount_kernel, dim3(1024), dim3(256), 0, v->stream, bitmap, words, v->counter_dev + 3);
     unsigned long long c[4] = {0, 0, 0, 0};
     e = hipMemcpyAsync(c, v->counter_dev, sizeof(c), hipMemcpyDeviceToHost, v->stream);
@@ -790,8 +1075,8 @@ int tsdf_raycast_evaluated_samples(const tsdf_volume *v, uint32_t width, uint32_
     }
     (void)hipMemsetAsync(v->counter_dev, 0, 4 * sizeof(unsigned long long), v->stream);
     dim3 grid((width + 15) / 16, (height + 15) / 16);
-    hipLaunchKernelGGL((process_ray_kernel<false, true, true, true, false>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp, verts,
-                       v->counter_dev, bitmap, v->occ, v->t_table);
+    hipLaunchKernelGGL((process_ray_kernel<false, true, true, true, false, false>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp, verts,
+                       v->counter_dev, bitmap, v->occ, v->t_table, TailQueue{nullptr, nullptr, 0, 0});
     unsigned long long c[4] = {0, 0, 0, 0};
     e = hipMemcpyAsync(c, v->counter_dev, sizeof(c), hipMemcpyDeviceToHost, v->stream);
     if (e == hipSuccess && host_per_ray)
@@ -815,23 +1100,10 @@ int tsdf_raycast_slab_device(const tsdf_volume *v, uint32_t width, uint32_t heig
     // as on a single GPU the march is split into sample ranges; the ranges' records are folded into the slab's
     // one record per pixel before it leaves this rank
     const size_t n_pix = (size_t)width * height;
-    const int kRaySegments = ray_segments();
     tsdf_volume *mv = const_cast<tsdf_volume *>(v);
-    if (mv->seg_cap < n_pix * kRaySegments) {
-        if (mv->seg_hits) (void)hipFree(mv->seg_hits);
-        mv->seg_hits = nullptr;
-        mv->seg_cap = 0;
-        TSDF_HIP(hipMalloc((void **)&mv->seg_hits, n_pix * kRaySegments * 4 * sizeof(float)), "ray segment records alloc");
-        mv->seg_cap = n_pix * kRaySegments;
-    }
-    rp.seg_len = (kMaxSamples + kRaySegments - 1) / kRaySegments;
-    dim3 grid((width + 15) / 16, (height + 15) / 16, kRaySegments);
-    if (v->fast_div)
-        hipLaunchKernelGGL((process_ray_kernel<true, false, true, true, true>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp,
-                           mv->seg_hits, (unsigned long long *)nullptr, (unsigned int *)nullptr, v->occ, v->t_table);
-    else
-        hipLaunchKernelGGL((process_ray_kernel<true, false, true, false, true>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp,
-                           mv->seg_hits, (unsigned long long *)nullptr, (unsigned int *)nullptr, v->occ, v->t_table);
+    int kRaySegments = 0;
+    rc = march_segments<true>(mv, rp, n_pix, kRaySegments);
+    if (rc != TSDF_OK) return rc;
     hipLaunchKernelGGL(merge_records_kernel, dim3((unsigned)((n_pix + 255) / 256)), dim3(256), 0, v->stream,
                        reinterpret_cast<const float4 *>(mv->seg_hits), (uint32_t)kRaySegments, (uint32_t)n_pix,
                        reinterpret_cast<float4 *>(device_hits));

@@ -456,9 +456,11 @@ int tsdf_volume_destroy(tsdf_volume *v) {
     if (v->occ.cell) (void)hipFree(v->occ.cell);
     if (v->occ.reach) (void)hipFree(v->occ.reach);
     if (v->occ_bits) (void)hipFree(v->occ_bits);
+    if (v->tail_entries) (void)hipFree(v->tail_entries);
+    if (v->tail_count) (void)hipFree(v->tail_count);
     if (v->t_table) (void)hipFree(v->t_table);
     if (v->seg_hits) (void)hipFree(v->seg_hits);
-    for (int w = 0; w < 2; w++)
+    for (int w = 0; w < 3; w++)
         if (v->tev[w]) {
             for (hipEvent_t e : *v->tev[w]) (void)hipEventDestroy(e);
             delete v->tev[w];
@@ -664,7 +666,7 @@ int tsdf_volume_get_weight_data(const tsdf_volume *v, float *host) {
 int tsdf_volume_set_timing(tsdf_volume *v, int enabled) {
     TSDF_REQUIRE(v, "null volume");
     v->timing = enabled ? 1 : 0;
-    for (int w = 0; w < 2; w++)
+    for (int w = 0; w < 3; w++)
         if (v->tev[w]) {
             for (hipEvent_t e : *v->tev[w]) (void)hipEventDestroy(e);
             v->tev[w]->clear();
@@ -673,7 +675,7 @@ int tsdf_volume_set_timing(tsdf_volume *v, int enabled) {
 }
 
 int tsdf_volume_kernel_time(tsdf_volume *v, int which, uint32_t *launches, float *average_ms) {
-    TSDF_REQUIRE(v && launches && average_ms && (which == 0 || which == 1), "bad argument");
+    TSDF_REQUIRE(v && launches && average_ms && which >= 0 && which <= 2, "bad argument");
     *launches = 0;
     *average_ms = 0.0f;
     if (!v->tev[which] || v->tev[which]->size() < 2) return TSDF_OK;
