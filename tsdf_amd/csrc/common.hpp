@@ -163,6 +163,7 @@ struct tsdf_volume {
     size_t brick_box_cap;
     uint16_t *tile_max;
     size_t tile_max_cap;
+    float *plane_const;      // float4 per resident plane (+ padding): z-only terms of the projection
     // optional HIP-event timing of the two dominant kernels on the volume's stream (tsdf_volume_set_timing)
     int timing;
     std::vector<hipEvent_t> *tev[3];  // [0] integrate_kernel, [1] process_ray_kernel, [2] process_ray_tail_kernel: start/stop pairs

@@ -123,8 +123,15 @@ __global__ __launch_bounds__(256) void brick_cull_kernel(const Geom g, const Bri
                                                          const uint32_t width, const uint32_t height,
                                                          const uint16_t *__restrict__ tile_max, const uint32_t tiles_x,
                                                          const int depth_test, uint32_t *__restrict__ list,
-                                                         uint4 *__restrict__ boxes, uint32_t *__restrict__ count) {
+                                                         uint4 *__restrict__ boxes, uint32_t *__restrict__ count,
+                                                         float4 *__restrict__ plane_const, const uint32_t n_plane_const) {
     const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    // side job: the per-plane constants of integrate_kernel (see there)
+    for (uint32_t p = b; p < n_plane_const; p += gridDim.x * 256) {
+        const uint32_t vz = g.z_store_begin + p;
+        const float cz = ((((int)vz + 0.5f) * g.vs.z) + g.offset_clear.z) + g.offset.z;
+        plane_const[p] = make_float4(cz, ip.m13 * cz, ip.m23 * cz, ip.m33 * cz);
+    }
     if (b >= bg.nx * bg.ny * bg.nz) return;
     const uint32_t bx = b % bg.nx, by = (b / bg.nx) % bg.ny, bz = b / (bg.nx * bg.ny);
     const uint32_t x0 = bx * kTileX, x1 = min(x0 + kTileX, g.X) - 1;
@@ -201,33 +208,34 @@ __global__ __launch_bounds__(256) void brick_cull_kernel(const Geom g, const Bri
 // image.z == cam.z, surface z == depth, w == 1 (adding -0 is the identity, adding +0 only turns a -0 into +0, and
 // a zero's sign reaches neither the rounded pixel nor the sdf).  The kernel then skips those multiplications and
 // the divisions by 1.
-// roundf(x): half away from zero, written out (trunc + compare) so that the distance to the rounding boundary
-// is available to round_quotients below.  Identical to roundf for every input (NaN and infinities included).
-__device__ inline float round_half_away(float q, float &dist_to_half) {
-    const float t = truncf(q);
-    const float d = fabsf(q - t);
-    dist_to_half = fabsf(d - 0.5f);
-    return (d >= 0.5f) ? t + copysignf(1.0f, q) : t;
-}
-
 // rx = roundf(a1 / b), ry = roundf(a2 / b) exactly as the reference's IEEE divisions + round() give them
-// (src/Utilities/cuda_coordinate_transforms.cu:25-26), at a fraction of the cost: the quotients are first formed
-// with the hardware reciprocal (relative error < 2.4e-7 against the correctly rounded quotient); unless such a
-// quotient lies within 4e-7*|q| of a rounding boundary (x.5) both round to the same integer.  The rare lanes that
-// are that close to a boundary, or whose divisor is tiny, redo the IEEE division.
-__device__ inline void round_quotients(float a1, float a2, float b, float &rx, float &ry) {
+// (src/Utilities/cuda_coordinate_transforms.cu:25-26), at a fraction of the cost.  The quotients are first formed with
+// the hardware reciprocal (relative error < 2.4e-7 against the correctly rounded quotient) and rounded as
+// floor(q + 1/2); h = 1/2 - |q - floor(q + 1/2)| is the distance of q to the nearest rounding boundary (x.5).
+//   * |q| <= L = max(width, height) + 2 and h > thr = 4e-7 * L: the IEEE quotient lies on the same side of the same
+//     boundaries, and away from a boundary floor(q + 1/2) == roundf(q) for either sign (the addition q + 1/2 is exact
+//     or errs by less than thr), so the result is the reference's;
+//   * |q| > L: the IEEE quotient is beyond the image as well (> max(width, height) + 1 in magnitude), whatever the
+//     two round to fails the reference's frustum test alike;
+//   * otherwise (also NaN / infinite quotients, zero or denormal divisors: h is NaN or <= thr) the lane redoes the IEEE
+//     division and roundf, and maps NaN to 0 as the target's float -> int conversion does.
+__device__ inline void round_quotients(float a1, float a2, float b, float thr, float &rx, float &ry) {
     const float rc = __builtin_amdgcn_rcpf(b);
     const float q1 = a1 * rc, q2 = a2 * rc;
-    float h1, h2;
-    rx = round_half_away(q1, h1);
-    ry = round_half_away(q2, h2);
-    const bool unsure = !(h1 > 4.0e-7f * fabsf(q1)) || !(h2 > 4.0e-7f * fabsf(q2)) || !(fabsf(b) >= 1.0e-30f);
-    if (unsure) {  // (also taken for NaN / infinite quotients)
+    rx = floorf(q1 + 0.5f);
+    ry = floorf(q2 + 0.5f);
+    const float h1 = 0.5f - fabsf(q1 - rx), h2 = 0.5f - fabsf(q2 - ry);
+    if (!(h1 > thr) || !(h2 > thr)) {
         rx = roundf(a1 / b);
         ry = roundf(a2 / b);
+        if (rx != rx) rx = 0.0f;
+        if (ry != ry) ry = 0.0f;
     }
 }
 
+// Per z plane, the terms of the projection that depend on z only (the same fp32 products the reference forms per voxel):
+// {cz, inv_pose.m13 * cz, inv_pose.m23 * cz, inv_pose.m33 * cz}, cz = the voxel-centre z of the plane (:343, :783-785).
+// Written by brick_cull_kernel once per frame; wave-uniform in integrate_kernel, so read with scalar loads.
 template <bool DEFORM, bool COUNT, bool STD>
 __global__ __launch_bounds__(256) void integrate_kernel(float *__restrict__ dist, float *__restrict__ weight,
                                                         const tsdf_deformation_node *__restrict__ nodes,
@@ -238,15 +246,18 @@ __global__ __launch_bounds__(256) void integrate_kernel(float *__restrict__ dist
                                                         unsigned long long *__restrict__ counter,
                                                         const OccGrid occ, const uint32_t *__restrict__ list,
                                                         const uint4 *__restrict__ boxes,
-                                                        const uint32_t *__restrict__ count) {
+                                                        const uint32_t *__restrict__ count,
+                                                        const float4 *__restrict__ plane_const) {
     // Depth tile of the current brick: the pixel box the cull kernel derived for it, staged once per brick with
     // coalesced row loads; the per-voxel depth look-ups then read LDS instead of gathering from L2.
-    __shared__ uint16_t tile[kTilePixels];
+    __shared__ uint16_t tile[kTilePixels + 2];  // [kTilePixels] stays 0: where look-ups that miss the box are pointed
+    __shared__ float4 plane_lds[kChunkZ + kBatchZ];  // this brick's rows of plane_const
     const uint32_t tid = threadIdx.y * kTileX + threadIdx.x;
     const uint32_t n_active = DEFORM ? bg.nx * bg.ny * bg.nz : *count;  // custom nodes: every brick
     const size_t plane = (size_t)g.X * g.Y;
     const float neg_trunc = -g.trunc;
     const float fwidth = (float)width, fheight = (float)height;
+    const float round_thr = 4.0e-7f * ((float)max(width, height) + 2.0f);  // see round_quotients
     uint32_t updated = 0;
 
     for (uint32_t i = blockIdx.x; i < n_active; i += gridDim.x) {
@@ -262,6 +273,11 @@ __global__ __launch_bounds__(256) void integrate_kernel(float *__restrict__ dist
         const uint32_t pitch = (box.z + 1u) & ~1u;  // even, so a row starts on a 4-byte boundary
         const bool staged = box.z != 0 && pitch * box.w <= (uint32_t)kTilePixels;
         __syncthreads();  // the previous brick's look-ups are done
+        if (!DEFORM && tid < (uint32_t)(kChunkZ + kBatchZ)) {
+            const uint32_t p = z0 - g.z_store_begin + tid;   // (plane_const is padded by kBatchZ rows)
+            if (p < g.z_store_end - g.z_store_begin + kBatchZ) plane_lds[tid] = plane_const[p];
+        }
+        if (tid == 0) tile[kTilePixels] = 0;
         if (staged) {
             for (uint32_t p = tid; p < pitch * box.w; p += kTileX * kTileY) {
                 const uint32_t ty = p / pitch, tx = p - ty * pitch;
@@ -294,15 +310,13 @@ __global__ __launch_bounds__(256) void integrate_kernel(float *__restrict__ dist
         for (uint32_t zb = z0; zb < z1; zb += kBatchZ, idx += plane * kBatchZ) {
             float camz_[kBatchZ], cz_[kBatchZ];
             int px_[kBatchZ], py_[kBatchZ];
-            uint16_t d_[kBatchZ];
+            uint32_t d_[kBatchZ];  // depth of the voxel's pixel, 0 = none
             bool act[kBatchZ];
 #pragma unroll
             for (int j = 0; j < kBatchZ; j++) {
                 const uint32_t vz = zb + j;
                 act[j] = vz < z1;
-                d_[j] = 0;
-                px_[j] = py_[j] = 0;
-                float cz;
+                float cz = 0.f;
                 if (DEFORM) {
                     // (custom nodes: x/y parts differ per voxel)
                     cz = 0.f;
@@ -316,33 +330,41 @@ __global__ __launch_bounds__(256) void integrate_kernel(float *__restrict__ dist
                     r2 = ip.m21 * cx + ip.m22 * cy;
                     r3 = ip.m31 * cx + ip.m32 * cy;
                     r4 = ip.m41 * cx + ip.m42 * cy;
+                }
+                // world_to_pixel (src/Utilities/cuda_coordinate_transforms.cu:10-30)
+                float camx, camy, camz;
+                if (DEFORM) {
+                    camx = (r1 + ip.m13 * cz) + ip.m14;
+                    camy = (r2 + ip.m23 * cz) + ip.m24;
+                    camz = (r3 + ip.m33 * cz) + ip.m34;
                 } else {
-                    cz = ((((int)vz + 0.5f) * g.vs.z) + g.offset_clear.z) + g.offset.z;
+                    const float4 pc = plane_lds[vz - z0];
+                    cz = pc.x;
+                    camx = (r1 + pc.y) + ip.m14;
+                    camy = (r2 + pc.z) + ip.m24;
+                    camz = (r3 + pc.w) + ip.m34;
                 }
                 cz_[j] = cz;
-                // world_to_pixel (src/Utilities/cuda_coordinate_transforms.cu:10-30)
-                const float camx = (r1 + ip.m13 * cz) + ip.m14;
-                const float camy = (r2 + ip.m23 * cz) + ip.m24;
-                const float camz = (r3 + ip.m33 * cz) + ip.m34;
                 camz_[j] = camz;
                 const float imx = STD ? k.m11 * camx + k.m13 * camz : k.m11 * camx + k.m12 * camy + k.m13 * camz;
                 const float imy = STD ? k.m22 * camy + k.m23 * camz : k.m21 * camx + k.m22 * camy + k.m23 * camz;
                 const float imz = STD ? camz : k.m31 * camx + k.m32 * camy + k.m33 * camz;
-                // pixel = (int)round(q) with the target's conversion (NaN -> 0, saturating: f2i_sat); the
-                // frustum test (:349) is done on the rounded floats, which order exactly like the saturated ints
+                // pixel = (int)round(q) with the target's conversion (NaN -> 0, saturating); the frustum test (:349) is
+                // done on the rounded floats, which order exactly like the saturated ints
                 float rx, ry;
-                round_quotients(imx, imy, imz, rx, ry);
-                if (rx != rx) rx = 0.0f;
-                if (ry != ry) ry = 0.0f;
-                if (act[j] && rx >= 0.0f && rx < fwidth && ry >= 0.0f && ry < fheight) {
-                    px_[j] = (int)rx;
-                    py_[j] = (int)ry;
-                    // the box contains every pixel a voxel of this brick can map to (cull kernel); the range
-                    // check only guards the LDS bounds should that ever be violated
-                    const uint32_t tx = (uint32_t)px_[j] - box.x, ty = (uint32_t)py_[j] - box.y;
-                    if (staged && tx < box.z && ty < box.w) d_[j] = tile[ty * pitch + tx];
-                    else d_[j] = depth[(uint32_t)py_[j] * width + (uint32_t)px_[j]];
-                }
+                round_quotients(imx, imy, imz, round_thr, rx, ry);
+                // (clamped before the conversion so that it is defined for any float; -1 and 65536 are off the image)
+                px_[j] = (int)__builtin_amdgcn_fmed3f(rx, -1.0f, 65536.0f);
+                py_[j] = (int)__builtin_amdgcn_fmed3f(ry, -1.0f, 65536.0f);
+                // The brick's pixel box (cull kernel) holds every pixel a voxel of this brick can map to, and it lies
+                // inside the image: a pixel in the box passes the frustum test.  The LDS read is unconditional (a slot
+                // holding 0 when outside) and the global gather a separate, rare branch, so that neither turns into a generic
+                // load that would have to be waited for plane by plane.
+                const uint32_t tx = (uint32_t)px_[j] - box.x, ty = (uint32_t)py_[j] - box.y;
+                const bool in_box = act[j] && staged && tx < box.z && ty < box.w;
+                d_[j] = tile[in_box ? ty * pitch + tx : (uint32_t)kTilePixels];
+                if (act[j] && !in_box && rx >= 0.0f && rx < fwidth && ry >= 0.0f && ry < fheight)
+                    d_[j] = depth[(uint32_t)py_[j] * width + (uint32_t)px_[j]];
                 if (DEFORM) {  // keep the per-voxel row sums for pass 2
                     r4_[j] = r4;
                 }
@@ -436,6 +458,9 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
         v->brick_box_cap = n_bricks;
     }
     uint4 *boxes = reinterpret_cast<uint4 *>(v->brick_boxes);
+    const uint32_t n_plane_const = g.z_store_end - g.z_store_begin + kBatchZ;  // padded: a batch may run past the last plane
+    if (!v->plane_const) TSDF_HIP(hipMalloc((void **)&v->plane_const, n_plane_const * 4 * sizeof(float)), "plane constants alloc");
+    float4 *plane_const = reinterpret_cast<float4 *>(v->plane_const);
 
     if (v->counting) TSDF_HIP(hipMemsetAsync(v->counter_dev, 0, sizeof(unsigned long long), v->stream), "reset counter");
     if (!v->nodes) {
@@ -446,7 +471,7 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
         hipLaunchKernelGGL(depth_tile_max_kernel, dim3(tiles_x, tiles_y), dim3(64), 0, v->stream, d_depth, width, height,
                            tiles_x, v->tile_max);
         hipLaunchKernelGGL(brick_cull_kernel, dim3((unsigned)((n_bricks + 255) / 256)), dim3(256), 0, v->stream, g, bg, ip, mk,
-                           width, height, v->tile_max, tiles_x, depth_test, v->brick_list, boxes, count);
+                           width, height, v->tile_max, tiles_x, depth_test, v->brick_list, boxes, count, plane_const, n_plane_const);
     }
     dim3 block(kTileX, kTileY, 1);
     dim3 grid((unsigned)std::min<size_t>(n_bricks, 256 * 6));  // resident at once (SGPR-limited to 6-7 blocks per CU)
@@ -458,7 +483,7 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
                             mkinv.m31 == 0.0f && mkinv.m32 == 0.0f && mkinv.m33 == 1.0f;
 #define LAUNCH(DEF, CNT, STDC)                                                                                       \
     hipLaunchKernelGGL((integrate_kernel<DEF, CNT, STDC>), grid, block, 0, v->stream, v->dist, v->weight, v->nodes, \
-                       g, bg, ip, mk, mkinv, width, height, d_depth, v->counter_dev, v->occ, v->brick_list, boxes, count)
+                       g, bg, ip, mk, mkinv, width, height, d_depth, v->counter_dev, v->occ, v->brick_list, boxes, count, plane_const)
     timing_begin(v, 0);
     if (v->nodes) {
         if (v->counting) LAUNCH(true, true, false); else LAUNCH(true, false, false);

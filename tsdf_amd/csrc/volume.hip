@@ -456,6 +456,7 @@ int tsdf_volume_destroy(tsdf_volume *v) {
     if (v->occ.cell) (void)hipFree(v->occ.cell);
     if (v->occ.reach) (void)hipFree(v->occ.reach);
     if (v->occ_bits) (void)hipFree(v->occ_bits);
+    if (v->plane_const) (void)hipFree(v->plane_const);
     if (v->tail_entries) (void)hipFree(v->tail_entries);
     if (v->tail_count) (void)hipFree(v->tail_count);
     if (v->t_table) (void)hipFree(v->t_table);
