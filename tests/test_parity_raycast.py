@@ -288,3 +288,52 @@ def test_sphere_golden_vectors(oracle):
         V, N = gv.raycast(160, 120, cam)
         assert_same_floats(V, f[tag + "_vertices"], "golden sphere vertices " + tag)
         assert_same_floats(N, f[tag + "_normals"], "golden sphere normals " + tag)
+
+
+_PROBE = r"""
+import sys, numpy as np
+import tsdf_amd
+from tsdf_amd import synth
+n = 96
+gv = tsdf_amd.TSDFVolume((n, n, n), (3000, 3000, 3000))
+bil = tsdf_amd.BilateralFilter(30.0, 4.5)
+for i in range(3):
+    d, cam = synth.depth_frame(i, 4, seed=0x5EED0002)
+    f = d.copy(); bil.filter(f, synth.WIDTH, synth.HEIGHT)
+    gv.integrate(f, synth.WIDTH, synth.HEIGHT, cam)
+    if i == 1:
+        gv.raycast(synth.WIDTH, synth.HEIGHT, cam)      # a ray cast between integrations (flag refresh schedule)
+d, cam = synth.depth_frame(0, 4, seed=0x5EED0002)
+V, N = gv.raycast(synth.WIDTH, synth.HEIGHT, cam)
+np.savez(sys.argv[1], V=V, N=N, D=gv.get_distance_data())
+"""
+
+
+@pytest.mark.parametrize("env", [
+    {"TSDF_RAY_SEGMENTS": "1", "TSDF_RAY_TRIP_BUDGET": "1", "TSDF_RAY_TAIL_LANES": "64"},     # everything in the tail kernel
+    {"TSDF_RAY_SEGMENTS": "3", "TSDF_RAY_TRIP_BUDGET": "2", "TSDF_RAY_TAIL_LANES": "4", "TSDF_RAY_TAIL_GRID": "7"},
+    {"TSDF_RAY_SEGMENTS": "16", "TSDF_RAY_TRIP_BUDGET": "100000"},                             # nothing in the tail kernel
+    {"TSDF_RAY_SEGMENTS": "64", "TSDF_RAY_TRIP_BUDGET": "5", "TSDF_RAY_TAIL_LANES": "8"},
+    {"TSDF_OCC_REBUILD_PERIOD": "0"},                                                          # sticky flags only
+    {"TSDF_OCC_REBUILD_PERIOD": "1"},                                                          # flags rebuilt every frame
+])
+def test_schedule_knobs_do_not_change_a_bit(oracle, tmp_path, env):
+    """How the march is cut into sample ranges, passes and lane groups, and when the occupancy flags are refreshed, is
+    scheduling only: every setting must give the oracle's image."""
+    import os
+    import subprocess
+    import sys
+    out = str(tmp_path / "probe.npz")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, **env)
+    e["PYTHONPATH"] = root + os.pathsep + e.get("PYTHONPATH", "")
+    subprocess.run([sys.executable, "-c", _PROBE, out], check=True, env=e, cwd=root, timeout=600)
+    got = np.load(out)
+    n = 96
+    ov = oracle.Volume((n, n, n), (3000, 3000, 3000))
+    ov.set_distance_data(got["D"])                      # (integrate parity is covered elsewhere)
+    _, cam = synth.depth_frame(0, 4, seed=0x5EED0002)
+    Vo, No = ov.raycast(W, H, cam.pose(), cam.kinv(), nthreads=oracle.max_threads())
+    assert np.array_equal(np.isnan(got["V"]), np.isnan(Vo))
+    assert_same_floats(got["V"], Vo, "vertices with %s" % env)
+    assert_same_floats(got["N"], No, "normals with %s" % env)
