@@ -7,7 +7,7 @@ ARCH     ?= gfx950
 # -ffp-contract=off: every fp32 op rounds on its own, in the reference's order (parity contract)
 HIPFLAGS  = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Iinclude -Itsdf_amd/csrc -Wall -Wno-unused-function
 CSRC      = tsdf_amd/csrc
-HIP_SRCS  = $(CSRC)/volume.hip $(CSRC)/integrate.hip $(CSRC)/raycast.hip $(CSRC)/bilateral.hip
+HIP_SRCS  = $(CSRC)/volume.hip $(CSRC)/integrate.hip $(CSRC)/raycast.hip $(CSRC)/bilateral.hip $(CSRC)/icp.hip
 HIP_OBJS  = $(HIP_SRCS:.hip=.o)
 LIBDIR    = tsdf_amd/lib
 
@@ -19,7 +19,12 @@ EIGEN_INC := $(shell for d in /usr/include/eigen3 /usr/local/include/eigen3; do 
 ifeq ($(EIGEN_INC),)
 EIGEN_INC = -I$(HOSTDIR)/eigen_compat
 endif
-HOSTFLAGS = -std=c++11 -O2 -ffp-contract=off -fPIC -Wall -Iinclude -I$(HOSTDIR)/include $(EIGEN_INC)
+# the same for Sophus (used only by the ICPOdometry interface)
+SOPHUS_INC := $(shell for d in /usr/include /usr/local/include; do [ -f $$d/sophus/se3.hpp ] && echo -I$$d && break; done)
+ifeq ($(SOPHUS_INC),)
+SOPHUS_INC = -I$(HOSTDIR)/sophus_compat
+endif
+HOSTFLAGS = -std=c++11 -O2 -ffp-contract=off -fPIC -Wall -Iinclude -I$(HOSTDIR)/include -I$(HOSTDIR)/third_party $(EIGEN_INC) $(SOPHUS_INC)
 HOST_SRCS = $(wildcard $(HOSTDIR)/src/*.cpp)
 HOST_OBJS = $(HOST_SRCS:.cpp=.o)
 
@@ -27,7 +32,7 @@ all: hip host oracle cpptest
 
 host: $(LIBDIR)/libtsdf_host.so
 
-$(HOSTDIR)/src/%.o: $(HOSTDIR)/src/%.cpp $(wildcard $(HOSTDIR)/include/*.hpp) $(wildcard $(HOSTDIR)/src/*.hpp) $(wildcard $(HOSTDIR)/eigen_compat/Eigen/*) include/tsdf_amd.h
+$(HOSTDIR)/src/%.o: $(HOSTDIR)/src/%.cpp $(wildcard $(HOSTDIR)/include/*.hpp) $(wildcard $(HOSTDIR)/src/*.hpp) $(wildcard $(HOSTDIR)/eigen_compat/Eigen/*) $(wildcard $(HOSTDIR)/sophus_compat/sophus/*) $(wildcard $(HOSTDIR)/third_party/ICP_CUDA/*) include/tsdf_amd.h
 	$(CXX) $(HOSTFLAGS) -c $< -o $@
 
 $(LIBDIR)/libtsdf_host.so: $(HOST_OBJS) $(LIBDIR)/libtsdf_hip.so

@@ -224,6 +224,7 @@ def main():
         out["roofline"] = roof_ray if dominant == "raycast" else roof_int
         out["roofline_other"] = roof_int if dominant == "raycast" else roof_ray
 
+        out["icp"] = icp_tracking(tsdf_amd, synth, depth_dev, frames, stream, not args.no_cpu_baseline)
         if not args.no_parity:
             out["parity"] = parity_gate(tsdf_amd, synth, n_small=96)
         if not args.no_cpu_baseline:
@@ -234,6 +235,41 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def icp_tracking(tsdf_amd, synth, depth_dev, frames, stream, with_cpu):
+    """Next-row measurement (BASELINE config 5): ICP tracking between two consecutive bilateral-filtered
+    frames of the stream -- both pyramids (initICPModel + initICP) and the 19 Gauss-Newton iterations of
+    getIncrementalTransformation, device resident.  Not part of `value`.  The oracle's ICP on one host thread beside it."""
+    import torch
+    bil = tsdf_amd.BilateralFilter(30.0, 4.5)
+    a = torch.empty((H * W,), dtype=torch.int16, device="cuda")
+    b = torch.empty((H * W,), dtype=torch.int16, device="cuda")
+    bil.filter_device(depth_dev[0].data_ptr(), a.data_ptr(), W, H, bits=16, stream=stream.cuda_stream)
+    bil.filter_device(depth_dev[1].data_ptr(), b.data_ptr(), W, H, bits=16, stream=stream.cuda_stream)
+    icp = tsdf_amd.ICPOdometry(W, H, 331.0, 234.6, 591.1, 590.1)
+    icp.set_stream(stream.cuda_stream)
+    reps = 20
+    for r in range(reps + 3):
+        if r == 3:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        icp.init_icp_device(a.data_ptr(), model=True)
+        icp.init_icp_device(b.data_ptr())
+        T = icp.get_incremental_transformation()
+    ms = (time.perf_counter() - t0) * 1e3 / reps
+    res = {"ms_per_frame": round(ms, 4), "iterations": [4, 5, 10], "inliers": icp.last_inliers,
+           "what": "initICPModel + initICP + getIncrementalTransformation, 640x480, 3 levels"}
+    if with_cpu:
+        import oracle as O
+        fa = a.cpu().numpy().view(np.uint16)
+        fb = b.cpu().numpy().view(np.uint16)
+        t0 = time.perf_counter()
+        To, _, inl = O.icp_incremental_transformation(fb, fa, W, H, 331.0, 234.6, 591.1, 590.1)
+        res["cpu_oracle_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+        res["cpu_cores"] = 1
+        res["max_abs_pose_difference_vs_oracle"] = float(np.max(np.abs(T - To)))
+    return res
 
 
 def load_traffic():

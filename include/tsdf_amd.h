@@ -41,6 +41,7 @@ extern "C" {
 
 typedef struct tsdf_volume tsdf_volume;       /* opaque: one TSDFVolume (or one Z-slab of it) */
 typedef struct tsdf_bilateral tsdf_bilateral; /* opaque: one BilateralFilter                  */
+typedef struct tsdf_icp tsdf_icp;             /* opaque: one ICPOdometry                      */
 
 /* Mirror of the reference's private state, src/include/TSDFVolume.hpp:269-303. */
 typedef struct tsdf_volume_info {
@@ -187,6 +188,31 @@ int tsdf_raycast_slab_device(const tsdf_volume *volume, uint32_t width, uint32_t
                              const float pose[16], const float kinv[9], float *device_hits);
 int tsdf_merge_hits_device(const float *device_hits_all, uint32_t n_slabs, uint32_t width,
                            uint32_t height, float *device_vertices, void *hip_stream);
+
+/* ---- ICP tracking: replaces third_party/ICP_CUDA ------------------------------------------ */
+/* ICPOdometry::ICPOdometry (third_party/ICP_CUDA/ICPOdometry.cpp:10-57): three pyramid levels of vertex / normal maps for
+ * the model ("prev") and the current frame; angle_thresh is the sine of the angle gate. */
+int tsdf_icp_create(int width, int height, float cx, float cy, float fx, float fy, float dist_thresh, float angle_thresh,
+                    tsdf_icp **out);
+void tsdf_icp_destroy(tsdf_icp *icp);
+int tsdf_icp_set_stream(tsdf_icp *icp, void *hip_stream);
+/* ICPOdometry::initICP (model = 0, ICPOdometry.cpp:64-78) / initICPModel (model = 1, :80-95): upload the depth (uint16 mm),
+ * pyrDown twice, createVMap + createNMap per level (Cuda/pyrdown.cu).  The host variant synchronises like the reference;
+ * the _device variant takes a device pointer and does not. */
+int tsdf_icp_init(tsdf_icp *icp, int model, const uint16_t *host_depth, float depth_cutoff);
+int tsdf_icp_init_device(tsdf_icp *icp, int model, const uint16_t *device_depth, float depth_cutoff);
+/* estimateStep (Cuda/estimate.cu:215-281) for one pyramid level: R (3x3 column-major, Eigen's data()) and t map current-frame
+ * points into the model frame; returns the 6x6 normal matrix A, b, {sum of squared residuals, inliers}. */
+int tsdf_icp_estimate_step(tsdf_icp *icp, int level, const float R[9], const float t[3], float A[36], float b[6],
+                           float residual_inliers[2]);
+/* ICPOdometry::getIncrementalTransformation (ICPOdometry.cpp:97-136): 4/5/10 iterations from the coarsest level down,
+ * T <- exp(A^-1 b) * T each (the solve and the exponential run on the device, the pose never leaves it between
+ * iterations).  T_prev_curr: 4x4 column-major double (Sophus::SE3d::matrix().data()), in/out. */
+int tsdf_icp_get_incremental_transformation(tsdf_icp *icp, double T_prev_curr[16], float *last_error, float *last_inliers);
+/* Tests / diagnostics: which = 0 vmap_prev, 1 nmap_prev, 2 vmap_curr, 3 nmap_curr (3*rows x cols floats of the level);
+ * the depth pyramid of the last init call. */
+int tsdf_icp_get_map(const tsdf_icp *icp, int which, int level, float *host_map);
+int tsdf_icp_get_depth_level(const tsdf_icp *icp, int level, uint16_t *host_depth);
 
 /* ---- bilateral filter -------------------------------------------------------------------- */
 /* Replaces BilateralFilter::BilateralFilter / ~BilateralFilter (src/BilateralFilter.cpp:15-51):

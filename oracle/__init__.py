@@ -17,7 +17,8 @@ _REF = os.path.join(_HERE, "_ref", "libref_bilateral.so")
 def build(force=False):
     """(Re)build the oracle .so (and oracle/_ref when /root/reference is mounted)."""
     if force or not os.path.exists(_LIB) or \
-            os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "tsdf_oracle.c")):
+            os.path.getmtime(_LIB) < max(os.path.getmtime(os.path.join(_HERE, f))
+                                         for f in ("tsdf_oracle.c", "icp_oracle.c", "tsdf_oracle.h")):
         subprocess.check_call(["make", "-C", _HERE, "-s", "all"])
     return _LIB
 
@@ -73,6 +74,17 @@ def lib():
         L.orc_pixel_to_image_plane.argtypes = [fp, C.c_uint16, C.c_uint16, fp]
         L.orc_image_plane_to_pixel.argtypes = [fp, fp, C.POINTER(C.c_int)]
         L.orc_max_threads.restype = C.c_int
+        u16p, dp = C.POINTER(C.c_uint16), C.POINTER(C.c_double)
+        L.orc_icp_pyr_down.argtypes = [u16p, C.c_int, C.c_int, u16p]
+        L.orc_icp_vmap.argtypes = [u16p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, fp]
+        L.orc_icp_nmap.argtypes = [fp, C.c_int, C.c_int, fp]
+        L.orc_icp_step.argtypes = [fp, fp, fp, fp, fp, fp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
+                                   C.c_float, C.c_float, fp, fp, fp, dp]
+        L.orc_ldlt_solve6.argtypes = [fp, fp, dp]
+        L.orc_se3_exp.argtypes = [dp, dp]
+        L.orc_mat4d_mul.argtypes = [dp, dp, dp]
+        L.orc_icp_incremental_transformation.argtypes = [u16p, u16p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                                                         C.c_float, C.c_float, C.c_float, C.c_float, dp, fp, fp]
         _lib = L
     return _lib
 
@@ -312,3 +324,75 @@ def ref_bilateral_u8(image, width, height, sigma_colour, sigma_space):
     img = np.ascontiguousarray(image, np.uint8).reshape(-1).copy()
     L.ref_bilateral_u8(img.ctypes.data_as(C.POINTER(C.c_uint8)), width, height, sigma_colour, sigma_space)
     return img.reshape(height, width)
+
+
+# ---- ICP tracking (icp_oracle.c) -------------------------------------------------------------------------------
+def _u16(a):
+    return np.ascontiguousarray(a, dtype=np.uint16)
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def icp_pyr_down(depth, rows, cols):
+    src = _u16(depth).reshape(rows, cols)
+    dst = np.empty((rows // 2, cols // 2), np.uint16)
+    lib().orc_icp_pyr_down(src.ctypes.data_as(C.POINTER(C.c_uint16)), rows, cols, dst.ctypes.data_as(C.POINTER(C.c_uint16)))
+    return dst
+
+
+def icp_vmap(depth, rows, cols, fx, fy, cx, cy, depth_cutoff=20.0):
+    """-> (3*rows, cols) float32, planar; never-written components are 0."""
+    d = _u16(depth).reshape(rows, cols)
+    v = np.zeros((3 * rows, cols), np.float32)
+    lib().orc_icp_vmap(d.ctypes.data_as(C.POINTER(C.c_uint16)), rows, cols, fx, fy, cx, cy, depth_cutoff, _fp(v))
+    return v
+
+
+def icp_nmap(vmap, rows, cols):
+    v = _f32(vmap, 3 * rows * cols)
+    n = np.zeros((3 * rows, cols), np.float32)
+    lib().orc_icp_nmap(_fp(v), rows, cols, _fp(n))
+    return n
+
+
+def icp_step(R, t, vmap_curr, nmap_curr, vmap_prev, nmap_prev, rows, cols, fx, fy, cx, cy, dist_thresh, angle_thresh):
+    """R: 3x3 column-major, t: 3 -> (A 6x6, b 6, residual, inliers, sums29 float64)."""
+    R, t = _f32(R, 9), _f32(t, 3)
+    arrs = [_f32(a, 3 * rows * cols) for a in (vmap_curr, nmap_curr, vmap_prev, nmap_prev)]
+    A, b, ri, sums = np.zeros(36, np.float32), np.zeros(6, np.float32), np.zeros(2, np.float32), np.zeros(29, np.float64)
+    lib().orc_icp_step(_fp(R), _fp(t), *[_fp(a) for a in arrs], rows, cols, fx, fy, cx, cy, dist_thresh, angle_thresh,
+                       _fp(A), _fp(b), _fp(ri), _dp(sums))
+    return A.reshape(6, 6), b, float(ri[0]), float(ri[1]), sums
+
+
+def ldlt_solve6(A, b):
+    A, b = _f32(A, 36), _f32(b, 6)
+    x = np.zeros(6, np.float64)
+    lib().orc_ldlt_solve6(_fp(A), _fp(b), _dp(x))
+    return x
+
+
+def se3_exp(a):
+    """a = (upsilon, omega) -> 4x4 (row/col indexed as a normal matrix)."""
+    a = np.ascontiguousarray(a, np.float64)
+    T = np.zeros(16, np.float64)
+    lib().orc_se3_exp(_dp(a), _dp(T))
+    return T.reshape(4, 4).T.copy()
+
+
+def icp_incremental_transformation(depth_curr, depth_model, width, height, cx, cy, fx, fy, dist_thresh=0.10,
+                                   angle_thresh=None, depth_cutoff=20.0, T=None):
+    """ICPOdometry::initICP(depth_curr) + initICPModel(depth_model) + getIncrementalTransformation(T).
+    -> (T 4x4 float64, last_error, last_inliers)."""
+    import math
+    if angle_thresh is None:
+        angle_thresh = float(np.float32(math.sin(np.float32(20.0) * np.float32(3.14159254) / np.float32(180.0))))
+    Tc = np.ascontiguousarray((np.eye(4) if T is None else np.asarray(T, np.float64)).T.reshape(-1))   # column-major
+    err, inl = C.c_float(), C.c_float()
+    a, b = _u16(depth_curr).reshape(-1), _u16(depth_model).reshape(-1)
+    lib().orc_icp_incremental_transformation(a.ctypes.data_as(C.POINTER(C.c_uint16)), b.ctypes.data_as(C.POINTER(C.c_uint16)),
+                                             width, height, cx, cy, fx, fy, dist_thresh, angle_thresh, depth_cutoff, _dp(Tc),
+                                             C.byref(err), C.byref(inl))
+    return Tc.reshape(4, 4).T.copy(), float(err.value), float(inl.value)

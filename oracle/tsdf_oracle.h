@@ -136,6 +136,21 @@ void orc_image_plane_to_pixel(const float k[9], const float cam[2], int out[2]);
 
 int orc_max_threads(void);
 
+/* ---- ICP tracking (third_party/ICP_CUDA) -- icp_oracle.c, PARITY UNPINNED (see its header) ------ */
+void orc_icp_pyr_down(const uint16_t *src, int src_rows, int src_cols, uint16_t *dst);
+void orc_icp_vmap(const uint16_t *depth, int rows, int cols, float fx, float fy, float cx, float cy, float depth_cutoff,
+                  float *vmap);
+void orc_icp_nmap(const float *vmap, int rows, int cols, float *nmap);
+void orc_icp_step(const float *R, const float *t, const float *vmap_curr, const float *nmap_curr, const float *vmap_prev,
+                  const float *nmap_prev, int rows, int cols, float fx, float fy, float cx, float cy, float dist_thresh,
+                  float angle_thresh, float *A, float *b, float *residual_inliers, double *sums29);
+void orc_ldlt_solve6(const float *A, const float *b, double *x);
+void orc_se3_exp(const double *a, double *T);
+void orc_mat4d_mul(const double *A, const double *B, double *C);
+void orc_icp_incremental_transformation(const uint16_t *depth_curr, const uint16_t *depth_model, int width, int height,
+                                        float cx, float cy, float fx, float fy, float dist_thresh, float angle_thresh,
+                                        float depth_cutoff, double *T, float *last_error, float *last_inliers);
+
 #ifdef __cplusplus
 }
 #endif

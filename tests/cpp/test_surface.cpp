@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "BilateralFilter.hpp"
+#include "ICP_CUDA/ICPOdometry.h"
 #include "GPURaycaster.hpp"
 #include "MarkAndSweepMC.hpp"
 #include "TSDFVolume.hpp"
@@ -79,6 +80,22 @@ int main(int argc, char **argv) {
 
     DepthImage *rendered = GPURaycaster(W, H).render_to_depth_image(*volume, *camera);
     dump(out + "/rendered_depth.u16", rendered->data(), (size_t)W * H * 2);
+
+    // ICP between the input depth (model) and the depth rendered from the volume, the way src/Tools/tsdf_icp.cpp does
+    {
+        ICPOdometry icp(W, H, 331.0f, 234.6f, 591.1f, 590.1f);
+        icp.initICPModel(filtered.data());
+        icp.initICP((unsigned short *)rendered->data());
+        Sophus::SE3d mesh_to_depth_transform;
+        icp.getIncrementalTransformation(mesh_to_depth_transform, 224, 96);
+        Eigen::Matrix<double, 4, 4> m = mesh_to_depth_transform.matrix();
+        dump(out + "/icp_transform.f64", m.data(), 16 * sizeof(double));
+        float stats[2] = {icp.lastError, icp.lastInliers};
+        dump(out + "/icp_stats.f32", stats, sizeof(stats));
+        Eigen::Matrix4f pose_f = mesh_to_depth_transform.cast<float>().matrix();
+        Eigen::Vector3f trans = pose_f.topRightCorner(3, 1);
+        std::cout << "icp trans : " << trans[0] << " " << trans[1] << " " << trans[2] << " inliers " << icp.lastInliers << std::endl;
+    }
     delete rendered;
 
     std::vector<float3> mesh_vertices;

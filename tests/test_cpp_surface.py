@@ -73,6 +73,13 @@ def test_cpp_surface_matches_the_oracle(tmp_path, oracle):
     mv = np.fromfile(str(tmp_path / "mesh_vertices.f32"), np.float32).reshape(-1, 3)
     assert mv.shape[0] > 1000 and mv.shape[0] % 3 == 0
     assert mv.min() >= 0 and mv.max() <= 3000
+    # ICPOdometry (the flow of src/Tools/tsdf_icp.cpp: model = input depth, current = depth rendered from the volume):
+    # same pose as the oracle's ICP on the same two images, within the tolerance of the fp32 sums (tests/test_parity_icp.py)
+    T = np.fromfile(str(tmp_path / "icp_transform.f64"), np.float64).reshape(4, 4).T
+    stats = np.fromfile(str(tmp_path / "icp_stats.f32"), np.float32)
+    To, erro, inlo = oracle.icp_incremental_transformation(rd, filtered, W, H, 331.0, 234.6, 591.1, 590.1)
+    assert np.max(np.abs(T - To)) < 2e-4, (T, To)
+    assert abs(stats[1] - inlo) <= 0.002 * inlo and inlo > 1000
 
 
 @pytest.mark.gpu
@@ -90,3 +97,31 @@ def test_reference_kinfu_runs_end_to_end_against_this_library(tmp_path):
     import re
     m = re.search(r"Writing (\d+) vertices and (\d+) triangles", out)
     assert m and int(m.group(1)) > 1000
+
+
+@pytest.mark.gpu
+def test_reference_tsdf_icp_runs_against_this_library(tmp_path):
+    """src/Tools/tsdf_icp.cpp of the reference, compiled unchanged (tools/linkcheck.sh): loads a .tsdf volume and a depth
+    PNG, renders the volume from the pose stored in it and runs ICPOdometry between the two images."""
+    tool = os.path.join(ROOT, "oracle", "_ref", "tsdf_icp")
+    if not os.path.exists(tool) or not os.path.exists(BIN):
+        pytest.skip("oracle/_ref/tsdf_icp not built (needs the reference tree at build time)")
+    # a volume file written by the class surface (test_surface saves <out>/volume.tsdf) ...
+    depth, cam = synth.depth_frame(2, 30, seed=0x5EED0001)
+    depth.tofile(str(tmp_path / "depth.u16"))
+    cam.pose().astype(np.float32).tofile(str(tmp_path / "pose.f32"))
+    r = subprocess.run([BIN, str(tmp_path / "depth.u16"), str(tmp_path / "pose.f32"), str(tmp_path), "64"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    # ... and a 16-bit depth PNG
+    synth._write_png16(str(tmp_path / "depth.png"), depth.reshape(H, W))
+    r = subprocess.run([tool, "-v", str(tmp_path / "volume.tsdf"), "-d", str(tmp_path / "depth.png")],
+                       capture_output=True, text=True, timeout=300)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out
+    assert "trans :" in out and "rot :" in out, out
+    import re
+    nums = [float(x) for x in re.findall(r"[-+]?\d*\.?\d+(?:[eE][-+]?\d+)?", out.split("trans :")[1])]
+    assert len(nums) >= 12 and np.all(np.isfinite(nums[:12]))
+    R = np.array(nums[3:12]).reshape(3, 3)
+    assert np.allclose(R @ R.T, np.eye(3), atol=1e-4)          # a rotation (printed in float)

@@ -22,5 +22,17 @@ g++ -std=c++11 -O1 -w $EIGEN -I"$ROOT/include" -c "$W/src/Tools/kinfu.cpp" -o "$
 mkdir -p "$OUT"
 g++ -o "$OUT/kinfu" "$W/kinfu.o" -L"$ROOT/tsdf_amd/lib" -ltsdf_host -ltsdf_hip -Wl,-rpath,'$ORIGIN/../../tsdf_amd/lib'
 echo "linkcheck: reference kinfu.cpp compiled unchanged and linked -> $OUT/kinfu"
+# the same for src/Tools/tsdf_icp.cpp (ICP between a saved volume and a depth image): it includes
+# "ICP_CUDA/ICPOdometry.h" (ours, under tsdf_amd/host/third_party) and <sophus/se3.hpp> (real Sophus or the bundled subset)
+ICPSRC="$REF/src/Tools/tsdf_icp.cpp"
+if [ -f "$ICPSRC" ]; then
+  ln -s "$ICPSRC" "$W/src/Tools/tsdf_icp.cpp"
+  SOPHUS=""
+  for d in /usr/include /usr/local/include; do [ -f "$d/sophus/se3.hpp" ] && SOPHUS="-I$d" && break; done
+  [ -z "$SOPHUS" ] && SOPHUS="-I$ROOT/tsdf_amd/host/sophus_compat"
+  g++ -std=c++11 -O1 -w $EIGEN $SOPHUS -I"$ROOT/include" -I"$ROOT/tsdf_amd/host/third_party" -c "$W/src/Tools/tsdf_icp.cpp" -o "$W/tsdf_icp.o"
+  g++ -o "$OUT/tsdf_icp" "$W/tsdf_icp.o" -L"$ROOT/tsdf_amd/lib" -ltsdf_host -ltsdf_hip -Wl,-rpath,'$ORIGIN/../../tsdf_amd/lib'
+  echo "linkcheck: reference tsdf_icp.cpp compiled unchanged and linked -> $OUT/tsdf_icp"
+fi
 # usage line only (no GPU needed): the binary must start and reject a bad command line like the reference
 "$OUT/kinfu" 2>&1 | head -2 || true

@@ -82,6 +82,15 @@ _SIGS = {
     "tsdf_volume_get_occupancy_data": (_i, [_vp, C.c_int, _vp, _vp, _vp]),
     "tsdf_raycast_slab_device": (_i, [_vp, _u32, _u32, _fp, _fp, _vp]),
     "tsdf_merge_hits_device": (_i, [_vp, _u32, _u32, _u32, _vp, _vp]),
+    "tsdf_icp_create": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, C.POINTER(_vp)]),
+    "tsdf_icp_destroy": (None, [_vp]),
+    "tsdf_icp_set_stream": (_i, [_vp, _vp]),
+    "tsdf_icp_init": (_i, [_vp, _i, _vp, _f]),
+    "tsdf_icp_init_device": (_i, [_vp, _i, _vp, _f]),
+    "tsdf_icp_estimate_step": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "tsdf_icp_get_incremental_transformation": (_i, [_vp, _vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "tsdf_icp_get_map": (_i, [_vp, _i, _i, _vp]),
+    "tsdf_icp_get_depth_level": (_i, [_vp, _i, _vp]),
     "tsdf_bilateral_create": (_i, [_f, _f, C.POINTER(_vp)]),
     "tsdf_bilateral_destroy": (_i, [_vp]),
     "tsdf_bilateral_filter_u8": (_i, [_vp, _vp, _i, _i]),

@@ -290,6 +290,78 @@ class BilateralFilter:
                  C.c_void_p(int(stream) if stream else 0)))
 
 
+class ICPOdometry:
+    """third_party/ICP_CUDA/ICPOdometry.h of the reference: projective point-to-plane ICP between a model depth image
+    (initICPModel) and the current one (initICP), three pyramid levels, 4/5/10 iterations."""
+
+    def __init__(self, width, height, cx, cy, fx, fy, dist_thresh=0.10, angle_thresh=None):
+        import math
+        if angle_thresh is None:   # sinf(20.f * 3.14159254f / 180.f), ICPOdometry.h:27
+            angle_thresh = float(np.float32(math.sin(np.float32(20.0) * np.float32(3.14159254) / np.float32(180.0))))
+        self.width, self.height = int(width), int(height)
+        self._h = C.c_void_p()
+        check(lib.tsdf_icp_create(self.width, self.height, float(cx), float(cy), float(fx), float(fy), float(dist_thresh),
+                                  float(angle_thresh), C.byref(self._h)))
+        self.last_error, self.last_inliers = 0.0, float(width * height)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib.tsdf_icp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def set_stream(self, hip_stream):
+        check(lib.tsdf_icp_set_stream(self._h, C.c_void_p(int(hip_stream) if hip_stream else 0)))
+
+    def _depth(self, depth):
+        d = np.ascontiguousarray(depth, dtype=np.uint16).reshape(-1)
+        if d.size != self.width * self.height:
+            raise ValueError("depth has %d pixels, expected %d" % (d.size, self.width * self.height))
+        return d
+
+    def init_icp(self, depth, depth_cutoff=20.0):
+        d = self._depth(depth)
+        check(lib.tsdf_icp_init(self._h, 0, d.ctypes.data, float(depth_cutoff)))
+
+    def init_icp_model(self, depth, depth_cutoff=20.0):
+        d = self._depth(depth)
+        check(lib.tsdf_icp_init(self._h, 1, d.ctypes.data, float(depth_cutoff)))
+
+    def init_icp_device(self, depth_ptr, model=False, depth_cutoff=20.0):
+        check(lib.tsdf_icp_init_device(self._h, 1 if model else 0, C.c_void_p(int(depth_ptr)), float(depth_cutoff)))
+
+    def estimate_step(self, level, R, t):
+        """R 3x3 (normal indexing), t 3 -> (A 6x6, b 6, residual, inliers) of one Gauss-Newton step at `level`."""
+        Rc = np.ascontiguousarray(np.asarray(R, np.float32).T.reshape(-1))   # column-major
+        tc = np.ascontiguousarray(t, np.float32).reshape(-1)
+        A, b, ri = np.zeros(36, np.float32), np.zeros(6, np.float32), np.zeros(2, np.float32)
+        check(lib.tsdf_icp_estimate_step(self._h, int(level), Rc.ctypes.data, tc.ctypes.data, A.ctypes.data, b.ctypes.data,
+                                         ri.ctypes.data))
+        return A.reshape(6, 6), b, float(ri[0]), float(ri[1])
+
+    def get_incremental_transformation(self, T=None):
+        """T_prev_curr (4x4 float64, identity by default) refined in place of the reference's Sophus::SE3d argument."""
+        Tc = np.ascontiguousarray((np.eye(4) if T is None else np.asarray(T, np.float64)).T.reshape(-1))
+        err, inl = C.c_float(), C.c_float()
+        check(lib.tsdf_icp_get_incremental_transformation(self._h, Tc.ctypes.data, C.byref(err), C.byref(inl)))
+        self.last_error, self.last_inliers = float(err.value), float(inl.value)
+        return Tc.reshape(4, 4).T.copy()
+
+    def get_map(self, which, level):
+        """which in vmap_prev | nmap_prev | vmap_curr | nmap_curr -> (3*rows, cols) float32 (planar)."""
+        rows, cols = self.height >> level, self.width >> level
+        m = np.empty((3 * rows, cols), np.float32)
+        check(lib.tsdf_icp_get_map(self._h, {"vmap_prev": 0, "nmap_prev": 1, "vmap_curr": 2, "nmap_curr": 3}[which], int(level),
+                                   m.ctypes.data))
+        return m
+
+    def get_depth_level(self, level):
+        d = np.empty((self.height >> level, self.width >> level), np.uint16)
+        check(lib.tsdf_icp_get_depth_level(self._h, int(level), d.ctypes.data))
+        return d
+
+
 class Camera:
     """The C++ Camera of the host library (same surface as src/include/Camera.hpp of the reference).
     Matrices come back as column-major float32 vectors, i.e. what Eigen's .data() yields."""

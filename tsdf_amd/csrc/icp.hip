@@ -1,0 +1,538 @@
+// ICP tracking for gfx950 (wave64): the replacement of the reference's third_party/ICP_CUDA --
+// pyrDown / createVMap / createNMap (Cuda/pyrdown.cu), estimateStep (Cuda/estimate.cu) and
+// ICPOdometry::getIncrementalTransformation (ICPOdometry.cpp:97-136).
+//
+// What is different from the reference's shape, and why:
+//   * The reference runs 19 iterations (10/5/4 over three pyramid levels), each = reduction kernel, second reduction
+//     kernel, device synchronise, 116-byte download, 6x6 LDLT + SE3 exponential on the host, next launch.  Here the
+//     pose lives on the device: icp_solve_kernel finishes the reduction, solves the 6x6 system in double and applies
+//     T <- exp(x) * T in place, so the 38 launches of a frame are queued back to back with no host round trip; the
+//     host reads the pose once at the end.
+//   * The reduction is deterministic: a fixed grid, per-thread fp32 partial sums (as in the reference), wave64 shuffle
+//     tree, fixed-order cross-wave and cross-block sums (the last stage in double).  The reference's sums depend on the
+//     threads x blocks the caller passes; those two arguments are accepted and ignored.
+//   * Maps keep the reference's planar layout (component c of pixel (x,y) at [(y + c*rows)*cols + x], NaN pattern
+//     0x7fffffff in component 0 of an invalid pixel); lane <-> x, so every plane access is coalesced.
+// Per-pixel arithmetic follows the reference's operation order with fp contraction off.
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "common.hpp"
+
+struct tsdf_icp {
+    int width, height;
+    float cx, cy, fx, fy;
+    float dist_thresh, angle_thresh;
+    int device;
+    hipStream_t stream;
+    uint16_t *depth[3];                      // pyramid scratch (used by both init calls)
+    float *vmap_prev[3], *nmap_prev[3];      // model
+    float *vmap_curr[3], *nmap_curr[3];      // current frame
+    float *partial;                          // kIcpBlocks x 32 floats: per-block sums of the 29 products
+    double *state;                           // device: [0..15] T (column-major), [16..17] residual, inliers,
+                                             //         [18..53] A (float values), [54..59] b
+    uint16_t *upload;                        // staging for host depth
+};
+
+namespace tsdf {
+
+constexpr int kIcpLevels = 3;
+constexpr int kIcpBlocks = 256;   // one workgroup per CU (icp_solve_kernel adds them as 8 groups of 32)
+constexpr int kIcpThreads = 256;
+constexpr int kIcpStateDoubles = 64;
+
+__device__ inline float nan_sentinel() { return __uint_as_float(0x7fffffffu); }
+
+// pyrDownGaussKernel (Cuda/pyrdown.cu:41-78), sigma_color = 30 (:87).  (The weighted sums are exact in fp32: the
+// weights are multiples of 1/256 and the values 16-bit, so the order of the additions does not matter.)
+__global__ __launch_bounds__(256) void icp_pyr_down_kernel(const uint16_t *__restrict__ src, int src_rows, int src_cols,
+                                                           uint16_t *__restrict__ dst) {
+    const int rows = src_rows / 2, cols = src_cols / 2;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    const int D = 5;
+    const float sigma_color = 30;
+    const int center = src[(size_t)(2 * y) * src_cols + 2 * x];
+    const int x_mi = max(0, 2 * x - D / 2) - 2 * x, y_mi = max(0, 2 * y - D / 2) - 2 * y;
+    const int x_ma = min(src_cols, 2 * x - D / 2 + D) - 2 * x, y_ma = min(src_rows, 2 * y - D / 2 + D) - 2 * y;
+    float sum = 0, wall = 0;
+    const float weights[3] = {0.375f, 0.25f, 0.0625f};
+    for (int yi = y_mi; yi < y_ma; ++yi)
+        for (int xi = x_mi; xi < x_ma; ++xi) {
+            const int val = src[(size_t)(2 * y + yi) * src_cols + (2 * x + xi)];
+            if (abs(val - center) < 3 * sigma_color) {
+                sum += val * weights[abs(xi)] * weights[abs(yi)];
+                wall += weights[abs(xi)] * weights[abs(yi)];
+            }
+        }
+    dst[(size_t)y * cols + x] = (uint16_t)(int)(sum / wall);
+}
+
+// computeVmapKernel (Cuda/pyrdown.cu:93-117)
+__global__ __launch_bounds__(256) void icp_vmap_kernel(const uint16_t *__restrict__ depth, int rows, int cols, float fx_inv,
+                                                       float fy_inv, float cx, float cy, float depth_cutoff,
+                                                       float *__restrict__ vmap) {
+    const int u = blockIdx.x * 64 + (threadIdx.x & 63), v = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (u >= cols || v >= rows) return;
+    const float z = depth[(size_t)v * cols + u] / 1000.f;  // mm -> metres
+    if (z != 0 && z < depth_cutoff) {
+        vmap[(size_t)v * cols + u] = z * (u - cx) * fx_inv;
+        vmap[(size_t)(v + rows) * cols + u] = z * (v - cy) * fy_inv;
+        vmap[(size_t)(v + rows * 2) * cols + u] = z;
+    } else {
+        vmap[(size_t)v * cols + u] = nan_sentinel();
+    }
+}
+
+// computeNmapKernel (Cuda/pyrdown.cu:135-172); Eigen's normalized(): n / sqrt(n.n) when n.n > 0
+__global__ __launch_bounds__(256) void icp_nmap_kernel(int rows, int cols, const float *__restrict__ vmap,
+                                                       float *__restrict__ nmap) {
+    const int u = blockIdx.x * 64 + (threadIdx.x & 63), v = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (u >= cols || v >= rows) return;
+    if (u == cols - 1 || v == rows - 1) {
+        nmap[(size_t)v * cols + u] = nan_sentinel();
+        return;
+    }
+    const float a0 = vmap[(size_t)v * cols + u], b0 = vmap[(size_t)v * cols + u + 1], c0 = vmap[(size_t)(v + 1) * cols + u];
+    if (!(a0 != a0) && !(b0 != b0) && !(c0 != c0)) {
+        const float a1 = vmap[(size_t)(v + rows) * cols + u], b1 = vmap[(size_t)(v + rows) * cols + u + 1],
+                    c1 = vmap[(size_t)(v + 1 + rows) * cols + u];
+        const float a2 = vmap[(size_t)(v + 2 * rows) * cols + u], b2 = vmap[(size_t)(v + 2 * rows) * cols + u + 1],
+                    c2 = vmap[(size_t)(v + 1 + 2 * rows) * cols + u];
+        const float px = b0 - a0, py = b1 - a1, pz = b2 - a2;
+        const float qx = c0 - a0, qy = c1 - a1, qz = c2 - a2;
+        float rx = py * qz - pz * qy, ry = pz * qx - px * qz, rz = px * qy - py * qx;
+        const float z = rx * rx + ry * ry + rz * rz;
+        if (z > 0.0f) {
+            const float l = sqrtf(z);
+            rx = rx / l;
+            ry = ry / l;
+            rz = rz / l;
+        }
+        nmap[(size_t)v * cols + u] = rx;
+        nmap[(size_t)(v + rows) * cols + u] = ry;
+        nmap[(size_t)(v + 2 * rows) * cols + u] = rz;
+    } else {
+        nmap[(size_t)v * cols + u] = nan_sentinel();
+    }
+}
+
+// __float2int_rn: to nearest even, saturating, NaN -> 0
+__device__ inline int float2int_rn(float f) {
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return 2147483647;
+    if (f <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)rintf(f);
+}
+
+// Reduction::operator() (Cuda/estimate.cu:139-209): projective association of the current frame's vertices into the
+// model, distance / angle gates, the 27 upper-triangular products of the row (n, v x n, n.(v_prev - v)) + inlier count.
+// The pose is read from the device state (T as doubles, narrowed to float like `rotationMatrix().cast<float>()`).
+__global__ __launch_bounds__(kIcpThreads) void icp_reduce_kernel(const double *__restrict__ state, const float *__restrict__ vmap_curr,
+                                                                const float *__restrict__ nmap_curr,
+                                                                const float *__restrict__ vmap_prev,
+                                                                const float *__restrict__ nmap_prev, int rows, int cols,
+                                                                float fx, float fy, float cx, float cy, float dist_thresh,
+                                                                float angle_thresh, float *__restrict__ partial) {
+    float R[9], t[3];  // column-major
+    for (int c = 0; c < 3; c++)
+        for (int r = 0; r < 3; r++) R[c * 3 + r] = (float)state[c * 4 + r];
+    for (int r = 0; r < 3; r++) t[r] = (float)state[12 + r];
+
+    float sum[29];
+#pragma unroll
+    for (int i = 0; i < 29; i++) sum[i] = 0.0f;
+    const int N = rows * cols;
+    for (int i = blockIdx.x * kIcpThreads + threadIdx.x; i < N; i += kIcpThreads * gridDim.x) {
+        const int y = i / cols, x = i - y * cols;
+        const float v0 = vmap_curr[(size_t)y * cols + x], v1 = vmap_curr[(size_t)(y + rows) * cols + x],
+                    v2 = vmap_curr[(size_t)(y + 2 * rows) * cols + x];
+        const float p0 = ((R[0] * v0 + R[3] * v1) + R[6] * v2) + t[0];
+        const float p1 = ((R[1] * v0 + R[4] * v1) + R[7] * v2) + t[1];
+        const float p2 = ((R[2] * v0 + R[5] * v1) + R[8] * v2) + t[2];
+        const int px = float2int_rn(p0 * fx / p2 + cx);
+        const int py = float2int_rn(p1 * fy / p2 + cy);
+        if (px >= 0 && py >= 0 && px < cols && py < rows && v2 > 0 && p2 > 0) {
+            const float w0 = vmap_prev[(size_t)py * cols + px], w1 = vmap_prev[(size_t)(py + rows) * cols + px],
+                        w2 = vmap_prev[(size_t)(py + 2 * rows) * cols + px];
+            const float n0 = nmap_curr[(size_t)y * cols + x], n1 = nmap_curr[(size_t)(y + rows) * cols + x],
+                        n2 = nmap_curr[(size_t)(y + 2 * rows) * cols + x];
+            const float m0 = (R[0] * n0 + R[3] * n1) + R[6] * n2;
+            const float m1 = (R[1] * n0 + R[4] * n1) + R[7] * n2;
+            const float m2 = (R[2] * n0 + R[5] * n1) + R[8] * n2;
+            const float q0 = nmap_prev[(size_t)py * cols + px], q1 = nmap_prev[(size_t)(py + rows) * cols + px],
+                        q2 = nmap_prev[(size_t)(py + 2 * rows) * cols + px];
+            const float c0 = m1 * q2 - m2 * q1, c1 = m2 * q0 - m0 * q2, c2 = m0 * q1 - m1 * q0;
+            const float sine = sqrtf((c0 * c0 + c1 * c1) + c2 * c2);
+            const float d0 = w0 - p0, d1 = w1 - p1, d2 = w2 - p2;
+            const float dist = sqrtf((d0 * d0 + d1 * d1) + d2 * d2);
+            if (sine < angle_thresh && dist < dist_thresh && !(n0 != n0) && !(q0 != q0)) {
+                float row[7];
+                row[0] = q0;
+                row[1] = q1;
+                row[2] = q2;
+                row[3] = p1 * q2 - p2 * q1;
+                row[4] = p2 * q0 - p0 * q2;
+                row[5] = p0 * q1 - p1 * q0;
+                row[6] = (q0 * d0 + q1 * d1) + q2 * d2;
+                int s = 0;
+#pragma unroll
+                for (int o = 0; o < 7; o++)
+#pragma unroll
+                    for (int in = o; in < 7; in++) sum[s++] += row[o] * row[in];
+                sum[28] += 1.0f;
+            }
+        }
+    }
+    // wave64 shuffle tree, then the four waves of the workgroup in a fixed order
+    __shared__ float shared[4][32];
+#pragma unroll
+    for (int i = 0; i < 29; i++) {
+        float v = sum[i];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+        sum[i] = v;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 29; i++) shared[wave][i] = sum[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < 29)
+        partial[blockIdx.x * 32 + threadIdx.x] =
+            ((shared[0][threadIdx.x] + shared[1][threadIdx.x]) + shared[2][threadIdx.x]) + shared[3][threadIdx.x];
+}
+
+// x = A^-1 b, 6x6 symmetric positive (semi-)definite, LDL^T with diagonal pivoting in double -- the job of
+// `A_icp.cast<double>().ldlt().solve(b_icp.cast<double>())` (ICPOdometry.cpp:131).  Zero pivots give zero components.
+// One lane runs this, so latency is everything: all loops are fully unrolled and the pivot exchanges are predicated
+// swaps at compile-time indices, which keeps the matrices in registers instead of scratch memory.
+__device__ inline void swap_if(bool c, double &a, double &b) {
+    const double t = a;
+    a = c ? b : a;
+    b = c ? t : b;
+}
+__device__ inline void ldlt_solve6(const float *A_in, const float *b_in, double *x) {
+    double A[6][6], L[6][6], D[6], y[6], z[6];
+    int perm[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        perm[i] = i;
+        y[i] = b_in[i];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            A[i][j] = A_in[i * 6 + j];
+            L[i][j] = 0.0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        // pivot: the largest remaining diagonal entry (first one on ties)
+        int p = k;
+        double best = fabs(A[k][k]);
+#pragma unroll
+        for (int i = k + 1; i < 6; i++) {
+            const double v = fabs(A[i][i]);
+            if (v > best) {
+                best = v;
+                p = i;
+            }
+        }
+#pragma unroll
+        for (int i = k + 1; i < 6; i++) {
+            const bool sw = (p == i);  // exchange rows / columns k and i of A, rows of L, the permutation, the rhs
+#pragma unroll
+            for (int j = 0; j < 6; j++) swap_if(sw, A[k][j], A[i][j]);
+#pragma unroll
+            for (int r = 0; r < 6; r++) swap_if(sw, A[r][k], A[r][i]);
+#pragma unroll
+            for (int j = 0; j < k; j++) swap_if(sw, L[k][j], L[i][j]);
+            const int tp = perm[k];
+            perm[k] = sw ? perm[i] : perm[k];
+            perm[i] = sw ? tp : perm[i];
+            swap_if(sw, y[k], y[i]);
+        }
+        D[k] = A[k][k];
+        L[k][k] = 1.0;
+        const bool nz = D[k] != 0.0;
+#pragma unroll
+        for (int i = k + 1; i < 6; i++) L[i][k] = nz ? A[i][k] / D[k] : 0.0;
+#pragma unroll
+        for (int i = k + 1; i < 6; i++)
+#pragma unroll
+            for (int j = k + 1; j < 6; j++) A[i][j] -= L[i][k] * D[k] * L[j][k];
+    }
+    // (y was permuted along with the rows: y = P b)
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j < i; j++) y[i] -= L[i][j] * y[j];
+#pragma unroll
+    for (int i = 0; i < 6; i++) z[i] = (D[i] != 0.0) ? y[i] / D[i] : 0.0;
+#pragma unroll
+    for (int i = 5; i >= 0; i--)
+#pragma unroll
+        for (int j = i + 1; j < 6; j++) z[i] -= L[j][i] * z[j];
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j < 6; j++)
+            if (perm[i] == j) x[j] = z[i];
+}
+
+// Sophus::SE3d::exp(a) for a = (upsilon, omega): R = exp(hat(omega)), translation = V * upsilon; E column-major 4x4.
+__device__ inline void se3_exp(const double *a, double *E) {
+    const double wx = a[3], wy = a[4], wz = a[5];
+    const double th2 = wx * wx + wy * wy + wz * wz, th = sqrt(th2);
+    const double W[3][3] = {{0, -wz, wy}, {wz, 0, -wx}, {-wy, wx, 0}};
+    double W2[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            W2[i][j] = 0;
+            for (int k = 0; k < 3; k++) W2[i][j] += W[i][k] * W[k][j];
+        }
+    double A, B, C;  // sin th / th, (1 - cos th) / th^2, (th - sin th) / th^3
+    if (th < 1e-10) {
+        A = 1.0 - th2 / 6.0;
+        B = 0.5 - th2 / 24.0;
+        C = 1.0 / 6.0 - th2 / 120.0;
+    } else {
+        A = sin(th) / th;
+        B = (1.0 - cos(th)) / th2;
+        C = (th - sin(th)) / (th2 * th);
+    }
+    for (int c = 0; c < 4; c++)
+        for (int r = 0; r < 4; r++) E[c * 4 + r] = (r == c) ? 1.0 : 0.0;
+    for (int i = 0; i < 3; i++) {
+        double ti = 0;
+        for (int j = 0; j < 3; j++) {
+            const double I = (i == j) ? 1.0 : 0.0;
+            E[j * 4 + i] = I + A * W[i][j] + B * W2[i][j];
+            ti += (I + B * W[i][j] + C * W2[i][j]) * a[j];
+        }
+        E[12 + i] = ti;
+    }
+}
+
+// Second stage of the reduction (reduceSum<29>, Cuda/estimate.cu:70-85) + the host part of estimateStep /
+// getIncrementalTransformation: A, b, residual, inliers; when `update` != 0 also x = A^-1 b and T <- exp(x) * T.
+__global__ __launch_bounds__(256) void icp_solve_kernel(const float *__restrict__ partial, int n_blocks, double *__restrict__ state,
+                                                        int update) {
+    // 29 entries x 8 groups of blocks: thread (entry, group) adds its 32 blocks in order (loads issued together), then
+    // one thread per entry adds the 8 group sums in order -- a fixed tree, in double
+    __shared__ double group_sum[8][32];
+    __shared__ float total[32];
+    const int entry = threadIdx.x & 31, group = threadIdx.x >> 5;
+    if (entry < 29) {
+        float v[32];
+#pragma unroll
+        for (int i = 0; i < 32; i++) {
+            const int b = group * 32 + i;
+            v[i] = b < n_blocks ? partial[b * 32 + entry] : 0.0f;
+        }
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < 32; i++) s += (double)v[i];
+        group_sum[group][entry] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 29) {
+        double s = 0.0;
+#pragma unroll
+        for (int g = 0; g < 8; g++) s += group_sum[g][threadIdx.x];
+        total[threadIdx.x] = (float)s;  // the reference hands fp32 sums to the host
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    float A[36], b[6];
+    int shift = 0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 7; ++j) {
+            const float value = total[shift++];
+            if (j == 6) b[i] = value;
+            else A[j * 6 + i] = A[i * 6 + j] = value;
+        }
+    state[16] = total[27];
+    state[17] = total[28];
+    for (int i = 0; i < 36; i++) state[18 + i] = A[i];
+    for (int i = 0; i < 6; i++) state[54 + i] = b[i];
+    if (!update) return;
+    double x[6], E[16], T[16], out[16];
+    ldlt_solve6(A, b, x);
+    se3_exp(x, E);
+    for (int i = 0; i < 16; i++) T[i] = state[i];
+    for (int c = 0; c < 4; c++)
+        for (int r = 0; r < 4; r++) {
+            double s = 0;
+            for (int k = 0; k < 4; k++) s += E[k * 4 + r] * T[c * 4 + k];
+            out[c * 4 + r] = s;
+        }
+    for (int i = 0; i < 16; i++) state[i] = out[i];
+}
+
+static void free_icp(tsdf_icp *f) {
+    for (int i = 0; i < kIcpLevels; i++) {
+        if (f->depth[i]) (void)hipFree(f->depth[i]);
+        if (f->vmap_prev[i]) (void)hipFree(f->vmap_prev[i]);
+        if (f->nmap_prev[i]) (void)hipFree(f->nmap_prev[i]);
+        if (f->vmap_curr[i]) (void)hipFree(f->vmap_curr[i]);
+        if (f->nmap_curr[i]) (void)hipFree(f->nmap_curr[i]);
+    }
+    if (f->partial) (void)hipFree(f->partial);
+    if (f->state) (void)hipFree(f->state);
+    if (f->upload) (void)hipFree(f->upload);
+    delete f;
+}
+
+// pyramid + vertex / normal maps of one depth image that is already in f->depth[0]
+static int build_maps(tsdf_icp *f, float **vmaps, float **nmaps, float depth_cutoff) {
+    for (int i = 1; i < kIcpLevels; i++) {
+        const int src_rows = f->height >> (i - 1), src_cols = f->width >> (i - 1);
+        dim3 grid((src_cols / 2 + 63) / 64, (src_rows / 2 + 3) / 4);
+        hipLaunchKernelGGL(icp_pyr_down_kernel, grid, dim3(256), 0, f->stream, f->depth[i - 1], src_rows, src_cols, f->depth[i]);
+    }
+    for (int i = 0; i < kIcpLevels; i++) {
+        const int rows = f->height >> i, cols = f->width >> i, div = 1 << i;
+        // Intr::operator()(level): every intrinsic divided by 2^level (Cuda/internal.h:63-67); 1.f / fx: createVMap (:131)
+        const float fx = f->fx / div, fy = f->fy / div, cx = f->cx / div, cy = f->cy / div;
+        dim3 grid((cols + 63) / 64, (rows + 3) / 4);
+        hipLaunchKernelGGL(icp_vmap_kernel, grid, dim3(256), 0, f->stream, f->depth[i], rows, cols, 1.f / fx, 1.f / fy, cx, cy,
+                           depth_cutoff, vmaps[i]);
+        hipLaunchKernelGGL(icp_nmap_kernel, grid, dim3(256), 0, f->stream, rows, cols, vmaps[i], nmaps[i]);
+    }
+    TSDF_HIP(hipGetLastError(), "ICP map kernels failed");
+    return TSDF_OK;
+}
+
+static void launch_step(tsdf_icp *f, int level, int update) {
+    const int rows = f->height >> level, cols = f->width >> level, div = 1 << level;
+    hipLaunchKernelGGL(icp_reduce_kernel, dim3(kIcpBlocks), dim3(kIcpThreads), 0, f->stream, f->state, f->vmap_curr[level],
+                       f->nmap_curr[level], f->vmap_prev[level], f->nmap_prev[level], rows, cols, f->fx / div, f->fy / div,
+                       f->cx / div, f->cy / div, f->dist_thresh, f->angle_thresh, f->partial);
+    hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(256), 0, f->stream, f->partial, kIcpBlocks, f->state, update);
+}
+
+}  // namespace tsdf
+
+using namespace tsdf;
+
+extern "C" {
+
+int tsdf_icp_create(int width, int height, float cx, float cy, float fx, float fy, float dist_thresh, float angle_thresh,
+                    tsdf_icp **out) {
+    TSDF_REQUIRE(out, "tsdf_icp_create: null argument");
+    *out = nullptr;
+    TSDF_REQUIRE(width >= 4 && height >= 4 && width <= 65535 && height <= 65535, "tsdf_icp_create: bad image size");
+    tsdf_icp *f = new (std::nothrow) tsdf_icp();
+    TSDF_REQUIRE(f, "out of host memory");
+    std::memset(f, 0, sizeof(*f));
+    f->width = width; f->height = height;
+    f->cx = cx; f->cy = cy; f->fx = fx; f->fy = fy;
+    f->dist_thresh = dist_thresh; f->angle_thresh = angle_thresh;
+    hipError_t e = hipGetDevice(&f->device);
+    for (int i = 0; i < kIcpLevels && e == hipSuccess; i++) {
+        const size_t px = (size_t)(height >> i) * (width >> i);
+        e = hipMalloc((void **)&f->depth[i], px * sizeof(uint16_t));
+        float **maps[4] = {&f->vmap_prev[i], &f->nmap_prev[i], &f->vmap_curr[i], &f->nmap_curr[i]};
+        for (int m = 0; m < 4 && e == hipSuccess; m++) {
+            e = hipMalloc((void **)maps[m], px * 3 * sizeof(float));
+            // the reference's maps start uninitialised and invalid pixels only ever get component 0 written: define the rest
+            if (e == hipSuccess) e = hipMemset(*maps[m], 0, px * 3 * sizeof(float));
+        }
+    }
+    if (e == hipSuccess) e = hipMalloc((void **)&f->partial, (size_t)kIcpBlocks * 32 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&f->state, kIcpStateDoubles * sizeof(double));
+    if (e == hipSuccess) e = hipMemset(f->state, 0, kIcpStateDoubles * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&f->upload, (size_t)width * height * sizeof(uint16_t));
+    if (e != hipSuccess) {
+        free_icp(f);
+        return hip_fail(e, "ICP alloc failed");
+    }
+    *out = f;
+    return TSDF_OK;
+}
+
+void tsdf_icp_destroy(tsdf_icp *f) {
+    if (f) free_icp(f);
+}
+
+int tsdf_icp_set_stream(tsdf_icp *f, void *hip_stream) {
+    TSDF_REQUIRE(f, "null ICP handle");
+    f->stream = (hipStream_t)hip_stream;
+    return TSDF_OK;
+}
+
+int tsdf_icp_init_device(tsdf_icp *f, int model, const uint16_t *device_depth, float depth_cutoff) {
+    TSDF_REQUIRE(f && device_depth, "tsdf_icp_init: null argument");
+    TSDF_HIP(hipMemcpyAsync(f->depth[0], device_depth, (size_t)f->width * f->height * sizeof(uint16_t), hipMemcpyDeviceToDevice,
+                            f->stream), "ICP depth copy");
+    return model ? build_maps(f, f->vmap_prev, f->nmap_prev, depth_cutoff) : build_maps(f, f->vmap_curr, f->nmap_curr, depth_cutoff);
+}
+
+int tsdf_icp_init(tsdf_icp *f, int model, const uint16_t *host_depth, float depth_cutoff) {
+    TSDF_REQUIRE(f && host_depth, "tsdf_icp_init: null argument");
+    TSDF_HIP(hipMemcpyAsync(f->depth[0], host_depth, (size_t)f->width * f->height * sizeof(uint16_t), hipMemcpyHostToDevice,
+                            f->stream), "ICP depth upload");
+    int rc = model ? build_maps(f, f->vmap_prev, f->nmap_prev, depth_cutoff) : build_maps(f, f->vmap_curr, f->nmap_curr, depth_cutoff);
+    if (rc != TSDF_OK) return rc;
+    TSDF_HIP(hipStreamSynchronize(f->stream), "ICP init");  // (the reference synchronises here too)
+    return TSDF_OK;
+}
+
+int tsdf_icp_get_map(const tsdf_icp *f, int which, int level, float *host_map) {
+    TSDF_REQUIRE(f && host_map && level >= 0 && level < kIcpLevels && which >= 0 && which < 4, "tsdf_icp_get_map: bad argument");
+    const float *src[4] = {f->vmap_prev[level], f->nmap_prev[level], f->vmap_curr[level], f->nmap_curr[level]};
+    const size_t bytes = (size_t)(f->height >> level) * (f->width >> level) * 3 * sizeof(float);
+    TSDF_HIP(hipMemcpyAsync(host_map, src[which], bytes, hipMemcpyDeviceToHost, f->stream), "ICP map download");
+    TSDF_HIP(hipStreamSynchronize(f->stream), "ICP map download");
+    return TSDF_OK;
+}
+
+int tsdf_icp_get_depth_level(const tsdf_icp *f, int level, uint16_t *host_depth) {
+    TSDF_REQUIRE(f && host_depth && level >= 0 && level < kIcpLevels, "tsdf_icp_get_depth_level: bad argument");
+    const size_t bytes = (size_t)(f->height >> level) * (f->width >> level) * sizeof(uint16_t);
+    TSDF_HIP(hipMemcpyAsync(host_depth, f->depth[level], bytes, hipMemcpyDeviceToHost, f->stream), "ICP depth download");
+    TSDF_HIP(hipStreamSynchronize(f->stream), "ICP depth download");
+    return TSDF_OK;
+}
+
+int tsdf_icp_estimate_step(tsdf_icp *f, int level, const float R[9], const float t[3], float A[36], float b[6],
+                           float residual_inliers[2]) {
+    TSDF_REQUIRE(f && R && t && A && b && residual_inliers && level >= 0 && level < kIcpLevels, "tsdf_icp_estimate_step: bad argument");
+    double T[16] = {0};
+    for (int c = 0; c < 3; c++)
+        for (int r = 0; r < 3; r++) T[c * 4 + r] = R[c * 3 + r];
+    for (int r = 0; r < 3; r++) T[12 + r] = t[r];
+    T[15] = 1.0;
+    TSDF_HIP(hipMemcpyAsync(f->state, T, sizeof(T), hipMemcpyHostToDevice, f->stream), "ICP pose upload");
+    launch_step(f, level, 0);
+    TSDF_HIP(hipGetLastError(), "ICP estimate kernels failed");
+    double out[kIcpStateDoubles];
+    TSDF_HIP(hipMemcpyAsync(out, f->state, sizeof(out), hipMemcpyDeviceToHost, f->stream), "ICP result download");
+    TSDF_HIP(hipStreamSynchronize(f->stream), "ICP estimate");
+    residual_inliers[0] = (float)out[16];
+    residual_inliers[1] = (float)out[17];
+    for (int i = 0; i < 36; i++) A[i] = (float)out[18 + i];
+    for (int i = 0; i < 6; i++) b[i] = (float)out[54 + i];
+    return TSDF_OK;
+}
+
+int tsdf_icp_get_incremental_transformation(tsdf_icp *f, double T_prev_curr[16], float *last_error, float *last_inliers) {
+    TSDF_REQUIRE(f && T_prev_curr, "tsdf_icp_get_incremental_transformation: null argument");
+    TSDF_HIP(hipMemcpyAsync(f->state, T_prev_curr, 16 * sizeof(double), hipMemcpyHostToDevice, f->stream), "ICP pose upload");
+    const int iterations[kIcpLevels] = {10, 5, 4};  // ICPOdometry.cpp:99-101
+    for (int i = kIcpLevels - 1; i >= 0; i--)
+        for (int j = 0; j < iterations[i]; j++) launch_step(f, i, 1);
+    TSDF_HIP(hipGetLastError(), "ICP kernels failed");
+    double out[18];
+    TSDF_HIP(hipMemcpyAsync(out, f->state, sizeof(out), hipMemcpyDeviceToHost, f->stream), "ICP pose download");
+    TSDF_HIP(hipStreamSynchronize(f->stream), "ICP");
+    std::memcpy(T_prev_curr, out, 16 * sizeof(double));
+    // lastError = sqrt(residual) / inliers, lastInliers = inliers of the last iteration (ICPOdometry.cpp:127-128)
+    if (last_error) *last_error = sqrtf((float)out[16]) / (float)out[17];
+    if (last_inliers) *last_inliers = (float)out[17];
+    return TSDF_OK;
+}
+
+}  // extern "C"
