@@ -104,3 +104,54 @@ def test_config2_reduced_256_cubed_stream(oracle):
     assert_same_floats(V, Vo, "config 2 vertices")
     assert_same_floats(Nn, No, "config 2 normals")
     assert (~np.isnan(V[:, 0])).mean() > 0.8
+
+
+def test_config4_1024_cubed_in_eight_slabs_equals_the_whole_volume():
+    """BASELINE configs[3]: a 1024^3 volume as 8 Z-slabs of 128 planes (+ one halo plane each).  On one GPU, slab by slab:
+    integrate into every slab and into the whole volume, ray cast every slab, merge by min-k -- distances, weights and the
+    picture must equal the whole volume's bit for bit.  (At 1024^3 a ray covers 4402 * 0.279 mm = 1228 mm, Q8: the camera
+    sits inside the volume, 1 m in front of the wall.)"""
+    import torch
+    from tests.helpers import camera_at
+    from tsdf_amd import multi
+    n, P = 1024, 8
+    cams = [camera_at((1500.0 + 40.0 * i, 1350.0 - 25.0 * i, 1400.0 - 30.0 * i), look_at=synth.LOOK_AT) for i in range(2)]
+    frames = []
+    for cam in cams:
+        z = synth.trace_depth(cam, W, H)
+        frames.append(np.clip(np.where(np.isfinite(z), np.rint(z), 0.0), 0, 65535).astype(np.uint16).reshape(-1))
+    whole = tsdf_amd.TSDFVolume((n, n, n), (3000.0,) * 3)
+    whole.set_counting(True)
+    updated = 0
+    for f, cam in zip(frames, cams):
+        whole.integrate(f, W, H, cam)
+        updated += whole.last_updated_voxels()
+    assert updated > 50_000_000
+    V, Nn = whole.raycast(W, H, cams[0])
+    assert (~np.isnan(V[:, 0])).mean() > 0.5
+    Dw = whole.get_distance_data().reshape(n, -1)
+    Ww = whole.get_weight_data().reshape(n, -1)
+    whole.close()
+
+    rc = tsdf_amd.GPURaycaster(W, H)
+    hits = torch.empty((P, W * H, 4), dtype=torch.float32, device="cuda")
+    for r in range(P):
+        zb, ze = multi.slab_range(n, P, r)
+        assert ze - zb == n // P
+        s = tsdf_amd.TSDFVolume((n, n, n), (3000.0,) * 3, slab=(zb, ze))
+        for f, cam in zip(frames, cams):
+            s.integrate(f, W, H, cam)
+        lo, hi = s.resident_planes()
+        assert (lo, hi) == (zb, min(ze + 1, n))
+        assert_same_floats(s.get_distance_data().reshape(hi - lo, -1), Dw[lo:hi], "slab %d distances" % r)
+        assert_same_floats(s.get_weight_data().reshape(hi - lo, -1), Ww[lo:hi], "slab %d weights" % r)
+        rc.raycast_slab_device(s, cams[0], hits[r].data_ptr())
+        s.synchronize()
+        s.close()
+    Vm = torch.empty((W * H, 3), dtype=torch.float32, device="cuda")
+    Nm = torch.empty((W * H, 3), dtype=torch.float32, device="cuda")
+    tsdf_amd.merge_hits_device(hits.data_ptr(), P, W, H, Vm.data_ptr())
+    tsdf_amd.compute_normals_device(W, H, Vm.data_ptr(), Nm.data_ptr())
+    torch.cuda.synchronize()
+    assert_same_floats(Vm.cpu().numpy(), V, "8-slab merge at 1024^3: vertices")
+    assert_same_floats(Nm.cpu().numpy(), Nn, "8-slab merge at 1024^3: normals")
