@@ -287,7 +287,11 @@ __global__ __launch_bounds__(256) void integrate_kernel(float *__restrict__ dist
         __syncthreads();
         if (vx >= g.X || vy >= g.Y) continue;
 
-        size_t idx = plane * (z0 - g.z_store_begin) + (size_t)g.X * vy + vx;
+        size_t idx = plane * (z0 - g.z_store_begin) + (size_t)g.X * vy + vx;  // (custom nodes only)
+        // distance / weight addressing: a wave-uniform base per plane (scalar registers) + one 32-bit lane offset that
+        // is the same for every plane, so the per-voxel loads and stores need no address arithmetic on the vector unit
+        const size_t brick_base = plane * (z0 - g.z_store_begin) + (size_t)g.X * (by * kTileY) + (size_t)bx * kTileX;
+        const uint32_t lane_off = threadIdx.y * g.X + threadIdx.x;
 
         // voxel centre, x and y parts: initialise_deformation (src/TSDF/TSDFVolume.cu:783-784) then
         // integrate_kernel's offset + translation (:343)
@@ -369,42 +373,43 @@ __global__ __launch_bounds__(256) void integrate_kernel(float *__restrict__ dist
                     r4_[j] = r4;
                 }
             }
+            // tsdf_[j] is NaN for a voxel this frame does not update
             float tsdf_[kBatchZ], pw_[kBatchZ], pd_[kBatchZ];
-            bool upd[kBatchZ];
 #pragma unroll
             for (int j = 0; j < kBatchZ; j++) {
-                upd[j] = false;
-                tsdf_[j] = pw_[j] = pd_[j] = 0.f;
-                if (d_[j] > 0) {  // (:355) also false for planes past the brick and pixels off the image
-                    // pixel_to_camera(...).z (cuda_coordinate_transforms.cu:132-146)
-                    float surf_z, voxel_cam_z;
-                    if (STD) {
-                        surf_z = (float)d_[j];
-                        voxel_cam_z = camz_[j];
-                    } else {
-                        const float ipz = kinv.m31 * px_[j] + kinv.m32 * py_[j] + kinv.m33;
-                        const float scale = (float)d_[j] / ipz;
-                        surf_z = ipz * scale;
-                        // world_to_camera(...).z (cuda_coordinate_transforms.cu:108-121): same numerator as camz
-                        const float w = ((DEFORM ? r4_[j] : r4) + ip.m43 * cz_[j]) + ip.m44;
-                        voxel_cam_z = camz_[j] / w;
-                    }
-                    const float sdf = surf_z - voxel_cam_z;
-                    if (sdf >= neg_trunc) {
-                        tsdf_[j] = (sdf > 0) ? fminf(sdf, g.trunc) : sdf;
-                        pw_[j] = weight[idx + plane * j];
-                        pd_[j] = dist[idx + plane * j];
-                        upd[j] = true;
-                    }
+                // pixel_to_camera(...).z (cuda_coordinate_transforms.cu:132-146)
+                float surf_z, voxel_cam_z;
+                if (STD) {
+                    surf_z = (float)d_[j];
+                    voxel_cam_z = camz_[j];
+                } else {
+                    const float ipz = kinv.m31 * px_[j] + kinv.m32 * py_[j] + kinv.m33;
+                    const float scale = (float)d_[j] / ipz;
+                    surf_z = ipz * scale;
+                    // world_to_camera(...).z (cuda_coordinate_transforms.cu:108-121): same numerator as camz
+                    const float w = ((DEFORM ? r4_[j] : r4) + ip.m43 * cz_[j]) + ip.m44;
+                    voxel_cam_z = camz_[j] / w;
+                }
+                const float sdf = surf_z - voxel_cam_z;
+                // depth > 0 (:355; also false for planes past the brick and pixels off the image) and sdf >= -trunc (:366)
+                const bool update = d_[j] != 0 && sdf >= neg_trunc;
+                // (sdf > 0) ? min(sdf, trunc) : sdf  ==  sdf < trunc ? sdf : trunc   (trunc > 0)
+                tsdf_[j] = update ? (sdf < g.trunc ? sdf : g.trunc) : NAN;
+                pw_[j] = pd_[j] = 0.f;
+                if (update) {
+                    const size_t pb = brick_base + plane * (size_t)(zb - z0 + j);
+                    pw_[j] = (weight + pb)[lane_off];
+                    pd_[j] = (dist + pb)[lane_off];
                 }
             }
 #pragma unroll
             for (int j = 0; j < kBatchZ; j++) {
-                if (upd[j]) {
+                if (tsdf_[j] == tsdf_[j]) {
                     const float new_weight = pw_[j] + 1.0f;
                     const float new_distance = ((pd_[j] * pw_[j]) + (tsdf_[j] * 1.0f)) / new_weight;
-                    weight[idx + plane * j] = new_weight;
-                    dist[idx + plane * j] = new_distance;
+                    const size_t pb = brick_base + plane * (size_t)(zb - z0 + j);
+                    (weight + pb)[lane_off] = new_weight;
+                    (dist + pb)[lane_off] = new_distance;
                     if (!(new_distance > occ.tau)) mark_occupied(occ, vx, vy, zb + j);
                     if (COUNT) updated++;
                 }
