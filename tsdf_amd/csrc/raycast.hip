@@ -233,6 +233,12 @@ __device__ inline bool compute_near_and_far_t(const F3 &o, const F3 &d, const F3
 constexpr int kMaxSamples = 4402;          // src/RayCaster/GPURaycaster.cu:369
 constexpr int kTableLen = kMaxSamples + 2;  // T[0..4402] is read
 constexpr int kDone = 0x7fffffff;
+// Cell-level positivity test.  In a cell the sample is located in EXACTLY (>= eps from its faces, all 8 voxels exist) the
+// reference's weights u, v, w lie strictly inside (0,1), so every product c_i * w_i of its sum is >= 0 in fp32 and the
+// term with the largest weight (>= 1/8) is >= c_i / 8: with all eight values above this (normal-range) threshold the
+// value the reference computes is > 0 whatever the rounding.  No margin like occ.tau is needed here -- that one covers
+// the APPROXIMATE location used at brick level.
+constexpr float kCellPositive = 1.0e-30f;
 constexpr int kRaySegmentsDefault = 8;      // sample ranges a ray's march is split into
 constexpr int kTailGridDefault = 256 * 10;   // workgroups of the tail kernel (5 fit a CU at 86 VGPRs: two rounds)
 constexpr int kTripBudgetDefault = 24;      // passes of the first kernel's loop before unfinished rays go to the tail kernel
@@ -444,8 +450,8 @@ __device__ inline float process_sample(float t, int k, const RayState &r, const 
             const float *b = dist + ((size_t)tc.plane * ((uint32_t)lz - g.z_store_begin) + (size_t)tc.row * (uint32_t)ly + (uint32_t)lx);
             const float c000 = b[0], c100 = b[1], c010 = b[tc.row], c110 = b[tc.row + 1];
             const float c001 = b[tc.plane], c101 = b[tc.plane + 1], c011 = b[tc.plane + tc.row], c111 = b[tc.plane + tc.row + 1];
-            const bool positive = c000 > occ.tau && c100 > occ.tau && c010 > occ.tau && c110 > occ.tau &&
-                                  c001 > occ.tau && c101 > occ.tau && c011 > occ.tau && c111 > occ.tau;
+            const bool positive = c000 > kCellPositive && c100 > kCellPositive && c010 > kCellPositive && c110 > kCellPositive &&
+                                  c001 > kCellPositive && c101 > kCellPositive && c011 > kCellPositive && c111 > kCellPositive;
             if (positive) {
                 jump = n_cell;
                 return 1.0f;
@@ -522,8 +528,8 @@ __device__ inline float process_sample_eager(float t, const RayState &r, const S
                 jump = n_cb;
                 return 1.0f;
             }
-            const bool positive = c000 > occ.tau && c100 > occ.tau && c010 > occ.tau && c110 > occ.tau &&
-                                  c001 > occ.tau && c101 > occ.tau && c011 > occ.tau && c111 > occ.tau;
+            const bool positive = c000 > kCellPositive && c100 > kCellPositive && c010 > kCellPositive && c110 > kCellPositive &&
+                                  c001 > kCellPositive && c101 > kCellPositive && c011 > kCellPositive && c111 > kCellPositive;
             if (!owned || positive) {
                 jump = n_cell;
                 return 1.0f;
