@@ -164,6 +164,11 @@ int tsdf_raycast_device(const tsdf_volume *volume, uint32_t width, uint32_t heig
 /* compute_normals alone (src/RayCaster/GPURaycaster.cu:393-427) on device buffers. */
 int tsdf_normals_device(uint32_t width, uint32_t height, const float *device_vertices,
                         float *device_normals, void *hip_stream);
+/* The per-pixel part of GPURaycaster::render_to_depth_image (src/RayCaster/GPURaycaster.cu:575-579) on device
+ * buffers: depth = (uint16_t)roundf(Camera::world_to_camera(vertex).z) with the vertex map of a ray cast; pixels the
+ * cast missed (NaN) and depths outside 1..65535 give 0 (the reference's conversion of NaN is undefined). */
+int tsdf_vertices_to_depth_device(uint32_t width, uint32_t height, const float *device_vertices,
+                                  const float inv_pose[16], uint16_t *device_depth, void *hip_stream);
 /* Diagnostics for the roofline model: S = trilinear samples evaluated, T = distinct voxels
  * touched by any tap, of one raycast with these arguments (runs an instrumented kernel). */
 int tsdf_raycast_stats(const tsdf_volume *volume, uint32_t width, uint32_t height, const float pose[16],

@@ -256,6 +256,13 @@ def compute_normals_device(width, height, vertices_ptr, normals_ptr, stream=0):
                                   C.c_void_p(int(stream) if stream else 0)))
 
 
+def vertices_to_depth_device(width, height, vertices_ptr, camera, depth_ptr, stream=0):
+    """The per-pixel part of GPURaycaster::render_to_depth_image on device buffers (uint16 mm, 0 = no hit)."""
+    ip = _mat(camera.inverse_pose(), 16)
+    check(lib.tsdf_vertices_to_depth_device(width, height, C.c_void_p(int(vertices_ptr)), ip.ctypes.data,
+                                            C.c_void_p(int(depth_ptr)), C.c_void_p(int(stream) if stream else 0)))
+
+
 def merge_hits_device(hits_all_ptr, n_slabs, width, height, vertices_ptr, stream=0):
     check(lib.tsdf_merge_hits_device(C.c_void_p(int(hits_all_ptr)), n_slabs, width, height,
                                      C.c_void_p(int(vertices_ptr)), C.c_void_p(int(stream) if stream else 0)))

@@ -852,6 +852,19 @@ __global__ __launch_bounds__(256) void normals_kernel(uint32_t width, uint32_t h
     N[idx * 3 + 2] = nz;
 }
 
+// render_to_depth_image, per pixel (src/RayCaster/GPURaycaster.cu:575-579 with Camera::world_to_camera, src/Camera.cpp:287-294):
+// camera-space z of the vertex (homogeneous product, divided by w), rounded half away from zero.
+__global__ __launch_bounds__(256) void vertices_to_depth_kernel(uint32_t n_pixels, const float *__restrict__ V, const Mat44 ip,
+                                                                uint16_t *__restrict__ depth) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels) return;
+    const float x = V[(size_t)i * 3 + 0], y = V[(size_t)i * 3 + 1], z = V[(size_t)i * 3 + 2];
+    const float cz = ((ip.m31 * x + ip.m32 * y) + ip.m33 * z) + ip.m34 * 1.0f;
+    const float cw = ((ip.m41 * x + ip.m42 * y) + ip.m43 * z) + ip.m44 * 1.0f;
+    const float r = roundf(cz / cw);
+    depth[i] = (r == r && r > 0.0f && r < 65536.0f) ? (uint16_t)r : (uint16_t)0;
+}
+
 // Per pixel, keep the record with the smallest k among n_slabs gathered buffers
 // (layout [slab][pixel][4]).  Ties cannot occur: a sample has exactly one owner.
 __global__ __launch_bounds__(256) void merge_hits_kernel(const float4 *__restrict__ hits, uint32_t n_slabs,
@@ -1025,6 +1038,18 @@ int tsdf_normals_device(uint32_t width, uint32_t height, const float *device_ver
                         void *hip_stream) {
     TSDF_REQUIRE(device_vertices && device_normals && width > 0 && height > 0, "tsdf_normals: bad argument");
     return launch_normals(width, height, device_vertices, device_normals, (hipStream_t)hip_stream);
+}
+
+int tsdf_vertices_to_depth_device(uint32_t width, uint32_t height, const float *device_vertices, const float inv_pose[16],
+                                  uint16_t *device_depth, void *hip_stream) {
+    TSDF_REQUIRE(device_vertices && inv_pose && device_depth && width > 0 && height > 0, "tsdf_vertices_to_depth: bad argument");
+    Mat44 ip;
+    memcpy(&ip, inv_pose, sizeof(ip));
+    const uint32_t n = width * height;
+    hipLaunchKernelGGL(vertices_to_depth_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, n, device_vertices, ip,
+                       device_depth);
+    TSDF_HIP(hipGetLastError(), "vertices to depth failed");
+    return TSDF_OK;
 }
 
 int tsdf_raycast_stats(const tsdf_volume *v, uint32_t width, uint32_t height, const float pose[16],
