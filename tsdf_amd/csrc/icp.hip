@@ -5,9 +5,9 @@
 // What is different from the reference's shape, and why:
 //   * The reference runs 19 iterations (10/5/4 over three pyramid levels), each = reduction kernel, second reduction
 //     kernel, device synchronise, 116-byte download, 6x6 LDLT + SE3 exponential on the host, next launch.  Here the
-//     pose lives on the device: icp_solve_kernel finishes the reduction, solves the 6x6 system in double and applies
-//     T <- exp(x) * T in place, so the 38 launches of a frame are queued back to back with no host round trip; the
-//     host reads the pose once at the end.
+//     pose lives on the device: the last workgroup of icp_reduce_kernel to finish adds up the partial sums, solves the
+//     6x6 system in double and applies T <- exp(x) * T in place, so a frame is 19 launches queued back to back with no
+//     host round trip; the host reads the pose once at the end.
 //   * The reduction is deterministic: a fixed grid, per-thread fp32 partial sums (as in the reference), wave64 shuffle
 //     tree, fixed-order cross-wave and cross-block sums (the last stage in double).  The reference's sums depend on the
 //     threads x blocks the caller passes; those two arguments are accepted and ignored.
@@ -30,6 +30,7 @@ struct tsdf_icp {
     float *vmap_prev[3], *nmap_prev[3];      // model
     float *vmap_curr[3], *nmap_curr[3];      // current frame
     float *partial;                          // kIcpBlocks x 32 floats: per-block sums of the 29 products
+    unsigned int *ticket;                    // workgroups of the current step that have delivered their sums
     double *state;                           // device: [0..15] T (column-major), [16..17] residual, inliers,
                                              //         [18..53] A (float values), [54..59] b
     uint16_t *upload;                        // staging for host depth
@@ -38,7 +39,7 @@ struct tsdf_icp {
 namespace tsdf {
 
 constexpr int kIcpLevels = 3;
-constexpr int kIcpBlocks = 256;   // one workgroup per CU (icp_solve_kernel adds them as 8 groups of 32)
+constexpr int kIcpBlocks = 256;   // one workgroup per CU (icp_finish_step adds them as 8 groups of 32)
 constexpr int kIcpThreads = 256;
 constexpr int kIcpStateDoubles = 64;
 
@@ -129,12 +130,14 @@ __device__ inline int float2int_rn(float f) {
 // Reduction::operator() (Cuda/estimate.cu:139-209): projective association of the current frame's vertices into the
 // model, distance / angle gates, the 27 upper-triangular products of the row (n, v x n, n.(v_prev - v)) + inlier count.
 // The pose is read from the device state (T as doubles, narrowed to float like `rotationMatrix().cast<float>()`).
-__global__ __launch_bounds__(kIcpThreads) void icp_reduce_kernel(const double *__restrict__ state, const float *__restrict__ vmap_curr,
+__device__ inline void icp_finish_step(const float *partial, int n_blocks, double *state, int update);
+
+__global__ __launch_bounds__(kIcpThreads) void icp_reduce_kernel(double *state, const float *__restrict__ vmap_curr,
                                                                 const float *__restrict__ nmap_curr,
                                                                 const float *__restrict__ vmap_prev,
                                                                 const float *__restrict__ nmap_prev, int rows, int cols,
                                                                 float fx, float fy, float cx, float cy, float dist_thresh,
-                                                                float angle_thresh, float *__restrict__ partial) {
+                                                                float angle_thresh, float *partial, unsigned int *ticket, int update) {
     float R[9], t[3];  // column-major
     for (int c = 0; c < 3; c++)
         for (int r = 0; r < 3; r++) R[c * 3 + r] = (float)state[c * 4 + r];
@@ -199,9 +202,21 @@ __global__ __launch_bounds__(kIcpThreads) void icp_reduce_kernel(const double *_
         for (int i = 0; i < 29; i++) shared[wave][i] = sum[i];
     }
     __syncthreads();
-    if (threadIdx.x < 29)
+    if (threadIdx.x < 29) {
         partial[blockIdx.x * 32 + threadIdx.x] =
             ((shared[0][threadIdx.x] + shared[1][threadIdx.x]) + shared[2][threadIdx.x]) + shared[3][threadIdx.x];
+        __threadfence();  // the partial sums are visible device-wide before this workgroup takes its ticket
+    }
+    // The workgroup that takes the last ticket finds every partial sum written and finishes the step (second reduction
+    // stage, solve, pose update) in the same launch: one kernel per Gauss-Newton iteration.
+    __shared__ bool is_last;
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!is_last) return;
+    if (threadIdx.x == 0) *ticket = 0;  // ready for the next launch
+    __threadfence();
+    icp_finish_step(partial, (int)gridDim.x, state, update);
 }
 
 // x = A^-1 b, 6x6 symmetric positive (semi-)definite, LDL^T with diagonal pivoting in double -- the job of
@@ -213,6 +228,50 @@ __device__ inline void swap_if(bool c, double &a, double &b) {
     a = c ? b : a;
     b = c ? t : b;
 }
+// The same factorisation without pivoting: for the positive definite, reasonably conditioned normal matrix of a
+// healthy ICP step it needs no row exchanges; returns false (result unused) when a pivot is not safely positive, and the
+// pivoted version above/below takes over.  ~250 dependent flops instead of ~4000 predicated moves.
+__device__ inline bool ldlt_solve6_unpivoted(const float *A_in, const float *b_in, double *x) {
+    double A[6][6], L[6][6], D[6], y[6];
+    double dmax = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        y[i] = b_in[i];
+#pragma unroll
+        for (int j = 0; j < 6; j++) A[i][j] = A_in[i * 6 + j];
+        dmax = fmax(dmax, fabs(A[i][i]));
+    }
+    bool ok = dmax > 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        D[k] = A[k][k];
+        ok = ok && D[k] > 1.0e-9 * dmax;
+        const double inv = 1.0 / D[k];
+#pragma unroll
+        for (int i = k + 1; i < 6; i++) L[i][k] = A[i][k] * inv;
+#pragma unroll
+        for (int i = k + 1; i < 6; i++)
+#pragma unroll
+            for (int j = k + 1; j <= i; j++) {
+                A[i][j] -= L[i][k] * D[k] * L[j][k];
+                A[j][i] = A[i][j];
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j < i; j++) y[i] -= L[i][j] * y[j];
+#pragma unroll
+    for (int i = 0; i < 6; i++) y[i] = y[i] / D[i];
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+#pragma unroll
+        for (int j = i + 1; j < 6; j++) y[i] -= L[j][i] * y[j];
+        x[i] = y[i];
+    }
+    return ok;
+}
+
 __device__ inline void ldlt_solve6(const float *A_in, const float *b_in, double *x) {
     double A[6][6], L[6][6], D[6], y[6], z[6];
     int perm[6];
@@ -293,10 +352,14 @@ __device__ inline void se3_exp(const double *a, double *E) {
             for (int k = 0; k < 3; k++) W2[i][j] += W[i][k] * W[k][j];
         }
     double A, B, C;  // sin th / th, (1 - cos th) / th^2, (th - sin th) / th^3
-    if (th < 1e-10) {
-        A = 1.0 - th2 / 6.0;
-        B = 0.5 - th2 / 24.0;
-        C = 1.0 / 6.0 - th2 / 120.0;
+    if (th2 < 0.0625) {
+        // |th| < 1/4 (every step of a converging ICP): the three entire functions by their power series in th^2, summed
+        // from the smallest term (Horner); the first omitted terms are < 1e-19 relative.  One lane evaluates this on the
+        // critical path of every iteration, and the library's double sin / cos cost several microseconds there.
+        const double t = th2;
+        A = 1.0 - t / 6.0 * (1.0 - t / 20.0 * (1.0 - t / 42.0 * (1.0 - t / 72.0 * (1.0 - t / 110.0 * (1.0 - t / 156.0 * (1.0 - t / 210.0))))));
+        B = 0.5 * (1.0 - t / 12.0 * (1.0 - t / 30.0 * (1.0 - t / 56.0 * (1.0 - t / 90.0 * (1.0 - t / 132.0 * (1.0 - t / 182.0 * (1.0 - t / 240.0)))))));
+        C = 1.0 / 6.0 * (1.0 - t / 20.0 * (1.0 - t / 42.0 * (1.0 - t / 72.0 * (1.0 - t / 110.0 * (1.0 - t / 156.0 * (1.0 - t / 210.0 * (1.0 - t / 272.0)))))));
     } else {
         A = sin(th) / th;
         B = (1.0 - cos(th)) / th2;
@@ -317,8 +380,10 @@ __device__ inline void se3_exp(const double *a, double *E) {
 
 // Second stage of the reduction (reduceSum<29>, Cuda/estimate.cu:70-85) + the host part of estimateStep /
 // getIncrementalTransformation: A, b, residual, inliers; when `update` != 0 also x = A^-1 b and T <- exp(x) * T.
-__global__ __launch_bounds__(256) void icp_solve_kernel(const float *__restrict__ partial, int n_blocks, double *__restrict__ state,
-                                                        int update) {
+// Run by the 256 threads of the workgroup that finishes last (see icp_reduce_kernel).
+// (Plain loads are enough for the other workgroups' sums: the fence + ticket order them, and this CU's L1 cannot hold a
+// stale copy -- nobody reads `partial` before this point in a launch, and the cache line of a workgroup's row is its own.)
+__device__ inline void icp_finish_step(const float *partial, int n_blocks, double *state, int update) {
     // 29 entries x 8 groups of blocks: thread (entry, group) adds its 32 blocks in order (loads issued together), then
     // one thread per entry adds the 8 group sums in order -- a fixed tree, in double
     __shared__ double group_sum[8][32];
@@ -359,7 +424,7 @@ __global__ __launch_bounds__(256) void icp_solve_kernel(const float *__restrict_
     for (int i = 0; i < 6; i++) state[54 + i] = b[i];
     if (!update) return;
     double x[6], E[16], T[16], out[16];
-    ldlt_solve6(A, b, x);
+    if (!ldlt_solve6_unpivoted(A, b, x)) ldlt_solve6(A, b, x);
     se3_exp(x, E);
     for (int i = 0; i < 16; i++) T[i] = state[i];
     for (int c = 0; c < 4; c++)
@@ -380,6 +445,7 @@ static void free_icp(tsdf_icp *f) {
         if (f->nmap_curr[i]) (void)hipFree(f->nmap_curr[i]);
     }
     if (f->partial) (void)hipFree(f->partial);
+    if (f->ticket) (void)hipFree(f->ticket);
     if (f->state) (void)hipFree(f->state);
     if (f->upload) (void)hipFree(f->upload);
     delete f;
@@ -409,8 +475,7 @@ static void launch_step(tsdf_icp *f, int level, int update) {
     const int rows = f->height >> level, cols = f->width >> level, div = 1 << level;
     hipLaunchKernelGGL(icp_reduce_kernel, dim3(kIcpBlocks), dim3(kIcpThreads), 0, f->stream, f->state, f->vmap_curr[level],
                        f->nmap_curr[level], f->vmap_prev[level], f->nmap_prev[level], rows, cols, f->fx / div, f->fy / div,
-                       f->cx / div, f->cy / div, f->dist_thresh, f->angle_thresh, f->partial);
-    hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(256), 0, f->stream, f->partial, kIcpBlocks, f->state, update);
+                       f->cx / div, f->cy / div, f->dist_thresh, f->angle_thresh, f->partial, f->ticket, update);
 }
 
 }  // namespace tsdf
@@ -442,6 +507,8 @@ int tsdf_icp_create(int width, int height, float cx, float cy, float fx, float f
         }
     }
     if (e == hipSuccess) e = hipMalloc((void **)&f->partial, (size_t)kIcpBlocks * 32 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&f->ticket, sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMemset(f->ticket, 0, sizeof(unsigned int));
     if (e == hipSuccess) e = hipMalloc((void **)&f->state, kIcpStateDoubles * sizeof(double));
     if (e == hipSuccess) e = hipMemset(f->state, 0, kIcpStateDoubles * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&f->upload, (size_t)width * height * sizeof(uint16_t));
