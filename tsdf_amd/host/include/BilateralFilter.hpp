@@ -1,8 +1,8 @@
 // Bilateral filter for 8/16-bit single-channel images, run on the GPU.  Same surface as the
 // reference's BilateralFilter (src/include/BilateralFilter.hpp:12-35): filter() works IN PLACE on
 // the caller's host buffer despite the const pointer.
-#ifndef BilateralFilter_hpp
-#define BilateralFilter_hpp
+#ifndef TSDF_AMD_HOST_BILATERAL_FILTER_INCLUDED
+#define TSDF_AMD_HOST_BILATERAL_FILTER_INCLUDED
 
 #include <cstdint>
 
@@ -24,4 +24,4 @@ private:
     tsdf_bilateral *m_handle;
 };
 
-#endif /* BilateralFilter_hpp */
+#endif /* TSDF_AMD_HOST_BILATERAL_FILTER_INCLUDED */

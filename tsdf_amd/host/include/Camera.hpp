@@ -1,7 +1,7 @@
 // Pinhole camera: intrinsics, pose and the coordinate transforms the hot path consumes.
 // Same public surface as the reference's Camera (src/include/Camera.hpp:17-215); host-only.
-#ifndef Camera_hpp
-#define Camera_hpp
+#ifndef TSDF_AMD_HOST_CAMERA_INCLUDED
+#define TSDF_AMD_HOST_CAMERA_INCLUDED
 
 #include <Eigen/Dense>
 #include <cstdint>
@@ -53,4 +53,4 @@ private:
     Eigen::Matrix4f m_pose_inverse;
 };
 
-#endif /* Camera_hpp */
+#endif /* TSDF_AMD_HOST_CAMERA_INCLUDED */

@@ -1,6 +1,7 @@
-#ifndef Definitions_hpp
-#define Definitions_hpp
+// The one shared constant of the class surface (the reference declares it in src/include/Definitions.hpp and defines
+// it in src/Utilities/Definitions.cpp): the vertex value that stands for "nothing here".
+#ifndef TSDF_AMD_HOST_DEFINITIONS_INCLUDED
+#define TSDF_AMD_HOST_DEFINITIONS_INCLUDED
 #include <Eigen/Core>
-// Marker for "no vertex here" (reference: src/Utilities/Definitions.cpp)
-extern const Eigen::Vector3f BAD_VERTEX;
+extern const Eigen::Matrix<float, 3, 1> BAD_VERTEX;   // (= Eigen::Vector3f)
 #endif

@@ -1,7 +1,7 @@
 // 16-bit depth image held in host memory.  Same surface as the reference's DepthImage
 // (src/include/DepthImage.hpp).
-#ifndef DEPTH_IMAGE_H
-#define DEPTH_IMAGE_H
+#ifndef TSDF_AMD_HOST_DEPTH_IMAGE_INCLUDED
+#define TSDF_AMD_HOST_DEPTH_IMAGE_INCLUDED
 
 #include <cstdint>
 #include <string>

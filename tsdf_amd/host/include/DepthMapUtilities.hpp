@@ -1,6 +1,6 @@
 // Depth map file readers.  Same functions as the reference's src/include/DepthMapUtilities.hpp.
-#ifndef DepthMapUtilities_h
-#define DepthMapUtilities_h
+#ifndef TSDF_AMD_HOST_DEPTH_MAP_UTILITIES_INCLUDED
+#define TSDF_AMD_HOST_DEPTH_MAP_UTILITIES_INCLUDED
 
 #include <cstdint>
 #include <string>

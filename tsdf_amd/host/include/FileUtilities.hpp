@@ -1,6 +1,6 @@
 // Small file helpers.  Same functions as the reference's src/include/FileUtilities.hpp (those the path uses).
-#ifndef FILE_UTLITIES_HPP
-#define FILE_UTLITIES_HPP
+#ifndef TSDF_AMD_HOST_FILE_UTILITIES_INCLUDED
+#define TSDF_AMD_HOST_FILE_UTILITIES_INCLUDED
 
 #include <functional>
 #include <string>

@@ -1,7 +1,7 @@
 // GPU ray caster (HIP, MI355X).  Same surface as the reference's GPURaycaster
 // (src/include/GPURaycaster.hpp:19-41).
-#ifndef GPURaycaster_hpp
-#define GPURaycaster_hpp
+#ifndef TSDF_AMD_HOST_GPU_RAYCASTER_INCLUDED
+#define TSDF_AMD_HOST_GPU_RAYCASTER_INCLUDED
 
 #include <Eigen/Core>
 
@@ -20,4 +20,4 @@ public:
     // ray cast, then camera-space z of every vertex rounded to uint16 mm; caller deletes the image
     DepthImage *render_to_depth_image(const TSDFVolume &volume, const Camera &camera) const;
 };
-#endif /* GPURaycaster_hpp */
+#endif /* TSDF_AMD_HOST_GPU_RAYCASTER_INCLUDED */

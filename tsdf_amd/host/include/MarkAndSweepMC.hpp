@@ -2,8 +2,8 @@
 // Same entry point as the reference's extract_surface (src/include/MarkAndSweepMC.hpp:8).  The reference runs
 // marching cubes on the GPU; here the distance array is copied to the host and triangulated there
 // (BASELINE north_star: "src/MarchingCubes stays host-side").
-#ifndef MarkAndSweepMC_hpp
-#define MarkAndSweepMC_hpp
+#ifndef TSDF_AMD_HOST_MARK_AND_SWEEPMC_INCLUDED
+#define TSDF_AMD_HOST_MARK_AND_SWEEPMC_INCLUDED
 
 #include <vector>
 

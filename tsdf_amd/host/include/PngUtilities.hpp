@@ -1,8 +1,8 @@
 // PNG file helpers (16-bit greyscale depth images, 8-bit greyscale, 8-bit RGB).
 // Same functions as the reference's src/include/PngUtilities.hpp; implemented on zlib alone
 // (libpng is not a build dependency here).
-#ifndef PngUtilities_hpp
-#define PngUtilities_hpp
+#ifndef TSDF_AMD_HOST_PNG_UTILITIES_INCLUDED
+#define TSDF_AMD_HOST_PNG_UTILITIES_INCLUDED
 
 #include <cstdint>
 #include <iostream>
@@ -17,4 +17,4 @@ bool save_png_to_file(const std::string file_name, uint32_t width, uint32_t heig
 bool save_png_to_file(const std::string file_name, uint32_t width, uint32_t height, const uint8_t *pixel_data);
 bool save_colour_png_to_file(const std::string file_name, uint32_t width, uint32_t height, const uint8_t *pixel_data);
 
-#endif /* PngUtilities_hpp */
+#endif /* TSDF_AMD_HOST_PNG_UTILITIES_INCLUDED */

@@ -1,7 +1,7 @@
 // An image held in host memory that can be written as (or read from) a PNG file.
 // Same surface as the reference's PngWrapper (src/include/PngWrapper.hpp).
-#ifndef PNGWRAPPER_H
-#define PNGWRAPPER_H
+#ifndef TSDF_AMD_HOST_PNG_WRAPPER_INCLUDED
+#define TSDF_AMD_HOST_PNG_WRAPPER_INCLUDED
 
 #include <cstdint>
 #include <string>
@@ -29,4 +29,4 @@ private:
     PNG_TYPE m_type;
 };
 
-#endif  // PNGWRAPPER_H
+#endif  // TSDF_AMD_HOST_PNG_WRAPPER_INCLUDED

@@ -1,7 +1,7 @@
 // Abstract ray caster: renders vertex and normal maps of a TSDFVolume from a camera.
 // Same surface as the reference's Raycaster (src/include/Raycaster.hpp:17-39).
-#ifndef Raycaster_hpp
-#define Raycaster_hpp
+#ifndef TSDF_AMD_HOST_RAYCASTER_INCLUDED
+#define TSDF_AMD_HOST_RAYCASTER_INCLUDED
 
 #include <Eigen/Core>
 
@@ -24,4 +24,4 @@ protected:
     uint16_t m_width;
     uint16_t m_height;
 };
-#endif /* Raycaster_hpp */
+#endif /* TSDF_AMD_HOST_RAYCASTER_INCLUDED */

@@ -1,7 +1,7 @@
 // Rendering of ray-cast vertex / normal maps to images.  Same functions as the reference's
 // src/include/RenderUtilities.hpp.
-#ifndef RenderUtilities_h
-#define RenderUtilities_h
+#ifndef TSDF_AMD_HOST_RENDER_UTILITIES_INCLUDED
+#define TSDF_AMD_HOST_RENDER_UTILITIES_INCLUDED
 
 #include <Eigen/Dense>
 #include <cstdint>
@@ -26,4 +26,4 @@ void save_rendered_scene_as_png(std::string filename, uint16_t width, uint16_t h
                                 const Eigen::Matrix<float, 3, Eigen::Dynamic> &normals, const Camera &camera,
                                 const Eigen::Vector3f &light_source);
 
-#endif  // RenderUtilities_h
+#endif  // TSDF_AMD_HOST_RENDER_UTILITIES_INCLUDED

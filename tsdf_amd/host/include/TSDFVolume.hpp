@@ -1,8 +1,8 @@
 // Dense TSDF voxel grid resident in GPU memory (MI355X): same public surface as the reference's
 // TSDFVolume (src/include/TSDFVolume.hpp:21-304) so callers such as src/Tools/kinfu.cpp compile
 // unchanged.  All device work goes through the C ABI of include/tsdf_amd.h.
-#ifndef TSDFVolume_hpp
-#define TSDFVolume_hpp
+#ifndef TSDF_AMD_HOST_TSDF_VOLUME_INCLUDED
+#define TSDF_AMD_HOST_TSDF_VOLUME_INCLUDED
 
 #include "Camera.hpp"
 
@@ -121,4 +121,4 @@ private:
     float3 m_global_translation;
     float3 m_global_rotation;
 };
-#endif /* TSDFVolume_hpp */
+#endif /* TSDF_AMD_HOST_TSDF_VOLUME_INCLUDED */

@@ -1,7 +1,7 @@
 // Replays a TUM RGB-D style directory: <dir>/ground_truth.txt with lines "<depth file stem> tx ty tz qx qy qz qw"
 // and <dir>/depth/<stem>.png (16-bit, 5000 units per metre).  Same surface as the reference's TUMDataLoader.
-#ifndef TUM_DATA_LOADER_H
-#define TUM_DATA_LOADER_H
+#ifndef TSDF_AMD_HOST_TUM_DATA_LOADER_INCLUDED
+#define TSDF_AMD_HOST_TUM_DATA_LOADER_INCLUDED
 
 #include <Eigen/Dense>
 #include <string>
