@@ -1,0 +1,124 @@
+"""Randomised differential test: seeded random volumes, cameras, images and depth maps through integrate + ray cast on
+the GPU and in the oracle, compared bit for bit.  The hand-written cases elsewhere aim at known corners; this sweep is
+for the corners nobody thought of (the culling bounds, the rounding guard band, the skipping slack, the tail queue ...).
+Sizes are small enough for the oracle to finish each case in well under a second on the GPU box's host cores."""
+import numpy as np
+import pytest
+
+import tsdf_amd
+from tests.helpers import Cam, assert_same_floats
+
+pytestmark = pytest.mark.gpu
+_SEEN = {"scenes": 0, "updated": 0, "hit": 0}
+
+
+def random_case(rng):
+    dims = tuple(int(v) for v in rng.integers(5, 72, size=3))
+    if rng.random() < 0.5:      # cubic voxels half of the time (anisotropic ones switch parts of the skipping off)
+        vs = float(rng.uniform(4.0, 60.0))
+        phys = tuple(d * vs for d in dims)
+    else:
+        phys = tuple(float(d * rng.uniform(4.0, 60.0)) for d in dims)
+    width, height = int(rng.integers(1, 200)), int(rng.integers(1, 160))
+    offset = tuple(float(v) for v in rng.uniform(-500, 500, size=3)) if rng.random() < 0.3 else None
+    return dims, phys, width, height, offset
+
+
+def random_camera(rng, dims, phys, offset, width, height):
+    centre = np.array(phys) / 2.0 + (np.array(offset) if offset else 0.0)
+    extent = float(max(phys))
+    # position: inside the volume, just outside it, or far away
+    mode = rng.integers(0, 3)
+    radius = (0.2, 0.9, 2.5)[mode] * extent
+    d = rng.normal(size=3)
+    d /= np.linalg.norm(d)
+    pos = centre + d * radius * rng.uniform(0.5, 1.0)
+    target = centre + rng.normal(size=3) * 0.15 * extent
+    cam = tsdf_amd.Camera(float(rng.uniform(0.6, 1.4) * width + 20), float(rng.uniform(0.6, 1.4) * width + 20),
+                          width / 2.0 + float(rng.uniform(-3, 3)), height / 2.0 + float(rng.uniform(-3, 3)))
+    cam.move_to(*pos)
+    cam.look_at(*target)
+    return cam, float(np.linalg.norm(pos - centre))
+
+
+def random_depth(rng, width, height, scale):
+    kind = rng.integers(0, 4)
+    n = width * height
+    if kind == 0:
+        d = np.full(n, scale, np.float64)
+    elif kind == 1:
+        d = scale * rng.uniform(0.3, 1.7, size=n)
+    elif kind == 2:
+        yy, xx = np.mgrid[0:height, 0:width]
+        d = (scale * (0.6 + 0.5 * np.sin(xx / 7.0) * np.cos(yy / 5.0))).reshape(-1)
+    else:
+        d = scale * (1.0 + 0.02 * rng.standard_normal(n))
+    d = np.clip(np.rint(d), 0, 65535)
+    d[rng.random(n) < rng.choice([0.0, 0.02, 0.5])] = 0
+    return d.astype(np.uint16)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_scene(oracle, seed):
+    rng = np.random.default_rng(0xF022 + seed)
+    dims, phys, width, height, offset = random_case(rng)
+    gv = tsdf_amd.TSDFVolume(dims, phys)
+    ov = oracle.Volume(dims, phys)
+    if offset is not None:
+        gv.offset(*offset); gv.clear()
+        ov.offset(*offset); ov.clear()
+    threads = oracle.max_threads()
+    cams = []
+    for f in range(int(rng.integers(1, 4))):
+        cam, dist_to_centre = random_camera(rng, dims, phys, offset, width, height)
+        depth = random_depth(rng, width, height, max(dist_to_centre, 50.0))
+        gv.integrate(depth, width, height, cam)
+        ov.integrate(depth, width, height, cam.inverse_pose(), cam.k(), cam.kinv(), nthreads=threads)
+        cams.append(cam)
+        if rng.random() < 0.5:       # a ray cast between integrations exercises the flag refresh schedule
+            gv.raycast(width, height, cam)
+    what = "seed %d dims %s image %dx%d" % (seed, dims, width, height)
+    assert_same_floats(gv.get_weight_data(), ov.weight, what + " weights")
+    assert_same_floats(gv.get_distance_data(), ov.dist, what + " distances")
+    for cam in cams[-2:]:
+        V, N = gv.raycast(width, height, cam)
+        Vo, No = ov.raycast(width, height, cam.pose(), cam.kinv(), nthreads=threads)
+        assert_same_floats(V, Vo, what + " vertices")
+        assert_same_floats(N, No, what + " normals")
+    _SEEN["scenes"] += 1
+    _SEEN["updated"] += int((ov.weight > 0).any())
+    _SEEN["hit"] += int((~np.isnan(Vo[:, 0])).any())
+
+
+def test_the_random_scenes_were_not_vacuous():
+    if _SEEN["scenes"] < 20:
+        pytest.skip("needs the whole sweep")
+    assert _SEEN["updated"] >= _SEEN["scenes"] // 2 and _SEEN["hit"] >= _SEEN["scenes"] // 3, _SEEN
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_distance_fields(oracle, seed):
+    """Arbitrary distance arrays (not produced by integrate): sign changes anywhere, NaNs, huge values."""
+    rng = np.random.default_rng(0xD157 + seed)
+    dims, phys, width, height, offset = random_case(rng)
+    n = dims[0] * dims[1] * dims[2]
+    gv = tsdf_amd.TSDFVolume(dims, phys)
+    ov = oracle.Volume(dims, phys)
+    if offset is not None:
+        gv.offset(*offset)
+        ov.offset(*offset)
+    trunc = gv.truncation_distance()
+    D = np.full(n, trunc, np.float32)
+    k = int(rng.integers(1, max(2, n // 20)))
+    idx = rng.choice(n, size=k, replace=False)
+    D[idx] = (rng.uniform(-1.0, 1.0, size=k) * trunc * rng.choice([1e-6, 0.01, 1.0], size=k)).astype(np.float32)
+    if rng.random() < 0.5:
+        D[rng.choice(n, size=3, replace=False)] = [np.nan, 1e30, -1e30]
+    gv.set_distance_data(D)
+    ov.set_distance_data(D)
+    for _ in range(2):
+        cam, _ = random_camera(rng, dims, phys, offset, width, height)
+        V, N = gv.raycast(width, height, cam)
+        Vo, No = ov.raycast(width, height, cam.pose(), cam.kinv(), nthreads=oracle.max_threads())
+        assert_same_floats(V, Vo, "seed %d dims %s vertices" % (seed, dims))
+        assert_same_floats(N, No, "seed %d normals" % seed)
