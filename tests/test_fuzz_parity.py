@@ -122,3 +122,36 @@ def test_random_distance_fields(oracle, seed):
         Vo, No = ov.raycast(width, height, cam.pose(), cam.kinv(), nthreads=oracle.max_threads())
         assert_same_floats(V, Vo, "seed %d dims %s vertices" % (seed, dims))
         assert_same_floats(N, No, "seed %d normals" % seed)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_slab_splits_equal_the_whole_volume(seed):
+    """Integrate + ray cast through 2..6 Z-slabs (owner-of-sample rule, min-k merge) == the whole volume, bit for bit."""
+    import torch
+    from tsdf_amd import multi
+    rng = np.random.default_rng(0x51AB + seed)
+    dims, phys, width, height, offset = random_case(rng)
+    P = int(rng.integers(2, min(6, dims[2]) + 1))
+    whole = tsdf_amd.TSDFVolume(dims, phys)
+    slabs = [tsdf_amd.TSDFVolume(dims, phys, slab=multi.slab_range(dims[2], P, r)) for r in range(P)]
+    cams = []
+    for f in range(int(rng.integers(1, 3))):
+        cam, dist_to_centre = random_camera(rng, dims, phys, None, width, height)
+        depth = random_depth(rng, width, height, max(dist_to_centre, 50.0))
+        for v in [whole] + slabs:
+            v.integrate(depth, width, height, cam)
+        cams.append(cam)
+    Dw = whole.get_distance_data().reshape(dims[2], -1)
+    rc = tsdf_amd.GPURaycaster(width, height)
+    for cam in cams:
+        V, N = whole.raycast(width, height, cam)
+        hits = torch.empty((P, width * height, 4), dtype=torch.float32, device="cuda")
+        for r, s in enumerate(slabs):
+            lo, hi = s.resident_planes()
+            assert_same_floats(s.get_distance_data().reshape(hi - lo, -1), Dw[lo:hi], "seed %d slab %d distances" % (seed, r))
+            rc.raycast_slab_device(s, cam, hits[r].data_ptr())
+            s.synchronize()
+        Vm = torch.empty((width * height, 3), dtype=torch.float32, device="cuda")
+        tsdf_amd.merge_hits_device(hits.data_ptr(), P, width, height, Vm.data_ptr())
+        torch.cuda.synchronize()
+        assert_same_floats(Vm.cpu().numpy(), V, "seed %d: %d slabs of %s, image %dx%d" % (seed, P, dims, width, height))
