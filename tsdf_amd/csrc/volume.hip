@@ -170,12 +170,20 @@ __global__ __launch_bounds__(256) void occupancy_flags_kernel(const uint16_t *__
 // reported empty.  O(1) work per brick, ~2 x 2 MiB of traffic at 512^3.
 constexpr int kSuper = 16;  // bricks per side of a super block = 2^(kReachLevels - 1)
 __global__ __launch_bounds__(256) void reach_mip_kernel(OccGrid occ) {
-    __shared__ unsigned char f[kSuper * kSuper * kSuper];  // 4096
+    __shared__ __align__(16) unsigned char f[kSuper * kSuper * kSuper];  // 4096
     __shared__ unsigned char l1[8 * 8 * 8], l2[4 * 4 * 4], l3[2 * 2 * 2], l4[1];
     const uint32_t ox = blockIdx.x * kSuper, oy = blockIdx.y * kSuper, oz = blockIdx.z * kSuper;
-    for (uint32_t i = threadIdx.x; i < kSuper * kSuper * kSuper; i += 256) {
-        const uint32_t x = ox + (i & 15), y = oy + ((i >> 4) & 15), z = oz + (i >> 8);
-        f[i] = (x < occ.nbx && y < occ.nby && z < occ.nbz) ? occ.fine[((size_t)z * occ.nby + y) * occ.nbx + x] : (unsigned char)1;
+    // a row of 16 bricks along x is 16 contiguous bytes: one 128-bit access per thread when the grid allows it
+    const bool vec = (occ.nbx & 15u) == 0 && oy + kSuper <= occ.nby && oz + kSuper <= occ.nbz;
+    if (vec) {
+        const uint32_t y = oy + (threadIdx.x & 15), z = oz + (threadIdx.x >> 4);
+        const uint4 row = *reinterpret_cast<const uint4 *>(occ.fine + ((size_t)z * occ.nby + y) * occ.nbx + ox);
+        *reinterpret_cast<uint4 *>(f + threadIdx.x * 16) = row;
+    } else {
+        for (uint32_t i = threadIdx.x; i < kSuper * kSuper * kSuper; i += 256) {
+            const uint32_t x = ox + (i & 15), y = oy + ((i >> 4) & 15), z = oz + (i >> 8);
+            f[i] = (x < occ.nbx && y < occ.nby && z < occ.nbz) ? occ.fine[((size_t)z * occ.nby + y) * occ.nbx + x] : (unsigned char)1;
+        }
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < 512; i += 256) {
@@ -205,22 +213,39 @@ __global__ __launch_bounds__(256) void reach_mip_kernel(OccGrid occ) {
         l4[0] = o;
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < kSuper * kSuper * kSuper; i += 256) {
-        const uint32_t lx = i & 15, ly = (i >> 4) & 15, lz = i >> 8;
-        const uint32_t x = ox + lx, y = oy + ly, z = oz + lz;
-        if (x >= occ.nbx || y >= occ.nby || z >= occ.nbz) continue;
-        unsigned char level = 0;
-        if (!f[i]) {
-            level = 1;
-            if (!l1[((lz >> 1) << 6) | ((ly >> 1) << 3) | (lx >> 1)]) {
-                level = 2;
-                if (!l2[((lz >> 2) << 4) | ((ly >> 2) << 2) | (lx >> 2)]) {
-                    level = 3;
-                    if (!l3[((lz >> 3) << 2) | ((ly >> 3) << 1) | (lx >> 3)]) level = l4[0] ? 4 : 5;
+    // every thread classifies one row of 16 bricks (i = its index in the super block)
+    unsigned char levels[16];
+    const uint32_t row0 = vec ? threadIdx.x * 16 : 0;
+    {
+        for (uint32_t e = 0; e < 16; e++) {
+            const uint32_t i = vec ? row0 + e : threadIdx.x + e * 256;
+            const uint32_t lx = i & 15, ly = (i >> 4) & 15, lz = i >> 8;
+            unsigned char level = 0;
+            if (!f[i]) {
+                level = 1;
+                if (!l1[((lz >> 1) << 6) | ((ly >> 1) << 3) | (lx >> 1)]) {
+                    level = 2;
+                    if (!l2[((lz >> 2) << 4) | ((ly >> 2) << 2) | (lx >> 2)]) {
+                        level = 3;
+                        if (!l3[((lz >> 3) << 2) | ((ly >> 3) << 1) | (lx >> 3)]) level = l4[0] ? 4 : 5;
+                    }
                 }
             }
+            levels[e] = level;
+            if (!vec) {
+                const uint32_t x = ox + lx, y = oy + ly, z = oz + lz;
+                if (x < occ.nbx && y < occ.nby && z < occ.nbz) occ.reach[((size_t)z * occ.nby + y) * occ.nbx + x] = level;
+            }
         }
-        occ.reach[((size_t)z * occ.nby + y) * occ.nbx + x] = level;
+    }
+    if (vec) {
+        const uint32_t y = oy + (threadIdx.x & 15), z = oz + (threadIdx.x >> 4);
+        uint4 out;
+        out.x = levels[0] | (levels[1] << 8) | (levels[2] << 16) | ((uint32_t)levels[3] << 24);
+        out.y = levels[4] | (levels[5] << 8) | (levels[6] << 16) | ((uint32_t)levels[7] << 24);
+        out.z = levels[8] | (levels[9] << 8) | (levels[10] << 16) | ((uint32_t)levels[11] << 24);
+        out.w = levels[12] | (levels[13] << 8) | (levels[14] << 16) | ((uint32_t)levels[15] << 24);
+        *reinterpret_cast<uint4 *>(occ.reach + ((size_t)z * occ.nby + y) * occ.nbx + ox) = out;
     }
 }
 
