@@ -144,6 +144,8 @@ _HOST_SIGS = {
     "tsdf_camera_world_to_pixel": (None, [_vp, _fp, _ip]),
     "tsdf_camera_pixel_to_image_plane": (None, [_vp, C.c_uint16, C.c_uint16, _fp]),
     "tsdf_camera_image_plane_to_pixel": (None, [_vp, _fp, _ip]),
+    "tsdf_host_marching_cubes_c": (C.c_size_t, [_vp, C.c_uint, C.c_uint, C.c_uint, _vp, _vp, _vp, C.c_size_t]),
+    "tsdf_host_mc_table": (None, [_vp]),
 }
 for _name, (_res, _args) in _HOST_SIGS.items():
     _fn = getattr(host, _name)

@@ -297,6 +297,29 @@ class BilateralFilter:
                  C.c_void_p(int(stream) if stream else 0)))
 
 
+def marching_cubes(distances, size, voxel_size, offset=(0.0, 0.0, 0.0)):
+    """Host marching cubes of the class surface (MarkAndSweepMC.cpp, what extract_surface runs on a volume's distances):
+    distances indexed x + y*X + z*X*Y -> (3*T, 3) float32 vertices, triangle t = rows 3t, 3t+1, 3t+2 (the reference then
+    wires them (i, i+2, i+1))."""
+    X, Y, Z = (int(v) for v in size)
+    d = np.ascontiguousarray(distances, dtype=np.float32).reshape(-1)
+    if d.size != X * Y * Z:
+        raise ValueError("expected %d distances, got %d" % (X * Y * Z, d.size))
+    vs = np.ascontiguousarray(voxel_size, dtype=np.float32)
+    off = np.ascontiguousarray(offset, dtype=np.float32)
+    n = _capi.host.tsdf_host_marching_cubes_c(d.ctypes.data, X, Y, Z, vs.ctypes.data, off.ctypes.data, None, 0)
+    out = np.empty((n, 3), np.float32)
+    _capi.host.tsdf_host_marching_cubes_c(d.ctypes.data, X, Y, Z, vs.ctypes.data, off.ctypes.data, out.ctypes.data, n)
+    return out
+
+
+def marching_cubes_table():
+    """The generated 256 x 32 triangle table (edge numbers, -1 terminated rows)."""
+    t = np.empty((256, 32), np.int8)
+    _capi.host.tsdf_host_mc_table(t.ctypes.data)
+    return t
+
+
 class ICPOdometry:
     """third_party/ICP_CUDA/ICPOdometry.h of the reference: projective point-to-plane ICP between a model depth image
     (initICPModel) and the current one (initICP), three pyramid levels, 4/5/10 iterations."""

@@ -3,7 +3,13 @@
 // as C++ callers.  Matrices cross as column-major float arrays.
 #include <cstring>
 
+#include <cstdint>
+#include <vector>
+
 #include "Camera.hpp"
+#include "MarkAndSweepMC.hpp"
+
+const int8_t *tsdf_host_mc_triangle_table();
 
 extern "C" {
 
@@ -55,4 +61,16 @@ void tsdf_camera_image_plane_to_pixel(const tsdf_camera *c, const float p[2], in
     out[0] = r[0]; out[1] = r[1];
 }
 
+
+// Marching cubes on a host distance array (MarkAndSweepMC.cpp): returns the number of vertices (3 per triangle) and, when
+// `out` is not null and holds at least `capacity` float3, writes them.
+size_t tsdf_host_marching_cubes_c(const float *dist, unsigned X, unsigned Y, unsigned Z, const float vs[3], const float offset[3],
+                                  float *out, size_t capacity) {
+    std::vector<float3> v;
+    tsdf_host_marching_cubes(dist, X, Y, Z, vs, offset, v);
+    if (out && capacity >= v.size()) memcpy(out, v.data(), v.size() * sizeof(float3));
+    return v.size();
+}
+// the generated 256 x 32 triangle table (edge numbers, -1 terminated rows)
+void tsdf_host_mc_table(signed char out[256 * 32]) { memcpy(out, tsdf_host_mc_triangle_table(), 256 * 32); }
 }  // extern "C"
