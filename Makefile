@@ -24,7 +24,7 @@ SOPHUS_INC := $(shell for d in /usr/include /usr/local/include; do [ -f $$d/soph
 ifeq ($(SOPHUS_INC),)
 SOPHUS_INC = -I$(HOSTDIR)/sophus_compat
 endif
-HOSTFLAGS = -std=c++11 -O2 -ffp-contract=off -fPIC -Wall -Iinclude -I$(HOSTDIR)/include -I$(HOSTDIR)/third_party $(EIGEN_INC) $(SOPHUS_INC)
+HOSTFLAGS = -std=c++11 -O2 -pthread -ffp-contract=off -fPIC -Wall -Iinclude -I$(HOSTDIR)/include -I$(HOSTDIR)/third_party $(EIGEN_INC) $(SOPHUS_INC)
 HOST_SRCS = $(wildcard $(HOSTDIR)/src/*.cpp)
 HOST_OBJS = $(HOST_SRCS:.cpp=.o)
 
@@ -36,7 +36,7 @@ $(HOSTDIR)/src/%.o: $(HOSTDIR)/src/%.cpp $(wildcard $(HOSTDIR)/include/*.hpp) $(
 	$(CXX) $(HOSTFLAGS) -c $< -o $@
 
 $(LIBDIR)/libtsdf_host.so: $(HOST_OBJS) $(LIBDIR)/libtsdf_hip.so
-	$(CXX) -shared -fPIC -o $@ $(HOST_OBJS) -L$(LIBDIR) -ltsdf_hip -lz -Wl,-rpath,'$$ORIGIN'
+	$(CXX) -shared -fPIC -pthread -o $@ $(HOST_OBJS) -L$(LIBDIR) -ltsdf_hip -lz -Wl,-rpath,'$$ORIGIN'
 
 hip: $(LIBDIR)/libtsdf_hip.so
 

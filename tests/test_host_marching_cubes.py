@@ -122,3 +122,17 @@ def test_empty_and_degenerate_inputs():
     assert tsdf_amd.marching_cubes(np.array([1, -1], np.float32), (2, 1, 1), (1, 1, 1)).shape == (0, 3)   # no cube at all
     with pytest.raises(ValueError):
         tsdf_amd.marching_cubes(np.ones(5, np.float32), (2, 2, 2), (1, 1, 1))
+
+
+def test_large_grids_are_marched_by_threads_in_the_same_order():
+    """Above 2^22 cubes the z range is cut over host threads; the concatenation must be the sequential cube order: compare
+    with two half volumes marched on their own (unit voxels, so the shifted offsets are exact)."""
+    n, h = 176, 88
+    rng = np.random.default_rng(5)
+    zz, yy, xx = np.mgrid[0:n, 0:n, 0:n]
+    D = (np.sqrt((xx - 80.0) ** 2 + (yy - 90.0) ** 2 + (zz - 88.0) ** 2) - 60.0 + rng.uniform(-0.3, 0.3, (n, n, n))).astype(np.float32)
+    whole = tsdf_amd.marching_cubes(D.reshape(-1), (n, n, n), (1, 1, 1))
+    lower = tsdf_amd.marching_cubes(D[:h + 1].reshape(-1), (n, n, h + 1), (1, 1, 1))
+    upper = tsdf_amd.marching_cubes(D[h:].reshape(-1), (n, n, n - h), (1, 1, 1), offset=(0, 0, float(h)))
+    assert whole.shape[0] > 100000
+    assert np.array_equal(whole, np.concatenate([lower, upper]))

@@ -15,6 +15,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <thread>
 
 #include "host_common.hpp"
 
@@ -126,13 +127,12 @@ inline float3 interpolate(float3 v0, float3 v1, float w0, float w1) {
 
 }  // namespace
 
-// Marching cubes over a host distance array (x fastest).  Appends three vertices per triangle.
-void tsdf_host_marching_cubes(const float *dist, unsigned X, unsigned Y, unsigned Z, const float vs[3], const float offset[3],
-                              std::vector<float3> &vertices) {
+// Cubes with z in [z_begin, z_end), in the reference's cube order (x fastest, then y, then z).
+static void march_slab(const float *dist, unsigned X, unsigned Y, unsigned z_begin, unsigned z_end, const float vs[3],
+                       const float offset[3], std::vector<float3> &vertices) {
     const Tables &t = tables();
-    if (X < 2 || Y < 2 || Z < 2) return;
     const size_t dy = X, dz = (size_t)X * Y;
-    for (unsigned z = 0; z + 1 < Z; z++)
+    for (unsigned z = z_begin; z < z_end; z++)
         for (unsigned y = 0; y + 1 < Y; y++)
             for (unsigned x = 0; x + 1 < X; x++) {
                 const size_t base = (size_t)x + y * dy + z * dz;
@@ -154,6 +154,34 @@ void tsdf_host_marching_cubes(const float *dist, unsigned X, unsigned Y, unsigne
                     vertices.push_back(interpolate(v[kEdge[e][0]], v[kEdge[e][1]], w[kEdge[e][0]], w[kEdge[e][1]]));
                 }
             }
+}
+
+// Marching cubes over a host distance array (x fastest).  Appends three vertices per triangle, cubes in the reference's
+// order; large grids are cut into z ranges marched by host threads and concatenated in that order.
+void tsdf_host_marching_cubes(const float *dist, unsigned X, unsigned Y, unsigned Z, const float vs[3], const float offset[3],
+                              std::vector<float3> &vertices) {
+    if (X < 2 || Y < 2 || Z < 2) return;
+    (void)tables();   // build the table before any thread needs it
+    const unsigned layers = Z - 1;
+    unsigned n_threads = std::thread::hardware_concurrency();
+    if (n_threads > 64) n_threads = 64;
+    if ((size_t)X * Y * layers < ((size_t)1 << 22) || n_threads < 2) n_threads = 1;
+    if (n_threads > layers) n_threads = layers;
+    if (n_threads == 1) {
+        march_slab(dist, X, Y, 0, layers, vs, offset, vertices);
+        return;
+    }
+    std::vector<std::vector<float3>> parts(n_threads);
+    std::vector<std::thread> workers;
+    for (unsigned i = 0; i < n_threads; i++) {
+        const unsigned z0 = (unsigned)((size_t)layers * i / n_threads), z1 = (unsigned)((size_t)layers * (i + 1) / n_threads);
+        workers.emplace_back([=, &parts] { march_slab(dist, X, Y, z0, z1, vs, offset, parts[i]); });
+    }
+    for (auto &w : workers) w.join();
+    size_t total = vertices.size();
+    for (const auto &p : parts) total += p.size();
+    vertices.reserve(total);
+    for (const auto &p : parts) vertices.insert(vertices.end(), p.begin(), p.end());
 }
 
 // the generated table, for tests: 256 x 32 edge numbers
