@@ -12,10 +12,12 @@
 #include <vector>
 
 #include "BilateralFilter.hpp"
+#include "BlockTSDFLoader.hpp"
 #include "ICP_CUDA/ICPOdometry.h"
 #include "GPURaycaster.hpp"
 #include "MarkAndSweepMC.hpp"
 #include "TSDFVolume.hpp"
+#include "tsdf_amd.h"
 
 static void dump(const std::string &path, const void *p, size_t bytes) {
     std::ofstream f(path, std::ios::binary);
@@ -103,6 +105,22 @@ int main(int argc, char **argv) {
     extract_surface(volume, mesh_vertices, mesh_triangles);
     std::cout << "mesh " << mesh_vertices.size() << " vertices " << mesh_triangles.size() << " triangles" << std::endl;
     dump(out + "/mesh_vertices.f32", mesh_vertices.data(), mesh_vertices.size() * sizeof(float3));
+
+    // text-format import (BlockTSDFLoader), when the driver left a file: load -> to_tsdf -> distances back
+    {
+        std::ifstream probe(out + "/block.txt");
+        if (probe.good()) {
+            BlockTSDFLoader loader;
+            if (!loader.load_from_file(out + "/block.txt")) return 8;
+            TSDFVolume *imported = loader.to_tsdf();
+            std::vector<float> d((size_t)imported->size().x * imported->size().y * imported->size().z);
+            if (tsdf_volume_get_distance_data(imported->handle(), d.data()) != 0) return 9;
+            dump(out + "/block_distances.f32", d.data(), d.size() * sizeof(float));
+            float dims[4] = {(float)imported->size().x, (float)imported->size().y, (float)imported->size().z, imported->physical_size().x};
+            dump(out + "/block_dims.f32", dims, sizeof(dims));
+            delete imported;
+        }
+    }
 
     delete loaded;
     delete camera;

@@ -39,10 +39,17 @@ def test_cpp_surface_matches_the_oracle(tmp_path, oracle):
     depth, cam = synth.depth_frame(2, 30, seed=0x5EED0001)
     depth.tofile(str(tmp_path / "depth.u16"))
     cam.pose().astype(np.float32).tofile(str(tmp_path / "pose.f32"))
+    # a text-format volume for BlockTSDFLoader::to_tsdf
+    from tests.test_block_loader import write_block_file
+    rng = np.random.default_rng(9)
+    Db = rng.uniform(-20, 20, size=(6, 5, 7)).astype(np.float32)
+    write_block_file(tmp_path / "block.txt", Db, np.ones_like(Db), (700.0, 500.0, 600.0))
     r = subprocess.run([BIN, str(tmp_path / "depth.u16"), str(tmp_path / "pose.f32"), str(tmp_path), str(n)],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "test_surface ok" in r.stdout
+    assert np.array_equal(np.fromfile(str(tmp_path / "block_distances.f32"), np.float32).reshape(6, 5, 7), Db)
+    assert list(np.fromfile(str(tmp_path / "block_dims.f32"), np.float32)) == [7.0, 5.0, 6.0, 700.0]
 
     filtered = np.fromfile(str(tmp_path / "filtered.u16"), np.uint16)
     exp_f = oracle.bilateral_u16(depth, W, H, 30.0, 4.5, nthreads=oracle.max_threads()).reshape(-1)

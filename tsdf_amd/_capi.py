@@ -146,6 +146,7 @@ _HOST_SIGS = {
     "tsdf_camera_image_plane_to_pixel": (None, [_vp, _fp, _ip]),
     "tsdf_host_marching_cubes_c": (C.c_size_t, [_vp, C.c_uint, C.c_uint, C.c_uint, _vp, _vp, _vp, C.c_size_t]),
     "tsdf_host_mc_table": (None, [_vp]),
+    "tsdf_host_block_loader_parse": (_i, [C.c_char_p, _vp, _vp, _vp, _vp, C.c_size_t]),
 }
 for _name, (_res, _args) in _HOST_SIGS.items():
     _fn = getattr(host, _name)

@@ -313,6 +313,19 @@ def marching_cubes(distances, size, voxel_size, offset=(0.0, 0.0, 0.0)):
     return out
 
 
+def load_block_tsdf(file_name):
+    """BlockTSDFLoader::load_from_file (text TSDF format) -> (complete, size xyz, physical size xyz, distances, weights)."""
+    size = np.zeros(3, np.uint32)
+    phys = np.zeros(3, np.float32)
+    path = str(file_name).encode()
+    ok = _capi.host.tsdf_host_block_loader_parse(path, size.ctypes.data, phys.ctypes.data, None, None, 0)
+    n = int(size[0]) * int(size[1]) * int(size[2])
+    d, w = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    if n:
+        ok = _capi.host.tsdf_host_block_loader_parse(path, size.ctypes.data, phys.ctypes.data, d.ctypes.data, w.ctypes.data, n)
+    return bool(ok), tuple(int(v) for v in size), tuple(float(v) for v in phys), d, w
+
+
 def marching_cubes_table():
     """The generated 256 x 32 triangle table (edge numbers, -1 terminated rows)."""
     t = np.empty((256, 32), np.int8)

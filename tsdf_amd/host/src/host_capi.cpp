@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "Camera.hpp"
+#include "BlockTSDFLoader.hpp"
 #include "MarkAndSweepMC.hpp"
 
 const int8_t *tsdf_host_mc_triangle_table();
@@ -73,4 +74,20 @@ size_t tsdf_host_marching_cubes_c(const float *dist, unsigned X, unsigned Y, uns
 }
 // the generated 256 x 32 triangle table (edge numbers, -1 terminated rows)
 void tsdf_host_mc_table(signed char out[256 * 32]) { memcpy(out, tsdf_host_mc_triangle_table(), 256 * 32); }
+
+// BlockTSDFLoader::load_from_file for bindings: 1 = complete file.  Sizes are always reported; the arrays are copied when
+// `capacity` (floats per array) suffices.
+int tsdf_host_block_loader_parse(const char *file_name, unsigned size[3], float physical[3], float *distances, float *weights,
+                                 size_t capacity) {
+    BlockTSDFLoader loader;
+    const bool ok = loader.load_from_file(file_name);
+    size[0] = loader.size_x(); size[1] = loader.size_y(); size[2] = loader.size_z();
+    for (int i = 0; i < 3; i++) physical[i] = loader.physical_size()[i];
+    const size_t n = loader.distances().size();
+    if (distances && weights && capacity >= n && n > 0) {
+        memcpy(distances, loader.distances().data(), n * sizeof(float));
+        memcpy(weights, loader.weights().data(), n * sizeof(float));
+    }
+    return ok ? 1 : 0;
+}
 }  // extern "C"
