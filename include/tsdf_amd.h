@@ -124,6 +124,11 @@ int tsdf_volume_deformation(tsdf_volume *volume, tsdf_deformation_node **device_
 int tsdf_volume_set_distance_data(tsdf_volume *volume, const float *host);
 int tsdf_volume_set_weight_data(tsdf_volume *volume, const float *host);
 int tsdf_volume_set_deformation(tsdf_volume *volume, const tsdf_deformation_node *host);
+/* TSDFVolume::deform_mesh (src/TSDF/TSDFVolume.cu:265-291, kernel :226-263): num_points xyz triples are replaced by the
+ * trilinear blend of the surrounding deformation nodes' translations, rotated by global_rotation and shifted by
+ * global_translation.  Points outside the volume are left unchanged (the reference reads uninitialised memory there). */
+int tsdf_volume_deform_points(const tsdf_volume *volume, int num_points, float *host_points);
+int tsdf_volume_deform_points_device(const tsdf_volume *volume, int num_points, float *device_points);
 /* Blocking D2H of every resident voxel (what save_to_file does, src/TSDF/TSDFVolume.cu:911-1027). */
 int tsdf_volume_get_distance_data(const tsdf_volume *volume, float *host);
 int tsdf_volume_get_weight_data(const tsdf_volume *volume, float *host);

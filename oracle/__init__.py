@@ -83,6 +83,7 @@ def lib():
         L.orc_ldlt_solve6.argtypes = [fp, fp, dp]
         L.orc_se3_exp.argtypes = [dp, dp]
         L.orc_mat4d_mul.argtypes = [dp, dp, dp]
+        L.orc_deform_points.argtypes = [C.POINTER(C.c_uint32), fp, fp, fp, fp, fp, fp, C.c_int, fp]
         L.orc_icp_incremental_transformation.argtypes = [u16p, u16p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
                                                          C.c_float, C.c_float, C.c_float, C.c_float, dp, fp, fp]
         _lib = L
@@ -396,3 +397,15 @@ def icp_incremental_transformation(depth_curr, depth_model, width, height, cx, c
                                              width, height, cx, cy, fx, fy, dist_thresh, angle_thresh, depth_cutoff, _dp(Tc),
                                              C.byref(err), C.byref(inl))
     return Tc.reshape(4, 4).T.copy(), float(err.value), float(inl.value)
+
+
+def deform_points(dims, vs, offset, offset_at_clear, nodes, global_rotation, global_translation, points):
+    """orc_deform_points: points (n,3) float32 -> deformed copy.  nodes: (N,6) float32 or None."""
+    d = np.ascontiguousarray(dims, np.uint32)
+    a = [_f32(x, 3) for x in (vs, offset, offset_at_clear)]
+    r, t = _f32(global_rotation, 3), _f32(global_translation, 3)
+    pts = np.ascontiguousarray(points, np.float32).reshape(-1, 3).copy()
+    nd = None if nodes is None else np.ascontiguousarray(nodes, np.float32).reshape(-1)
+    lib().orc_deform_points(d.ctypes.data_as(C.POINTER(C.c_uint32)), _fp(a[0]), _fp(a[1]), _fp(a[2]),
+                            _fp(nd) if nd is not None else None, _fp(r), _fp(t), pts.shape[0], _fp(pts))
+    return pts

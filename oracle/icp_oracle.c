@@ -323,3 +323,76 @@ void orc_icp_incremental_transformation(const uint16_t *depth_curr, const uint16
         free(dc[i]); free(dm[i]); free(vc[i]); free(nc[i]); free(vp[i]); free(np_[i]);
     }
 }
+
+/* ---- mesh deformation: deformation_kernel + get_trilinear_elements + rotate
+ * (src/TSDF/TSDFVolume.cu:101-263).  nodes: X*Y*Z x {translation xyz, rotation xyz} or NULL for the regular grid that
+ * clear() leaves (voxel centre + offset_at_clear).  The two cases the reference leaves undefined follow the product's
+ * definition: points outside the volume are unchanged, neighbour indices past the array are clamped to the last node.
+ * PARITY UNPINNED (no reference tests; cosf / sinf are the host libm's here and in the product). */
+void orc_deform_points(const uint32_t dims[3], const float vs[3], const float offset[3], const float offset_at_clear[3],
+                       const float *nodes, const float global_rotation[3], const float global_translation[3], int num_points,
+                       float *points) {
+    const float eps = 0.001f;
+    const float c1 = cosf(global_rotation[0]), c2 = cosf(global_rotation[1]), c3 = cosf(global_rotation[2]);
+    const float s1 = sinf(global_rotation[0]), s2 = sinf(global_rotation[1]), s3 = sinf(global_rotation[2]);
+    const long long X = dims[0], Y = dims[1], Z = dims[2], n_nodes = X * Y * Z;
+    for (int p = 0; p < num_points; p++) {
+        float pt[3], adj[3];
+        int vox[3], lower[3];
+        float uvw[3];
+        int inside = 1;
+        for (int a = 0; a < 3; a++) {
+            pt[a] = points[p * 3 + a] - offset[a];
+            const float mx = dims[a] * vs[a];
+            adj[a] = pt[a];
+            if ((pt[a] > mx) && (pt[a] - mx < eps)) adj[a] = mx - eps;
+            if (pt[a] < -eps) adj[a] = 0.0f;
+            const float f = floorf(adj[a] / vs[a]);
+            vox[a] = (f != f) ? 0 : (f >= 2147483648.0f ? 2147483647 : (f <= -2147483648.0f ? (-2147483647 - 1) : (int)f));
+            if (!(vox[a] >= 0 && (uint32_t)vox[a] < dims[a])) inside = 0;
+        }
+        if (!inside) continue;
+        for (int a = 0; a < 3; a++) {
+            const float centre = (vox[a] + 0.5f) * vs[a] + 0.0f;
+            lower[a] = (adj[a] < centre) ? vox[a] - 1 : vox[a];
+            if (lower[a] < 0) lower[a] = 0;
+            const float lc = (lower[a] + 0.5f) * vs[a] + 0.0f;
+            uvw[a] = (adj[a] - lc) / vs[a];
+        }
+        const float u = uvw[0], v = uvw[1], w = uvw[2];
+        const long long dx = 1, dy = X, dz = X * Y;
+        long long ind[8];
+        ind[0] = lower[0] + (lower[1] * dy) + (lower[2] * dz);
+        ind[1] = ind[0] + dx; ind[2] = ind[1] + dz; ind[3] = ind[0] + dz;
+        ind[4] = ind[0] + dy; ind[5] = ind[1] + dy; ind[6] = ind[2] + dy; ind[7] = ind[3] + dy;
+        float co[8];
+        co[0] = (1 - u) * (1 - v) * (1 - w);
+        co[1] = u * (1 - v) * (1 - w);
+        co[2] = u * (1 - v) * w;
+        co[3] = (1 - u) * (1 - v) * w;
+        co[4] = (1 - u) * v * (1 - w);
+        co[5] = u * v * (1 - w);
+        co[6] = (1 - u) * v * w;
+        co[7] = u * v * w;
+        float d[3] = {0.0f, 0.0f, 0.0f};
+        for (int k = 0; k < 8; k++) {
+            long long i = ind[k] < n_nodes - 1 ? ind[k] : n_nodes - 1;
+            float t[3];
+            if (nodes) {
+                t[0] = nodes[i * 6 + 0]; t[1] = nodes[i * 6 + 1]; t[2] = nodes[i * 6 + 2];
+            } else {
+                const int nz = (int)(i / dz), ny = (int)((i - nz * dz) / dy), nx = (int)(i - nz * dz - ny * dy);
+                t[0] = ((nx + 0.5f) * vs[0]) + offset_at_clear[0];
+                t[1] = ((ny + 0.5f) * vs[1]) + offset_at_clear[1];
+                t[2] = ((nz + 0.5f) * vs[2]) + offset_at_clear[2];
+            }
+            for (int a = 0; a < 3; a++) d[a] = (t[a] * co[k]) + d[a];
+        }
+        const float rx = (c2 * c3) * d[0] - (c2 * s3) * d[1] + s2 * d[2];
+        const float ry = (c1 * s3 + s1 * s2 * c3) * d[0] + (c1 * c3 - s1 * s2 * s3) * d[1] - (s1 * c2) * d[2];
+        const float rz = (s1 * s3 - c1 * s2 * c3) * d[0] + (s1 * c3 + c1 * s2 * s3) * d[1] + (c1 * c2) * d[2];
+        points[p * 3 + 0] = global_translation[0] + rx;
+        points[p * 3 + 1] = global_translation[1] + ry;
+        points[p * 3 + 2] = global_translation[2] + rz;
+    }
+}

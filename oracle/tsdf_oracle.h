@@ -151,6 +151,11 @@ void orc_icp_incremental_transformation(const uint16_t *depth_curr, const uint16
                                         float cx, float cy, float fx, float fy, float dist_thresh, float angle_thresh,
                                         float depth_cutoff, double *T, float *last_error, float *last_inliers);
 
+/* ---- mesh deformation (src/TSDF/TSDFVolume.cu:101-263) -- icp_oracle.c, PARITY UNPINNED ---------- */
+void orc_deform_points(const uint32_t dims[3], const float vs[3], const float offset[3], const float offset_at_clear[3],
+                       const float *nodes, const float global_rotation[3], const float global_translation[3], int num_points,
+                       float *points);
+
 #ifdef __cplusplus
 }
 #endif

@@ -78,6 +78,8 @@ _SIGS = {
     "tsdf_raycast_stats": (_i, [_vp, _u32, _u32, _fp, _fp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                 C.POINTER(C.c_uint64)]),
     "tsdf_raycast_evaluated_samples": (_i, [_vp, _u32, _u32, _fp, _fp, C.POINTER(C.c_uint64), _vp]),
+    "tsdf_volume_deform_points": (_i, [_vp, _i, _vp]),
+    "tsdf_volume_deform_points_device": (_i, [_vp, _i, _vp]),
     "tsdf_volume_occupancy": (_i, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "tsdf_volume_get_occupancy_data": (_i, [_vp, C.c_int, _vp, _vp, _vp]),
     "tsdf_raycast_slab_device": (_i, [_vp, _u32, _u32, _fp, _fp, _vp]),

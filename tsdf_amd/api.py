@@ -76,6 +76,14 @@ class TSDFVolume:
             return None
         return np.array(self.info().offset, np.float32)
 
+    def set_global_transform(self, rotation, translation):
+        """m_global_rotation (three angles) / m_global_translation, used by deform_mesh and stored in .tsdf files."""
+        i = self.info()
+        off = np.array(i.offset, np.float32)
+        r = np.ascontiguousarray(rotation, np.float32)
+        t = np.ascontiguousarray(translation, np.float32)
+        check(lib.tsdf_volume_set_header(self._h, _fp(off), float(i.truncation_distance), float(i.max_weight), _fp(t), _fp(r)))
+
     def resident_planes(self):
         i = self.info()
         return int(i.z_store_begin), int(i.z_store_end)
@@ -136,6 +144,12 @@ class TSDFVolume:
         """nodes: (voxels, 6) float32 = translation xyz + rotation xyz (DeformationNode, TSDFVolume.hpp:23-26)."""
         a = self._host(nodes, 6)
         check(lib.tsdf_volume_set_deformation(self._h, a.ctypes.data))
+
+    def deform_mesh(self, points):
+        """TSDFVolume::deform_mesh (src/TSDF/TSDFVolume.cu:265-291): points (n,3) float32 -> deformed copy."""
+        p = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3).copy()
+        check(lib.tsdf_volume_deform_points(self._h, p.shape[0], p.ctypes.data))
+        return p
 
     def get_distance_data(self):
         a = np.empty(self.resident_voxels(), np.float32)

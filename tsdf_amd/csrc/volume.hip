@@ -372,6 +372,83 @@ static int init_nodes(tsdf_volume *v) {
     return TSDF_OK;
 }
 
+// deformation_kernel + get_trilinear_elements + rotate (src/TSDF/TSDFVolume.cu:101-263): mesh points are pushed through
+// the volume's deformation field -- the trilinear blend of the eight surrounding nodes' translations -- then through the
+// global rotation and translation.  Kept as the reference has it, quirks included: the point is clamped with
+// POINT_EPSILON = 0.001 (:22, :117-122), node positions carry no offset here (centre_of_voxel_at with its default, :136,
+// :150), coefficients 6 and 7 belong to the other one's node (indices :164-171 vs coefficients :174-181).  The rotation
+// matrix entries are the reference's float products of cos / sin of the three angles (:213-224); they are the same for
+// every point, so the host forms them once (rot9, row-major).  Two cases the reference leaves undefined are defined here:
+// a point outside the volume (it only prints, then blends uninitialised memory) is returned unchanged, and a neighbour
+// index past the array (points in the last half voxel of an axis: lower + 1 is not clamped) is clamped to the last node.
+// nodes == nullptr: the regular grid clear() leaves (voxel centre + the offset at clear time).
+__global__ __launch_bounds__(256) void deform_points_kernel(const tsdf_deformation_node *__restrict__ nodes, const Geom g,
+                                                            const Mat33 rot, const F3 translation, const int num_points,
+                                                            float *__restrict__ points) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= num_points) return;
+    const float kPointEpsilon = 0.001f;
+    float px = points[idx * 3 + 0] - g.offset.x, py = points[idx * 3 + 1] - g.offset.y, pz = points[idx * 3 + 2] - g.offset.z;
+    const float mx = g.X * g.vs.x, my = g.Y * g.vs.y, mz = g.Z * g.vs.z;
+    float ax = px, ay = py, az = pz;
+    if ((px > mx) && (px - mx < kPointEpsilon)) ax = mx - kPointEpsilon;
+    if ((py > my) && (py - my < kPointEpsilon)) ay = my - kPointEpsilon;
+    if ((pz > mz) && (pz - mz < kPointEpsilon)) az = mz - kPointEpsilon;
+    if (px < -kPointEpsilon) ax = 0.0f;
+    if (py < -kPointEpsilon) ay = 0.0f;
+    if (pz < -kPointEpsilon) az = 0.0f;
+    const int vx = f2i_sat(floorf(ax / g.vs.x)), vy = f2i_sat(floorf(ay / g.vs.y)), vz = f2i_sat(floorf(az / g.vs.z));
+    if (!(vx >= 0 && vy >= 0 && vz >= 0 && (uint32_t)vx < g.X && (uint32_t)vy < g.Y && (uint32_t)vz < g.Z)) return;
+    const float cx = (vx + 0.5f) * g.vs.x + 0.0f, cy = (vy + 0.5f) * g.vs.y + 0.0f, cz = (vz + 0.5f) * g.vs.z + 0.0f;
+    int lx = (ax < cx) ? vx - 1 : vx, ly = (ay < cy) ? vy - 1 : vy, lz = (az < cz) ? vz - 1 : vz;
+    lx = max(lx, 0); ly = max(ly, 0); lz = max(lz, 0);
+    const float lcx = (lx + 0.5f) * g.vs.x + 0.0f, lcy = (ly + 0.5f) * g.vs.y + 0.0f, lcz = (lz + 0.5f) * g.vs.z + 0.0f;
+    const float u = (ax - lcx) / g.vs.x, v = (ay - lcy) / g.vs.y, w = (az - lcz) / g.vs.z;
+    const long long n_nodes = (long long)g.X * g.Y * g.Z;
+    const long long dx = 1, dy = g.X, dz = (long long)g.X * g.Y;
+    long long ind[8];
+    ind[0] = lx + (ly * dy) + (lz * dz);
+    ind[1] = ind[0] + dx;
+    ind[2] = ind[1] + dz;
+    ind[3] = ind[0] + dz;
+    ind[4] = ind[0] + dy;
+    ind[5] = ind[1] + dy;
+    ind[6] = ind[2] + dy;
+    ind[7] = ind[3] + dy;
+    float co[8];
+    co[0] = (1 - u) * (1 - v) * (1 - w);
+    co[1] = u * (1 - v) * (1 - w);
+    co[2] = u * (1 - v) * w;
+    co[3] = (1 - u) * (1 - v) * w;
+    co[4] = (1 - u) * v * (1 - w);
+    co[5] = u * v * (1 - w);
+    co[6] = (1 - u) * v * w;
+    co[7] = u * v * w;
+    float dxs = 0.0f, dys = 0.0f, dzs = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const long long i = min(ind[k], n_nodes - 1);
+        float tx, ty, tz;
+        if (nodes) {
+            tx = nodes[i].translation[0]; ty = nodes[i].translation[1]; tz = nodes[i].translation[2];
+        } else {
+            const int nz = (int)(i / dz), ny = (int)((i - (long long)nz * dz) / dy), nx = (int)(i - (long long)nz * dz - (long long)ny * dy);
+            tx = ((nx + 0.5f) * g.vs.x) + g.offset_clear.x;
+            ty = ((ny + 0.5f) * g.vs.y) + g.offset_clear.y;
+            tz = ((nz + 0.5f) * g.vs.z) + g.offset_clear.z;
+        }
+        dxs = (tx * co[k]) + dxs;
+        dys = (ty * co[k]) + dys;
+        dzs = (tz * co[k]) + dzs;
+    }
+    const float rx = (rot.m11 * dxs - rot.m12 * dys) + rot.m13 * dzs;   // rot holds the reference's nine products, signs as at :219-221
+    const float ry = (rot.m21 * dxs + rot.m22 * dys) - rot.m23 * dzs;
+    const float rz = (rot.m31 * dxs + rot.m32 * dys) + rot.m33 * dzs;
+    points[idx * 3 + 0] = translation.x + rx;
+    points[idx * 3 + 1] = translation.y + ry;
+    points[idx * 3 + 2] = translation.z + rz;
+}
+
 }  // namespace tsdf
 
 using namespace tsdf;
@@ -609,6 +686,50 @@ int tsdf_volume_get_occupancy_data(const tsdf_volume *cv, int force_rebuild, uin
     if (e == hipSuccess) e = hipStreamSynchronize(v->stream);
     if (e != hipSuccess) return hip_fail(e, "read occupancy");
     return TSDF_OK;
+}
+
+// rotate() of the reference (src/TSDF/TSDFVolume.cu:213-224): the nine float products of the cosines / sines of the three
+// angles, as the kernel's per-point code forms them; the kernel applies the signs.
+static void rotation_products(const float r[3], float m[9]) {
+    const float c1 = cosf(r[0]), c2 = cosf(r[1]), c3 = cosf(r[2]);
+    const float s1 = sinf(r[0]), s2 = sinf(r[1]), s3 = sinf(r[2]);
+    m[0] = (c2 * c3);            m[1] = (c2 * s3);             m[2] = s2;
+    m[3] = (c1 * s3 + s1 * s2 * c3); m[4] = (c1 * c3 - s1 * s2 * s3); m[5] = (s1 * c2);
+    m[6] = (s1 * s3 - c1 * s2 * c3); m[7] = (s1 * c3 + c1 * s2 * s3); m[8] = (c1 * c2);
+}
+
+int tsdf_volume_deform_points_device(const tsdf_volume *v, int num_points, float *device_points) {
+    TSDF_REQUIRE(v && device_points && num_points >= 0, "tsdf_volume_deform_points: bad argument");
+    TSDF_REQUIRE(v->z_begin == 0 && v->z_end == v->g.Z, "tsdf_volume_deform_points needs a whole volume");
+    if (num_points == 0) return TSDF_OK;
+    float m[9];
+    rotation_products(v->global_rotation, m);
+    Mat33 rot;   // column-major members: mRC
+    rot.m11 = m[0]; rot.m12 = m[1]; rot.m13 = m[2];
+    rot.m21 = m[3]; rot.m22 = m[4]; rot.m23 = m[5];
+    rot.m31 = m[6]; rot.m32 = m[7]; rot.m33 = m[8];
+    const F3 t = {v->global_translation[0], v->global_translation[1], v->global_translation[2]};
+    hipLaunchKernelGGL(deform_points_kernel, dim3((unsigned)((num_points + 255) / 256)), dim3(256), 0, v->stream, v->nodes, v->g, rot, t,
+                       num_points, device_points);
+    TSDF_HIP(hipGetLastError(), "Deformation kernel failed");
+    return TSDF_OK;
+}
+
+int tsdf_volume_deform_points(const tsdf_volume *v, int num_points, float *host_points) {
+    TSDF_REQUIRE(v && host_points && num_points >= 0, "tsdf_volume_deform_points: bad argument");
+    if (num_points == 0) return TSDF_OK;
+    float *d = nullptr;
+    const size_t bytes = (size_t)num_points * 3 * sizeof(float);
+    TSDF_HIP(hipMalloc((void **)&d, bytes), "d_points");
+    hipError_t e = hipMemcpyAsync(d, host_points, bytes, hipMemcpyHostToDevice, v->stream);
+    int rc = e == hipSuccess ? tsdf_volume_deform_points_device(v, num_points, d) : hip_fail(e, "Failed to copy points to device for deformation");
+    if (rc == TSDF_OK) {
+        e = hipMemcpyAsync(host_points, d, bytes, hipMemcpyDeviceToHost, v->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(v->stream);
+        if (e != hipSuccess) rc = hip_fail(e, "Failed to copy points from device after deformation");
+    }
+    (void)hipFree(d);
+    return rc;
 }
 
 int tsdf_volume_mark_dirty(tsdf_volume *v) {

@@ -146,19 +146,9 @@ void TSDFVolume::raycast(uint16_t width, uint16_t height, const Camera &camera,
     raycaster.raycast(*this, camera, vertices, normals);
 }
 
-// Mesh deformation belongs to the reference's non-rigid SceneFusion branch
-// (src/TSDF/TSDFVolume.cu:101-291), outside the hot path.  With the regular grid that
-// clear() creates and zero global rotation/translation the reference's blend returns each
-// point (to rounding); that identity case is what is provided here.
+// reference: src/TSDF/TSDFVolume.cu:265-291 (upload, deformation_kernel, download), in place like there
 void TSDFVolume::deform_mesh(const int num_points, float3 *points) const {
-    (void)num_points;
-    (void)points;
-    tsdf_volume_info i;
-    check(tsdf_volume_get_info(m_handle, &i), "Couldn't query TSDF");
-    if (i.deformation_materialised) {
-        std::cout << "deform_mesh: custom deformation fields are not supported by this build; mesh left undeformed"
-                  << std::endl;
-    }
+    check(tsdf_volume_deform_points(m_handle, num_points, reinterpret_cast<float *>(points)), "Deformation kernel failed");
 }
 
 // ---- file format (reference: src/TSDF/TSDFVolume.cu:911-1027 writer, :463-664 reader):
