@@ -34,8 +34,8 @@ SEED = 0x5EED0003            # config 3 stream
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--grid", type=int, default=512)
     ap.add_argument("--physical", type=float, default=3000.0)
     ap.add_argument("--stream-frames", type=int, default=200, help="length of the synthetic trajectory")
