@@ -103,8 +103,9 @@ static uint32_t occupancy_rebuild_period() {
 // Max depth per 16x16 pixel tile (0 = the tile holds no valid depth).  One wave per tile.
 __global__ __launch_bounds__(64) void depth_tile_max_kernel(const uint16_t *__restrict__ depth, uint32_t width,
                                                             uint32_t height, uint32_t tiles_x,
-                                                            uint16_t *__restrict__ tile_max) {
+                                                            uint16_t *__restrict__ tile_max, uint32_t *__restrict__ brick_count) {
     const uint32_t tx = blockIdx.x, ty = blockIdx.y;
+    if (tx == 0 && ty == 0 && threadIdx.x == 0) *brick_count = 0;  // for brick_cull_kernel, the next launch on the stream
     uint32_t m = 0;
     for (uint32_t i = threadIdx.x; i < kDepthTile * kDepthTile; i += 64) {
         uint32_t x = tx * kDepthTile + (i & (kDepthTile - 1)), y = ty * kDepthTile + (i / kDepthTile);
@@ -472,9 +473,8 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
         // the depth tests need surface z == depth and w == 1 exactly (rigid pose, standard intrinsics)
         const int depth_test = (ip.m41 == 0.0f && ip.m42 == 0.0f && ip.m43 == 0.0f && ip.m44 == 1.0f &&
                                 mkinv.m31 == 0.0f && mkinv.m32 == 0.0f && mkinv.m33 == 1.0f) ? 1 : 0;
-        TSDF_HIP(hipMemsetAsync(count, 0, sizeof(uint32_t), v->stream), "reset brick count");
         hipLaunchKernelGGL(depth_tile_max_kernel, dim3(tiles_x, tiles_y), dim3(64), 0, v->stream, d_depth, width, height,
-                           tiles_x, v->tile_max);
+                           tiles_x, v->tile_max, count);
         hipLaunchKernelGGL(brick_cull_kernel, dim3((unsigned)((n_bricks + 255) / 256)), dim3(256), 0, v->stream, g, bg, ip, mk,
                            width, height, v->tile_max, tiles_x, depth_test, v->brick_list, boxes, count, plane_const, n_plane_const);
     }

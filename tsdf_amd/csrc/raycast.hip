@@ -868,8 +868,9 @@ __global__ __launch_bounds__(256) void vertices_to_depth_kernel(uint32_t n_pixel
 // Per pixel, keep the record with the smallest k among n_slabs gathered buffers
 // (layout [slab][pixel][4]).  Ties cannot occur: a sample has exactly one owner.
 __global__ __launch_bounds__(256) void merge_hits_kernel(const float4 *__restrict__ hits, uint32_t n_slabs,
-                                                         uint32_t n_pixels, float *__restrict__ V) {
+                                                         uint32_t n_pixels, float *__restrict__ V, uint32_t *__restrict__ reset) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (reset && i == 0) *reset = 0;  // the tail queue's counter, for the next ray cast (saves a memset launch per frame)
     if (i >= n_pixels) return;
     float4 best = hits[i];
     for (uint32_t s = 1; s < n_slabs; s++) {
@@ -883,8 +884,9 @@ __global__ __launch_bounds__(256) void merge_hits_kernel(const float4 *__restric
 
 // Same min-k select, keeping the winning record (used to fold a slab's sample ranges into its one record).
 __global__ __launch_bounds__(256) void merge_records_kernel(const float4 *__restrict__ hits, uint32_t n_sets,
-                                                            uint32_t n_pixels, float4 *__restrict__ out) {
+                                                            uint32_t n_pixels, float4 *__restrict__ out, uint32_t *__restrict__ reset) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (reset && i == 0) *reset = 0;
     if (i >= n_pixels) return;
     float4 best = hits[i];
     for (uint32_t s = 1; s < n_sets; s++) {
@@ -955,8 +957,10 @@ static int march_segments(tsdf_volume *v, RayParams &rp, size_t n_pix, int &n_se
         TSDF_HIP(hipMalloc(&v->tail_entries, n_rec * sizeof(uint2)), "ray tail queue alloc");
         v->tail_cap = n_rec;
     }
-    if (!v->tail_count) TSDF_HIP(hipMalloc((void **)&v->tail_count, 2 * sizeof(uint32_t)), "ray tail counter alloc");
-    TSDF_HIP(hipMemsetAsync(v->tail_count, 0, 2 * sizeof(uint32_t), v->stream), "ray tail counter reset");
+    if (!v->tail_count) {   // zeroed once; every march's merge kernel leaves it at zero again
+        TSDF_HIP(hipMalloc((void **)&v->tail_count, 2 * sizeof(uint32_t)), "ray tail counter alloc");
+        TSDF_HIP(hipMemsetAsync(v->tail_count, 0, 2 * sizeof(uint32_t), v->stream), "ray tail counter reset");
+    }
     TailQueue tail = {reinterpret_cast<uint2 *>(v->tail_entries), v->tail_count, (uint32_t)trip_budget(), (uint32_t)tail_lanes()};
     rp.seg_len = (kMaxSamples + n_segments - 1) / n_segments;
     dim3 grid((rp.width + 15) / 16, (rp.height + 15) / 16, n_segments);
@@ -1003,7 +1007,7 @@ int tsdf_raycast_device(const tsdf_volume *v, uint32_t width, uint32_t height, c
     rc = march_segments<false>(mv, rp, n_pix, kRaySegments);
     if (rc != TSDF_OK) return rc;
     hipLaunchKernelGGL(merge_hits_kernel, dim3((unsigned)((n_pix + 255) / 256)), dim3(256), 0, v->stream,
-                       reinterpret_cast<const float4 *>(mv->seg_hits), (uint32_t)kRaySegments, (uint32_t)n_pix, device_vertices);
+                       reinterpret_cast<const float4 *>(mv->seg_hits), (uint32_t)kRaySegments, (uint32_t)n_pix, device_vertices, mv->tail_count);
     TSDF_HIP(hipGetLastError(), "merge ray segments failed");
     if (device_normals) return launch_normals(width, height, device_vertices, device_normals, v->stream);
     return TSDF_OK;
@@ -1137,7 +1141,7 @@ int tsdf_raycast_slab_device(const tsdf_volume *v, uint32_t width, uint32_t heig
     if (rc != TSDF_OK) return rc;
     hipLaunchKernelGGL(merge_records_kernel, dim3((unsigned)((n_pix + 255) / 256)), dim3(256), 0, v->stream,
                        reinterpret_cast<const float4 *>(mv->seg_hits), (uint32_t)kRaySegments, (uint32_t)n_pix,
-                       reinterpret_cast<float4 *>(device_hits));
+                       reinterpret_cast<float4 *>(device_hits), mv->tail_count);
     TSDF_HIP(hipGetLastError(), "process_ray (slab) failed");
     return TSDF_OK;
 }
@@ -1148,7 +1152,7 @@ int tsdf_merge_hits_device(const float *device_hits_all, uint32_t n_slabs, uint3
                  "tsdf_merge_hits: bad argument");
     uint32_t n = width * height;
     hipLaunchKernelGGL(merge_hits_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream,
-                       reinterpret_cast<const float4 *>(device_hits_all), n_slabs, n, device_vertices);
+                       reinterpret_cast<const float4 *>(device_hits_all), n_slabs, n, device_vertices, (uint32_t *)nullptr);
     TSDF_HIP(hipGetLastError(), "merge hits failed");
     return TSDF_OK;
 }
