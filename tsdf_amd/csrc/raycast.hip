@@ -670,8 +670,20 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
     __syncthreads();
 
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const int imx = blockIdx.x * 16 + (wave & 1u) * 8 + (lane & 7u);
-    const int imy = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    // Workgroups are dealt to the 8 XCDs round robin in launch order; remap the linear tile index so that each XCD (own
+    // L2) gets one contiguous eighth of the image's tiles instead of every eighth tile.
+    uint32_t tile_x = blockIdx.x, tile_y = blockIdx.y;
+    {
+        const uint32_t n_tiles = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const uint32_t per_xcd = n_tiles / 8;
+        if (lin < per_xcd * 8) {   // (the last n_tiles % 8 tiles keep their place)
+            const uint32_t remapped = (lin & 7u) * per_xcd + (lin >> 3);
+            tile_y = remapped / gridDim.x;
+            tile_x = remapped - tile_y * gridDim.x;
+        }
+    }
+    const int imx = tile_x * 16 + (wave & 1u) * 8 + (lane & 7u);
+    const int imy = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
     const bool in_image = imx < (int)rp.width && imy < (int)rp.height;
 
     float ix = NAN, iy = NAN, iz = NAN;
