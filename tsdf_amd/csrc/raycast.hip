@@ -21,6 +21,7 @@ struct RayParams {
     uint32_t width, height;
     uint32_t own_lo, own_hi;  // slab ownership (planes of the lower trilinear tap)
     uint32_t seg_len;         // > 0: blockIdx.z handles samples [z*seg_len, (z+1)*seg_len) and writes records
+    uint32_t slab_ranges;     // > 0 (slabs): blockIdx.z handles that part of each ray's own stretch through the slab
 };
 
 // Division by a loop-invariant voxel edge.  The reference divides (IEEE, correctly rounded); when FASTDIV is
@@ -265,6 +266,19 @@ static int tail_grid() {
         return v < 1 ? 1 : v;
     }();
     return n;
+}
+// Parts a ray's stretch through a slab is cut into: in proportion to the slab's share of the grid (a whole volume
+// uses ray_segments() ranges), at least 2.
+static int slab_ray_ranges(const tsdf_volume *v) {
+    static const int forced = [] {
+        const char *e = getenv("TSDF_RAY_SLAB_RANGES");  // tuning aid
+        int n = e ? atoi(e) : 0;
+        return n < 0 ? 0 : (n > 64 ? 64 : n);
+    }();
+    if (forced) return forced;
+    const uint32_t planes = v->z_end - v->z_begin, Z = v->g.Z ? v->g.Z : 1;
+    const int n = (int)(((uint64_t)ray_segments() * planes + Z - 1) / Z);
+    return n < 2 ? 2 : (n > 64 ? 64 : n);
 }
 static int trip_budget() {
     static const int n = [] {
@@ -661,8 +675,12 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
                                                           unsigned int *__restrict__ touched,
                                                           const OccGrid occ, const float *__restrict__ t_table,
                                                           const TailQueue tail) {
-    const int k_lo = (int)(blockIdx.z * rp.seg_len);
-    const int k_hi = rp.seg_len ? min(kMaxSamples, k_lo + (int)rp.seg_len) : kMaxSamples;
+    // Whole volume: range z of the workgroup grid is the fixed sample interval [z * seg_len, (z+1) * seg_len).
+    // Slab (rp.slab_ranges > 0): a slab owns only a short stretch of every ray, a different one per ray, so the ranges
+    // are cut per ray out of ITS stretch (below); any sample index may be needed and the whole table is staged.
+    const bool per_ray_ranges = SLAB && rp.slab_ranges > 0;
+    const int k_lo = per_ray_ranges ? 0 : (int)(blockIdx.z * rp.seg_len);
+    const int k_hi = (rp.seg_len && !per_ray_ranges) ? min(kMaxSamples, k_lo + (int)rp.seg_len) : kMaxSamples;
     __shared__ float T[kTableLen];
     // T[1] (the step) plus the part of the table this range reads: T[k_lo .. k_hi]
     for (int i = k_lo + (int)threadIdx.x; i <= k_hi; i += 256) T[i] = t_table[i];
@@ -694,6 +712,12 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
     RayState ray;
     int k_first, k_end;
     setup_ray<SLAB>(imx, imy, in_image, k_lo, k_hi, T, rp, g, step_size, ray, k_first, k_end);
+    if (per_ray_ranges && k_end > k_first) {
+        // part blockIdx.z of rp.slab_ranges equal parts of this ray's stretch [k_first, k_end) through the slab
+        const int len = k_end - k_first, a = k_first + (int)(((long long)len * blockIdx.z) / rp.slab_ranges);
+        k_end = k_first + (int)(((long long)len * (blockIdx.z + 1)) / rp.slab_ranges);
+        k_first = a;
+    }
     const TriConst tc = make_tri_const(g);
     SkipCtx sc = make_skip_ctx(g, step_size);
     set_ray<SKIP>(sc, ray, step_size, g);
@@ -932,6 +956,7 @@ static RayParams make_params(const tsdf_volume *v, uint32_t width, uint32_t heig
     rp.own_lo = v->z_begin;
     rp.own_hi = v->z_end;
     rp.seg_len = 0;
+    rp.slab_ranges = 0;
     return rp;
 }
 
@@ -953,7 +978,7 @@ static int check_ray_args(const tsdf_volume *v, uint32_t width, uint32_t height,
 // process_ray_tail_kernel for the rays it handed over.  Leaves one {k,x,y,z} record per (range, pixel) in v->seg_hits.
 template <bool SLAB>
 static int march_segments(tsdf_volume *v, RayParams &rp, size_t n_pix, int &n_segments) {
-    n_segments = ray_segments();
+    n_segments = SLAB ? slab_ray_ranges(v) : ray_segments();
     const size_t n_rec = n_pix * n_segments;
     if (v->seg_cap < n_rec) {
         if (v->seg_hits) (void)hipFree(v->seg_hits);
@@ -975,6 +1000,7 @@ static int march_segments(tsdf_volume *v, RayParams &rp, size_t n_pix, int &n_se
     }
     TailQueue tail = {reinterpret_cast<uint2 *>(v->tail_entries), v->tail_count, (uint32_t)trip_budget(), (uint32_t)tail_lanes()};
     rp.seg_len = (kMaxSamples + n_segments - 1) / n_segments;
+    rp.slab_ranges = SLAB ? (uint32_t)n_segments : 0u;
     dim3 grid((rp.width + 15) / 16, (rp.height + 15) / 16, n_segments);
     timing_begin(v, 1);
     if (v->fast_div)
