@@ -155,3 +155,52 @@ def test_random_slab_splits_equal_the_whole_volume(seed):
         tsdf_amd.merge_hits_device(hits.data_ptr(), P, width, height, Vm.data_ptr())
         torch.cuda.synchronize()
         assert_same_floats(Vm.cpu().numpy(), V, "seed %d: %d slabs of %s, image %dx%d" % (seed, P, dims, width, height))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_bilateral_filters(oracle, seed):
+    """Random image sizes (smaller than, equal to and larger than the tiles and the kernel), sigmas and contents, 8 and 16 bit."""
+    rng = np.random.default_rng(0xB11A + seed)
+    w, h = int(rng.integers(1, 90)), int(rng.integers(1, 70))
+    sc, ss = float(rng.uniform(0.5, 40.0)), float(rng.uniform(0.4, 6.0))
+    bil = tsdf_amd.BilateralFilter(sc, ss)
+    for bits in (8, 16):
+        hi = 256 if bits == 8 else int(rng.choice([300, 5000, 65536]))
+        img = rng.integers(0, hi, size=w * h).astype(np.uint8 if bits == 8 else np.uint16)
+        if rng.random() < 0.5:
+            img[rng.random(w * h) < 0.1] = 0
+        got = img.copy()
+        bil.filter(got, w, h)
+        exp = oracle.bilateral_u8(img, w, h, sc, ss) if bits == 8 else oracle.bilateral_u16(img, w, h, sc, ss, nthreads=4)
+        assert np.array_equal(got, np.asarray(exp).reshape(-1)), "seed %d %dx%d sigma (%.2f, %.2f) %d bit" % (seed, w, h, sc, ss, bits)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_icp_steps(oracle, seed):
+    """Random plane / sphere scenes and poses through one ICP step: same inliers, sums within 1e-4 of the oracle's."""
+    rng = np.random.default_rng(0x1C9 + seed)
+    W, H = 640, 480
+    yy, xx = np.mgrid[0:H, 0:W]
+    def scene(shift):
+        z = 1500.0 + 0.3 * (xx - 320 + shift[0]) + 0.2 * (yy - 240 + shift[1]) + 80.0 * np.sin((xx + shift[0]) / 40.0) * np.cos((yy + shift[1]) / 55.0)
+        d = np.clip(np.rint(z + shift[2]), 0, 65535).astype(np.uint16)
+        d[rng.random((H, W)) < 0.02] = 0
+        return d.reshape(-1)
+    d0, d1 = scene((0, 0, 0)), scene(tuple(rng.uniform(-2, 2, size=3)))
+    icp = tsdf_amd.ICPOdometry(W, H, 331.0, 234.6, 591.1, 590.1)
+    icp.init_icp_model(d0)
+    icp.init_icp(d1)
+    T = oracle.se3_exp(rng.normal(size=6) * np.array([0.004, 0.004, 0.004, 0.002, 0.002, 0.002]))
+    R, t = T[:3, :3].astype(np.float32), T[:3, 3].astype(np.float32)
+    level = int(rng.integers(0, 3))
+    rows, cols, div = H >> level, W >> level, 1 << level
+    A, b, res, inl = icp.estimate_step(level, R, t)
+    maps = [icp.get_map(k, level) for k in ("vmap_curr", "nmap_curr", "vmap_prev", "nmap_prev")]
+    import math
+    ang = float(np.float32(math.sin(np.float32(20.0) * np.float32(3.14159254) / np.float32(180.0))))
+    Ao, bo, reso, inlo, _ = oracle.icp_step(R.T.reshape(-1), t, *maps, rows, cols, np.float32(591.1) / div, np.float32(590.1) / div,
+                                            np.float32(331.0) / div, np.float32(234.6) / div, 0.10, ang)
+    assert inl == inlo and inl > 100
+    assert np.max(np.abs(A - Ao)) <= 1e-4 * np.max(np.abs(Ao))
+    assert np.max(np.abs(b - bo)) <= 1e-4 * max(np.max(np.abs(bo)), 1e-6 * np.max(np.abs(Ao)))
+    assert abs(res - reso) <= 1e-4 * max(reso, 1e-12)
