@@ -31,6 +31,41 @@ def test_headers_of_the_class_surface_compile_standalone():
                             "-x", "c++", "-"], input=src.encode(), check=True)
 
 
+def test_file_utilities_on_the_host(tmp_path):
+    """The small host helpers of src/include/FileUtilities.hpp (no GPU involved): a throw-away program linked against
+    libtsdf_host.so."""
+    src = r"""
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include "FileUtilities.hpp"
+int main(int argc, char **argv) {
+    if (!match_file_name("depth_", 4, "_x", "png", "depth_0012_x.png")) return 1;
+    if (match_file_name("depth_", 4, "_x", "png", "depth_001a_x.png")) return 2;      // not all digits
+    if (match_file_name("depth_", 4, "_x", "png", "depth_00123_x.png")) return 3;     // wrong length
+    if (match_file_name("depth_", 4, "", "png", "depth_0012.pgm")) return 4;          // wrong extension
+    std::string last;
+    if (!read_last_line(argv[1], last) || last != "the last line") return 5;
+    if (read_last_line(std::string(argv[1]) + ".missing", last)) return 6;
+    setenv("HOME", "/somewhere", 1);
+    if (std::string(get_home_directory()) != "/somewhere") return 7;
+    if (path_to_file_on_desktop("a.png") != "/somewhere/Desktop/a.png") return 8;
+    bool is_dir = false;
+    if (!file_exists(argv[1], is_dir) || is_dir) return 9;
+    std::puts("file utilities ok");
+    return 0;
+}
+"""
+    (tmp_path / "t.cpp").write_text(src)
+    (tmp_path / "lines.txt").write_text("first\n\nthe last line\n\n\n")
+    lib = os.path.join(ROOT, "tsdf_amd", "lib")
+    exe = str(tmp_path / "t")
+    subprocess.run(["g++", "-std=c++11", "-I" + os.path.join(ROOT, "tsdf_amd", "host", "include"), str(tmp_path / "t.cpp"), "-o", exe,
+                    "-L" + lib, "-ltsdf_host", "-ltsdf_hip", "-Wl,-rpath," + lib], check=True)
+    r = subprocess.run([exe, str(tmp_path / "lines.txt")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "file utilities ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
 @pytest.mark.gpu
 def test_cpp_surface_matches_the_oracle(tmp_path, oracle):
     if not os.path.exists(BIN):
