@@ -63,3 +63,29 @@ def test_identity_field_and_zero_transform_reproduce_interior_points(oracle):
 def test_cpp_class_and_empty_input():
     v = tsdf_amd.TSDFVolume((8, 8, 8), (80.0, 80.0, 80.0))
     assert v.deform_mesh(np.zeros((0, 3), np.float32)).shape == (0, 3)
+
+
+def test_sphere_mesh_through_a_twist_field_like_the_reference_fixture(oracle):
+    """The scenario of the reference's src/Tests/test_MC_main.cpp:12-152 (a sphere SDF, a 'banana' twist written into the
+    deformation nodes, extract_surface, then the mesh pushed through the field), at 48^3 instead of 200^3: mesh of the
+    sphere by the host marching cubes, deformed on the GPU, equal to the oracle's deformation of the same vertices."""
+    n, phys = 48, 2000.0
+    v = tsdf_amd.TSDFVolume((n, n, n), (phys,) * 3)
+    vs = phys / n
+    zz, yy, xx = np.mgrid[0:n, 0:n, 0:n]
+    c = [((a + np.float32(0.5)) * np.float32(vs)).astype(np.float32) for a in (xx, yy, zz)]
+    d = np.sqrt((c[0] - phys / 2) ** 2 + (c[1] - phys / 2) ** 2 + (c[2] - phys / 2) ** 2) - phys / 2.5
+    v.set_distance_data(d.astype(np.float32).reshape(-1))
+    # build_twist_translation_data: rotate every node about an axis at x = 1.5 * extent by twice its polar angle
+    cx, cy = 1.5 * phys, 0.5 * phys
+    theta = np.arctan2(c[1] - cy, c[0] - cx) * 2
+    tx = (np.cos(theta) * (c[0] - cx) - np.sin(theta) * (c[1] - cy)) + cx
+    ty = (np.sin(theta) * (c[0] - cx) + np.cos(theta) * (c[1] - cy)) + cy
+    nodes = np.stack([tx, ty, c[2], 0 * tx, 0 * tx, 0 * tx], axis=-1).reshape(-1, 6).astype(np.float32)
+    v.set_deformation(nodes)
+    mesh = tsdf_amd.marching_cubes(v.get_distance_data(), (n, n, n), (vs,) * 3)
+    assert mesh.shape[0] > 3000 and np.all(np.abs(np.linalg.norm(mesh - phys / 2, axis=1) - phys / 2.5) < 0.1 * vs)
+    bent = v.deform_mesh(mesh)
+    exp = oracle.deform_points((n, n, n), v.voxel_size(), (0, 0, 0), (0, 0, 0), nodes, (0, 0, 0), (0, 0, 0), mesh)
+    assert_same_floats(bent, exp, "twisted sphere")
+    assert np.max(np.linalg.norm(bent - mesh, axis=1)) > 100.0       # it really bends
