@@ -34,5 +34,13 @@ if [ -f "$ICPSRC" ]; then
   g++ -o "$OUT/tsdf_icp" "$W/tsdf_icp.o" -L"$ROOT/tsdf_amd/lib" -ltsdf_host -ltsdf_hip -Wl,-rpath,'$ORIGIN/../../tsdf_amd/lib'
   echo "linkcheck: reference tsdf_icp.cpp compiled unchanged and linked -> $OUT/tsdf_icp"
 fi
+# src/Tools/tsdf_view.cpp: slices of a distance array as colour PNGs -- only the PNG utilities of the class surface
+VIEWSRC="$REF/src/Tools/tsdf_view.cpp"
+if [ -f "$VIEWSRC" ]; then
+  ln -s "$VIEWSRC" "$W/src/Tools/tsdf_view.cpp"
+  g++ -std=c++11 -O1 -w $EIGEN -I"$ROOT/include" -c "$W/src/Tools/tsdf_view.cpp" -o "$W/tsdf_view.o"
+  g++ -o "$OUT/tsdf_view" "$W/tsdf_view.o" -L"$ROOT/tsdf_amd/lib" -ltsdf_host -ltsdf_hip -Wl,-rpath,'$ORIGIN/../../tsdf_amd/lib'
+  echo "linkcheck: reference tsdf_view.cpp compiled unchanged and linked -> $OUT/tsdf_view"
+fi
 # usage line only (no GPU needed): the binary must start and reject a bad command line like the reference
 "$OUT/kinfu" 2>&1 | head -2 || true

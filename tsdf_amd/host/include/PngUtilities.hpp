@@ -8,6 +8,8 @@
 #include <iostream>
 #include <string>
 
+#include <Eigen/Dense>   // as the reference's header does (its tools rely on what this brings in)
+
 // 16-bit greyscale -> width*height host-endian values (new[]-allocated, caller frees); nullptr on failure
 uint16_t *load_png_from_file(const std::string file_name, uint32_t &width, uint32_t &height);
 // 8-bit RGB -> width*height*3 bytes (new[]-allocated); nullptr on failure
