@@ -98,6 +98,37 @@ def test_reference_tsdf_view_writes_its_slice_images(tmp_path):
         assert len(zlib.decompress(idat)) == h * (1 + 3 * w)
 
 
+def test_reference_pgm2png_converts_a_depth_map(tmp_path):
+    """src/Tools/pgm2png.cpp of the reference, compiled unchanged: read_nyu_depth_map (16-bit PGM, bytes of every sample
+    swapped after the read, src/Utilities/DepthMapUtilities.cpp:29-31) + save_png_to_file (16-bit greyscale PNG)."""
+    tool = os.path.join(ROOT, "oracle", "_ref", "pgm2png")
+    if not os.path.exists(tool):
+        pytest.skip("oracle/_ref/pgm2png not built (needs the reference tree at build time)")
+    w, h = 7, 5
+    img = (np.arange(w * h, dtype=np.uint32) * 1234 % 65536).astype(np.uint16).reshape(h, w)
+    with open(tmp_path / "d.pgm", "wb") as f:
+        f.write(b"P5 %d %d 65535\n" % (w, h))
+        f.write(img.astype(">u2").tobytes())
+    r = subprocess.run([tool, str(tmp_path / "d.pgm")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+    import struct
+    import zlib
+    data = (tmp_path / "d.png").read_bytes()
+    pw, ph, depth, colour = struct.unpack(">IIBB", data[16:26])
+    assert (pw, ph, depth, colour) == (w, h, 16, 0)
+    idat, pos = b"", 8
+    while pos < len(data):
+        ln, tag = struct.unpack(">I4s", data[pos:pos + 8])
+        if tag == b"IDAT":
+            idat += data[pos + 8:pos + 8 + ln]
+        pos += 12 + ln
+    raw = zlib.decompress(idat)
+    rows = [raw[y * (1 + 2 * w):(y + 1) * (1 + 2 * w)] for y in range(h)]
+    assert all(row[0] == 0 for row in rows)                       # filter type none
+    got = np.frombuffer(b"".join(row[1:] for row in rows), ">u2").reshape(h, w)
+    assert np.array_equal(got, img.byteswap())                    # the reference's byte swap of every sample
+
+
 @pytest.mark.gpu
 def test_cpp_surface_matches_the_oracle(tmp_path, oracle):
     if not os.path.exists(BIN):

@@ -42,5 +42,12 @@ if [ -f "$VIEWSRC" ]; then
   g++ -o "$OUT/tsdf_view" "$W/tsdf_view.o" -L"$ROOT/tsdf_amd/lib" -ltsdf_host -ltsdf_hip -Wl,-rpath,'$ORIGIN/../../tsdf_amd/lib'
   echo "linkcheck: reference tsdf_view.cpp compiled unchanged and linked -> $OUT/tsdf_view"
 fi
+# src/Tools/pgm2png.cpp (NYU 16-bit PGM depth map -> PNG); it includes the headers by bare name
+PGMSRC="$REF/src/Tools/pgm2png.cpp"
+if [ -f "$PGMSRC" ]; then
+  g++ -std=c++11 -O1 -w $EIGEN -I"$ROOT/include" -I"$ROOT/tsdf_amd/host/include" -c "$PGMSRC" -o "$W/pgm2png.o"
+  g++ -o "$OUT/pgm2png" "$W/pgm2png.o" -L"$ROOT/tsdf_amd/lib" -ltsdf_host -ltsdf_hip -Wl,-rpath,'$ORIGIN/../../tsdf_amd/lib'
+  echo "linkcheck: reference pgm2png.cpp compiled unchanged and linked -> $OUT/pgm2png"
+fi
 # usage line only (no GPU needed): the binary must start and reject a bad command line like the reference
 "$OUT/kinfu" 2>&1 | head -2 || true
