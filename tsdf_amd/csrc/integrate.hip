@@ -500,6 +500,11 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
 #undef LAUNCH
     timing_end(v, 0);
     TSDF_HIP(hipGetLastError(), "Integrate kernel failed");
+    if (getenv("TSDF_DEBUG_BRICKS") && !v->nodes) {   // diagnostics: how many bricks survived the cull
+        uint32_t n_active = 0;
+        (void)hipMemcpy(&n_active, count, sizeof(n_active), hipMemcpyDeviceToHost);
+        fprintf(stderr, "tsdf: %u of %zu bricks active (%.1f M voxels processed)\n", n_active, n_bricks, n_active * 4096.0 / 1e6);
+    }
     v->reach_dirty = 1;  // bricks may have been flagged
     // The kernel only sets occupancy flags.  A voxel that was low when first seen (sensor dropouts smeared by the
     // bilateral filter put phantom surfaces into free space) and has since been averaged back up keeps its bricks
