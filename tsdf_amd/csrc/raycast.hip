@@ -12,39 +12,9 @@
 
 namespace tsdf {
 
-struct RayParams {
-    F3 origin;
-    Mat33 rot;
-    Mat33 kinv;
-    F3 space_min;
-    F3 space_max;
-    uint32_t width, height;
-    uint32_t own_lo, own_hi;  // slab ownership (planes of the lower trilinear tap)
-    uint32_t seg_len;         // > 0: blockIdx.z handles samples [z*seg_len, (z+1)*seg_len) and writes records
-    uint32_t slab_ranges;     // > 0 (slabs): blockIdx.z handles that part of each ray's own stretch through the slab
-};
-
-// Division by a loop-invariant voxel edge.  The reference divides (IEEE, correctly rounded); when FASTDIV is
-// set the quotient is formed as q0 = a*y, r = fma(-b, q0, a), q = fma(r, y, q0) with y = RN(1/b).  That
-// sequence is used ONLY after volume.hip has checked it against the IEEE quotient for EVERY finite fp32
-// numerator with |a| >= kFastDivMin for this very b (verify_fast_division, ~2^32 cases per voxel
-// edge, a few ms once per volume), so on that domain it is the same function in three instructions instead
-// of the ~14 of a full fp32 division; numerators outside the domain take the IEEE division.
 struct InvDiv {
     float b, y;
 };
-template <bool FASTDIV>
-__device__ inline float div_by(float a, const InvDiv &d) {
-    if (FASTDIV) {
-        const float mag = fabsf(a);
-        if (mag >= kFastDivMin && mag < INFINITY) {  // the verified domain
-            float q0 = a * d.y;
-            float r = __builtin_fmaf(-d.b, q0, a);
-            return __builtin_fmaf(r, d.y, q0);
-        }
-    }
-    return a / d.b;
-}
 
 // Loop-invariant pieces of trilinearly_interpolate (:60-71) and of tsdf_value_at, same float expressions.
 struct TriConst {
@@ -53,7 +23,7 @@ struct TriConst {
     InvDiv dx, dy, dz;
     uint32_t row, plane;              // X, X*Y
 };
-__device__ inline TriConst make_tri_const(const Geom &g) {
+__host__ __device__ inline TriConst make_tri_const(const Geom &g) {
     TriConst c;
     c.max_x = g.X * g.vs.x;
     c.max_y = g.Y * g.vs.y;
@@ -67,6 +37,38 @@ __device__ inline TriConst make_tri_const(const Geom &g) {
     c.row = g.X;
     c.plane = g.X * g.Y;  // X, Y <= 65535
     return c;
+}
+
+struct RayParams {
+    F3 origin;
+    Mat33 rot;
+    Mat33 kinv;
+    F3 space_min;
+    F3 space_max;
+    uint32_t width, height;
+    uint32_t own_lo, own_hi;  // slab ownership (planes of the lower trilinear tap)
+    uint32_t seg_len;         // > 0: blockIdx.z handles samples [z*seg_len, (z+1)*seg_len) and writes records
+    uint32_t slab_ranges;     // > 0 (slabs): blockIdx.z handles that part of each ray's own stretch through the slab
+    TriConst tc;              // loop-invariant pieces of the interpolation, formed once on the host (same IEEE operations)
+};
+
+// Division by a loop-invariant voxel edge.  The reference divides (IEEE, correctly rounded); when FASTDIV is
+// set the quotient is formed as q0 = a*y, r = fma(-b, q0, a), q = fma(r, y, q0) with y = RN(1/b).  That
+// sequence is used ONLY after volume.hip has checked it against the IEEE quotient for EVERY finite fp32
+// numerator with |a| >= kFastDivMin for this very b (verify_fast_division, ~2^32 cases per voxel
+// edge, a few ms once per volume), so on that domain it is the same function in three instructions instead
+// of the ~14 of a full fp32 division; numerators outside the domain take the IEEE division.
+template <bool FASTDIV>
+__device__ inline float div_by(float a, const InvDiv &d) {
+    if (FASTDIV) {
+        const float mag = fabsf(a);
+        if (mag >= kFastDivMin && mag < INFINITY) {  // the verified domain
+            float q0 = a * d.y;
+            float r = __builtin_fmaf(-d.b, q0, a);
+            return __builtin_fmaf(r, d.y, q0);
+        }
+    }
+    return a / d.b;
 }
 
 // trilinearly_interpolate (src/RayCaster/GPURaycaster.cu:53-124) with voxel_for_point, centre_of_voxel_at and
@@ -605,8 +607,20 @@ __device__ inline void setup_ray(int imx, int imy, bool in_image, int k_lo, int 
     k_end = 0;
     if (intersects) {
         // smallest k in [max(k_lo,1), k_hi] with T[k] >= max_t (k_hi when there is none): only this range's
-        // part of the table is staged, and only this range's samples are marched
+        // part of the table is staged, and only this range's samples are marched.  T[k] is k * step up to the
+        // rounding of its k additions (under one sample over the whole table), so the answer lies within a few
+        // entries of max_t / step: the bisection starts from that window when it brackets the answer, from the whole
+        // range otherwise (NaN / infinite max_t included).
         int lo = max(k_lo, 1), hi = k_hi;
+        {
+            const int c = f2i_sat(max_t * __builtin_amdgcn_rcpf(step_size));
+            const int a = max(lo, min(hi, c - 4)), b = min(hi, max(lo, c + 4));
+            const bool below = a == lo || T[a - 1] < max_t, above = b == hi || T[b] >= max_t;
+            if (below && above) {
+                lo = a;
+                hi = b;
+            }
+        }
         while (lo < hi) {
             int mid = (lo + hi) >> 1;
             if (T[mid] >= max_t) hi = mid; else lo = mid + 1;
@@ -718,13 +732,34 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
         k_end = k_first + (int)(((long long)len * (blockIdx.z + 1)) / rp.slab_ranges);
         k_first = a;
     }
-    const TriConst tc = make_tri_const(g);
+    const TriConst &tc = rp.tc;
     SkipCtx sc = make_skip_ctx(g, step_size);
     set_ray<SKIP>(sc, ray, step_size, g);
 
     int k = (k_end <= k_first) ? kDone : k_first;  // next sample of this lane's ray (kDone when finished)
     BrickCache bc = {0, 0, false};
     SampleWork work = {0, 0, 0, 0};
+
+    // Lead-in: most (tile, range) pairs start in empty space and many never leave it.  Jumping from block to block needs
+    // only the brick look-up, so it gets a loop of its own -- a fraction of the instructions of the full pass below --
+    // that runs until every lane has either finished or arrived in a flagged brick (its classification is kept in bc).
+    if (SKIP && !STATS) {
+        while (true) {
+            const bool hopping = k != kDone && sc.skip_ok && k >= bc.k_brick_end;
+            if (__ballot(hopping) == 0ull) break;
+            if (hopping) {
+                const float t = T[k];
+                const float fx = ((t * ray.dx) + ray.sx) * sc.inv_vx, fy = ((t * ray.dy) + ray.sy) * sc.inv_vy, fz = ((t * ray.dz) + ray.sz) * sc.inv_vz;
+                int n;
+                const bool empty = locate<SLAB>(fx, fy, fz, sc, g, occ, rp, n);
+                bc.k_brick_end = k + n;
+                if (empty) {
+                    k += n;
+                    if (k >= k_end) k = kDone;
+                }
+            }
+        }
+    }
 
     for (uint32_t trip = 0; __ballot(k != kDone) != 0ull; trip++) {
         if (TAIL && trip >= tail.trip_budget) break;
@@ -803,7 +838,7 @@ __global__ __launch_bounds__(256) void process_ray_tail_kernel(const float *__re
     const uint32_t lane = threadIdx.x & 63u, lanes_per_ray = tail.lanes;
     const int j = (int)(lane & (lanes_per_ray - 1)), leader = (int)(lane & ~(uint32_t)(lanes_per_ray - 1));
     const float previous_tsdf = g.trunc, step_size = T[1];
-    const TriConst tc = make_tri_const(g);
+    const TriConst &tc = rp.tc;
     SkipCtx sc = make_skip_ctx(g, step_size);
     // A wave takes as many consecutive queue entries as it has groups (they are rays of one tile and one sample range,
     // alike in length), works on them until all are finished, then takes the next batch: waves round robin.
@@ -957,6 +992,7 @@ static RayParams make_params(const tsdf_volume *v, uint32_t width, uint32_t heig
     rp.own_hi = v->z_end;
     rp.seg_len = 0;
     rp.slab_ranges = 0;
+    rp.tc = make_tri_const(g);
     return rp;
 }
 
