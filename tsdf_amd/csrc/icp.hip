@@ -33,7 +33,6 @@ struct tsdf_icp {
     unsigned int *ticket;                    // workgroups of the current step that have delivered their sums
     double *state;                           // device: [0..15] T (column-major), [16..17] residual, inliers,
                                              //         [18..53] A (float values), [54..59] b
-    uint16_t *upload;                        // staging for host depth
 };
 
 namespace tsdf {
@@ -447,7 +446,6 @@ static void free_icp(tsdf_icp *f) {
     if (f->partial) (void)hipFree(f->partial);
     if (f->ticket) (void)hipFree(f->ticket);
     if (f->state) (void)hipFree(f->state);
-    if (f->upload) (void)hipFree(f->upload);
     delete f;
 }
 
@@ -511,7 +509,6 @@ int tsdf_icp_create(int width, int height, float cx, float cy, float fx, float f
     if (e == hipSuccess) e = hipMemset(f->ticket, 0, sizeof(unsigned int));
     if (e == hipSuccess) e = hipMalloc((void **)&f->state, kIcpStateDoubles * sizeof(double));
     if (e == hipSuccess) e = hipMemset(f->state, 0, kIcpStateDoubles * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void **)&f->upload, (size_t)width * height * sizeof(uint16_t));
     if (e != hipSuccess) {
         free_icp(f);
         return hip_fail(e, "ICP alloc failed");
