@@ -1057,6 +1057,11 @@ static int march_segments(tsdf_volume *v, RayParams &rp, size_t n_pix, int &n_se
                            v->occ, v->t_table, tail);
     timing_end(v, 2);
     TSDF_HIP(hipGetLastError(), "process_ray (tail) failed");
+    if (getenv("TSDF_DEBUG_RAYS")) {   // diagnostics: how many (ray, range) pairs went through the tail queue (synchronises)
+        uint32_t n_tail = 0;
+        (void)hipMemcpy(&n_tail, v->tail_count, sizeof(n_tail), hipMemcpyDeviceToHost);
+        fprintf(stderr, "tsdf: %u of %zu (ray, range) pairs finished by the tail kernel\n", n_tail, n_rec);
+    }
     return TSDF_OK;
 }
 
