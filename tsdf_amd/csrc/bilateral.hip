@@ -63,9 +63,12 @@ __global__ __launch_bounds__(256) void bilateral_kernel(const PIX *__restrict__ 
         for (int cy = fy; cy <= ly_; cy++) {
             int conv = col[(cy - ty0) * span];
             int delta = abs(conv - current);
-            double conv_weight = krow[cy - fy] * similarity[delta];
-            sum = (float)((double)sum + (conv_weight * (double)conv));
-            total_weight = (float)((double)total_weight + conv_weight);
+            const float weight = krow[cy - fy] * similarity[delta];   // the float product the reference widens (:99)
+            sum = (float)((double)sum + ((double)weight * (double)conv));
+            // total_weight + weight evaluated in double and narrowed (:102) == the fp32 sum: both operands are floats, so
+            // the double sum is exact unless the smaller is below 2^-29 of the larger, and then both roundings return the
+            // larger operand (weights are >= 0).  One fp32 add instead of two conversions and a double add.
+            total_weight = total_weight + weight;
         }
     }
     out[(size_t)y * width + x] = (PIX)(int)floorf(sum / total_weight);
