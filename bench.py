@@ -174,8 +174,12 @@ def main():
 
     # ---- warmup, then the timed region -------------------------------------------------------------
     for i in range(Wu):
+        if i == Wu - 1:
+            vol.set_counting(True)            # voxels updated by the frame just before the timed region (byte model below)
         step(i, False)
     torch.cuda.synchronize()
+    U_before = vol.last_updated_voxels() if Wu > 0 else None
+    vol.set_counting(False)
     vol.set_timing(True)      # HIP events around the two dominant kernels, on the stream they are launched on
     barrier()
     torch.cuda.synchronize()
@@ -230,8 +234,11 @@ def main():
         vol.set_counting(True)
         bil.filter_device(depth_dev[last].data_ptr(), filt_dev.data_ptr(), W, H, bits=16, stream=stream.cuda_stream)
         vol.integrate_device(filt_dev.data_ptr(), W, H, cams[last])
-        U = vol.last_updated_voxels()
+        U_after = vol.last_updated_voxels()
         vol.set_counting(False)
+        # the kernel time is an average over the timed launches; the updated-voxel count drifts as the camera moves, so the
+        # bytes are priced at the mean of the frame before and the frame after the timed region
+        U = (U_before + U_after) // 2 if U_before is not None else U_after
         ray_bytes = 4 * st["touched"] + 12 * W * H     # 4*T + vertex store (normals kernel: +12*W*H)
         int_bytes = 16 * U + 2 * W * H                 # 16*U + depth frame
         # the march is two kernels (bulk + tail queue); its bytes are priced against their summed duration.  The
@@ -255,7 +262,7 @@ def main():
         roof_int = {"kernel": "integrate_kernel", "bound": "hbm", "achieved": round(int_gbs, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(int_gbs / HBM_PEAK_GBS, 5), "traffic": traffic.get("integrate_kernel"),
                     "algorithmic_bytes": int_bytes, "avg_launch_ms": round(int_ms, 4), "launches_timed": kern["integrate"][0],
-                    "U_voxels_updated": U, "dense_bytes": 16 * N_vox}
+                    "U_voxels_updated": U, "U_first_last": [U_before, U_after], "dense_bytes": 16 * N_vox}
         # the fraction against the measured device-to-device copy rate as well as the nominal peak
         copy_gbs = measured_copy_gbs(torch)
         for r_ in (roof_ray, roof_int):

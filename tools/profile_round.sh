@@ -8,7 +8,7 @@ root=$(pwd)
 out=$root/gpurun_out
 mkdir -p $out/profiles_$tag
 cd /tmp && export TMPDIR=/tmp
-cmd="python $root/bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-parity"
+cmd="python $root/bench.py --no-cpu-baseline --no-parity"   # default steps: the PMC averages cover the launches bench.py prices
 timeout 300 rocprofv3 --kernel-trace --stats -d $out/prof_stats -o bench -- $cmd > $out/prof_stats.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/prof_fetch -o bench -- $cmd > $out/prof_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/prof_write -o bench -- $cmd > $out/prof_write.log 2>&1
