@@ -134,10 +134,12 @@ struct tsdf_volume {
     float *vert_buf;
     float *norm_buf;
     size_t ray_cap;
-    // per-range hit records of the segmented ray march (kRaySegments x W*H float4), raycast.hip
-    float *seg_hits;
-    size_t seg_cap;
-    // rays the first ray-cast kernel hands to the tail kernel: uint2 per (pixel, sample range) + {appended, taken}
+    // per pixel: the smallest sample index found <= 0 so far by the ray march (0xffffffff = none); every kernel of the
+    // march lowers it with atomicMin, resolve_hits_kernel turns it into the vertex and resets it (raycast.hip)
+    uint32_t *ray_best;
+    size_t ray_best_cap;
+    int ray_best_dirty;      // 1 = a march was started whose resolve kernel was not launched: refill before the next one
+    // stretches of rays the first ray-cast kernel hands to the tail kernel: uint2 per piece + {appended, taken}
     void *tail_entries;
     uint32_t *tail_count;
     size_t tail_cap;

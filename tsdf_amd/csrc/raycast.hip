@@ -242,8 +242,11 @@ constexpr int kDone = 0x7fffffff;
 // value the reference computes is > 0 whatever the rounding.  No margin like occ.tau is needed here -- that one covers
 // the APPROXIMATE location used at brick level.
 constexpr float kCellPositive = 1.0e-30f;
-constexpr int kRaySegmentsDefault = 8;      // sample ranges a ray's march is split into
+constexpr int kRaySegmentsDefault = 6;      // sample ranges a ray's march is split into
 constexpr int kTailGridDefault = 256 * 10;   // workgroups of the tail kernel (5 fit a CU at 86 VGPRs: two rounds)
+// What is left of a ray's range when the pass budget runs out is queued in up to kTailPieces pieces of at least
+// kTailPieceMin samples, so that a long stretch is marched by several groups of the tail kernel at once.
+constexpr int kTailPieces = 8, kTailPieceMin = 256;
 constexpr int kTripBudgetDefault = 24;      // passes of the first kernel's loop before unfinished rays go to the tail kernel
 static int ray_segments() {
     static const int n = [] {
@@ -281,6 +284,14 @@ static int slab_ray_ranges(const tsdf_volume *v) {
     const uint32_t planes = v->z_end - v->z_begin, Z = v->g.Z ? v->g.Z : 1;
     const int n = (int)(((uint64_t)ray_segments() * planes + Z - 1) / Z);
     return n < 2 ? 2 : (n > 64 ? 64 : n);
+}
+static int tail_piece_min() {
+    static const int n = [] {
+        const char *e = getenv("TSDF_RAY_TAIL_PIECE");  // tuning aid
+        int v = e ? atoi(e) : kTailPieceMin;
+        return v < 1 ? 1 : v;
+    }();
+    return n;
 }
 static int trip_budget() {
     static const int n = [] {
@@ -663,23 +674,34 @@ __device__ inline SkipCtx make_skip_ctx(const Geom &g, float step_size) {
     return sc;
 }
 
-// Unfinished rays handed from process_ray_kernel to process_ray_tail_kernel.
+// Unfinished rays handed from process_ray_kernel to process_ray_tail_kernel, and the per-pixel result of the march.
 struct TailQueue {
-    uint2 *entries;        // {pixel index, sample range << 26 | k_end << 13 | next sample k}
+    uint2 *entries;        // {pixel index, k_end << 13 | next sample k}: samples [k, k_end) of that pixel's ray
     uint32_t *count;       // [0] entries appended
     uint32_t trip_budget;  // passes of the marching loop before a wave hands its unfinished rays over
     uint32_t lanes;        // lanes per ray in the tail kernel (power of two, 4..64)
+    uint32_t *best;        // per pixel: smallest sample index found <= 0 so far (kNoHit = none)
+    int piece_min;         // shortest piece a handed-over stretch is cut into
 };
+constexpr uint32_t kNoHit = 0xffffffffu;
+
+// best[] is only ever lowered (atomicMin at device scope) during a march; a reader that sees an old, larger value merely
+// misses a shortcut.  Read past this XCD's L2 so that hits found on the other XCDs show up.
+__device__ inline uint32_t load_best(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // One lane per pixel, a wave is an 8x8 pixel tile of coherent rays, a workgroup a 16x16 tile.  Every pass of the loop
 // does the same straight-line work for all lanes (process_sample), so lanes do not serialise on divergent code paths.
-// Sample-range splitting: with rp.seg_len > 0 the z index of the workgroup selects a contiguous range of sample
-// indices; every range is marched independently (first owned sample <= 0 -> record {k,x,y,z}) and a min-k merge picks
-// the ray's first hit, exactly as for Z-slabs.
+// Sample-range splitting (SEG): with rp.seg_len > 0 the z index of the workgroup selects a contiguous range of sample
+// indices; every range is marched independently and lowers tail.best[pixel] to the index of its first sample <= 0.  The
+// smallest index over all ranges is the sample the reference's serial loop stops at -- every sample before it was
+// evaluated positive or proven positive by the range it belongs to -- and resolve_hits_kernel recomputes that one sample
+// to form the vertex.  A range that starts at or after an index already in best[] has nothing to contribute and leaves
+// (ranges are dispatched in ascending order, so later ones usually find the earlier ones' hits).
 // TAIL: most rays finish within a few dozen passes, a few (those grazing a surface, e.g. the skirts the bilateral filter
-// leaves at depth discontinuities) need hundreds of evaluated samples.  After tail.trip_budget passes a wave appends its
-// unfinished rays to a queue and leaves; process_ray_tail_kernel finishes them with 16 lanes per ray.
-//   SLAB / SEG: out = float4 records {k, x, y, z} (per slab, or per sample range); otherwise packed float3 vertices.
+// leaves at depth discontinuities) need hundreds of evaluated samples.  After tail.trip_budget passes a wave appends what
+// is left of its unfinished rays to a queue, in pieces, and leaves; process_ray_tail_kernel finishes them with 16 lanes per
+// piece.
+//   SEG: nothing is written but best[]; otherwise out = packed float3 vertices (diagnostic variants).
 //   STATS: counters[1] += samples evaluated, counters[2] += hits, touched bitmap marked per tap.  With
 //          SKIP=false the counts are those of the reference's march.
 template <bool SLAB, bool STATS, bool SKIP, bool FASTDIV, bool SEG, bool TAIL>
@@ -718,8 +740,8 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
     const int imy = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
     const bool in_image = imx < (int)rp.width && imy < (int)rp.height;
 
+    static_assert(SEG || !(SLAB || TAIL), "slabs and the tail queue go with sample ranges");
     float ix = NAN, iy = NAN, iz = NAN;
-    float hit_k = INFINITY;
     const float previous_tsdf = g.trunc;  // Q7
     const float step_size = T[1];         // = (float)((double)trunc * 0.05), :324
 
@@ -736,7 +758,9 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
     SkipCtx sc = make_skip_ctx(g, step_size);
     set_ray<SKIP>(sc, ray, step_size, g);
 
+    const size_t idx = (size_t)imy * rp.width + imx;
     int k = (k_end <= k_first) ? kDone : k_first;  // next sample of this lane's ray (kDone when finished)
+    if (SEG && blockIdx.z > 0 && k != kDone && load_best(&tail.best[idx]) <= (uint32_t)k_first) k = kDone;
     BrickCache bc = {0, 0, false};
     SampleWork work = {0, 0, 0, 0};
 
@@ -771,8 +795,8 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
             if (jump > 0) {
                 k += jump;
             } else if (tsdf <= 0) {
-                refine_hit(t, tsdf, previous_tsdf, step_size, ray, rp, ix, iy, iz);
-                hit_k = (float)k;
+                if (SEG) atomicMin(&tail.best[idx], (uint32_t)k);
+                else refine_hit(t, tsdf, previous_tsdf, step_size, ray, rp, ix, iy, iz);
                 k = kDone;
             } else {
                 k += 1;  // positive (or NaN) sample: the reference steps on; `previous_tsdf < 0` never holds (Q7)
@@ -781,23 +805,33 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
         }
     }
 
-    const size_t idx = (size_t)imy * rp.width + imx;
     if (TAIL) {
-        // hand the unfinished rays over (one atomic per wave); their records are written by the tail kernel
-        const unsigned long long unfinished = __ballot(k != kDone);
-        if (unfinished != 0ull) {
+        // hand over what is left of the unfinished rays, in pieces (one atomic per wave); a ray whose hit is already known
+        // to lie at or before its next sample is dropped
+        int len = 0;
+        uint32_t n_sub = 0;
+        if (k != kDone && load_best(&tail.best[idx]) > (uint32_t)k) {
+            len = k_end - k;
+            n_sub = (uint32_t)min(kTailPieces, (len + tail.piece_min - 1) / tail.piece_min);
+        }
+        if (__ballot(n_sub != 0) != 0ull) {
+            uint32_t incl = n_sub;   // inclusive prefix sum over the wave
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t up = __shfl_up(incl, o);
+                if ((int)lane >= o) incl += up;
+            }
+            const uint32_t total = __shfl(incl, 63);
             uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&tail.count[0], (uint32_t)__popcll(unfinished));
-            base = __shfl(base, 0);
-            if (k != kDone)
-                tail.entries[base + __popcll(unfinished & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)idx, (blockIdx.z << 26) | ((uint32_t)k_end << 13) | (uint32_t)k);
+            if (lane == 0) base = atomicAdd(&tail.count[0], total);
+            base = __shfl(base, 0) + incl - n_sub;
+            for (uint32_t s_ = 0; s_ < n_sub; s_++) {
+                const int a = k + (int)((uint32_t)len * s_ / n_sub), b = k + (int)((uint32_t)len * (s_ + 1) / n_sub);
+                tail.entries[base + s_] = make_uint2((uint32_t)idx, ((uint32_t)b << 13) | (uint32_t)a);
+            }
         }
     }
-    if (in_image && !(TAIL && k != kDone)) {
-        if (SLAB || SEG) {
-            const size_t rec = SEG ? (size_t)blockIdx.z * rp.width * rp.height + idx : idx;
-            reinterpret_cast<float4 *>(out)[rec] = make_float4(hit_k, ix, iy, iz);
-        } else if (STATS && SKIP) {  // diagnostics: per-ray work instead of the vertex
+    if (!SEG && in_image) {
+        if (STATS && SKIP) {  // diagnostics: per-ray work instead of the vertex
             out[idx * 3 + 0] = (float)work.samples;
             out[idx * 3 + 1] = (float)work.hops;
             out[idx * 3 + 2] = (float)work.cell_tests;
@@ -821,80 +855,112 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
     }
 }
 
-// The rays process_ray_kernel did not finish.  lanes_per_ray lanes per ray: the group's lanes take the ray's next samples
-// k .. k+15, each classifying / evaluating its own (process_sample without the per-brick memory).  The first lane of
-// the group with a value <= 0 is the ray's hit -- everything before it was evaluated positive or proven positive --
-// otherwise the ray advances past everything the group has dealt with.  Sample k of a ray is computed by the same
+// The stretches of rays process_ray_kernel did not finish.  lanes_per_ray lanes per queue entry: the group's lanes take
+// the next samples k .. k+15 of the entry's ray, each classifying / evaluating its own (process_sample without the
+// per-brick memory).  The first lane of the group with a value <= 0 has the stretch's first hit -- everything before it
+// was evaluated positive or proven positive -- and lowers best[pixel] to it; otherwise the group advances past everything
+// it has dealt with, and gives up once best[pixel] shows a hit at or before its next sample (the pieces of one ray are
+// worked on side by side; when an early one hits, the later ones stop).  Sample k of a ray is computed by the same
 // expressions whichever lane does it, so the result does not depend on the schedule.  Groups take queue entries round
 // robin until none is left (persistent workgroups); every pass of the loop is uniform across the wave.
 template <bool SLAB, bool FASTDIV>
 __global__ __launch_bounds__(256) void process_ray_tail_kernel(const float *__restrict__ dist, const Geom g, const RayParams rp,
-                                                               float *__restrict__ out, const OccGrid occ,
-                                                               const float *__restrict__ t_table, const TailQueue tail) {
+                                                               const OccGrid occ, const float *__restrict__ t_table,
+                                                               const TailQueue tail) {
     __shared__ float T[kTableLen];
     for (int i = (int)threadIdx.x; i < kTableLen; i += 256) T[i] = t_table[i];
     __syncthreads();
     const uint32_t n_entries = tail.count[0];
     const uint32_t lane = threadIdx.x & 63u, lanes_per_ray = tail.lanes;
     const int j = (int)(lane & (lanes_per_ray - 1)), leader = (int)(lane & ~(uint32_t)(lanes_per_ray - 1));
-    const float previous_tsdf = g.trunc, step_size = T[1];
+    const float step_size = T[1];
     const TriConst &tc = rp.tc;
     SkipCtx sc = make_skip_ctx(g, step_size);
-    // A wave takes as many consecutive queue entries as it has groups (they are rays of one tile and one sample range,
-    // alike in length), works on them until all are finished, then takes the next batch: waves round robin.
+    // A wave takes as many consecutive queue entries as it has groups (pieces of one ray, or of rays of one tile and one
+    // sample range: alike in length), works on them until all are finished, then takes the next batch: waves round robin.
     const uint32_t groups_per_wave = 64 / lanes_per_ray;
     const uint32_t n_waves = gridDim.x * 4, wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
     for (uint32_t batch = wave_id * groups_per_wave; batch < n_entries; batch += n_waves * groups_per_wave) {
-    RayState ray = {0, 0, 0, 0, 0, 0};
-    int k = kDone, k_end = 0;   // the group's ray (all its lanes hold the same values); kDone: none
-    size_t rec = 0;
-    const uint32_t e = batch + (lane / lanes_per_ray);
-    if (e < n_entries) {
-        const uint2 q = tail.entries[e];
-        const uint32_t seg = q.y >> 26;
-        float max_t;
-        (void)ray_geometry((int)(q.x % rp.width), (int)(q.x / rp.width), true, rp, ray, max_t);
-        set_ray<true>(sc, ray, step_size, g);
-        k = (int)(q.y & 0x1fffu);
-        k_end = (int)((q.y >> 13) & 0x1fffu);
-        rec = (size_t)seg * rp.width * rp.height + q.x;
-    }
-    while (true) {
-        if (__ballot(k != kDone) == 0ull) break;
-        const int kk = k + j;
-        float cx = NAN, cy = NAN, cz = NAN;
-        int adv = 0;
-        bool hit = false;
-        if (k != kDone && kk < k_end) {
-            const float t = T[kk];
-            int jump;
-            const float tsdf = process_sample_eager<SLAB, FASTDIV>(t, ray, sc, dist, g, tc, rp, occ, jump);
-            if (jump > 0) {
-                adv = j + jump;
-            } else if (tsdf <= 0) {
-                refine_hit(t, tsdf, previous_tsdf, step_size, ray, rp, cx, cy, cz);
-                hit = true;
-            } else {
-                adv = j + 1;
-            }
+        RayState ray = {0, 0, 0, 0, 0, 0};
+        int k = kDone, k_end = 0;   // the group's stretch (all its lanes hold the same values); kDone: none
+        uint32_t *best = tail.best;
+        const uint32_t e = batch + (lane / lanes_per_ray);
+        if (e < n_entries) {
+            const uint2 q = tail.entries[e];
+            float max_t;
+            (void)ray_geometry((int)(q.x % rp.width), (int)(q.x / rp.width), true, rp, ray, max_t);
+            set_ray<true>(sc, ray, step_size, g);
+            k = (int)(q.y & 0x1fffu);
+            k_end = (int)((q.y >> 13) & 0x1fffu);
+            best += q.x;
         }
-        // furthest sample (relative to k) the group has dealt with
-        for (int o = 1; o < (int)lanes_per_ray; o <<= 1) adv = max(adv, __shfl_xor(adv, o));
-        const unsigned long long hits = __ballot(hit);
-        const unsigned long long mine = (hits >> leader) & (lanes_per_ray == 64 ? ~0ull : ((1ull << lanes_per_ray) - 1ull));
-        if (k != kDone) {
-            if (mine) {
-                if (j == __builtin_ctzll(mine)) reinterpret_cast<float4 *>(out)[rec] = make_float4((float)kk, cx, cy, cz);
-                k = kDone;
-            } else {
-                k += adv;
-                if (k >= k_end) {
-                    if (j == 0) reinterpret_cast<float4 *>(out)[rec] = make_float4(INFINITY, NAN, NAN, NAN);
+        while (true) {
+            if (__ballot(k != kDone) == 0ull) break;
+            const int kk = k + j;
+            int adv = 0;
+            bool hit = false;
+            uint32_t known = kNoHit;
+            if (k != kDone && j == 0) known = load_best(best);   // in flight together with the sample's loads
+            if (k != kDone && kk < k_end) {
+                const float t = T[kk];
+                int jump;
+                const float tsdf = process_sample_eager<SLAB, FASTDIV>(t, ray, sc, dist, g, tc, rp, occ, jump);
+                if (jump > 0) {
+                    adv = j + jump;
+                } else if (tsdf <= 0) {
+                    hit = true;
+                } else {
+                    adv = j + 1;
+                }
+            }
+            // furthest sample (relative to k) the group has dealt with
+            for (int o = 1; o < (int)lanes_per_ray; o <<= 1) adv = max(adv, __shfl_xor(adv, o));
+            known = __shfl(known, leader);
+            const unsigned long long hits = __ballot(hit);
+            const unsigned long long mine = (hits >> leader) & (lanes_per_ray == 64 ? ~0ull : ((1ull << lanes_per_ray) - 1ull));
+            if (k != kDone) {
+                if (mine) {
+                    if (j == __builtin_ctzll(mine)) atomicMin(best, (uint32_t)kk);
                     k = kDone;
+                } else {
+                    k += adv;
+                    if (k >= k_end || known <= (uint32_t)k) k = kDone;
                 }
             }
         }
     }
+}
+
+// The vertex of every pixel from best[]: the ray's first sample <= 0 is recomputed -- the same expressions on the same
+// values as when the march found it -- and refined into the hit point as the reference does (process_ray :336-350);
+// no hit -> NaN.  Resets best[] (and the tail queue's counter) for the next march.
+//   SLAB: out = float4 records {k, x, y, z} for the min-k merge across slabs; otherwise packed float3 vertices.
+template <bool SLAB, bool FASTDIV>
+__global__ __launch_bounds__(256) void resolve_hits_kernel(const float *__restrict__ dist, const Geom g, const RayParams rp,
+                                                           const float *__restrict__ t_table, uint32_t *__restrict__ best,
+                                                           float *__restrict__ out, uint32_t *__restrict__ reset) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *reset = 0;
+    if (i >= rp.width * rp.height) return;
+    const uint32_t kb = best[i];
+    best[i] = kNoHit;
+    float ix = NAN, iy = NAN, iz = NAN;
+    if (kb != kNoHit) {
+        RayState ray;
+        float max_t;
+        (void)ray_geometry((int)(i % rp.width), (int)(i / rp.width), true, rp, ray, max_t);
+        const float t = t_table[kb], step_size = t_table[1];
+        const float px = (t * ray.dx) + ray.sx, py = (t * ray.dy) + ray.sy, pz = (t * ray.dz) + ray.sz;
+        bool owned;
+        const float tsdf = trilinear<SLAB, false, FASTDIV>(px, py, pz, dist, g, rp.tc, rp, owned, nullptr);
+        refine_hit(t, tsdf, g.trunc, step_size, ray, rp, ix, iy, iz);   // previous_tsdf == trunc (Q7)
+    }
+    if (SLAB) {
+        reinterpret_cast<float4 *>(out)[i] = make_float4(kb != kNoHit ? (float)kb : INFINITY, ix, iy, iz);
+    } else {
+        out[(size_t)i * 3 + 0] = ix;
+        out[(size_t)i * 3 + 1] = iy;
+        out[(size_t)i * 3 + 2] = iz;
     }
 }
 
@@ -939,9 +1005,8 @@ __global__ __launch_bounds__(256) void vertices_to_depth_kernel(uint32_t n_pixel
 // Per pixel, keep the record with the smallest k among n_slabs gathered buffers
 // (layout [slab][pixel][4]).  Ties cannot occur: a sample has exactly one owner.
 __global__ __launch_bounds__(256) void merge_hits_kernel(const float4 *__restrict__ hits, uint32_t n_slabs,
-                                                         uint32_t n_pixels, float *__restrict__ V, uint32_t *__restrict__ reset) {
+                                                         uint32_t n_pixels, float *__restrict__ V) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (reset && i == 0) *reset = 0;  // the tail queue's counter, for the next ray cast (saves a memset launch per frame)
     if (i >= n_pixels) return;
     float4 best = hits[i];
     for (uint32_t s = 1; s < n_slabs; s++) {
@@ -951,20 +1016,6 @@ __global__ __launch_bounds__(256) void merge_hits_kernel(const float4 *__restric
     V[(size_t)i * 3 + 0] = best.y;
     V[(size_t)i * 3 + 1] = best.z;
     V[(size_t)i * 3 + 2] = best.w;
-}
-
-// Same min-k select, keeping the winning record (used to fold a slab's sample ranges into its one record).
-__global__ __launch_bounds__(256) void merge_records_kernel(const float4 *__restrict__ hits, uint32_t n_sets,
-                                                            uint32_t n_pixels, float4 *__restrict__ out, uint32_t *__restrict__ reset) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (reset && i == 0) *reset = 0;
-    if (i >= n_pixels) return;
-    float4 best = hits[i];
-    for (uint32_t s = 1; s < n_sets; s++) {
-        float4 h = hits[(size_t)s * n_pixels + i];
-        if (h.x < best.x) best = h;
-    }
-    out[i] = best;
 }
 
 __global__ __launch_bounds__(256) void popcount_kernel(const unsigned int *__restrict__ words, size_t n,
@@ -1010,58 +1061,74 @@ static int check_ray_args(const tsdf_volume *v, uint32_t width, uint32_t height,
     return TSDF_OK;
 }
 
-// The production march: process_ray_kernel over kRaySegments sample ranges per ray with a pass budget, then
-// process_ray_tail_kernel for the rays it handed over.  Leaves one {k,x,y,z} record per (range, pixel) in v->seg_hits.
+// The production march: process_ray_kernel over the sample ranges of every ray with a pass budget, process_ray_tail_kernel
+// for the stretches it handed over, resolve_hits_kernel for the vertices (packed float3, or {k,x,y,z} records for a slab).
 template <bool SLAB>
-static int march_segments(tsdf_volume *v, RayParams &rp, size_t n_pix, int &n_segments) {
-    n_segments = SLAB ? slab_ray_ranges(v) : ray_segments();
-    const size_t n_rec = n_pix * n_segments;
-    if (v->seg_cap < n_rec) {
-        if (v->seg_hits) (void)hipFree(v->seg_hits);
-        v->seg_hits = nullptr;
-        v->seg_cap = 0;
-        TSDF_HIP(hipMalloc((void **)&v->seg_hits, n_rec * 4 * sizeof(float)), "ray segment records alloc");
-        v->seg_cap = n_rec;
+static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out) {
+    const size_t n_pix = (size_t)rp.width * rp.height;
+    const int n_segments = SLAB ? slab_ray_ranges(v) : ray_segments();
+    const size_t n_entries = n_pix * n_segments * kTailPieces;   // every range unfinished and cut into all its pieces
+    if (v->ray_best_cap < n_pix) {
+        if (v->ray_best) (void)hipFree(v->ray_best);
+        v->ray_best = nullptr;
+        v->ray_best_cap = 0;
+        TSDF_HIP(hipMalloc((void **)&v->ray_best, n_pix * sizeof(uint32_t)), "ray result alloc");
+        v->ray_best_cap = n_pix;
+        v->ray_best_dirty = 1;
     }
-    if (v->tail_cap < n_rec) {
+    if (v->tail_cap < n_entries) {
         if (v->tail_entries) (void)hipFree(v->tail_entries);
         v->tail_entries = nullptr;
         v->tail_cap = 0;
-        TSDF_HIP(hipMalloc(&v->tail_entries, n_rec * sizeof(uint2)), "ray tail queue alloc");
-        v->tail_cap = n_rec;
+        TSDF_HIP(hipMalloc(&v->tail_entries, n_entries * sizeof(uint2)), "ray tail queue alloc");
+        v->tail_cap = n_entries;
     }
-    if (!v->tail_count) {   // zeroed once; every march's merge kernel leaves it at zero again
+    if (!v->tail_count) {
         TSDF_HIP(hipMalloc((void **)&v->tail_count, 2 * sizeof(uint32_t)), "ray tail counter alloc");
+        v->ray_best_dirty = 1;
+    }
+    if (v->ray_best_dirty) {   // otherwise the previous march's resolve kernel left both reset
+        TSDF_HIP(hipMemsetAsync(v->ray_best, 0xff, v->ray_best_cap * sizeof(uint32_t), v->stream), "ray result reset");
         TSDF_HIP(hipMemsetAsync(v->tail_count, 0, 2 * sizeof(uint32_t), v->stream), "ray tail counter reset");
     }
-    TailQueue tail = {reinterpret_cast<uint2 *>(v->tail_entries), v->tail_count, (uint32_t)trip_budget(), (uint32_t)tail_lanes()};
+    v->ray_best_dirty = 1;
+    TailQueue tail = {reinterpret_cast<uint2 *>(v->tail_entries), v->tail_count, (uint32_t)trip_budget(), (uint32_t)tail_lanes(), v->ray_best, tail_piece_min()};
     rp.seg_len = (kMaxSamples + n_segments - 1) / n_segments;
     rp.slab_ranges = SLAB ? (uint32_t)n_segments : 0u;
     dim3 grid((rp.width + 15) / 16, (rp.height + 15) / 16, n_segments);
     timing_begin(v, 1);
     if (v->fast_div)
         hipLaunchKernelGGL((process_ray_kernel<SLAB, false, true, true, true, true>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp,
-                           v->seg_hits, (unsigned long long *)nullptr, (unsigned int *)nullptr, v->occ, v->t_table, tail);
+                           (float *)nullptr, (unsigned long long *)nullptr, (unsigned int *)nullptr, v->occ, v->t_table, tail);
     else
         hipLaunchKernelGGL((process_ray_kernel<SLAB, false, true, false, true, true>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp,
-                           v->seg_hits, (unsigned long long *)nullptr, (unsigned int *)nullptr, v->occ, v->t_table, tail);
+                           (float *)nullptr, (unsigned long long *)nullptr, (unsigned int *)nullptr, v->occ, v->t_table, tail);
     timing_end(v, 1);
     TSDF_HIP(hipGetLastError(), "process_ray failed");
-    // persistent workgroups: 16 groups of 16 lanes each, fetching rays until the queue is empty
+    // persistent workgroups: groups of 16 lanes, fetching queue entries until none is left
     timing_begin(v, 2);
     if (v->fast_div)
-        hipLaunchKernelGGL((process_ray_tail_kernel<SLAB, true>), dim3(tail_grid()), dim3(256), 0, v->stream, v->dist, v->g, rp, v->seg_hits,
+        hipLaunchKernelGGL((process_ray_tail_kernel<SLAB, true>), dim3(tail_grid()), dim3(256), 0, v->stream, v->dist, v->g, rp,
                            v->occ, v->t_table, tail);
     else
-        hipLaunchKernelGGL((process_ray_tail_kernel<SLAB, false>), dim3(tail_grid()), dim3(256), 0, v->stream, v->dist, v->g, rp, v->seg_hits,
+        hipLaunchKernelGGL((process_ray_tail_kernel<SLAB, false>), dim3(tail_grid()), dim3(256), 0, v->stream, v->dist, v->g, rp,
                            v->occ, v->t_table, tail);
     timing_end(v, 2);
     TSDF_HIP(hipGetLastError(), "process_ray (tail) failed");
-    if (getenv("TSDF_DEBUG_RAYS")) {   // diagnostics: how many (ray, range) pairs went through the tail queue (synchronises)
+    if (getenv("TSDF_DEBUG_RAYS")) {   // diagnostics: how much went through the tail queue (synchronises)
         uint32_t n_tail = 0;
         (void)hipMemcpy(&n_tail, v->tail_count, sizeof(n_tail), hipMemcpyDeviceToHost);
-        fprintf(stderr, "tsdf: %u of %zu (ray, range) pairs finished by the tail kernel\n", n_tail, n_rec);
+        fprintf(stderr, "tsdf: %u pieces of the %zu (ray, range) pairs finished by the tail kernel\n", n_tail, n_pix * n_segments);
     }
+    const dim3 rgrid((unsigned)((n_pix + 255) / 256));
+    if (v->fast_div)
+        hipLaunchKernelGGL((resolve_hits_kernel<SLAB, true>), rgrid, dim3(256), 0, v->stream, v->dist, v->g, rp, v->t_table, v->ray_best, out,
+                           v->tail_count);
+    else
+        hipLaunchKernelGGL((resolve_hits_kernel<SLAB, false>), rgrid, dim3(256), 0, v->stream, v->dist, v->g, rp, v->t_table, v->ray_best, out,
+                           v->tail_count);
+    TSDF_HIP(hipGetLastError(), "resolve ray hits failed");
+    v->ray_best_dirty = 0;
     return TSDF_OK;
 }
 
@@ -1080,14 +1147,8 @@ int tsdf_raycast_device(const tsdf_volume *v, uint32_t width, uint32_t height, c
     rc = occupancy_refresh(const_cast<tsdf_volume *>(v));
     if (rc != TSDF_OK) return rc;
     RayParams rp = make_params(v, width, height, pose, kinv);
-    const size_t n_pix = (size_t)width * height;
-    tsdf_volume *mv = const_cast<tsdf_volume *>(v);
-    int kRaySegments = 0;
-    rc = march_segments<false>(mv, rp, n_pix, kRaySegments);
+    rc = march_and_resolve<false>(const_cast<tsdf_volume *>(v), rp, device_vertices);
     if (rc != TSDF_OK) return rc;
-    hipLaunchKernelGGL(merge_hits_kernel, dim3((unsigned)((n_pix + 255) / 256)), dim3(256), 0, v->stream,
-                       reinterpret_cast<const float4 *>(mv->seg_hits), (uint32_t)kRaySegments, (uint32_t)n_pix, device_vertices, mv->tail_count);
-    TSDF_HIP(hipGetLastError(), "merge ray segments failed");
     if (device_normals) return launch_normals(width, height, device_vertices, device_normals, v->stream);
     return TSDF_OK;
 }
@@ -1155,7 +1216,7 @@ int tsdf_raycast_stats(const tsdf_volume *v, uint32_t width, uint32_t height, co
     (void)hipMemsetAsync(v->counter_dev, 0, 4 * sizeof(unsigned long long), v->stream);
     dim3 grid((width + 15) / 16, (height + 15) / 16);
     hipLaunchKernelGGL((process_ray_kernel<false, true, false, false, false, false>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp, verts,
-                       v->counter_dev, bitmap, v->occ, v->t_table, TailQueue{nullptr, nullptr, 0, 0});
+                       v->counter_dev, bitmap, v->occ, v->t_table, TailQueue{nullptr, nullptr, 0, 0, nullptr, 0});
     hipLaunchKernelGGL(popcount_kernel, dim3(1024), dim3(256), 0, v->stream, bitmap, words, v->counter_dev + 3);
     unsigned long long c[4] = {0, 0, 0, 0};
     e = hipMemcpyAsync(c, v->counter_dev, sizeof(c), hipMemcpyDeviceToHost, v->stream);
@@ -1190,7 +1251,7 @@ int tsdf_raycast_evaluated_samples(const tsdf_volume *v, uint32_t width, uint32_
     (void)hipMemsetAsync(v->counter_dev, 0, 4 * sizeof(unsigned long long), v->stream);
     dim3 grid((width + 15) / 16, (height + 15) / 16);
     hipLaunchKernelGGL((process_ray_kernel<false, true, true, true, false, false>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp, verts,
-                       v->counter_dev, bitmap, v->occ, v->t_table, TailQueue{nullptr, nullptr, 0, 0});
+                       v->counter_dev, bitmap, v->occ, v->t_table, TailQueue{nullptr, nullptr, 0, 0, nullptr, 0});
     unsigned long long c[4] = {0, 0, 0, 0};
     e = hipMemcpyAsync(c, v->counter_dev, sizeof(c), hipMemcpyDeviceToHost, v->stream);
     if (e == hipSuccess && host_per_ray)
@@ -1211,18 +1272,8 @@ int tsdf_raycast_slab_device(const tsdf_volume *v, uint32_t width, uint32_t heig
     rc = occupancy_refresh(const_cast<tsdf_volume *>(v));
     if (rc != TSDF_OK) return rc;
     RayParams rp = make_params(v, width, height, pose, kinv);
-    // as on a single GPU the march is split into sample ranges; the ranges' records are folded into the slab's
-    // one record per pixel before it leaves this rank
-    const size_t n_pix = (size_t)width * height;
-    tsdf_volume *mv = const_cast<tsdf_volume *>(v);
-    int kRaySegments = 0;
-    rc = march_segments<true>(mv, rp, n_pix, kRaySegments);
-    if (rc != TSDF_OK) return rc;
-    hipLaunchKernelGGL(merge_records_kernel, dim3((unsigned)((n_pix + 255) / 256)), dim3(256), 0, v->stream,
-                       reinterpret_cast<const float4 *>(mv->seg_hits), (uint32_t)kRaySegments, (uint32_t)n_pix,
-                       reinterpret_cast<float4 *>(device_hits), mv->tail_count);
-    TSDF_HIP(hipGetLastError(), "process_ray (slab) failed");
-    return TSDF_OK;
+    // as on a single GPU the march is split into sample ranges; one {k,x,y,z} record per pixel leaves this rank
+    return march_and_resolve<true>(const_cast<tsdf_volume *>(v), rp, device_hits);
 }
 
 int tsdf_merge_hits_device(const float *device_hits_all, uint32_t n_slabs, uint32_t width, uint32_t height,
@@ -1231,7 +1282,7 @@ int tsdf_merge_hits_device(const float *device_hits_all, uint32_t n_slabs, uint3
                  "tsdf_merge_hits: bad argument");
     uint32_t n = width * height;
     hipLaunchKernelGGL(merge_hits_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream,
-                       reinterpret_cast<const float4 *>(device_hits_all), n_slabs, n, device_vertices, (uint32_t *)nullptr);
+                       reinterpret_cast<const float4 *>(device_hits_all), n_slabs, n, device_vertices);
     TSDF_HIP(hipGetLastError(), "merge hits failed");
     return TSDF_OK;
 }

@@ -562,7 +562,7 @@ int tsdf_volume_destroy(tsdf_volume *v) {
     if (v->tail_entries) (void)hipFree(v->tail_entries);
     if (v->tail_count) (void)hipFree(v->tail_count);
     if (v->t_table) (void)hipFree(v->t_table);
-    if (v->seg_hits) (void)hipFree(v->seg_hits);
+    if (v->ray_best) (void)hipFree(v->ray_best);
     for (int w = 0; w < 3; w++)
         if (v->tev[w]) {
             for (hipEvent_t e : *v->tev[w]) (void)hipEventDestroy(e);
