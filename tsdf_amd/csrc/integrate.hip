@@ -35,8 +35,14 @@ namespace tsdf {
 
 constexpr int kTileX = 64;  // one wave along x
 constexpr int kTileY = 4;   // waves per workgroup
-constexpr int kChunkZ = 16; // planes walked by one workgroup
-constexpr int kBatchZ = 4;  // planes whose loads are issued together
+#ifndef TSDF_CHUNK_Z
+#define TSDF_CHUNK_Z 32
+#endif
+constexpr int kChunkZ = TSDF_CHUNK_Z; // planes walked by one workgroup
+#ifndef TSDF_BATCH_Z
+#define TSDF_BATCH_Z 4
+#endif
+constexpr int kBatchZ = TSDF_BATCH_Z;  // planes whose loads are issued together
 constexpr int kTilePixels = 8192;  // LDS depth tile of a brick: 16 KiB
 
 struct Projected {
@@ -238,7 +244,7 @@ __device__ inline void round_quotients(float a1, float a2, float b, float thr, f
 // {cz, inv_pose.m13 * cz, inv_pose.m23 * cz, inv_pose.m33 * cz}, cz = the voxel-centre z of the plane (:343, :783-785).
 // Written by brick_cull_kernel once per frame; wave-uniform in integrate_kernel, so read with scalar loads.
 template <bool DEFORM, bool COUNT, bool STD>
-__global__ __launch_bounds__(256) void integrate_kernel(float *__restrict__ dist, float *__restrict__ weight,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void integrate_kernel(float *__restrict__ dist, float *__restrict__ weight,
                                                         const tsdf_deformation_node *__restrict__ nodes,
                                                         const Geom g, const BrickGrid bg, const Mat44 ip, const Mat33 k,
                                                         const Mat33 kinv, const uint32_t width,
@@ -311,8 +317,11 @@ __global__ __launch_bounds__(256) void integrate_kernel(float *__restrict__ dist
 
         // The planes of the brick are processed kBatchZ at a time in three passes -- project + gather depth,
         // decide + load distance/weight, blend + store -- so that the depth gathers of a batch, and then its
-        // HBM loads, are all in flight together instead of one dependent chain per plane.
-        for (uint32_t zb = z0; zb < z1; zb += kBatchZ, idx += plane * kBatchZ) {
+        // HBM loads, are all in flight together instead of one dependent chain per plane.  The batches are software
+        // pipelined: the loads of batch b+1 are issued before batch b is blended and stored, so that there is always a
+        // batch of loads in flight (two register sets, used alternately).
+        auto project_and_load = [&](const uint32_t zb, float (&tsdf_)[kBatchZ], float (&pw_)[kBatchZ], float (&pd_)[kBatchZ]) {
+            const size_t idx_b = idx + plane * (size_t)(zb - z0);
             float camz_[kBatchZ], cz_[kBatchZ];
             int px_[kBatchZ], py_[kBatchZ];
             uint32_t d_[kBatchZ];  // depth of the voxel's pixel, 0 = none
@@ -326,7 +335,7 @@ __global__ __launch_bounds__(256) void integrate_kernel(float *__restrict__ dist
                     // (custom nodes: x/y parts differ per voxel)
                     cz = 0.f;
                     if (act[j]) {
-                        const tsdf_deformation_node &nd = nodes[idx + plane * j];
+                        const tsdf_deformation_node &nd = nodes[idx_b + plane * j];
                         cx = nd.translation[0] + g.offset.x;
                         cy = nd.translation[1] + g.offset.y;
                         cz = nd.translation[2] + g.offset.z;
@@ -375,7 +384,6 @@ __global__ __launch_bounds__(256) void integrate_kernel(float *__restrict__ dist
                 }
             }
             // tsdf_[j] is NaN for a voxel this frame does not update
-            float tsdf_[kBatchZ], pw_[kBatchZ], pd_[kBatchZ];
 #pragma unroll
             for (int j = 0; j < kBatchZ; j++) {
                 // pixel_to_camera(...).z (cuda_coordinate_transforms.cu:132-146)
@@ -403,6 +411,8 @@ __global__ __launch_bounds__(256) void integrate_kernel(float *__restrict__ dist
                     pd_[j] = (dist + pb)[lane_off];
                 }
             }
+        };
+        auto blend_and_store = [&](const uint32_t zb, const float (&tsdf_)[kBatchZ], const float (&pw_)[kBatchZ], const float (&pd_)[kBatchZ]) {
 #pragma unroll
             for (int j = 0; j < kBatchZ; j++) {
                 if (tsdf_[j] == tsdf_[j]) {
@@ -415,6 +425,17 @@ __global__ __launch_bounds__(256) void integrate_kernel(float *__restrict__ dist
                     if (COUNT) updated++;
                 }
             }
+        };
+        static_assert(kChunkZ % (2 * kBatchZ) == 0, "the pipeline alternates two register sets");
+        float tsdf_a[kBatchZ], pw_a[kBatchZ], pd_a[kBatchZ], tsdf_b[kBatchZ], pw_b[kBatchZ], pd_b[kBatchZ];
+        project_and_load(z0, tsdf_a, pw_a, pd_a);
+#pragma unroll
+        for (uint32_t o = 0; o < (uint32_t)kChunkZ; o += 2 * kBatchZ) {
+            // (batches past z1 -- the last bricks of a grid whose depth is not a multiple of kChunkZ -- are all inactive)
+            project_and_load(z0 + o + kBatchZ, tsdf_b, pw_b, pd_b);
+            blend_and_store(z0 + o, tsdf_a, pw_a, pd_a);
+            if (o + 2 * kBatchZ < (uint32_t)kChunkZ) project_and_load(z0 + o + 2 * kBatchZ, tsdf_a, pw_a, pd_a);
+            blend_and_store(z0 + o + kBatchZ, tsdf_b, pw_b, pd_b);
         }
     }
     if (COUNT) {
