@@ -124,6 +124,36 @@ def test_random_distance_fields(oracle, seed):
         assert_same_floats(N, No, "seed %d normals" % seed)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_smooth_distance_fields(oracle, seed):
+    """Smooth fields of every magnitude with shallow zero crossings: where the ray march's look-ahead after an evaluated
+    sample (a bound on how fast the interpolant can fall inside a cell) reaches furthest, and where its safety margin is
+    all that separates a skipped sample from a hit."""
+    rng = np.random.default_rng(0x5A00 + seed)
+    dims, phys, width, height, offset = random_case(rng)
+    gv = tsdf_amd.TSDFVolume(dims, phys)
+    ov = oracle.Volume(dims, phys)
+    if offset is not None:
+        gv.offset(*offset)
+        ov.offset(*offset)
+    trunc = gv.truncation_distance()
+    z, y, x = np.meshgrid(*(np.arange(d, dtype=np.float64) for d in dims[::-1]), indexing="ij")
+    s = np.zeros(x.shape)
+    for _ in range(3):
+        f = rng.uniform(0.02, 0.6, size=3)          # radians per voxel: from half a grid to ten voxels per period
+        s += np.sin(f[0] * x + f[1] * y + f[2] * z + rng.uniform(0, 6.28)) / 3.0
+    amp = trunc * float(rng.choice([1e-5, 1e-3, 0.05, 1.0]))
+    D = np.minimum(amp * (s + rng.uniform(0.1, 0.9)), trunc).astype(np.float32).ravel()
+    gv.set_distance_data(D)
+    ov.set_distance_data(D)
+    for _ in range(2):
+        cam, _ = random_camera(rng, dims, phys, offset, width, height)
+        V, N = gv.raycast(width, height, cam)
+        Vo, No = ov.raycast(width, height, cam.pose(), cam.kinv(), nthreads=oracle.max_threads())
+        assert_same_floats(V, Vo, "seed %d dims %s amplitude %g vertices" % (seed, dims, amp))
+        assert_same_floats(N, No, "seed %d normals" % seed)
+
+
 @pytest.mark.parametrize("seed", range(10))
 def test_random_slab_splits_equal_the_whole_volume(seed):
     """Integrate + ray cast through 2..6 Z-slabs (owner-of-sample rule, min-k merge) == the whole volume, bit for bit."""

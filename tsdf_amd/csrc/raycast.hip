@@ -310,6 +310,7 @@ struct SkipCtx {
     float inv_step;                // ~ 1 / step
     float tx, ty, tz;              // ~ |voxel size / dir| : t needed to cross one voxel (inf for a zero component)
     bool px_, py_, pz_;            // dir component > 0
+    float su, sv, sw;              // ~ |step * dir / voxel size| : movement per sample in cell units, per axis
     float eps;                     // guard band at the dual-cell faces, in voxels
     bool skip_ok;                  // skipping allowed for this ray (short enough steps)
 };
@@ -373,6 +374,28 @@ __device__ inline int wave_min(int v) {
     return v;
 }
 
+
+// Look-ahead after an evaluated sample.  Inside one dual cell the interpolant f is trilinear in the cell coordinates
+// (u,v,w), so |df/du| <= Rx = the largest difference along the cell's four x edges (a convex combination of them), same for
+// v and w: n samples further on, still inside the cell, f has dropped by at most n * (su*Rx + sv*Ry + sw*Rz).  The sample
+// just evaluated is `val` > 0 (the reference's fp32 value); the values the reference would compute for the next samples
+// differ from f at the exact positions by its rounding (a few 1e-6 * largest |corner|; 2e-5 is allowed) and the positions are known
+// to 2*eps in each coordinate.  So while  val - margin - n * 1.01 * per_sample > 0  sample k+n cannot be <= 0.  Returns
+// that n, at most `limit` (the samples known to stay inside the cell); 0 when anything is NaN or infinite.
+__device__ inline int lipschitz_lookahead(float val, float c000, float c100, float c010, float c110, float c001, float c101, float c011,
+                                          float c111, const SkipCtx &sc, int limit) {
+    const float rx = fmaxf(fmaxf(fabsf(c100 - c000), fabsf(c110 - c010)), fmaxf(fabsf(c101 - c001), fabsf(c111 - c011)));
+    const float ry = fmaxf(fmaxf(fabsf(c010 - c000), fabsf(c110 - c100)), fmaxf(fabsf(c011 - c001), fabsf(c111 - c101)));
+    const float rz = fmaxf(fmaxf(fabsf(c001 - c000), fabsf(c101 - c100)), fmaxf(fabsf(c011 - c010), fabsf(c111 - c110)));
+    const float rsum = (rx + ry) + rz;
+    const float margin = 4.0f * sc.eps * rsum + 2.0e-5f * (fabsf(c000) + rsum);   // |corner| <= |c000| + rsum
+    const float per_sample = 1.01f * ((sc.su * rx + sc.sv * ry) + sc.sw * rz);
+    const float x = 0.99f * (val - margin) * __builtin_amdgcn_rcpf(per_sample);   // (inf when the cell is flat: limit applies)
+    // fmaxf / fminf drop a NaN operand, so NaN corners must be caught explicitly: rsum is NaN or inf then
+    if (!(rsum < INFINITY) || !(x > 0.0f)) return 0;
+    return (int)fminf(x, (float)limit);
+}
+
 // ---- one sample of one ray ------------------------------------------------------------------------------------
 struct RayState {
     float dx, dy, dz;  // direction (not normalised: Q6)
@@ -395,6 +418,7 @@ __device__ inline void set_ray(SkipCtx &sc, const RayState &r, float step_size, 
     sc.ty = r.dy != 0 ? fabsf(g.vs.y * __builtin_amdgcn_rcpf(r.dy)) : INFINITY;
     sc.tz = r.dz != 0 ? fabsf(g.vs.z * __builtin_amdgcn_rcpf(r.dz)) : INFINITY;
     sc.px_ = r.dx > 0; sc.py_ = r.dy > 0; sc.pz_ = r.dz > 0;
+    sc.su = fabsf(r.dx) * step_size * sc.inv_vx; sc.sv = fabsf(r.dy) * step_size * sc.inv_vy; sc.sw = fabsf(r.dz) * step_size * sc.inv_vz;
     // one step must stay well inside the one-voxel slack on every axis
     sc.skip_ok = SKIP && fabsf(r.dx) * step_size < 0.25f * g.vs.x && fabsf(r.dy) * step_size < 0.25f * g.vs.y &&
                  fabsf(r.dz) * step_size < 0.25f * g.vs.z;
@@ -424,10 +448,11 @@ __device__ inline void refine_hit(float t, float tsdf, float previous_tsdf, floa
 template <bool SLAB, bool STATS, bool FASTDIV>
 __device__ inline float process_sample(float t, int k, const RayState &r, const SkipCtx &sc, BrickCache &bc,
                                        const float *__restrict__ dist, const Geom &g, const TriConst &tc, const RayParams &rp,
-                                       const OccGrid &occ, unsigned int *__restrict__ touched, SampleWork &work, int &jump) {
+                                       const OccGrid &occ, unsigned int *__restrict__ touched, SampleWork &work, int &jump, int &ahead) {
     const float px = (t * r.dx) + r.sx, py = (t * r.dy) + r.sy, pz = (t * r.dz) + r.sz;
     const float cell_lo = sc.eps, cell_hi = 1.0f - sc.eps, cell_half = 0.5f - sc.eps;
     jump = 0;
+    ahead = 0;   // samples after this one proven positive, valid when the returned value is > 0
     if (sc.skip_ok) {
         // position in voxel units (approximate)
         const float fx = px * sc.inv_vx, fy = py * sc.inv_vy, fz = pz * sc.inv_vz;
@@ -492,14 +517,16 @@ __device__ inline float process_sample(float t, int k, const RayState &r, const 
             const float v = div_by<FASTDIV>(py - lcy, tc.dy);
             const float w = div_by<FASTDIV>(pz - lcz, tc.dz);
             if (STATS) work.samples++;
-            return c000 * (1 - u) * (1 - v) * (1 - w) +
-                   c001 * (1 - u) * (1 - v) * w +
-                   c010 * (1 - u) * v * (1 - w) +
-                   c011 * (1 - u) * v * w +
-                   c100 * u * (1 - v) * (1 - w) +
-                   c101 * u * (1 - v) * w +
-                   c110 * u * v * (1 - w) +
-                   c111 * u * v * w;
+            const float val = c000 * (1 - u) * (1 - v) * (1 - w) +
+                              c001 * (1 - u) * (1 - v) * w +
+                              c010 * (1 - u) * v * (1 - w) +
+                              c011 * (1 - u) * v * w +
+                              c100 * u * (1 - v) * (1 - w) +
+                              c101 * u * (1 - v) * w +
+                              c110 * u * v * (1 - w) +
+                              c111 * u * v * w;
+            ahead = lipschitz_lookahead(val, c000, c100, c010, c110, c001, c101, c011, c111, sc, n_cell - 1);
+            return val;
         }
     }
     bool owned;
@@ -515,10 +542,11 @@ __device__ inline float process_sample(float t, int k, const RayState &r, const 
 // cost bandwidth in the bulk kernel.)
 template <bool SLAB, bool FASTDIV>
 __device__ inline float process_sample_eager(float t, const RayState &r, const SkipCtx &sc, const float *__restrict__ dist,
-                                             const Geom &g, const TriConst &tc, const RayParams &rp, const OccGrid &occ, int &jump) {
+                                             const Geom &g, const TriConst &tc, const RayParams &rp, const OccGrid &occ, int &jump, int &ahead) {
     const float px = (t * r.dx) + r.sx, py = (t * r.dy) + r.sy, pz = (t * r.dz) + r.sz;
     const float cell_lo = sc.eps, cell_hi = 1.0f - sc.eps, cell_half = 0.5f - sc.eps;
     jump = 0;
+    ahead = 0;
     if (sc.skip_ok) {
         const float fx = px * sc.inv_vx, fy = py * sc.inv_vy, fz = pz * sc.inv_vz;
         int n_brick;
@@ -567,14 +595,16 @@ __device__ inline float process_sample_eager(float t, const RayState &r, const S
             const float u = div_by<FASTDIV>(px - lcx, tc.dx);
             const float v = div_by<FASTDIV>(py - lcy, tc.dy);
             const float w = div_by<FASTDIV>(pz - lcz, tc.dz);
-            return c000 * (1 - u) * (1 - v) * (1 - w) +
-                   c001 * (1 - u) * (1 - v) * w +
-                   c010 * (1 - u) * v * (1 - w) +
-                   c011 * (1 - u) * v * w +
-                   c100 * u * (1 - v) * (1 - w) +
-                   c101 * u * (1 - v) * w +
-                   c110 * u * v * (1 - w) +
-                   c111 * u * v * w;
+            const float val = c000 * (1 - u) * (1 - v) * (1 - w) +
+                              c001 * (1 - u) * (1 - v) * w +
+                              c010 * (1 - u) * v * (1 - w) +
+                              c011 * (1 - u) * v * w +
+                              c100 * u * (1 - v) * (1 - w) +
+                              c101 * u * (1 - v) * w +
+                              c110 * u * v * (1 - w) +
+                              c111 * u * v * w;
+            ahead = lipschitz_lookahead(val, c000, c100, c010, c110, c001, c101, c011, c111, sc, n_cell - 1);
+            return val;
         }
     }
     bool owned;
@@ -669,6 +699,7 @@ __device__ inline SkipCtx make_skip_ctx(const Geom &g, float step_size) {
     // handful of roundings of 2^-24 relative each) must agree with the reference's exact one
     sc.eps = fmaxf(1.0e-3f, 2.0e-6f * (float)max(g.X, max(g.Y, g.Z)));
     sc.tx = sc.ty = sc.tz = INFINITY;
+    sc.su = sc.sv = sc.sw = INFINITY;
     sc.px_ = sc.py_ = sc.pz_ = false;
     sc.skip_ok = false;
     return sc;
@@ -790,8 +821,8 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
         if (STATS) work.trips++;
         if (k != kDone) {
             const float t = T[k];
-            int jump;
-            const float tsdf = process_sample<SLAB, STATS, FASTDIV>(t, k, ray, sc, bc, dist, g, tc, rp, occ, touched, work, jump);
+            int jump, ahead;
+            const float tsdf = process_sample<SLAB, STATS, FASTDIV>(t, k, ray, sc, bc, dist, g, tc, rp, occ, touched, work, jump, ahead);
             if (jump > 0) {
                 k += jump;
             } else if (tsdf <= 0) {
@@ -799,7 +830,9 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
                 else refine_hit(t, tsdf, previous_tsdf, step_size, ray, rp, ix, iy, iz);
                 k = kDone;
             } else {
-                k += 1;  // positive (or NaN) sample: the reference steps on; `previous_tsdf < 0` never holds (Q7)
+                // positive (or NaN) sample: the reference steps on; `previous_tsdf < 0` never holds (Q7).  The samples the
+                // look-ahead proved positive are passed with it (ahead is 0 for a NaN).
+                k += 1 + (tsdf > 0 ? ahead : 0);
             }
             if (k != kDone && k >= k_end) k = kDone;
         }
@@ -903,14 +936,14 @@ __global__ __launch_bounds__(256) void process_ray_tail_kernel(const float *__re
             if (k != kDone && j == 0) known = load_best(best);   // in flight together with the sample's loads
             if (k != kDone && kk < k_end) {
                 const float t = T[kk];
-                int jump;
-                const float tsdf = process_sample_eager<SLAB, FASTDIV>(t, ray, sc, dist, g, tc, rp, occ, jump);
+                int jump, ahead;
+                const float tsdf = process_sample_eager<SLAB, FASTDIV>(t, ray, sc, dist, g, tc, rp, occ, jump, ahead);
                 if (jump > 0) {
                     adv = j + jump;
                 } else if (tsdf <= 0) {
                     hit = true;
                 } else {
-                    adv = j + 1;
+                    adv = j + 1 + (tsdf > 0 ? ahead : 0);
                 }
             }
             // furthest sample (relative to k) the group has dealt with
