@@ -816,6 +816,36 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
         }
     }
 
+    // Entry: a ray that starts on a face of the grid spends its first samples in the outer half-voxel shell, where the
+    // reference extrapolates (Q10) and nothing can be skipped.  The rays of a tile do that together, so these samples get
+    // a loop of their own that only interpolates -- a third of the instructions of a full pass.
+    if (SKIP && !STATS) {
+        while (true) {
+            bool shell = false;
+            float t = 0.f, px = 0.f, py = 0.f, pz = 0.f;
+            if (k != kDone) {
+                t = T[k];
+                px = (t * ray.dx) + ray.sx; py = (t * ray.dy) + ray.sy; pz = (t * ray.dz) + ray.sz;
+                // lower tap index of the sample's dual cell, as process_sample derives it: off the lattice on some axis?
+                const int lx = (int)floorf(px * sc.inv_vx - 0.5f), ly = (int)floorf(py * sc.inv_vy - 0.5f), lz = (int)floorf(pz * sc.inv_vz - 0.5f);
+                shell = !((uint32_t)lx < g.X - 1 && (uint32_t)ly < g.Y - 1 && (uint32_t)lz < g.Z - 1);
+            }
+            if (__ballot(shell) == 0ull) break;
+            if (shell) {
+                bool owned;
+                const float tsdf = trilinear<SLAB, false, FASTDIV>(px, py, pz, dist, g, tc, rp, owned, nullptr);
+                if (tsdf <= 0) {
+                    if (SEG) atomicMin(&tail.best[idx], (uint32_t)k);
+                    else refine_hit(t, tsdf, previous_tsdf, step_size, ray, rp, ix, iy, iz);
+                    k = kDone;
+                } else {
+                    k += 1;
+                    if (k >= k_end) k = kDone;
+                }
+            }
+        }
+    }
+
     for (uint32_t trip = 0; __ballot(k != kDone) != 0ull; trip++) {
         if (TAIL && trip >= tail.trip_budget) break;
         if (STATS) work.trips++;
