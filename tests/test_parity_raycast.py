@@ -313,6 +313,8 @@ np.savez(sys.argv[1], V=V, N=N, D=gv.get_distance_data())
     {"TSDF_RAY_SEGMENTS": "1", "TSDF_RAY_TRIP_BUDGET": "1", "TSDF_RAY_TAIL_LANES": "64"},     # everything in the tail kernel
     {"TSDF_RAY_SEGMENTS": "1", "TSDF_RAY_TRIP_BUDGET": "1", "TSDF_RAY_TAIL_PIECE": "1"},      # ... in the shortest pieces
     {"TSDF_RAY_SEGMENTS": "2", "TSDF_RAY_TRIP_BUDGET": "3", "TSDF_RAY_TAIL_PIECE": "100000"}, # ... never cut
+    {"TSDF_RAY_SEGMENTS": "2", "TSDF_RAY_TRIP_BUDGET": "2", "TSDF_RAY_TAIL_LANES": "1", "TSDF_RAY_TAIL_PIECE": "7"},
+    {"TSDF_RAY_SEGMENTS": "8", "TSDF_RAY_TRIP_BUDGET": "24", "TSDF_RAY_TAIL_LANES": "16", "TSDF_RAY_TAIL_PIECE": "256"},  # round 1g
     {"TSDF_RAY_SEGMENTS": "3", "TSDF_RAY_TRIP_BUDGET": "2", "TSDF_RAY_TAIL_LANES": "4", "TSDF_RAY_TAIL_GRID": "7"},
     {"TSDF_RAY_SEGMENTS": "16", "TSDF_RAY_TRIP_BUDGET": "100000"},                             # nothing in the tail kernel
     {"TSDF_RAY_SEGMENTS": "64", "TSDF_RAY_TRIP_BUDGET": "5", "TSDF_RAY_TAIL_LANES": "8"},

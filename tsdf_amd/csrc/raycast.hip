@@ -242,12 +242,13 @@ constexpr int kDone = 0x7fffffff;
 // value the reference computes is > 0 whatever the rounding.  No margin like occ.tau is needed here -- that one covers
 // the APPROXIMATE location used at brick level.
 constexpr float kCellPositive = 1.0e-30f;
+constexpr int kTailLanesDefault = 4;        // lanes per queue entry in the tail kernel
 constexpr int kRaySegmentsDefault = 6;      // sample ranges a ray's march is split into
 constexpr int kTailGridDefault = 256 * 10;   // workgroups of the tail kernel (5 fit a CU at 86 VGPRs: two rounds)
 // What is left of a ray's range when the pass budget runs out is queued in up to kTailPieces pieces of at least
 // kTailPieceMin samples, so that a long stretch is marched by several groups of the tail kernel at once.
-constexpr int kTailPieces = 8, kTailPieceMin = 256;
-constexpr int kTripBudgetDefault = 24;      // passes of the first kernel's loop before unfinished rays go to the tail kernel
+constexpr int kTailPieces = 8, kTailPieceMin = 64;
+constexpr int kTripBudgetDefault = 18;      // passes of the first kernel's loop before unfinished rays go to the tail kernel
 static int ray_segments() {
     static const int n = [] {
         const char *e = getenv("TSDF_RAY_SEGMENTS");  // tuning aid
@@ -258,9 +259,9 @@ static int ray_segments() {
 }
 static int tail_lanes() {
     static const int n = [] {
-        const char *e = getenv("TSDF_RAY_TAIL_LANES");  // tuning aid: 4, 8, 16, 32 or 64
-        int v = e ? atoi(e) : 16;
-        return (v == 4 || v == 8 || v == 32 || v == 64) ? v : 16;
+        const char *e = getenv("TSDF_RAY_TAIL_LANES");  // tuning aid: a power of two, 1..64
+        int v = e ? atoi(e) : kTailLanesDefault;
+        return (v >= 1 && v <= 64 && (v & (v - 1)) == 0) ? v : kTailLanesDefault;
     }();
     return n;
 }
