@@ -62,11 +62,15 @@ template <bool FASTDIV>
 __device__ inline float div_by(float a, const InvDiv &d) {
     if (FASTDIV) {
         const float mag = fabsf(a);
-        if (mag >= kFastDivMin && mag < INFINITY) {  // the verified domain
-            float q0 = a * d.y;
-            float r = __builtin_fmaf(-d.b, q0, a);
-            return __builtin_fmaf(r, d.y, q0);
+        const bool verified = mag >= kFastDivMin && mag < INFINITY;  // the verified domain
+        const float q0 = a * d.y;
+        const float r = __builtin_fmaf(-d.b, q0, a);
+        float q = __builtin_fmaf(r, d.y, q0);
+        // the IEEE sequence sits behind a wave-uniform branch: left to itself the compiler computes both and selects
+        if (__builtin_expect(__ballot(!verified) != 0ull, 0)) {
+            if (!verified) q = a / d.b;
         }
+        return q;
     }
     return a / d.b;
 }
@@ -247,7 +251,7 @@ constexpr int kRaySegmentsDefault = 6;      // sample ranges a ray's march is sp
 constexpr int kTailGridDefault = 256 * 10;   // workgroups of the tail kernel (5 fit a CU at 86 VGPRs: two rounds)
 // What is left of a ray's range when the pass budget runs out is queued in up to kTailPieces pieces of at least
 // kTailPieceMin samples, so that a long stretch is marched by several groups of the tail kernel at once.
-constexpr int kTailPieces = 8, kTailPieceMin = 64;
+constexpr int kTailPieces = 32, kTailPieceMin = 64;
 constexpr int kTripBudgetDefault = 18;      // passes of the first kernel's loop before unfinished rays go to the tail kernel
 static int ray_segments() {
     static const int n = [] {
@@ -995,6 +999,58 @@ __global__ __launch_bounds__(256) void process_ray_tail_kernel(const float *__re
     }
 }
 
+// Alternative finish (experiment): one lane per queue entry, marching it like process_ray_kernel's main loop (per-brick
+// memory, dependent look-ups) until every entry of the wave's batch is done.
+template <bool SLAB, bool FASTDIV>
+__global__ __launch_bounds__(256) void process_ray_queue_kernel(const float *__restrict__ dist, const Geom g, const RayParams rp,
+                                                                const OccGrid occ, const float *__restrict__ t_table,
+                                                                const TailQueue tail) {
+    __shared__ float T[kTableLen];
+    for (int i = (int)threadIdx.x; i < kTableLen; i += 256) T[i] = t_table[i];
+    __syncthreads();
+    const uint32_t n_entries = tail.count[0];
+    const uint32_t lane = threadIdx.x & 63u;
+    const float step_size = T[1];
+    const TriConst &tc = rp.tc;
+    SkipCtx sc = make_skip_ctx(g, step_size);
+    const uint32_t n_waves = gridDim.x * 4, wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (uint32_t batch = wave_id * 64u; batch < n_entries; batch += n_waves * 64u) {
+        RayState ray = {0, 0, 0, 0, 0, 0};
+        int k = kDone, k_end = 0;
+        uint32_t *best = tail.best;
+        const uint32_t e = batch + lane;
+        if (e < n_entries) {
+            const uint2 q = tail.entries[e];
+            float max_t;
+            (void)ray_geometry((int)(q.x % rp.width), (int)(q.x / rp.width), true, rp, ray, max_t);
+            set_ray<true>(sc, ray, step_size, g);
+            k = (int)(q.y & 0x1fffu);
+            k_end = (int)((q.y >> 13) & 0x1fffu);
+            best += q.x;
+            if (load_best(best) <= (uint32_t)k) k = kDone;
+        }
+        BrickCache bc = {0, 0, false};
+        SampleWork work = {0, 0, 0, 0};
+        for (uint32_t trip = 0; __ballot(k != kDone) != 0ull; trip++) {
+            if (k != kDone) {
+                const float t = T[k];
+                int jump, ahead;
+                const float tsdf = process_sample<SLAB, false, FASTDIV>(t, k, ray, sc, bc, dist, g, tc, rp, occ, nullptr, work, jump, ahead);
+                if (jump > 0) {
+                    k += jump;
+                } else if (tsdf <= 0) {
+                    atomicMin(best, (uint32_t)k);
+                    k = kDone;
+                } else {
+                    k += 1 + (tsdf > 0 ? ahead : 0);
+                }
+                if (k != kDone && k >= k_end) k = kDone;
+                if (k != kDone && (trip & 7u) == 7u && load_best(best) <= (uint32_t)k) k = kDone;
+            }
+        }
+    }
+}
+
 // The vertex of every pixel from best[]: the ray's first sample <= 0 is recomputed -- the same expressions on the same
 // values as when the march found it -- and refined into the hit point as the reference does (process_ray :336-350);
 // no hit -> NaN.  Resets best[] (and the tail queue's counter) for the next march.
@@ -1171,7 +1227,11 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out) {
     TSDF_HIP(hipGetLastError(), "process_ray failed");
     // persistent workgroups: groups of 16 lanes, fetching queue entries until none is left
     timing_begin(v, 2);
-    if (v->fast_div)
+    static const int tail_mode = getenv("TSDF_RAY_TAIL_MODE") ? atoi(getenv("TSDF_RAY_TAIL_MODE")) : 0;
+    if (tail_mode == 1)
+        hipLaunchKernelGGL((process_ray_queue_kernel<SLAB, true>), dim3(tail_grid()), dim3(256), 0, v->stream, v->dist, v->g, rp,
+                           v->occ, v->t_table, tail);
+    else if (v->fast_div)
         hipLaunchKernelGGL((process_ray_tail_kernel<SLAB, true>), dim3(tail_grid()), dim3(256), 0, v->stream, v->dist, v->g, rp,
                            v->occ, v->t_table, tail);
     else
