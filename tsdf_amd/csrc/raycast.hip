@@ -131,7 +131,7 @@ __device__ inline float trilinear(float px, float py, float pz, const float *__r
     const uint32_t ox = ((uint32_t)lx + 1 < g.X) ? 1u : 0u;
     const uint32_t oy = ((uint32_t)ly + 1 < g.Y) ? tc.row : 0u;
     const uint32_t oz = ((uint32_t)lz + 1 < g.Z) ? tc.plane : 0u;
-    const float *b000 = dist + ((size_t)tc.plane * ((uint32_t)lz - g.z_store_begin) + (size_t)tc.row * (uint32_t)ly + (uint32_t)lx);
+    const float *b000 = dist + ((size_t)tc.plane * ((uint32_t)lz - g.z_store_begin) + (tc.row * (uint32_t)ly + (uint32_t)lx));   // (X * Y < 2^32)
     if (STATS) {
         const size_t gi = (size_t)tc.plane * (uint32_t)lz + (size_t)tc.row * (uint32_t)ly + (uint32_t)lx;
         const uint32_t offs[8] = {0, oz, oy, oy + oz, ox, ox + oz, ox + oy, ox + oy + oz};
@@ -366,7 +366,7 @@ __device__ inline bool locate(float fx, float fy, float fz, const SkipCtx &c, co
         }
     }
     const int bx = vx >> kBrickShift, by = vy >> kBrickShift, bz = vz >> kBrickShift;
-    const int reach = occ.reach[((size_t)bz * occ.nby + by) * occ.nbx + bx];
+    const int reach = occ.reach[((uint32_t)bz * occ.nby + (uint32_t)by) * occ.nbx + (uint32_t)bx];   // (fewer than 2^32 bricks: volume.hip)
     // aligned block of 4 * 2^(reach-1) voxels per side (the brick itself when reach is 0)
     const int shift = kBrickShift + max(reach, 1) - 1, size = 1 << shift;
     const int x0 = (vx >> shift) << shift, y0 = (vy >> shift) << shift, z0 = (vz >> shift) << shift;
@@ -491,7 +491,7 @@ __device__ inline float process_sample(float t, int k, const RayState &r, const 
                                                         (float)(qz << kBrickShift) + e, (float)((qx + 1) << kBrickShift) - e,
                                                         (float)((qy + 1) << kBrickShift) - e, (float)((qz + 1) << kBrickShift) - e);
                 bc.k_cellbrick_end = k + n_cb;
-                bc.cellbrick_clear = occ.cell[((size_t)qz * occ.nby + qy) * occ.nbx + qx] == 0;
+                bc.cellbrick_clear = occ.cell[((uint32_t)qz * occ.nby + (uint32_t)qy) * occ.nbx + (uint32_t)qx] == 0;
             }
             if (bc.cellbrick_clear && k < bc.k_cellbrick_end) {
                 jump = bc.k_cellbrick_end - k;
@@ -504,7 +504,7 @@ __device__ inline float process_sample(float t, int k, const RayState &r, const 
                 jump = n_cell;  // not this rank's samples (and possibly not its planes): passed unevaluated
                 return 1.0f;
             }
-            const float *b = dist + ((size_t)tc.plane * ((uint32_t)lz - g.z_store_begin) + (size_t)tc.row * (uint32_t)ly + (uint32_t)lx);
+            const float *b = dist + ((size_t)tc.plane * ((uint32_t)lz - g.z_store_begin) + (tc.row * (uint32_t)ly + (uint32_t)lx));   // (X * Y < 2^32)
             const float c000 = b[0], c100 = b[1], c010 = b[tc.row], c110 = b[tc.row + 1];
             const float c001 = b[tc.plane], c101 = b[tc.plane + 1], c011 = b[tc.plane + tc.row], c111 = b[tc.plane + tc.row + 1];
             const bool positive = c000 > kCellPositive && c100 > kCellPositive && c010 > kCellPositive && c110 > kCellPositive &&
@@ -572,9 +572,9 @@ __device__ inline float process_sample_eager(float t, const RayState &r, const S
         unsigned char cell_flag = 1;
         float c000 = 0, c100 = 0, c010 = 0, c110 = 0, c001 = 0, c101 = 0, c011 = 0, c111 = 0;
         if (safe) {
-            cell_flag = occ.cell[((size_t)qz * occ.nby + qy) * occ.nbx + qx];
+            cell_flag = occ.cell[((uint32_t)qz * occ.nby + (uint32_t)qy) * occ.nbx + (uint32_t)qx];
             if (owned) {  // (a slab holds the planes of the samples it owns, and only those for certain)
-                const float *b = dist + ((size_t)tc.plane * ((uint32_t)lz - g.z_store_begin) + (size_t)tc.row * (uint32_t)ly + (uint32_t)lx);
+                const float *b = dist + ((size_t)tc.plane * ((uint32_t)lz - g.z_store_begin) + (tc.row * (uint32_t)ly + (uint32_t)lx));   // (X * Y < 2^32)
                 c000 = b[0]; c100 = b[1]; c010 = b[tc.row]; c110 = b[tc.row + 1];
                 c001 = b[tc.plane]; c101 = b[tc.plane + 1]; c011 = b[tc.plane + tc.row]; c111 = b[tc.plane + tc.row + 1];
             }

@@ -514,6 +514,11 @@ int tsdf_volume_create_slab(uint32_t sx, uint32_t sy, uint32_t sz, float px, flo
     v->occ.nby = (sy + kBrick - 1) / kBrick;
     v->occ.nbz = (sz + kBrick - 1) / kBrick;
     v->occ.tau = 0.01f * g.trunc;
+    if (v->occ.fine_count() >= ((size_t)1 << 32)) {   // the ray caster indexes bricks with 32 bits (grids beyond ~6500^3)
+        delete v;
+        set_error("tsdf_volume_create: grid of %u x %u x %u voxels is too large", (unsigned)sx, (unsigned)sy, (unsigned)sz);
+        return TSDF_ERR_INVALID;
+    }
     hipError_t e = hipGetDevice(&v->device);
     if (e == hipSuccess) e = hipMalloc((void **)&v->occ.fine, v->occ.fine_count());
     if (e == hipSuccess) e = hipMalloc((void **)&v->occ.cell, v->occ.fine_count());
