@@ -505,8 +505,10 @@ __device__ inline float process_sample(float t, int k, const RayState &r, const 
                 return 1.0f;
             }
             const float *b = dist + ((size_t)tc.plane * ((uint32_t)lz - g.z_store_begin) + (tc.row * (uint32_t)ly + (uint32_t)lx));   // (X * Y < 2^32)
-            const float c000 = b[0], c100 = b[1], c010 = b[tc.row], c110 = b[tc.row + 1];
-            const float c001 = b[tc.plane], c101 = b[tc.plane + 1], c011 = b[tc.plane + tc.row], c111 = b[tc.plane + tc.row + 1];
+            // (pairs along x through one pointer each, so that they can be fetched as 64-bit loads)
+            const float *b_y = b + tc.row, *b_z = b + tc.plane, *b_yz = b_z + tc.row;
+            const float c000 = b[0], c100 = b[1], c010 = b_y[0], c110 = b_y[1];
+            const float c001 = b_z[0], c101 = b_z[1], c011 = b_yz[0], c111 = b_yz[1];
             const bool positive = c000 > kCellPositive && c100 > kCellPositive && c010 > kCellPositive && c110 > kCellPositive &&
                                   c001 > kCellPositive && c101 > kCellPositive && c011 > kCellPositive && c111 > kCellPositive;
             if (positive) {
@@ -575,8 +577,9 @@ __device__ inline float process_sample_eager(float t, const RayState &r, const S
             cell_flag = occ.cell[((uint32_t)qz * occ.nby + (uint32_t)qy) * occ.nbx + (uint32_t)qx];
             if (owned) {  // (a slab holds the planes of the samples it owns, and only those for certain)
                 const float *b = dist + ((size_t)tc.plane * ((uint32_t)lz - g.z_store_begin) + (tc.row * (uint32_t)ly + (uint32_t)lx));   // (X * Y < 2^32)
-                c000 = b[0]; c100 = b[1]; c010 = b[tc.row]; c110 = b[tc.row + 1];
-                c001 = b[tc.plane]; c101 = b[tc.plane + 1]; c011 = b[tc.plane + tc.row]; c111 = b[tc.plane + tc.row + 1];
+                const float *b_y = b + tc.row, *b_z = b + tc.plane, *b_yz = b_z + tc.row;
+                c000 = b[0]; c100 = b[1]; c010 = b_y[0]; c110 = b_y[1];
+                c001 = b_z[0]; c101 = b_z[1]; c011 = b_yz[0]; c111 = b_yz[1];
             }
         }
         if (empty) {
