@@ -193,8 +193,9 @@ class TSDFVolume:
         return tuple(out)
 
     def set_timing(self, enabled):
-        """HIP-event timing of integrate_kernel / process_ray_kernel launches on the volume's stream."""
-        check(lib.tsdf_volume_set_timing(self._h, 1 if enabled else 0))
+        """HIP-event timing of integrate_kernel / process_ray_kernel launches on the volume's stream: True = every
+        launch, an integer n > 1 = every n-th launch, False / 0 = off."""
+        check(lib.tsdf_volume_set_timing(self._h, int(enabled)))
 
     def kernel_time(self, which):
         """(launches, average ms) of which = 'integrate' | 'raycast' | 'raycast_tail' since set_timing(True)."""

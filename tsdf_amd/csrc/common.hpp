@@ -136,8 +136,9 @@ struct tsdf_volume {
     size_t ray_cap;
     // per pixel: the smallest sample index found <= 0 so far by the ray march (0xffffffff = none); every kernel of the
     // march lowers it with atomicMin, resolve_hits_kernel turns it into the vertex and resets it (raycast.hip)
-    uint32_t *ray_best;
+    uint32_t *ray_best;      // two copies of ray_best_cap words, used alternately (ray_best_side)
     size_t ray_best_cap;
+    int ray_best_side;
     int ray_best_dirty;      // 1 = a march was started whose resolve kernel was not launched: refill before the next one
     // stretches of rays the first ray-cast kernel hands to the tail kernel: uint2 per piece + {appended, taken}
     void *tail_entries;
@@ -167,7 +168,8 @@ struct tsdf_volume {
     size_t tile_max_cap;
     float *plane_const;      // float4 per resident plane (+ padding): z-only terms of the projection
     // optional HIP-event timing of the two dominant kernels on the volume's stream (tsdf_volume_set_timing)
-    int timing;
+    int timing;                   // 0 = off, n = every n-th launch of each kernel is bracketed
+    uint32_t timing_launches[3];
     std::vector<hipEvent_t> *tev[3];  // [0] integrate_kernel, [1] process_ray_kernel, [2] process_ray_tail_kernel: start/stop pairs
     // diagnostics
     int counting;

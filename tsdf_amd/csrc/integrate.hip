@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                 // load that would have to be waited for plane by plane.
                 const uint32_t tx = (uint32_t)px_[j] - box.x, ty = (uint32_t)py_[j] - box.y;
                 const bool in_box = act[j] && staged && tx < box.z && ty < box.w;
-                d_[j] = tile[in_box ? ty * pitch + tx : (uint32_t)kTilePixels];
+                d_[j] = tile[in_box ? __umul24(ty, pitch) + tx : (uint32_t)kTilePixels];   // (in the box both factors are < 2^13: 24-bit multiply, full rate)
                 if (act[j] && !in_box && rx >= 0.0f && rx < fwidth && ry >= 0.0f && ry < fheight)
                     d_[j] = depth[(uint32_t)py_[j] * width + (uint32_t)px_[j]];
                 if (DEFORM) {  // keep the per-voxel row sums for pass 2

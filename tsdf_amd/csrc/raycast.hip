@@ -131,7 +131,7 @@ __device__ inline float trilinear(float px, float py, float pz, const float *__r
     const uint32_t ox = ((uint32_t)lx + 1 < g.X) ? 1u : 0u;
     const uint32_t oy = ((uint32_t)ly + 1 < g.Y) ? tc.row : 0u;
     const uint32_t oz = ((uint32_t)lz + 1 < g.Z) ? tc.plane : 0u;
-    const float *b000 = dist + ((size_t)tc.plane * ((uint32_t)lz - g.z_store_begin) + (tc.row * (uint32_t)ly + (uint32_t)lx));   // (X * Y < 2^32)
+    const float *b000 = dist + ((size_t)tc.plane * ((uint32_t)lz - g.z_store_begin) + (__umul24(tc.row, (uint32_t)ly) + (uint32_t)lx));   // (X, Y < 2^16: 24-bit multiply, X * Y < 2^32)
     if (STATS) {
         const size_t gi = (size_t)tc.plane * (uint32_t)lz + (size_t)tc.row * (uint32_t)ly + (uint32_t)lx;
         const uint32_t offs[8] = {0, oz, oy, oy + oz, ox, ox + oz, ox + oy, ox + oy + oz};
@@ -366,7 +366,7 @@ __device__ inline bool locate(float fx, float fy, float fz, const SkipCtx &c, co
         }
     }
     const int bx = vx >> kBrickShift, by = vy >> kBrickShift, bz = vz >> kBrickShift;
-    const int reach = occ.reach[((uint32_t)bz * occ.nby + (uint32_t)by) * occ.nbx + (uint32_t)bx];   // (fewer than 2^32 bricks: volume.hip)
+    const int reach = occ.reach[(__umul24((uint32_t)bz, occ.nby) + (uint32_t)by) * occ.nbx + (uint32_t)bx];   // (fewer than 2^32 bricks: volume.hip)
     // aligned block of 4 * 2^(reach-1) voxels per side (the brick itself when reach is 0)
     const int shift = kBrickShift + max(reach, 1) - 1, size = 1 << shift;
     const int x0 = (vx >> shift) << shift, y0 = (vy >> shift) << shift, z0 = (vz >> shift) << shift;
@@ -491,7 +491,7 @@ __device__ inline float process_sample(float t, int k, const RayState &r, const 
                                                         (float)(qz << kBrickShift) + e, (float)((qx + 1) << kBrickShift) - e,
                                                         (float)((qy + 1) << kBrickShift) - e, (float)((qz + 1) << kBrickShift) - e);
                 bc.k_cellbrick_end = k + n_cb;
-                bc.cellbrick_clear = occ.cell[((uint32_t)qz * occ.nby + (uint32_t)qy) * occ.nbx + (uint32_t)qx] == 0;
+                bc.cellbrick_clear = occ.cell[(__umul24((uint32_t)qz, occ.nby) + (uint32_t)qy) * occ.nbx + (uint32_t)qx] == 0;
             }
             if (bc.cellbrick_clear && k < bc.k_cellbrick_end) {
                 jump = bc.k_cellbrick_end - k;
@@ -504,7 +504,7 @@ __device__ inline float process_sample(float t, int k, const RayState &r, const 
                 jump = n_cell;  // not this rank's samples (and possibly not its planes): passed unevaluated
                 return 1.0f;
             }
-            const float *b = dist + ((size_t)tc.plane * ((uint32_t)lz - g.z_store_begin) + (tc.row * (uint32_t)ly + (uint32_t)lx));   // (X * Y < 2^32)
+            const float *b = dist + ((size_t)tc.plane * ((uint32_t)lz - g.z_store_begin) + (__umul24(tc.row, (uint32_t)ly) + (uint32_t)lx));   // (X, Y < 2^16: 24-bit multiply, X * Y < 2^32)
             // (pairs along x through one pointer each, so that they can be fetched as 64-bit loads)
             const float *b_y = b + tc.row, *b_z = b + tc.plane, *b_yz = b_z + tc.row;
             const float c000 = b[0], c100 = b[1], c010 = b_y[0], c110 = b_y[1];
@@ -574,9 +574,9 @@ __device__ inline float process_sample_eager(float t, const RayState &r, const S
         unsigned char cell_flag = 1;
         float c000 = 0, c100 = 0, c010 = 0, c110 = 0, c001 = 0, c101 = 0, c011 = 0, c111 = 0;
         if (safe) {
-            cell_flag = occ.cell[((uint32_t)qz * occ.nby + (uint32_t)qy) * occ.nbx + (uint32_t)qx];
+            cell_flag = occ.cell[(__umul24((uint32_t)qz, occ.nby) + (uint32_t)qy) * occ.nbx + (uint32_t)qx];
             if (owned) {  // (a slab holds the planes of the samples it owns, and only those for certain)
-                const float *b = dist + ((size_t)tc.plane * ((uint32_t)lz - g.z_store_begin) + (tc.row * (uint32_t)ly + (uint32_t)lx));   // (X * Y < 2^32)
+                const float *b = dist + ((size_t)tc.plane * ((uint32_t)lz - g.z_store_begin) + (__umul24(tc.row, (uint32_t)ly) + (uint32_t)lx));   // (X, Y < 2^16: 24-bit multiply, X * Y < 2^32)
                 const float *b_y = b + tc.row, *b_z = b + tc.plane, *b_yz = b_z + tc.row;
                 c000 = b[0]; c100 = b[1]; c010 = b_y[0]; c110 = b_y[1];
                 c001 = b_z[0]; c101 = b_z[1]; c011 = b_yz[0]; c111 = b_yz[1];
@@ -1054,20 +1054,14 @@ __global__ __launch_bounds__(256) void process_ray_queue_kernel(const float *__r
     }
 }
 
-// The vertex of every pixel from best[]: the ray's first sample <= 0 is recomputed -- the same expressions on the same
-// values as when the march found it -- and refined into the hit point as the reference does (process_ray :336-350);
-// no hit -> NaN.  Resets best[] (and the tail queue's counter) for the next march.
-//   SLAB: out = float4 records {k, x, y, z} for the min-k merge across slabs; otherwise packed float3 vertices.
+// The vertex of a pixel from best[]: the ray's first sample <= 0 is recomputed -- the same expressions on the same values
+// as when the march found it -- and refined into the hit point as the reference does (process_ray :336-350); no hit -> NaN.
 template <bool SLAB, bool FASTDIV>
-__global__ __launch_bounds__(256) void resolve_hits_kernel(const float *__restrict__ dist, const Geom g, const RayParams rp,
-                                                           const float *__restrict__ t_table, uint32_t *__restrict__ best,
-                                                           float *__restrict__ out, uint32_t *__restrict__ reset) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) *reset = 0;
-    if (i >= rp.width * rp.height) return;
+__device__ inline uint32_t resolve_pixel(uint32_t i, const float *__restrict__ dist, const Geom &g, const RayParams &rp,
+                                         const float *__restrict__ t_table, const uint32_t *__restrict__ best, float &ix, float &iy,
+                                         float &iz) {
     const uint32_t kb = best[i];
-    best[i] = kNoHit;
-    float ix = NAN, iy = NAN, iz = NAN;
+    ix = iy = iz = NAN;
     if (kb != kNoHit) {
         RayState ray;
         float max_t;
@@ -1078,6 +1072,24 @@ __global__ __launch_bounds__(256) void resolve_hits_kernel(const float *__restri
         const float tsdf = trilinear<SLAB, false, FASTDIV>(px, py, pz, dist, g, rp.tc, rp, owned, nullptr);
         refine_hit(t, tsdf, g.trunc, step_size, ray, rp, ix, iy, iz);   // previous_tsdf == trunc (Q7)
     }
+    return kb;
+}
+
+// The vertices of all pixels.  best[] is double buffered: a march lowers one copy, this kernel reads it and resets the OTHER
+// one (consumed by the previous march's resolve) for the next march, together with the tail queue's counter -- so a
+// pixel's word may be read by several workgroups (resolve_normals_kernel) without racing against its reset.
+//   SLAB: out = float4 records {k, x, y, z} for the min-k merge across slabs; otherwise packed float3 vertices.
+template <bool SLAB, bool FASTDIV>
+__global__ __launch_bounds__(256) void resolve_hits_kernel(const float *__restrict__ dist, const Geom g, const RayParams rp,
+                                                           const float *__restrict__ t_table, const uint32_t *__restrict__ best,
+                                                           uint32_t *__restrict__ best_next, float *__restrict__ out,
+                                                           uint32_t *__restrict__ reset) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *reset = 0;
+    if (i >= rp.width * rp.height) return;
+    best_next[i] = kNoHit;
+    float ix, iy, iz;
+    const uint32_t kb = resolve_pixel<SLAB, FASTDIV>(i, dist, g, rp, t_table, best, ix, iy, iz);
     if (SLAB) {
         reinterpret_cast<float4 *>(out)[i] = make_float4(kb != kNoHit ? (float)kb : INFINITY, ix, iy, iz);
     } else {
@@ -1085,6 +1097,54 @@ __global__ __launch_bounds__(256) void resolve_hits_kernel(const float *__restri
         out[(size_t)i * 3 + 1] = iy;
         out[(size_t)i * 3 + 2] = iz;
     }
+}
+
+// Vertices and normals in one launch (whole volume): a workgroup resolves a 16x16 pixel tile plus the column to its right
+// and the row below (LDS), then forms the normals as normals_kernel does (compute_normals, Q11) from those.
+template <bool FASTDIV>
+__global__ __launch_bounds__(256) void resolve_normals_kernel(const float *__restrict__ dist, const Geom g, const RayParams rp,
+                                                              const float *__restrict__ t_table, const uint32_t *__restrict__ best,
+                                                              uint32_t *__restrict__ best_next, float *__restrict__ V,
+                                                              float *__restrict__ N, uint32_t *__restrict__ reset) {
+    constexpr int kT = 16, kS = kT + 1;
+    __shared__ float vx[kS * kS], vy[kS * kS], vz[kS * kS];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *reset = 0;
+    const uint32_t x0 = blockIdx.x * kT, y0 = blockIdx.y * kT;
+    for (uint32_t s_ = threadIdx.x; s_ < (uint32_t)(kS * kS); s_ += 256) {
+        const uint32_t ly = s_ / kS, lx = s_ - ly * kS, x = x0 + lx, y = y0 + ly;
+        float ix = NAN, iy = NAN, iz = NAN;
+        if (x < rp.width && y < rp.height) {
+            const uint32_t i = y * rp.width + x;
+            (void)resolve_pixel<false, FASTDIV>(i, dist, g, rp, t_table, best, ix, iy, iz);
+            if (lx < (uint32_t)kT && ly < (uint32_t)kT) {   // this workgroup's own pixel
+                best_next[i] = kNoHit;
+                V[(size_t)i * 3 + 0] = ix;
+                V[(size_t)i * 3 + 1] = iy;
+                V[(size_t)i * 3 + 2] = iz;
+            }
+        }
+        vx[s_] = ix; vy[s_] = iy; vz[s_] = iz;
+    }
+    __syncthreads();
+    const uint32_t lx = threadIdx.x & 15u, ly = threadIdx.x >> 4, x = x0 + lx, y = y0 + ly;
+    if (x >= rp.width || y >= rp.height) return;
+    float nx = 0, ny = 0, nz = 0;
+    if (y != rp.height - 1 && x != rp.width - 1) {
+        const uint32_t a = ly * kS + lx, r = a + 1, b = a + kS;
+        float v2x = vx[r] - vx[a], v2y = vy[r] - vy[a], v2z = vz[r] - vz[a];
+        float v1x = vx[b] - vx[a], v1y = vy[b] - vy[a], v1z = vz[b] - vz[a];
+        float cx = v1y * v2z - v1z * v2y;
+        float cy = v1z * v2x - v1x * v2z;
+        float cz = v1x * v2y - v1y * v2x;
+        float l = sqrtf(cx * cx + cy * cy + cz * cz);
+        nx = cx / l;
+        ny = cy / l;
+        nz = cz / l;
+    }
+    const size_t idx = (size_t)y * rp.width + x;
+    N[idx * 3 + 0] = nx;
+    N[idx * 3 + 1] = ny;
+    N[idx * 3 + 2] = nz;
 }
 
 // compute_normals (src/RayCaster/GPURaycaster.cu:393-427): Q11
@@ -1187,7 +1247,7 @@ static int check_ray_args(const tsdf_volume *v, uint32_t width, uint32_t height,
 // The production march: process_ray_kernel over the sample ranges of every ray with a pass budget, process_ray_tail_kernel
 // for the stretches it handed over, resolve_hits_kernel for the vertices (packed float3, or {k,x,y,z} records for a slab).
 template <bool SLAB>
-static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out) {
+static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *normals = nullptr) {
     const size_t n_pix = (size_t)rp.width * rp.height;
     const int n_segments = SLAB ? slab_ray_ranges(v) : ray_segments();
     const size_t n_entries = n_pix * n_segments * kTailPieces;   // every range unfinished and cut into all its pieces
@@ -1195,7 +1255,7 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out) {
         if (v->ray_best) (void)hipFree(v->ray_best);
         v->ray_best = nullptr;
         v->ray_best_cap = 0;
-        TSDF_HIP(hipMalloc((void **)&v->ray_best, n_pix * sizeof(uint32_t)), "ray result alloc");
+        TSDF_HIP(hipMalloc((void **)&v->ray_best, 2 * n_pix * sizeof(uint32_t)), "ray result alloc");   // (double buffered)
         v->ray_best_cap = n_pix;
         v->ray_best_dirty = 1;
     }
@@ -1211,11 +1271,12 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out) {
         v->ray_best_dirty = 1;
     }
     if (v->ray_best_dirty) {   // otherwise the previous march's resolve kernel left both reset
-        TSDF_HIP(hipMemsetAsync(v->ray_best, 0xff, v->ray_best_cap * sizeof(uint32_t), v->stream), "ray result reset");
+        TSDF_HIP(hipMemsetAsync(v->ray_best, 0xff, 2 * v->ray_best_cap * sizeof(uint32_t), v->stream), "ray result reset");
         TSDF_HIP(hipMemsetAsync(v->tail_count, 0, 2 * sizeof(uint32_t), v->stream), "ray tail counter reset");
     }
     v->ray_best_dirty = 1;
-    TailQueue tail = {reinterpret_cast<uint2 *>(v->tail_entries), v->tail_count, (uint32_t)trip_budget(), (uint32_t)tail_lanes(), v->ray_best, tail_piece_min()};
+    TailQueue tail = {reinterpret_cast<uint2 *>(v->tail_entries), v->tail_count, (uint32_t)trip_budget(), (uint32_t)tail_lanes(), v->ray_best + (size_t)v->ray_best_side * v->ray_best_cap, tail_piece_min()};
+    uint32_t *best_next = v->ray_best + (size_t)(1 - v->ray_best_side) * v->ray_best_cap;
     rp.seg_len = (kMaxSamples + n_segments - 1) / n_segments;
     rp.slab_ranges = SLAB ? (uint32_t)n_segments : 0u;
     dim3 grid((rp.width + 15) / 16, (rp.height + 15) / 16, n_segments);
@@ -1247,14 +1308,23 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out) {
         (void)hipMemcpy(&n_tail, v->tail_count, sizeof(n_tail), hipMemcpyDeviceToHost);
         fprintf(stderr, "tsdf: %u pieces of the %zu (ray, range) pairs finished by the tail kernel\n", n_tail, n_pix * n_segments);
     }
-    const dim3 rgrid((unsigned)((n_pix + 255) / 256));
-    if (v->fast_div)
-        hipLaunchKernelGGL((resolve_hits_kernel<SLAB, true>), rgrid, dim3(256), 0, v->stream, v->dist, v->g, rp, v->t_table, v->ray_best, out,
+    const dim3 rgrid((unsigned)((n_pix + 255) / 256)), tgrid((rp.width + 15) / 16, (rp.height + 15) / 16);
+    if (!SLAB && normals) {
+        if (v->fast_div)
+            hipLaunchKernelGGL((resolve_normals_kernel<true>), tgrid, dim3(256), 0, v->stream, v->dist, v->g, rp, v->t_table, tail.best, best_next,
+                               out, normals, v->tail_count);
+        else
+            hipLaunchKernelGGL((resolve_normals_kernel<false>), tgrid, dim3(256), 0, v->stream, v->dist, v->g, rp, v->t_table, tail.best, best_next,
+                               out, normals, v->tail_count);
+    } else if (v->fast_div) {
+        hipLaunchKernelGGL((resolve_hits_kernel<SLAB, true>), rgrid, dim3(256), 0, v->stream, v->dist, v->g, rp, v->t_table, tail.best, best_next, out,
                            v->tail_count);
-    else
-        hipLaunchKernelGGL((resolve_hits_kernel<SLAB, false>), rgrid, dim3(256), 0, v->stream, v->dist, v->g, rp, v->t_table, v->ray_best, out,
+    } else {
+        hipLaunchKernelGGL((resolve_hits_kernel<SLAB, false>), rgrid, dim3(256), 0, v->stream, v->dist, v->g, rp, v->t_table, tail.best, best_next, out,
                            v->tail_count);
+    }
     TSDF_HIP(hipGetLastError(), "resolve ray hits failed");
+    v->ray_best_side = 1 - v->ray_best_side;
     v->ray_best_dirty = 0;
     return TSDF_OK;
 }
@@ -1274,10 +1344,7 @@ int tsdf_raycast_device(const tsdf_volume *v, uint32_t width, uint32_t height, c
     rc = occupancy_refresh(const_cast<tsdf_volume *>(v));
     if (rc != TSDF_OK) return rc;
     RayParams rp = make_params(v, width, height, pose, kinv);
-    rc = march_and_resolve<false>(const_cast<tsdf_volume *>(v), rp, device_vertices);
-    if (rc != TSDF_OK) return rc;
-    if (device_normals) return launch_normals(width, height, device_vertices, device_normals, v->stream);
-    return TSDF_OK;
+    return march_and_resolve<false>(const_cast<tsdf_volume *>(v), rp, device_vertices, device_normals);
 }
 
 int tsdf_raycast(const tsdf_volume *cv, uint32_t width, uint32_t height, const float pose[16], const float kinv[9],

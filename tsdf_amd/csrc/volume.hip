@@ -345,6 +345,7 @@ int verify_fast_division(tsdf_volume *v) {
 
 void timing_begin(tsdf_volume *v, int which) {
     if (!v->timing) return;
+    if (v->timing_launches[which]++ % (uint32_t)v->timing != 0) return;   // every timing-th launch is bracketed
     if (!v->tev[which]) v->tev[which] = new std::vector<hipEvent_t>();
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return;
@@ -817,7 +818,8 @@ int tsdf_volume_get_weight_data(const tsdf_volume *v, float *host) {
 
 int tsdf_volume_set_timing(tsdf_volume *v, int enabled) {
     TSDF_REQUIRE(v, "null volume");
-    v->timing = enabled ? 1 : 0;
+    v->timing = enabled > 0 ? enabled : 0;
+    for (int w = 0; w < 3; w++) v->timing_launches[w] = 0;
     for (int w = 0; w < 3; w++)
         if (v->tev[w]) {
             for (hipEvent_t e : *v->tev[w]) (void)hipEventDestroy(e);
