@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--stream-frames", type=int, default=200, help="length of the synthetic trajectory")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
-    ap.add_argument("--event-period", type=int, default=8,
+    ap.add_argument("--event-period", type=int, default=16,
                     help="per-stage and per-kernel HIP events are recorded on every n-th timed step (0 = on the first one only): each record costs "
                          "a few microseconds of stream time, 9 %% of the step when every launch is bracketed")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: filter frame i+1 after, not during, the exchange of frame i")
@@ -140,7 +140,7 @@ def main():
         vol.integrate_device(fbuf.data_ptr(), W, H, cam)
         if timed: e[2].record(stream)
         if world == 1:
-            rc.raycast_device(vol, cam, vert_dev.data_ptr(), norm_dev.data_ptr())   # vertices and normals in one go
+            rc.raycast_device(vol, cam, vert_dev.data_ptr(), None if os.environ.get('BENCH_SPLIT_NORMALS') else norm_dev.data_ptr())   # vertices and normals in one go
             if timed: e[3].record(stream)
         else:
             rc.raycast_slab_device(vol, cam, hits_mine.data_ptr())
@@ -164,7 +164,7 @@ def main():
                 dist.all_gather_into_tensor(hits_all.view(-1), hits_mine.view(-1))
             tsdf_amd.merge_hits_device(hits_all.data_ptr(), world, W, H, vert_dev.data_ptr(), stream.cuda_stream)
         if timed: e[4].record(stream)
-        if world > 1:    # (a whole volume's ray cast has formed the normals with the vertices)
+        if world > 1 or os.environ.get('BENCH_SPLIT_NORMALS'):    # (a whole volume's ray cast has formed the normals with the vertices)
             tsdf_amd.compute_normals_device(W, H, vert_dev.data_ptr(), norm_dev.data_ptr(), stream.cuda_stream)
         if timed:
             e[5].record(stream)
