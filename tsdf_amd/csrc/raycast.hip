@@ -1100,18 +1100,31 @@ __global__ __launch_bounds__(256) void resolve_hits_kernel(const float *__restri
 }
 
 // Vertices and normals in one launch (whole volume): a workgroup resolves a 16x16 pixel tile plus the column to its right
-// and the row below (LDS), then forms the normals as normals_kernel does (compute_normals, Q11) from those.
+// and the row below -- 289 pixels, one per thread of its five waves -- into LDS, then forms the normals as normals_kernel
+// does (compute_normals, Q11) from those.
+constexpr int kResolveThreads = 320;
 template <bool FASTDIV>
-__global__ __launch_bounds__(256) void resolve_normals_kernel(const float *__restrict__ dist, const Geom g, const RayParams rp,
-                                                              const float *__restrict__ t_table, const uint32_t *__restrict__ best,
-                                                              uint32_t *__restrict__ best_next, float *__restrict__ V,
-                                                              float *__restrict__ N, uint32_t *__restrict__ reset) {
+__global__ __launch_bounds__(kResolveThreads) void resolve_normals_kernel(const float *__restrict__ dist, const Geom g, const RayParams rp,
+                                                                          const float *__restrict__ t_table, const uint32_t *__restrict__ best,
+                                                                          uint32_t *__restrict__ best_next, float *__restrict__ V,
+                                                                          float *__restrict__ N, uint32_t *__restrict__ reset) {
     constexpr int kT = 16, kS = kT + 1;
+    static_assert(kS * kS <= kResolveThreads, "one thread per pixel of the tile and its halo");
     __shared__ float vx[kS * kS], vy[kS * kS], vz[kS * kS];
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *reset = 0;
     const uint32_t x0 = blockIdx.x * kT, y0 = blockIdx.y * kT;
-    for (uint32_t s_ = threadIdx.x; s_ < (uint32_t)(kS * kS); s_ += 256) {
-        const uint32_t ly = s_ / kS, lx = s_ - ly * kS, x = x0 + lx, y = y0 + ly;
+    // own pixels first (threads 0..255, row-major in the tile), then the halo column and row
+    const uint32_t s_ = threadIdx.x;
+    if (s_ < (uint32_t)(kS * kS)) {
+        uint32_t lx, ly;
+        if (s_ < (uint32_t)(kT * kT)) {
+            lx = s_ & 15u; ly = s_ >> 4;
+        } else if (s_ < (uint32_t)(kT * kT + kT)) {
+            lx = kT; ly = s_ - kT * kT;          // right column
+        } else {
+            lx = s_ - (kT * kT + kT); ly = kT;   // bottom row, corner included
+        }
+        const uint32_t x = x0 + lx, y = y0 + ly;
         float ix = NAN, iy = NAN, iz = NAN;
         if (x < rp.width && y < rp.height) {
             const uint32_t i = y * rp.width + x;
@@ -1123,9 +1136,11 @@ __global__ __launch_bounds__(256) void resolve_normals_kernel(const float *__res
                 V[(size_t)i * 3 + 2] = iz;
             }
         }
-        vx[s_] = ix; vy[s_] = iy; vz[s_] = iz;
+        const uint32_t slot = ly * kS + lx;
+        vx[slot] = ix; vy[slot] = iy; vz[slot] = iz;
     }
     __syncthreads();
+    if (threadIdx.x >= (uint32_t)(kT * kT)) return;
     const uint32_t lx = threadIdx.x & 15u, ly = threadIdx.x >> 4, x = x0 + lx, y = y0 + ly;
     if (x >= rp.width || y >= rp.height) return;
     float nx = 0, ny = 0, nz = 0;
@@ -1311,10 +1326,10 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
     const dim3 rgrid((unsigned)((n_pix + 255) / 256)), tgrid((rp.width + 15) / 16, (rp.height + 15) / 16);
     if (!SLAB && normals) {
         if (v->fast_div)
-            hipLaunchKernelGGL((resolve_normals_kernel<true>), tgrid, dim3(256), 0, v->stream, v->dist, v->g, rp, v->t_table, tail.best, best_next,
+            hipLaunchKernelGGL((resolve_normals_kernel<true>), tgrid, dim3(kResolveThreads), 0, v->stream, v->dist, v->g, rp, v->t_table, tail.best, best_next,
                                out, normals, v->tail_count);
         else
-            hipLaunchKernelGGL((resolve_normals_kernel<false>), tgrid, dim3(256), 0, v->stream, v->dist, v->g, rp, v->t_table, tail.best, best_next,
+            hipLaunchKernelGGL((resolve_normals_kernel<false>), tgrid, dim3(kResolveThreads), 0, v->stream, v->dist, v->g, rp, v->t_table, tail.best, best_next,
                                out, normals, v->tail_count);
     } else if (v->fast_div) {
         hipLaunchKernelGGL((resolve_hits_kernel<SLAB, true>), rgrid, dim3(256), 0, v->stream, v->dist, v->g, rp, v->t_table, tail.best, best_next, out,
