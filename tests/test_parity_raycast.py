@@ -100,6 +100,25 @@ def test_small_odd_image_sizes(oracle):
         compare(oracle, gv, ov, cam, width=w, height=h, what="%dx%d" % (w, h))
 
 
+def test_alternating_image_sizes_on_one_volume(oracle):
+    """The per-pixel first-hit words live in the volume handle, double buffered across ray casts: casting a large, a
+    small and again the large image from different poses must not see each other's leftovers."""
+    n = 48
+    dist = sphere_tsdf(oracle, n, 512.0, 150.0)
+    gv, ov = volumes_with(oracle, (n, n, n), (512.0,) * 3, dist)
+    poses = [camera_at((256, 256, -400)), camera_at((-300, 200, 100), look_at=(256, 256, 256)), camera_at((256, 700, 900), look_at=(256, 256, 256))]
+    for rnd, (w, h) in enumerate(((160, 120), (33, 20), (160, 120), (160, 120), (8, 8), (33, 20), (160, 120))):
+        base = poses[rnd % len(poses)]
+        k = base.k().copy()
+        k[0] *= w / 640.0; k[4] *= h / 480.0; k[6] = w / 2.0; k[7] = h / 2.0
+        cam = Cam(base.pose(), base.inverse_pose(), k, oracle.mat3_inverse(k))
+        compare(oracle, gv, ov, cam, width=w, height=h, what="cast %d at %dx%d" % (rnd, w, h))
+        if rnd == 3:       # vertices only in between (the other resolve kernel)
+            Vv = tsdf_amd.GPURaycaster(w, h).get_vertices(gv, cam)
+            Vo, _ = ov.raycast(w, h, cam.pose(), cam.kinv(), nthreads=oracle.max_threads())
+            assert_same_floats(Vv, Vo, "vertices only, cast %d" % rnd)
+
+
 def test_ray_timeout_cap_of_4402_samples(oracle):
     # Q8: with an empty (all +trunc) grid every ray marches until the far face or the 4402-sample cap; at
     # 448^3 / 3000 mm the step is 0.638 mm, so the cap (2808 mm of camera-z) comes first

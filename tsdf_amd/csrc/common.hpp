@@ -139,6 +139,7 @@ struct tsdf_volume {
     uint32_t *ray_best;      // two copies of ray_best_cap words, used alternately (ray_best_side)
     size_t ray_best_cap;
     int ray_best_side;
+    size_t ray_best_pixels;  // image size of the last march (a different one refills both copies)
     int ray_best_dirty;      // 1 = a march was started whose resolve kernel was not launched: refill before the next one
     // stretches of rays the first ray-cast kernel hands to the tail kernel: uint2 per piece + {appended, taken}
     void *tail_entries;

@@ -1285,6 +1285,10 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
         TSDF_HIP(hipMalloc((void **)&v->tail_count, 2 * sizeof(uint32_t)), "ray tail counter alloc");
         v->ray_best_dirty = 1;
     }
+    if (v->ray_best_pixels != n_pix) {   // the copy this march's resolve does not read was reset for another image size
+        v->ray_best_pixels = n_pix;
+        v->ray_best_dirty = 1;
+    }
     if (v->ray_best_dirty) {   // otherwise the previous march's resolve kernel left both reset
         TSDF_HIP(hipMemsetAsync(v->ray_best, 0xff, 2 * v->ray_best_cap * sizeof(uint32_t), v->stream), "ray result reset");
         TSDF_HIP(hipMemsetAsync(v->tail_count, 0, 2 * sizeof(uint32_t), v->stream), "ray tail counter reset");
