@@ -5,6 +5,7 @@
 // previous_tsdf == trunc: Q7, 4402-sample cap: Q8, t accumulated by repeated float adds: Q9, unclamped
 // point in the interpolation weights: Q10); fp contraction is off so every evaluated sample is
 // bit-identical.  How the loop is reorganised for wave64 is described at process_ray_kernel below.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 
@@ -251,7 +252,7 @@ constexpr int kRaySegmentsDefault = 6;      // sample ranges a ray's march is sp
 constexpr int kTailGridDefault = 256 * 10;   // workgroups of the tail kernel (5 fit a CU at 86 VGPRs: two rounds)
 // What is left of a ray's range when the pass budget runs out is queued in up to kTailPieces pieces of at least
 // kTailPieceMin samples, so that a long stretch is marched by several groups of the tail kernel at once.
-constexpr int kTailPieces = 32, kTailPieceMin = 64;
+constexpr int kTailPieces = 16, kTailPieceMin = 64;
 constexpr int kTripBudgetDefault = 18;      // passes of the first kernel's loop before unfinished rays go to the tail kernel
 static int ray_segments() {
     static const int n = [] {
@@ -1265,7 +1266,11 @@ template <bool SLAB>
 static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *normals = nullptr) {
     const size_t n_pix = (size_t)rp.width * rp.height;
     const int n_segments = SLAB ? slab_ray_ranges(v) : ray_segments();
-    const size_t n_entries = n_pix * n_segments * kTailPieces;   // every range unfinished and cut into all its pieces
+    // queue capacity: every range unfinished and cut into all the pieces its length allows (a range holds at most
+    // ceil(kMaxSamples / n_segments) samples, whole volume or slab)
+    const int max_len = (kMaxSamples + n_segments - 1) / n_segments;
+    const int max_pieces = std::min(kTailPieces, (max_len + tail_piece_min() - 1) / tail_piece_min());
+    const size_t n_entries = n_pix * n_segments * (size_t)std::max(max_pieces, 1);
     if (v->ray_best_cap < n_pix) {
         if (v->ray_best) (void)hipFree(v->ray_best);
         v->ray_best = nullptr;
