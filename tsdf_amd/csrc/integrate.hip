@@ -18,7 +18,7 @@
 //        (c) for rigid poses / standard intrinsics (surface z == depth, w == 1 exactly): if the nearest corner
 //            lies more than trunc behind the largest depth of those tiles, every sdf is < -trunc.
 //      Surviving bricks are appended to a compact list.
-//   3. integrate_kernel: a persistent grid walks the list.  Per voxel, the reference's arithmetic in its
+//   3. integrate_kernel: one workgroup per listed brick.  Per voxel, the reference's arithmetic in its
 //      operation order (fp contraction is off): world_to_pixel -> depth gather -> pixel_to_camera.z ->
 //      world_to_camera.z -> sdf -> running weighted mean.  Distance and weight are loaded only under the
 //      update predicate and stored with the same mask, so the algorithmic traffic is 16 B per updated voxel +
@@ -500,7 +500,12 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
                            width, height, v->tile_max, tiles_x, depth_test, v->brick_list, boxes, count, plane_const, n_plane_const);
     }
     dim3 block(kTileX, kTileY, 1);
-    dim3 grid((unsigned)std::min<size_t>(n_bricks, 256 * 6));  // resident at once (SGPR-limited to 6-7 blocks per CU)
+    // One workgroup per brick of the grid; those beyond the list's length leave at once.  The dispatcher hands the next brick to
+    // whichever compute unit frees a slot, which balances the uneven bricks better than a resident grid walking the list
+    // with a fixed stride did (0.136 vs 0.144 ms: 5 300 bricks over 1 536 resident workgroups are 3.3 rounds).
+    // TSDF_INT_GRID_PER_CU = n > 0 restores a resident grid of n workgroups per compute unit (tuning aid).
+    static const int grid_per_cu = [] { const char *e = getenv("TSDF_INT_GRID_PER_CU"); return e ? atoi(e) : 0; }();
+    dim3 grid((unsigned)(grid_per_cu > 0 ? std::min<size_t>(n_bricks, (size_t)256 * grid_per_cu) : n_bricks));
     bool finite = true;
     for (int i = 0; i < 16; i++) finite = finite && std::isfinite(inv_pose[i]);
     for (int i = 0; i < 9; i++) finite = finite && std::isfinite(k[i]) && std::isfinite(kinv[i]);
