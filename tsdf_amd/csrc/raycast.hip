@@ -940,9 +940,10 @@ __global__ __launch_bounds__(256) void process_ray_tail_kernel(const float *__re
                                                                const OccGrid occ, const float *__restrict__ t_table,
                                                                const TailQueue tail) {
     __shared__ float T[kTableLen];
+    const uint32_t n_entries = tail.count[0];
+    if ((size_t)blockIdx.x * 4u * (64u / tail.lanes) >= n_entries) return;   // nothing for this workgroup: skip the staging too
     for (int i = (int)threadIdx.x; i < kTableLen; i += 256) T[i] = t_table[i];
     __syncthreads();
-    const uint32_t n_entries = tail.count[0];
     const uint32_t lane = threadIdx.x & 63u, lanes_per_ray = tail.lanes;
     const int j = (int)(lane & (lanes_per_ray - 1)), leader = (int)(lane & ~(uint32_t)(lanes_per_ray - 1));
     const float step_size = T[1];
