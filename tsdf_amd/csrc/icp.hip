@@ -29,10 +29,10 @@ struct tsdf_icp {
     uint16_t *depth[3];                      // pyramid scratch (used by both init calls)
     float *vmap_prev[3], *nmap_prev[3];      // model
     float *vmap_curr[3], *nmap_curr[3];      // current frame
-    float *partial;                          // kIcpBlocks x 32 floats: per-block sums of the 29 products
-    unsigned int *ticket;                    // workgroups of the current step that have delivered their sums
-    double *state;                           // device: [0..15] T (column-major), [16..17] residual, inliers,
-                                             //         [18..53] A (float values), [54..59] b
+    float *partial;                          // 2 x kIcpBlocks x 32 floats: per-block sums of the 29 products (two steps)
+    double *state;                           // device, 2 x kIcpStateDoubles: [0..15] T (column-major), [16..17] residual,
+                                             //         inliers, [18..53] A (float values), [54..59] b
+    int side;                                // which copy of state / partial holds the latest step
 };
 
 namespace tsdf {
@@ -129,18 +129,36 @@ __device__ inline int float2int_rn(float f) {
 // Reduction::operator() (Cuda/estimate.cu:139-209): projective association of the current frame's vertices into the
 // model, distance / angle gates, the 27 upper-triangular products of the row (n, v x n, n.(v_prev - v)) + inlier count.
 // The pose is read from the device state (T as doubles, narrowed to float like `rotationMatrix().cast<float>()`).
-__device__ inline void icp_finish_step(const float *partial, int n_blocks, double *state, int update);
+__device__ inline void icp_finish_step(const float *partial, int n_blocks, const double *state_in, int update, double *pose_out,
+                                       double *state_out);
 
-__global__ __launch_bounds__(kIcpThreads) void icp_reduce_kernel(double *state, const float *__restrict__ vmap_curr,
+// One Gauss-Newton step's sums.  `pending` != 0: the previous launch left its per-workgroup sums in partial_prev and the
+// pose they were taken at in state_in; EVERY workgroup finishes that step first (second reduction stage, solve, pose
+// update: icp_finish_step, the same fixed-order arithmetic, so all arrive at the same pose) and workgroup 0 records
+// it in state_out.  The kernel boundary orders the two launches -- no fence, no ticket, no workgroup waiting for the others
+// across the chip's eight L2s (that hand-over cost more than the whole reduction: 24 -> 14 us per step).
+__global__ __launch_bounds__(kIcpThreads) void icp_reduce_kernel(const double *__restrict__ state_in, double *__restrict__ state_out,
+                                                                const float *__restrict__ partial_prev, int pending,
+                                                                const float *__restrict__ vmap_curr,
                                                                 const float *__restrict__ nmap_curr,
                                                                 const float *__restrict__ vmap_prev,
                                                                 const float *__restrict__ nmap_prev, int rows, int cols,
                                                                 float fx, float fy, float cx, float cy, float dist_thresh,
-                                                                float angle_thresh, float *partial, unsigned int *ticket, int update) {
+                                                                float angle_thresh, float *__restrict__ partial) {
+    __shared__ double pose[16];
+    if (pending) {
+        icp_finish_step(partial_prev, (int)gridDim.x, state_in, 1, pose, blockIdx.x == 0 ? state_out : nullptr);
+    } else {
+        if (threadIdx.x < 16) {
+            pose[threadIdx.x] = state_in[threadIdx.x];
+            if (blockIdx.x == 0) state_out[threadIdx.x] = state_in[threadIdx.x];
+        }
+    }
+    __syncthreads();
     float R[9], t[3];  // column-major
     for (int c = 0; c < 3; c++)
-        for (int r = 0; r < 3; r++) R[c * 3 + r] = (float)state[c * 4 + r];
-    for (int r = 0; r < 3; r++) t[r] = (float)state[12 + r];
+        for (int r = 0; r < 3; r++) R[c * 3 + r] = (float)pose[c * 4 + r];
+    for (int r = 0; r < 3; r++) t[r] = (float)pose[12 + r];
 
     float sum[29];
 #pragma unroll
@@ -204,18 +222,14 @@ __global__ __launch_bounds__(kIcpThreads) void icp_reduce_kernel(double *state, 
     if (threadIdx.x < 29) {
         partial[blockIdx.x * 32 + threadIdx.x] =
             ((shared[0][threadIdx.x] + shared[1][threadIdx.x]) + shared[2][threadIdx.x]) + shared[3][threadIdx.x];
-        __threadfence();  // the partial sums are visible device-wide before this workgroup takes its ticket
     }
-    // The workgroup that takes the last ticket finds every partial sum written and finishes the step (second reduction
-    // stage, solve, pose update) in the same launch: one kernel per Gauss-Newton iteration.
-    __shared__ bool is_last;
-    __syncthreads();
-    if (threadIdx.x == 0) is_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
-    __syncthreads();
-    if (!is_last) return;
-    if (threadIdx.x == 0) *ticket = 0;  // ready for the next launch
-    __threadfence();
-    icp_finish_step(partial, (int)gridDim.x, state, update);
+}
+
+// Finishes the last step of a sequence (nothing follows whose prologue would): one workgroup.
+__global__ __launch_bounds__(kIcpThreads) void icp_finish_kernel(const double *__restrict__ state_in, double *__restrict__ state_out,
+                                                                const float *__restrict__ partial_prev, int n_blocks, int update) {
+    __shared__ double pose[16];
+    icp_finish_step(partial_prev, n_blocks, state_in, update, pose, state_out);
 }
 
 // x = A^-1 b, 6x6 symmetric positive (semi-)definite, LDL^T with diagonal pivoting in double -- the job of
@@ -379,10 +393,10 @@ __device__ inline void se3_exp(const double *a, double *E) {
 
 // Second stage of the reduction (reduceSum<29>, Cuda/estimate.cu:70-85) + the host part of estimateStep /
 // getIncrementalTransformation: A, b, residual, inliers; when `update` != 0 also x = A^-1 b and T <- exp(x) * T.
-// Run by the 256 threads of the workgroup that finishes last (see icp_reduce_kernel).
-// (Plain loads are enough for the other workgroups' sums: the fence + ticket order them, and this CU's L1 cannot hold a
-// stale copy -- nobody reads `partial` before this point in a launch, and the cache line of a workgroup's row is its own.)
-__device__ inline void icp_finish_step(const float *partial, int n_blocks, double *state, int update) {
+// Run by all 256 threads of a workgroup; the pose after the step goes to pose_out (shared memory, for the caller's
+// __syncthreads), the whole state to state_out when that is not null.  The sums were written by the previous launch.
+__device__ inline void icp_finish_step(const float *partial, int n_blocks, const double *state_in, int update, double *pose_out,
+                                       double *state_out) {
     // 29 entries x 8 groups of blocks: thread (entry, group) adds its 32 blocks in order (loads issued together), then
     // one thread per entry adds the 8 group sums in order -- a fixed tree, in double
     __shared__ double group_sum[8][32];
@@ -417,22 +431,29 @@ __device__ inline void icp_finish_step(const float *partial, int n_blocks, doubl
             if (j == 6) b[i] = value;
             else A[j * 6 + i] = A[i * 6 + j] = value;
         }
-    state[16] = total[27];
-    state[17] = total[28];
-    for (int i = 0; i < 36; i++) state[18 + i] = A[i];
-    for (int i = 0; i < 6; i++) state[54 + i] = b[i];
-    if (!update) return;
-    double x[6], E[16], T[16], out[16];
-    if (!ldlt_solve6_unpivoted(A, b, x)) ldlt_solve6(A, b, x);
-    se3_exp(x, E);
-    for (int i = 0; i < 16; i++) T[i] = state[i];
-    for (int c = 0; c < 4; c++)
-        for (int r = 0; r < 4; r++) {
-            double s = 0;
-            for (int k = 0; k < 4; k++) s += E[k * 4 + r] * T[c * 4 + k];
-            out[c * 4 + r] = s;
-        }
-    for (int i = 0; i < 16; i++) state[i] = out[i];
+    if (state_out) {
+        state_out[16] = total[27];
+        state_out[17] = total[28];
+        for (int i = 0; i < 36; i++) state_out[18 + i] = A[i];
+        for (int i = 0; i < 6; i++) state_out[54 + i] = b[i];
+    }
+    double T[16], out[16];
+    for (int i = 0; i < 16; i++) T[i] = out[i] = state_in[i];
+    if (update) {
+        double x[6], E[16];
+        if (!ldlt_solve6_unpivoted(A, b, x)) ldlt_solve6(A, b, x);
+        se3_exp(x, E);
+        for (int c = 0; c < 4; c++)
+            for (int r = 0; r < 4; r++) {
+                double s = 0;
+                for (int k = 0; k < 4; k++) s += E[k * 4 + r] * T[c * 4 + k];
+                out[c * 4 + r] = s;
+            }
+    }
+    for (int i = 0; i < 16; i++) {
+        pose_out[i] = out[i];
+        if (state_out) state_out[i] = out[i];
+    }
 }
 
 static void free_icp(tsdf_icp *f) {
@@ -444,7 +465,6 @@ static void free_icp(tsdf_icp *f) {
         if (f->nmap_curr[i]) (void)hipFree(f->nmap_curr[i]);
     }
     if (f->partial) (void)hipFree(f->partial);
-    if (f->ticket) (void)hipFree(f->ticket);
     if (f->state) (void)hipFree(f->state);
     delete f;
 }
@@ -469,11 +489,23 @@ static int build_maps(tsdf_icp *f, float **vmaps, float **nmaps, float depth_cut
     return TSDF_OK;
 }
 
-static void launch_step(tsdf_icp *f, int level, int update) {
+// Launches the sums of one step at `level`, taken at the pose the pending step (if any) leads to.
+static void launch_step(tsdf_icp *f, int level, int pending) {
     const int rows = f->height >> level, cols = f->width >> level, div = 1 << level;
-    hipLaunchKernelGGL(icp_reduce_kernel, dim3(kIcpBlocks), dim3(kIcpThreads), 0, f->stream, f->state, f->vmap_curr[level],
+    const int in = f->side, out = 1 - f->side;
+    hipLaunchKernelGGL(icp_reduce_kernel, dim3(kIcpBlocks), dim3(kIcpThreads), 0, f->stream, f->state + in * kIcpStateDoubles,
+                       f->state + out * kIcpStateDoubles, f->partial + (size_t)in * kIcpBlocks * 32, pending, f->vmap_curr[level],
                        f->nmap_curr[level], f->vmap_prev[level], f->nmap_prev[level], rows, cols, f->fx / div, f->fy / div,
-                       f->cx / div, f->cy / div, f->dist_thresh, f->angle_thresh, f->partial, f->ticket, update);
+                       f->cx / div, f->cy / div, f->dist_thresh, f->angle_thresh, f->partial + (size_t)out * kIcpBlocks * 32);
+    f->side = out;
+}
+
+// Finishes the step whose sums the last launch_step left (with or without the pose update).
+static void launch_finish(tsdf_icp *f, int update) {
+    const int in = f->side, out = 1 - f->side;
+    hipLaunchKernelGGL(icp_finish_kernel, dim3(1), dim3(kIcpThreads), 0, f->stream, f->state + in * kIcpStateDoubles,
+                       f->state + out * kIcpStateDoubles, f->partial + (size_t)in * kIcpBlocks * 32, kIcpBlocks, update);
+    f->side = out;
 }
 
 }  // namespace tsdf
@@ -504,11 +536,9 @@ int tsdf_icp_create(int width, int height, float cx, float cy, float fx, float f
             if (e == hipSuccess) e = hipMemset(*maps[m], 0, px * 3 * sizeof(float));
         }
     }
-    if (e == hipSuccess) e = hipMalloc((void **)&f->partial, (size_t)kIcpBlocks * 32 * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void **)&f->ticket, sizeof(unsigned int));
-    if (e == hipSuccess) e = hipMemset(f->ticket, 0, sizeof(unsigned int));
-    if (e == hipSuccess) e = hipMalloc((void **)&f->state, kIcpStateDoubles * sizeof(double));
-    if (e == hipSuccess) e = hipMemset(f->state, 0, kIcpStateDoubles * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&f->partial, (size_t)2 * kIcpBlocks * 32 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&f->state, 2 * kIcpStateDoubles * sizeof(double));
+    if (e == hipSuccess) e = hipMemset(f->state, 0, 2 * kIcpStateDoubles * sizeof(double));
     if (e != hipSuccess) {
         free_icp(f);
         return hip_fail(e, "ICP alloc failed");
@@ -569,11 +599,12 @@ int tsdf_icp_estimate_step(tsdf_icp *f, int level, const float R[9], const float
         for (int r = 0; r < 3; r++) T[c * 4 + r] = R[c * 3 + r];
     for (int r = 0; r < 3; r++) T[12 + r] = t[r];
     T[15] = 1.0;
-    TSDF_HIP(hipMemcpyAsync(f->state, T, sizeof(T), hipMemcpyHostToDevice, f->stream), "ICP pose upload");
+    TSDF_HIP(hipMemcpyAsync(f->state + f->side * kIcpStateDoubles, T, sizeof(T), hipMemcpyHostToDevice, f->stream), "ICP pose upload");
     launch_step(f, level, 0);
+    launch_finish(f, 0);
     TSDF_HIP(hipGetLastError(), "ICP estimate kernels failed");
     double out[kIcpStateDoubles];
-    TSDF_HIP(hipMemcpyAsync(out, f->state, sizeof(out), hipMemcpyDeviceToHost, f->stream), "ICP result download");
+    TSDF_HIP(hipMemcpyAsync(out, f->state + f->side * kIcpStateDoubles, sizeof(out), hipMemcpyDeviceToHost, f->stream), "ICP result download");
     TSDF_HIP(hipStreamSynchronize(f->stream), "ICP estimate");
     residual_inliers[0] = (float)out[16];
     residual_inliers[1] = (float)out[17];
@@ -584,13 +615,19 @@ int tsdf_icp_estimate_step(tsdf_icp *f, int level, const float R[9], const float
 
 int tsdf_icp_get_incremental_transformation(tsdf_icp *f, double T_prev_curr[16], float *last_error, float *last_inliers) {
     TSDF_REQUIRE(f && T_prev_curr, "tsdf_icp_get_incremental_transformation: null argument");
-    TSDF_HIP(hipMemcpyAsync(f->state, T_prev_curr, 16 * sizeof(double), hipMemcpyHostToDevice, f->stream), "ICP pose upload");
+    TSDF_HIP(hipMemcpyAsync(f->state + f->side * kIcpStateDoubles, T_prev_curr, 16 * sizeof(double), hipMemcpyHostToDevice, f->stream),
+             "ICP pose upload");
     const int iterations[kIcpLevels] = {10, 5, 4};  // ICPOdometry.cpp:99-101
+    int pending = 0;   // every launch finishes the step before it, the last step gets a launch of its own
     for (int i = kIcpLevels - 1; i >= 0; i--)
-        for (int j = 0; j < iterations[i]; j++) launch_step(f, i, 1);
+        for (int j = 0; j < iterations[i]; j++) {
+            launch_step(f, i, pending);
+            pending = 1;
+        }
+    launch_finish(f, 1);
     TSDF_HIP(hipGetLastError(), "ICP kernels failed");
     double out[18];
-    TSDF_HIP(hipMemcpyAsync(out, f->state, sizeof(out), hipMemcpyDeviceToHost, f->stream), "ICP pose download");
+    TSDF_HIP(hipMemcpyAsync(out, f->state + f->side * kIcpStateDoubles, sizeof(out), hipMemcpyDeviceToHost, f->stream), "ICP pose download");
     TSDF_HIP(hipStreamSynchronize(f->stream), "ICP");
     std::memcpy(T_prev_curr, out, 16 * sizeof(double));
     // lastError = sqrt(residual) / inliers, lastInliers = inliers of the last iteration (ICPOdometry.cpp:127-128)
