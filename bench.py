@@ -121,7 +121,7 @@ def main():
     filt2 = [filt_dev, torch.empty_like(filt_dev)] if overlap else [filt_dev, filt_dev]
     prefiltered = {}        # frame index -> (event on the side stream, timing pair or None)
 
-    def step(i, timed):
+    def step(i, timed, timed_next=False):
         e = [torch.cuda.Event(enable_timing=True) for _ in range(6)] if timed else None
         cam = cams[i]
         fbuf = filt2[i % 2]
@@ -149,7 +149,7 @@ def main():
                 cast = torch.cuda.Event()
                 cast.record(stream)            # integrate(i) and the slab cast are done: the other buffer is free, the CUs too
                 side.wait_event(cast)
-                pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if timed else None
+                pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if timed_next else None   # (it is the next step's filter)
                 if pair: pair[0].record(side)
                 bil.filter_device(depth_dev[i + 1].data_ptr(), filt2[(i + 1) % 2].data_ptr(), W, H, bits=16, stream=side.cuda_stream)
                 if pair: pair[1].record(side)
@@ -190,7 +190,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(Wu, Wu + K):
-        step(i, (i - Wu) % period == 0)
+        step(i, (i - Wu) % period == 0, (i + 1 - Wu) % period == 0 and i + 1 < Wu + K)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -200,7 +200,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    stage_ms = {s: float(np.mean([a.elapsed_time(b) for a, b in ev[s]])) for s in stage_names}
+    stage_ms = {s: (float(np.mean([a.elapsed_time(b) for a, b in ev[s]])) if ev[s] else None) for s in stage_names}   # (None: not sampled)
     kern = {w: vol.kernel_time(w) for w in ("integrate", "raycast", "raycast_tail")}     # (launches, avg ms), kernel only
     vol.set_timing(False)
     ms_per_step = elapsed * 1e3 / K
@@ -228,7 +228,7 @@ def main():
                    "overlap": "bilateral(i+1) on a second stream during the exchange of frame i" if overlap else "none"},
         "integrate_mvoxels_per_s": round(N_vox / (stage_ms["integrate"] * 1e-3) / 1e6, 1),
         "raycast_mrays_per_s": round(W * H / ((stage_ms["raycast"] + stage_ms["exchange"] + stage_ms["normals"]) * 1e-3) / 1e6, 2),
-        "stage_ms": {s: round(v, 4) for s, v in stage_ms.items()},
+        "stage_ms": {s: (round(v, 4) if v is not None else None) for s, v in stage_ms.items()},
         # sum of the finite vertex coordinates of the last frame's picture: equal between runs that differ only in schedule
         "last_frame_vertex_checksum": float(torch.nan_to_num(vert_dev.double(), nan=0.0).sum().item()),
     }
@@ -286,7 +286,15 @@ def main():
             out["cpu_baseline"] = cpu_baseline(vol, frames[last], cams[last], n, args.physical, args.cpu_budget_s)
 
     if rank == 0:
-        print(json.dumps(out))
+        def finite(o):      # strict JSON: a non-finite number (an unsampled average, an empty ratio) becomes null
+            if isinstance(o, float):
+                return o if math.isfinite(o) else None
+            if isinstance(o, dict):
+                return {k: finite(v) for k, v in o.items()}
+            if isinstance(o, (list, tuple)):
+                return [finite(v) for v in o]
+            return o
+        print(json.dumps(finite(out), allow_nan=False))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
