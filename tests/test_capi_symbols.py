@@ -45,6 +45,8 @@ def test_invalid_sizes_are_rejected_before_touching_the_device():
         tsdf_amd.TSDFVolume((8, 8, 8), (3000.0, 0.0, 3000.0))
     with pytest.raises(ValueError):
         tsdf_amd.TSDFVolume((70000, 8, 8))
+    with pytest.raises(ValueError, match="too large"):      # the ray caster indexes 4^3-voxel bricks with 32 bits
+        tsdf_amd.TSDFVolume((65535, 65535, 65535), (1e6, 1e6, 1e6))
     with pytest.raises(ValueError):
         tsdf_amd.BilateralFilter(0.0, 2.0)
 
