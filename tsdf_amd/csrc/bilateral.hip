@@ -24,16 +24,19 @@
 namespace tsdf {
 
 constexpr int kBTile = 16;
-constexpr int kMaxRadius = 24;  // LDS tile (16+2*24)^2 * 2 B = 8 KiB
+constexpr int kMaxRadius = 24;  // LDS tile (16+2*24)^2 * 10 B = 40 KiB
 
 template <typename PIX>
 __global__ __launch_bounds__(256) void bilateral_kernel(const PIX *__restrict__ in, PIX *__restrict__ out,
                                                         int width, int height, int radius,
                                                         const float *__restrict__ kernel,
                                                         const float *__restrict__ similarity) {
+    // the tile twice: as doubles (the widened operand of the reference's product, converted once per pixel here instead of
+    // once per tap) and as 16-bit integers (for the intensity difference)
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    uint16_t *tile = reinterpret_cast<uint16_t *>(smem_raw);
     const int span = kBTile + 2 * radius;
+    double *tile_d = reinterpret_cast<double *>(smem_raw);
+    uint16_t *tile = reinterpret_cast<uint16_t *>(tile_d + span * span);
     const int tx0 = blockIdx.x * kBTile - radius;
     const int ty0 = blockIdx.y * kBTile - radius;
     for (int i = threadIdx.x; i < span * span; i += 256) {
@@ -42,6 +45,7 @@ __global__ __launch_bounds__(256) void bilateral_kernel(const PIX *__restrict__ 
         uint16_t v = 0;
         if (gx >= 0 && gx < width && gy >= 0 && gy < height) v = in[(size_t)gy * width + gx];
         tile[i] = v;
+        tile_d[i] = (double)(int)v;
     }
     __syncthreads();
 
@@ -59,12 +63,13 @@ __global__ __launch_bounds__(256) void bilateral_kernel(const PIX *__restrict__ 
     float sum = 0;
     for (int cx = fx; cx <= lx_; cx++) {
         const uint16_t *col = tile + (cx - tx0);
+        const double *col_d = tile_d + (cx - tx0);
         const float *krow = kernel + (cx - fx) * ny;
         for (int cy = fy; cy <= ly_; cy++) {
             int conv = col[(cy - ty0) * span];
             int delta = abs(conv - current);
             const float weight = krow[cy - fy] * similarity[delta];   // the float product the reference widens (:99)
-            sum = (float)((double)sum + ((double)weight * (double)conv));
+            sum = (float)((double)sum + ((double)weight * col_d[(cy - ty0) * span]));
             // total_weight + weight evaluated in double and narrowed (:102) == the fp32 sum: both operands are floats, so
             // the double sum is exact unless the smaller is below 2^-29 of the larger, and then both roundings return the
             // larger operand (weights are >= 0).  One fp32 add instead of two conversions and a double add.
@@ -78,7 +83,7 @@ template <typename PIX>
 static int launch_bilateral(const tsdf_bilateral *f, const PIX *in, PIX *out, int width, int height, hipStream_t s) {
     dim3 grid((width + kBTile - 1) / kBTile, (height + kBTile - 1) / kBTile);
     int span = kBTile + 2 * f->radius;
-    size_t smem = (size_t)span * span * sizeof(uint16_t);
+    size_t smem = (size_t)span * span * (sizeof(double) + sizeof(uint16_t));
     hipLaunchKernelGGL((bilateral_kernel<PIX>), grid, dim3(256), smem, s, in, out, width, height, f->radius,
                        f->kernel_dev, f->similarity_dev);
     TSDF_HIP(hipGetLastError(), "bilateral filter kernel failed");
