@@ -314,8 +314,8 @@ static int trip_budget() {
 struct SkipCtx {
     float inv_vx, inv_vy, inv_vz;  // ~ 1 / voxel size
     float inv_step;                // ~ 1 / step
-    float tx, ty, tz;              // ~ |voxel size / dir| : t needed to cross one voxel (inf for a zero component)
-    bool px_, py_, pz_;            // dir component > 0
+    float tx, ty, tz;              // ~ voxel size / dir, signed: t needed to cross one voxel (+inf for a zero component)
+    float posx, posy, posz;        // 1 when the ray moves towards +axis (or not at all on that axis), else 0
     float su, sv, sw;              // ~ |step * dir / voxel size| : movement per sample in cell units, per axis
     float eps;                     // guard band at the dual-cell faces, in voxels
     bool skip_ok;                  // skipping allowed for this ray (short enough steps)
@@ -327,14 +327,20 @@ struct SkipCtx {
 // good to ~1e-2 voxel, which the one-voxel slack of the brick-level flags absorbs), ALL = false returns floor(x) and so
 // keeps up to one step of margin (cell-level boxes, whose only slack is eps).
 template <bool ALL>
-__device__ inline int samples_to_exit(float fx, float fy, float fz, const SkipCtx &c, float lox, float loy, float loz,
-                                      float hix, float hiy, float hiz) {
-    const float ex = (c.px_ ? hix - fx : fx - lox) * c.tx;
-    const float ey = (c.py_ ? hiy - fy : fy - loy) * c.ty;
-    const float ez = (c.pz_ ? hiz - fz : fz - loz) * c.tz;
+__device__ inline int samples_until(float ax, float ay, float az, const SkipCtx &c) {
+    // a = signed distance (voxels) from the sample to the face of the box the ray leaves through on each axis: it has the
+    // sign of the direction component, like t per voxel, so the products are the (non-negative) exit parameters
+    const float ex = ax * c.tx, ey = ay * c.ty, ez = az * c.tz;
     // fminf ignores a NaN (0 * inf when the ray runs inside a face of the box)
     const float x = fminf(ex, fminf(ey, ez)) * c.inv_step;
     return (int)fminf(fmaxf(ALL ? ceilf(x) : x, 1.0f), 8192.0f);
+}
+// ... for the axis-aligned cube [lo, lo + size)^3 given by its integer corner: the exit face is lo + size on the axes the
+// ray ascends, lo on the others.
+template <bool ALL>
+__device__ inline int samples_to_exit(float fx, float fy, float fz, const SkipCtx &c, int lox, int loy, int loz, float size) {
+    return samples_until<ALL>(__builtin_fmaf(size, c.posx, (float)lox) - fx, __builtin_fmaf(size, c.posy, (float)loy) - fy,
+                              __builtin_fmaf(size, c.posz, (float)loz) - fz, c);
 }
 
 // Locates the sample at voxel coordinate f = p / vs in the brick grid.  Returns true when the samples from this
@@ -355,14 +361,12 @@ __device__ inline bool locate(float fx, float fy, float fz, const SkipCtx &c, co
         const int cz0 = (vz >> kSlabSkipShift) << kSlabSkipShift, bz0 = (vz >> kBrickShift) << kBrickShift;
         if (cz0 + kSlabSkip < own_lo || cz0 - 2 >= own_hi) {
             const int cx0 = (vx >> kSlabSkipShift) << kSlabSkipShift, cy0 = (vy >> kSlabSkipShift) << kSlabSkipShift;
-            n = samples_to_exit<true>(fx, fy, fz, c, (float)cx0, (float)cy0, (float)cz0, (float)(cx0 + kSlabSkip),
-                                (float)(cy0 + kSlabSkip), (float)(cz0 + kSlabSkip));
+            n = samples_to_exit<true>(fx, fy, fz, c, cx0, cy0, cz0, (float)kSlabSkip);
             return true;
         }
         if (bz0 + kBrick < own_lo || bz0 - 2 >= own_hi) {
             const int bx0 = (vx >> kBrickShift) << kBrickShift, by0 = (vy >> kBrickShift) << kBrickShift;
-            n = samples_to_exit<true>(fx, fy, fz, c, (float)bx0, (float)by0, (float)bz0, (float)(bx0 + kBrick), (float)(by0 + kBrick),
-                                (float)(bz0 + kBrick));
+            n = samples_to_exit<true>(fx, fy, fz, c, bx0, by0, bz0, (float)kBrick);
             return true;
         }
     }
@@ -371,7 +375,7 @@ __device__ inline bool locate(float fx, float fy, float fz, const SkipCtx &c, co
     // aligned block of 4 * 2^(reach-1) voxels per side (the brick itself when reach is 0)
     const int shift = kBrickShift + max(reach, 1) - 1, size = 1 << shift;
     const int x0 = (vx >> shift) << shift, y0 = (vy >> shift) << shift, z0 = (vz >> shift) << shift;
-    n = samples_to_exit<true>(fx, fy, fz, c, (float)x0, (float)y0, (float)z0, (float)(x0 + size), (float)(y0 + size), (float)(z0 + size));
+    n = samples_to_exit<true>(fx, fy, fz, c, x0, y0, z0, (float)size);
     return reach != 0;
 }
 
@@ -420,10 +424,10 @@ struct SampleWork {  // diagnostics (STATS)
 // The per-ray part of the skipping arithmetic.
 template <bool SKIP>
 __device__ inline void set_ray(SkipCtx &sc, const RayState &r, float step_size, const Geom &g) {
-    sc.tx = r.dx != 0 ? fabsf(g.vs.x * __builtin_amdgcn_rcpf(r.dx)) : INFINITY;
-    sc.ty = r.dy != 0 ? fabsf(g.vs.y * __builtin_amdgcn_rcpf(r.dy)) : INFINITY;
-    sc.tz = r.dz != 0 ? fabsf(g.vs.z * __builtin_amdgcn_rcpf(r.dz)) : INFINITY;
-    sc.px_ = r.dx > 0; sc.py_ = r.dy > 0; sc.pz_ = r.dz > 0;
+    sc.tx = r.dx != 0 ? g.vs.x * __builtin_amdgcn_rcpf(r.dx) : INFINITY;
+    sc.ty = r.dy != 0 ? g.vs.y * __builtin_amdgcn_rcpf(r.dy) : INFINITY;
+    sc.tz = r.dz != 0 ? g.vs.z * __builtin_amdgcn_rcpf(r.dz) : INFINITY;
+    sc.posx = r.dx < 0 ? 0.0f : 1.0f; sc.posy = r.dy < 0 ? 0.0f : 1.0f; sc.posz = r.dz < 0 ? 0.0f : 1.0f;
     sc.su = fabsf(r.dx) * step_size * sc.inv_vx; sc.sv = fabsf(r.dy) * step_size * sc.inv_vy; sc.sw = fabsf(r.dz) * step_size * sc.inv_vz;
     // one step must stay well inside the one-voxel slack on every axis
     sc.skip_ok = SKIP && fabsf(r.dx) * step_size < 0.25f * g.vs.x && fabsf(r.dy) * step_size < 0.25f * g.vs.y &&
@@ -488,9 +492,9 @@ __device__ inline float process_sample(float t, int k, const RayState &r, const 
                 // up to the exit of that brick (shrunk by eps, in cell coordinates) cannot hit.
                 const int qx = lx >> kBrickShift, qy = ly >> kBrickShift, qz = lz >> kBrickShift;
                 const float e = sc.eps;
-                const int n_cb = samples_to_exit<false>(cx, cy, cz, sc, (float)(qx << kBrickShift) + e, (float)(qy << kBrickShift) + e,
-                                                        (float)(qz << kBrickShift) + e, (float)((qx + 1) << kBrickShift) - e,
-                                                        (float)((qy + 1) << kBrickShift) - e, (float)((qz + 1) << kBrickShift) - e);
+                const int n_cb = samples_until<false>(((float)(qx << kBrickShift) + __builtin_fmaf(kBrick - 2.0f * e, sc.posx, e)) - cx,
+                                                      ((float)(qy << kBrickShift) + __builtin_fmaf(kBrick - 2.0f * e, sc.posy, e)) - cy,
+                                                      ((float)(qz << kBrickShift) + __builtin_fmaf(kBrick - 2.0f * e, sc.posz, e)) - cz, sc);
                 bc.k_cellbrick_end = k + n_cb;
                 bc.cellbrick_clear = occ.cell[(__umul24((uint32_t)qz, occ.nby) + (uint32_t)qy) * occ.nbx + (uint32_t)qx] == 0;
             }
@@ -500,7 +504,8 @@ __device__ inline float process_sample(float t, int k, const RayState &r, const 
             }
             if (STATS) work.cell_tests++;
             // samples until the ray leaves the cell shrunk by eps
-            const int n_cell = samples_to_exit<false>(rx, ry, rz, sc, cell_lo, cell_lo, cell_lo, cell_hi, cell_hi, cell_hi);
+            const int n_cell = samples_until<false>(__builtin_fmaf(cell_hi - cell_lo, sc.posx, cell_lo) - rx, __builtin_fmaf(cell_hi - cell_lo, sc.posy, cell_lo) - ry,
+                                                    __builtin_fmaf(cell_hi - cell_lo, sc.posz, cell_lo) - rz, sc);
             if (SLAB && !((uint32_t)lz >= rp.own_lo && (uint32_t)lz < rp.own_hi)) {
                 jump = n_cell;  // not this rank's samples (and possibly not its planes): passed unevaluated
                 return 1.0f;
@@ -567,10 +572,11 @@ __device__ inline float process_sample_eager(float t, const RayState &r, const S
                           (uint32_t)lx < g.X - 1 && (uint32_t)ly < g.Y - 1 && (uint32_t)lz < g.Z - 1;
         const int qx = lx >> kBrickShift, qy = ly >> kBrickShift, qz = lz >> kBrickShift;
         const float e = sc.eps;
-        const int n_cb = samples_to_exit<false>(cx, cy, cz, sc, (float)(qx << kBrickShift) + e, (float)(qy << kBrickShift) + e,
-                                                (float)(qz << kBrickShift) + e, (float)((qx + 1) << kBrickShift) - e,
-                                                (float)((qy + 1) << kBrickShift) - e, (float)((qz + 1) << kBrickShift) - e);
-        const int n_cell = samples_to_exit<false>(rx, ry, rz, sc, cell_lo, cell_lo, cell_lo, cell_hi, cell_hi, cell_hi);
+        const int n_cb = samples_until<false>(((float)(qx << kBrickShift) + __builtin_fmaf(kBrick - 2.0f * e, sc.posx, e)) - cx,
+                                              ((float)(qy << kBrickShift) + __builtin_fmaf(kBrick - 2.0f * e, sc.posy, e)) - cy,
+                                              ((float)(qz << kBrickShift) + __builtin_fmaf(kBrick - 2.0f * e, sc.posz, e)) - cz, sc);
+        const int n_cell = samples_until<false>(__builtin_fmaf(cell_hi - cell_lo, sc.posx, cell_lo) - rx, __builtin_fmaf(cell_hi - cell_lo, sc.posy, cell_lo) - ry,
+                                                    __builtin_fmaf(cell_hi - cell_lo, sc.posz, cell_lo) - rz, sc);
         const bool owned = !SLAB || ((uint32_t)lz >= rp.own_lo && (uint32_t)lz < rp.own_hi);
         unsigned char cell_flag = 1;
         float c000 = 0, c100 = 0, c010 = 0, c110 = 0, c001 = 0, c101 = 0, c011 = 0, c111 = 0;
@@ -709,7 +715,7 @@ __device__ inline SkipCtx make_skip_ctx(const Geom &g, float step_size) {
     sc.eps = fmaxf(1.0e-3f, 2.0e-6f * (float)max(g.X, max(g.Y, g.Z)));
     sc.tx = sc.ty = sc.tz = INFINITY;
     sc.su = sc.sv = sc.sw = INFINITY;
-    sc.px_ = sc.py_ = sc.pz_ = false;
+    sc.posx = sc.posy = sc.posz = 1.0f;
     sc.skip_ok = false;
     return sc;
 }
