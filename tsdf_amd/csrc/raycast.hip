@@ -515,17 +515,20 @@ __device__ inline float process_sample(float t, int k, const RayState &r, const 
             const float *b_y = b + tc.row, *b_z = b + tc.plane, *b_yz = b_z + tc.row;
             const float c000 = b[0], c100 = b[1], c010 = b_y[0], c110 = b_y[1];
             const float c001 = b_z[0], c101 = b_z[1], c011 = b_yz[0], c111 = b_yz[1];
-            const bool positive = c000 > kCellPositive && c100 > kCellPositive && c010 > kCellPositive && c110 > kCellPositive &&
-                                  c001 > kCellPositive && c101 > kCellPositive && c011 > kCellPositive && c111 > kCellPositive;
+            // all corners above the threshold.  (fminf drops a NaN corner; that is fine here: inside the cell every weight is
+            // non-zero, so with a NaN corner every sample of the cell is NaN, which the reference steps over as well)
+            const bool positive = fminf(fminf(fminf(c000, c100), fminf(c010, c110)), fminf(fminf(c001, c101), fminf(c011, c111))) > kCellPositive;
             if (positive) {
                 jump = n_cell;
                 return 1.0f;
             }
             // trilinearly_interpolate (:84-121) for lower = (lx,ly,lz), which is what the reference derives for a
             // sample this far from the cell faces
-            const float lcx = (lx + 0.5f) * g.vs.x + 0.0f;
-            const float lcy = (ly + 0.5f) * g.vs.y + 0.0f;
-            const float lcz = (lz + 0.5f) * g.vs.z + 0.0f;
+            // (lower + 0.5f) * vs + 0.0f: lf* are the lower indices as floats already (exact integers), and adding 0.0f to
+            // a positive product is the identity
+            const float lcx = (lfx + 0.5f) * g.vs.x;
+            const float lcy = (lfy + 0.5f) * g.vs.y;
+            const float lcz = (lfz + 0.5f) * g.vs.z;
             const float u = div_by<FASTDIV>(px - lcx, tc.dx);
             const float v = div_by<FASTDIV>(py - lcy, tc.dy);
             const float w = div_by<FASTDIV>(pz - lcz, tc.dz);
@@ -598,15 +601,18 @@ __device__ inline float process_sample_eager(float t, const RayState &r, const S
                 jump = n_cb;
                 return 1.0f;
             }
-            const bool positive = c000 > kCellPositive && c100 > kCellPositive && c010 > kCellPositive && c110 > kCellPositive &&
-                                  c001 > kCellPositive && c101 > kCellPositive && c011 > kCellPositive && c111 > kCellPositive;
+            // all corners above the threshold.  (fminf drops a NaN corner; that is fine here: inside the cell every weight is
+            // non-zero, so with a NaN corner every sample of the cell is NaN, which the reference steps over as well)
+            const bool positive = fminf(fminf(fminf(c000, c100), fminf(c010, c110)), fminf(fminf(c001, c101), fminf(c011, c111))) > kCellPositive;
             if (!owned || positive) {
                 jump = n_cell;
                 return 1.0f;
             }
-            const float lcx = (lx + 0.5f) * g.vs.x + 0.0f;
-            const float lcy = (ly + 0.5f) * g.vs.y + 0.0f;
-            const float lcz = (lz + 0.5f) * g.vs.z + 0.0f;
+            // (lower + 0.5f) * vs + 0.0f: lf* are the lower indices as floats already (exact integers), and adding 0.0f to
+            // a positive product is the identity
+            const float lcx = (lfx + 0.5f) * g.vs.x;
+            const float lcy = (lfy + 0.5f) * g.vs.y;
+            const float lcz = (lfz + 0.5f) * g.vs.z;
             const float u = div_by<FASTDIV>(px - lcx, tc.dx);
             const float v = div_by<FASTDIV>(py - lcy, tc.dy);
             const float w = div_by<FASTDIV>(pz - lcz, tc.dz);
