@@ -947,17 +947,19 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
 // worked on side by side; when an early one hits, the later ones stop).  Sample k of a ray is computed by the same
 // expressions whichever lane does it, so the result does not depend on the schedule.  Groups take queue entries round
 // robin until none is left (persistent workgroups); every pass of the loop is uniform across the wave.
-template <bool SLAB, bool FASTDIV>
+//   LANES: lanes per queue entry fixed at compile time (the group reductions become DPP operations), 0 = tail.lanes.
+template <bool SLAB, bool FASTDIV, int LANES>
 __global__ __launch_bounds__(256) void process_ray_tail_kernel(const float *__restrict__ dist, const Geom g, const RayParams rp,
                                                                const OccGrid occ, const float *__restrict__ t_table,
                                                                const TailQueue tail) {
     __shared__ float T[kTableLen];
     const uint32_t n_entries = tail.count[0];
-    if ((size_t)blockIdx.x * 4u * (64u / tail.lanes) >= n_entries) return;   // nothing for this workgroup: skip the staging too
+    const uint32_t lanes_per_ray = LANES ? (uint32_t)LANES : tail.lanes;
+    if ((size_t)blockIdx.x * 4u * (64u / lanes_per_ray) >= n_entries) return;   // nothing for this workgroup: skip the staging too
     for (int i = (int)threadIdx.x; i < kTableLen; i += 256) T[i] = t_table[i];
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63u, lanes_per_ray = tail.lanes;
-    const int j = (int)(lane & (lanes_per_ray - 1)), leader = (int)(lane & ~(uint32_t)(lanes_per_ray - 1));
+    const uint32_t lane = threadIdx.x & 63u;
+    const int j = (int)(lane & (lanes_per_ray - 1));
     const float step_size = T[1];
     const TriConst &tc = rp.tc;
     SkipCtx sc = make_skip_ctx(g, step_size);
@@ -998,71 +1000,22 @@ __global__ __launch_bounds__(256) void process_ray_tail_kernel(const float *__re
                     adv = j + 1 + (tsdf > 0 ? ahead : 0);
                 }
             }
-            // furthest sample (relative to k) the group has dealt with
-            for (int o = 1; o < (int)lanes_per_ray; o <<= 1) adv = max(adv, __shfl_xor(adv, o));
-            known = __shfl(known, leader);
-            const unsigned long long hits = __ballot(hit);
-            const unsigned long long mine = (hits >> leader) & (lanes_per_ray == 64 ? ~0ull : ((1ull << lanes_per_ray) - 1ull));
+            // over the group: the furthest sample (relative to k) it has dealt with, its first lane with a hit, and the
+            // leader's view of best[] (the other lanes hold kNoHit, the largest value)
+            int first = hit ? j : (int)lanes_per_ray;
+            for (int o = 1; o < (int)lanes_per_ray; o <<= 1) {
+                adv = max(adv, __shfl_xor(adv, o));
+                first = min(first, __shfl_xor(first, o));
+                known = min(known, (uint32_t)__shfl_xor((int)known, o));
+            }
             if (k != kDone) {
-                if (mine) {
-                    if (j == __builtin_ctzll(mine)) atomicMin(best, (uint32_t)kk);
+                if (first < (int)lanes_per_ray) {
+                    if (j == first) atomicMin(best, (uint32_t)kk);
                     k = kDone;
                 } else {
                     k += adv;
                     if (k >= k_end || known <= (uint32_t)k) k = kDone;
                 }
-            }
-        }
-    }
-}
-
-// Alternative finish (experiment): one lane per queue entry, marching it like process_ray_kernel's main loop (per-brick
-// memory, dependent look-ups) until every entry of the wave's batch is done.
-template <bool SLAB, bool FASTDIV>
-__global__ __launch_bounds__(256) void process_ray_queue_kernel(const float *__restrict__ dist, const Geom g, const RayParams rp,
-                                                                const OccGrid occ, const float *__restrict__ t_table,
-                                                                const TailQueue tail) {
-    __shared__ float T[kTableLen];
-    for (int i = (int)threadIdx.x; i < kTableLen; i += 256) T[i] = t_table[i];
-    __syncthreads();
-    const uint32_t n_entries = tail.count[0];
-    const uint32_t lane = threadIdx.x & 63u;
-    const float step_size = T[1];
-    const TriConst &tc = rp.tc;
-    SkipCtx sc = make_skip_ctx(g, step_size);
-    const uint32_t n_waves = gridDim.x * 4, wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
-    for (uint32_t batch = wave_id * 64u; batch < n_entries; batch += n_waves * 64u) {
-        RayState ray = {0, 0, 0, 0, 0, 0};
-        int k = kDone, k_end = 0;
-        uint32_t *best = tail.best;
-        const uint32_t e = batch + lane;
-        if (e < n_entries) {
-            const uint2 q = tail.entries[e];
-            float max_t;
-            (void)ray_geometry((int)(q.x % rp.width), (int)(q.x / rp.width), true, rp, ray, max_t);
-            set_ray<true>(sc, ray, step_size, g);
-            k = (int)(q.y & 0x1fffu);
-            k_end = (int)((q.y >> 13) & 0x1fffu);
-            best += q.x;
-            if (load_best(best) <= (uint32_t)k) k = kDone;
-        }
-        BrickCache bc = {0, 0, false};
-        SampleWork work = {0, 0, 0, 0};
-        for (uint32_t trip = 0; __ballot(k != kDone) != 0ull; trip++) {
-            if (k != kDone) {
-                const float t = T[k];
-                int jump, ahead;
-                const float tsdf = process_sample<SLAB, false, FASTDIV>(t, k, ray, sc, bc, dist, g, tc, rp, occ, nullptr, work, jump, ahead);
-                if (jump > 0) {
-                    k += jump;
-                } else if (tsdf <= 0) {
-                    atomicMin(best, (uint32_t)k);
-                    k = kDone;
-                } else {
-                    k += 1 + (tsdf > 0 ? ahead : 0);
-                }
-                if (k != kDone && k >= k_end) k = kDone;
-                if (k != kDone && (trip & 7u) == 7u && load_best(best) <= (uint32_t)k) k = kDone;
             }
         }
     }
@@ -1328,16 +1281,17 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
     TSDF_HIP(hipGetLastError(), "process_ray failed");
     // persistent workgroups: groups of 16 lanes, fetching queue entries until none is left
     timing_begin(v, 2);
-    static const int tail_mode = getenv("TSDF_RAY_TAIL_MODE") ? atoi(getenv("TSDF_RAY_TAIL_MODE")) : 0;
-    if (tail_mode == 1)
-        hipLaunchKernelGGL((process_ray_queue_kernel<SLAB, true>), dim3(tail_grid()), dim3(256), 0, v->stream, v->dist, v->g, rp,
-                           v->occ, v->t_table, tail);
+    // (the default group width is compiled in; another one, a tuning aid, takes the variant that reads it at run time)
+    const bool fixed_lanes = tail_lanes() == kTailLanesDefault;
+    const dim3 tgrid_(tail_grid());
+    if (v->fast_div && fixed_lanes)
+        hipLaunchKernelGGL((process_ray_tail_kernel<SLAB, true, kTailLanesDefault>), tgrid_, dim3(256), 0, v->stream, v->dist, v->g, rp, v->occ, v->t_table, tail);
     else if (v->fast_div)
-        hipLaunchKernelGGL((process_ray_tail_kernel<SLAB, true>), dim3(tail_grid()), dim3(256), 0, v->stream, v->dist, v->g, rp,
-                           v->occ, v->t_table, tail);
+        hipLaunchKernelGGL((process_ray_tail_kernel<SLAB, true, 0>), tgrid_, dim3(256), 0, v->stream, v->dist, v->g, rp, v->occ, v->t_table, tail);
+    else if (fixed_lanes)
+        hipLaunchKernelGGL((process_ray_tail_kernel<SLAB, false, kTailLanesDefault>), tgrid_, dim3(256), 0, v->stream, v->dist, v->g, rp, v->occ, v->t_table, tail);
     else
-        hipLaunchKernelGGL((process_ray_tail_kernel<SLAB, false>), dim3(tail_grid()), dim3(256), 0, v->stream, v->dist, v->g, rp,
-                           v->occ, v->t_table, tail);
+        hipLaunchKernelGGL((process_ray_tail_kernel<SLAB, false, 0>), tgrid_, dim3(256), 0, v->stream, v->dist, v->g, rp, v->occ, v->t_table, tail);
     timing_end(v, 2);
     TSDF_HIP(hipGetLastError(), "process_ray (tail) failed");
     if (getenv("TSDF_DEBUG_RAYS")) {   // diagnostics: how much went through the tail queue (synchronises)
