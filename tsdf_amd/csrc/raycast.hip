@@ -401,7 +401,7 @@ __device__ inline int lipschitz_lookahead(float val, float c000, float c100, flo
     const float margin = 4.0f * sc.eps * rsum + 2.0e-5f * (fabsf(c000) + rsum);   // |corner| <= |c000| + rsum
     const float per_sample = 1.01f * ((sc.su * rx + sc.sv * ry) + sc.sw * rz);
     const float x = 0.99f * (val - margin) * __builtin_amdgcn_rcpf(per_sample);   // (inf when the cell is flat: limit applies)
-    // fmaxf / fminf drop a NaN operand, so NaN corners must be caught explicitly: rsum is NaN or inf then
+    // (a NaN corner makes val, hence x, NaN -- fmaxf / fminf would drop it from the slopes; an infinite one makes rsum infinite)
     if (!(rsum < INFINITY) || !(x > 0.0f)) return 0;
     return (int)fminf(x, (float)limit);
 }
