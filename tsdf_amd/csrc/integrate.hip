@@ -123,6 +123,8 @@ __global__ __launch_bounds__(64) void depth_tile_max_kernel(const uint16_t *__re
 
 struct BrickGrid {
     uint32_t nx, ny, nz;  // bricks per axis over the resident planes
+    uint32_t z_extra;     // planes (<= kBatchZ) appended to the bricks of the last z layer: a slab's halo plane, which would
+                          // otherwise cost a whole layer of bricks that project 32 planes to update one
 };
 
 // One thread per 64x4x32 brick: decide whether any voxel of it can be updated by this frame (see the header).
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(256) void brick_cull_kernel(const Geom g, const Bri
     const uint32_t bx = b % bg.nx, by = (b / bg.nx) % bg.ny, bz = b / (bg.nx * bg.ny);
     const uint32_t x0 = bx * kTileX, x1 = min(x0 + kTileX, g.X) - 1;
     const uint32_t y0 = by * kTileY, y1 = min(y0 + kTileY, g.Y) - 1;
-    const uint32_t z0 = g.z_store_begin + bz * kChunkZ, z1 = min(z0 + kChunkZ, g.z_store_end) - 1;
+    const uint32_t z0 = g.z_store_begin + bz * kChunkZ, z1 = min(z0 + kChunkZ + (bz + 1 == bg.nz ? bg.z_extra : 0u), g.z_store_end) - 1;
 
     bool all_pos = true, all_neg = true;
     bool left = true, right = true, top = true, bottom = true;
@@ -276,7 +278,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         const uint32_t vx = bx * kTileX + threadIdx.x;
         const uint32_t vy = by * kTileY + threadIdx.y;
         const uint32_t z0 = g.z_store_begin + bz * kChunkZ;
-        const uint32_t z1 = min(z0 + kChunkZ, g.z_store_end);  // exclusive
+        const uint32_t z_extra = bz + 1 == bg.nz ? bg.z_extra : 0u;
+        const uint32_t z1 = min(z0 + kChunkZ + z_extra, g.z_store_end);  // exclusive
         // stage the brick's pixel box (whole workgroup; falls back to global gathers when it is unknown or too big)
         uint4 box = make_uint4(0, 0, 0, 0);
         if (!DEFORM) box = boxes[i];
@@ -440,6 +443,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             if (o + 2 * kBatchZ < (uint32_t)kChunkZ) project_and_load(z0 + o + 2 * kBatchZ, tsdf_a, pw_a, pd_a);
             blend_and_store(z0 + o + kBatchZ, tsdf_b, pw_b, pd_b);
         }
+        if (z_extra != 0) {   // (uniform; after the pipeline, not inside it)
+            project_and_load(z0 + kChunkZ, tsdf_a, pw_a, pd_a);
+            blend_and_store(z0 + kChunkZ, tsdf_a, pw_a, pd_a);
+        }
     }
     if (COUNT) {
         // wave reduction then one atomic per wave
@@ -459,7 +466,12 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
     BrickGrid bg;
     bg.nx = (g.X + kTileX - 1) / kTileX;
     bg.ny = (g.Y + kTileY - 1) / kTileY;
-    bg.nz = (g.z_store_end - g.z_store_begin + kChunkZ - 1) / kChunkZ;
+    {
+        const uint32_t planes = g.z_store_end - g.z_store_begin, full = planes / kChunkZ, rest = planes % kChunkZ;
+        const bool append = full >= 1 && rest >= 1 && rest <= (uint32_t)kBatchZ;
+        bg.nz = append ? full : (planes + kChunkZ - 1) / kChunkZ;
+        bg.z_extra = append ? rest : 0;
+    }
     const size_t n_bricks = (size_t)bg.nx * bg.ny * bg.nz;
     TSDF_REQUIRE(n_bricks < 0xFFFFFFFFull, "volume too large for the brick list");
 
