@@ -185,6 +185,23 @@ def test_slab_volumes_integrate_their_planes_plus_one_halo_plane(oracle):
         assert_same_floats(s.get_distance_data(), full[lo:hi], "slab [%d,%d)" % (zb, ze))
 
 
+@pytest.mark.parametrize("planes", [32, 33, 36, 37, 64, 65, 68, 70])
+def test_depths_around_the_brick_layers(oracle, planes):
+    """The integrate kernel walks 32-plane bricks; up to 4 left-over planes (a slab's halo plane, typically) ride on the
+    last full layer, more get a layer of their own.  Whole volumes and slabs of every such depth, two frames each."""
+    frames = [synth.depth_frame(i, 8, seed=5) for i in (1, 4)]
+    size, phys = (72, 20, planes), (2700.0, 750.0, planes * 37.5)
+    gv, ov, up = run_both(oracle, size, phys, frames)
+    check(gv, ov, up, "%d planes" % planes)
+    if planes >= 36:    # the same planes as a slab [2, planes - 1) plus its halo plane
+        s = tsdf_amd.TSDFVolume(size, phys, slab=(2, planes - 1))
+        for d, cam in frames:
+            s.integrate(d, W, H, cam)
+        lo, hi = s.resident_planes()
+        assert_same_floats(s.get_distance_data(), ov.dist.reshape(planes, -1)[lo:hi], "slab of %d resident planes" % (hi - lo))
+        assert_same_floats(s.get_weight_data(), ov.weight.reshape(planes, -1)[lo:hi], "slab weights")
+
+
 def test_committed_golden_vectors(oracle):
     """tests/golden/oracle_integrate_raycast.npz (generated by tests/golden/make_golden.py)."""
     from tests.helpers import Cam
