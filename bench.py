@@ -162,9 +162,9 @@ def main():
                 hits_all.copy_(h_all)
             else:
                 dist.all_gather_into_tensor(hits_all.view(-1), hits_mine.view(-1))
-            tsdf_amd.merge_hits_device(hits_all.data_ptr(), world, W, H, vert_dev.data_ptr(), stream.cuda_stream)
+            tsdf_amd.merge_hits_normals_device(hits_all.data_ptr(), world, W, H, vert_dev.data_ptr(), norm_dev.data_ptr(), stream.cuda_stream)   # merged vertices and their normals in one go
         if timed: e[4].record(stream)
-        if world > 1 or os.environ.get('BENCH_SPLIT_NORMALS'):    # (a whole volume's ray cast has formed the normals with the vertices)
+        if os.environ.get('BENCH_SPLIT_NORMALS'):    # (the ray cast, or the merge of the slabs' records, has formed the normals with the vertices)
             tsdf_amd.compute_normals_device(W, H, vert_dev.data_ptr(), norm_dev.data_ptr(), stream.cuda_stream)
         if timed:
             e[5].record(stream)

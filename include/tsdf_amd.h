@@ -199,6 +199,9 @@ int tsdf_raycast_slab_device(const tsdf_volume *volume, uint32_t width, uint32_t
                              const float pose[16], const float kinv[9], float *device_hits);
 int tsdf_merge_hits_device(const float *device_hits_all, uint32_t n_slabs, uint32_t width,
                            uint32_t height, float *device_vertices, void *hip_stream);
+/* The same select and compute_normals (src/RayCaster/GPURaycaster.cu:393-427) on the merged map in one launch. */
+int tsdf_merge_hits_normals_device(const float *device_hits_all, uint32_t n_slabs, uint32_t width, uint32_t height,
+                                   float *device_vertices, float *device_normals, void *hip_stream);
 
 /* ---- ICP tracking: replaces third_party/ICP_CUDA ------------------------------------------ */
 /* ICPOdometry::ICPOdometry (third_party/ICP_CUDA/ICPOdometry.cpp:10-57): three pyramid levels of vertex / normal maps for

@@ -198,6 +198,11 @@ def test_slab_hit_records_merge_to_the_single_volume_result(oracle):
     torch.cuda.synchronize()
     assert_same_floats(V.cpu().numpy(), Vw, "merged vertices")
     assert_same_floats(Nn.cpu().numpy(), Nw, "merged normals")
+    V2, N2 = torch.zeros_like(V), torch.zeros_like(V)          # the same in one launch
+    tsdf_amd.merge_hits_normals_device(hits.data_ptr(), len(slabs), W, H, V2.data_ptr(), N2.data_ptr())
+    torch.cuda.synchronize()
+    assert_same_floats(V2.cpu().numpy(), Vw, "merged vertices (one launch)")
+    assert_same_floats(N2.cpu().numpy(), Nw, "merged normals (one launch)")
 
 
 # ---------------------------------------------------------------------------------------------------------

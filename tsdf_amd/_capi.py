@@ -85,6 +85,7 @@ _SIGS = {
     "tsdf_raycast_slab_device": (_i, [_vp, _u32, _u32, _fp, _fp, _vp]),
     "tsdf_vertices_to_depth_device": (_i, [_u32, _u32, _vp, _vp, _vp, _vp]),
     "tsdf_merge_hits_device": (_i, [_vp, _u32, _u32, _u32, _vp, _vp]),
+    "tsdf_merge_hits_normals_device": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp]),
     "tsdf_icp_create": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, C.POINTER(_vp)]),
     "tsdf_icp_destroy": (None, [_vp]),
     "tsdf_icp_set_stream": (_i, [_vp, _vp]),

@@ -283,6 +283,13 @@ def merge_hits_device(hits_all_ptr, n_slabs, width, height, vertices_ptr, stream
                                      C.c_void_p(int(vertices_ptr)), C.c_void_p(int(stream) if stream else 0)))
 
 
+def merge_hits_normals_device(hits_all_ptr, n_slabs, width, height, vertices_ptr, normals_ptr, stream=0):
+    """Min-k select over the gathered slab records and the normals of the merged map, one launch."""
+    check(lib.tsdf_merge_hits_normals_device(C.c_void_p(int(hits_all_ptr)), n_slabs, width, height,
+                                             C.c_void_p(int(vertices_ptr)), C.c_void_p(int(normals_ptr)),
+                                             C.c_void_p(int(stream) if stream else 0)))
+
+
 class BilateralFilter:
     """src/include/BilateralFilter.hpp:12-35.  filter() works in place on a host image, as the reference does."""
 

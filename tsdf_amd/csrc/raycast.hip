@@ -1183,6 +1183,66 @@ __global__ __launch_bounds__(256) void merge_hits_kernel(const float4 *__restric
     V[(size_t)i * 3 + 2] = best.w;
 }
 
+// The same select together with the normals (compute_normals, Q11) in one launch: a workgroup merges a 16x16 pixel tile
+// plus the column to its right and the row below -- one pixel per thread of its five waves -- into LDS, like
+// resolve_normals_kernel.
+__global__ __launch_bounds__(kResolveThreads) void merge_hits_normals_kernel(const float4 *__restrict__ hits, uint32_t n_slabs,
+                                                                             uint32_t width, uint32_t height, float *__restrict__ V,
+                                                                             float *__restrict__ N) {
+    constexpr int kT = 16, kS = kT + 1;
+    __shared__ float vx[kS * kS], vy[kS * kS], vz[kS * kS];
+    const uint32_t x0 = blockIdx.x * kT, y0 = blockIdx.y * kT, n_pixels = width * height;
+    const uint32_t s_ = threadIdx.x;
+    if (s_ < (uint32_t)(kS * kS)) {
+        uint32_t lx, ly;
+        if (s_ < (uint32_t)(kT * kT)) {
+            lx = s_ & 15u; ly = s_ >> 4;
+        } else if (s_ < (uint32_t)(kT * kT + kT)) {
+            lx = kT; ly = s_ - kT * kT;
+        } else {
+            lx = s_ - (kT * kT + kT); ly = kT;
+        }
+        const uint32_t x = x0 + lx, y = y0 + ly;
+        float4 best = make_float4(INFINITY, NAN, NAN, NAN);
+        if (x < width && y < height) {
+            const uint32_t i = y * width + x;
+            best = hits[i];
+            for (uint32_t s2 = 1; s2 < n_slabs; s2++) {
+                const float4 h = hits[(size_t)s2 * n_pixels + i];
+                if (h.x < best.x) best = h;
+            }
+            if (lx < (uint32_t)kT && ly < (uint32_t)kT) {
+                V[(size_t)i * 3 + 0] = best.y;
+                V[(size_t)i * 3 + 1] = best.z;
+                V[(size_t)i * 3 + 2] = best.w;
+            }
+        }
+        const uint32_t slot = ly * kS + lx;
+        vx[slot] = best.y; vy[slot] = best.z; vz[slot] = best.w;
+    }
+    __syncthreads();
+    if (threadIdx.x >= (uint32_t)(kT * kT)) return;
+    const uint32_t lx = threadIdx.x & 15u, ly = threadIdx.x >> 4, x = x0 + lx, y = y0 + ly;
+    if (x >= width || y >= height) return;
+    float nx = 0, ny = 0, nz = 0;
+    if (y != height - 1 && x != width - 1) {
+        const uint32_t a = ly * kS + lx, r = a + 1, b = a + kS;
+        float v2x = vx[r] - vx[a], v2y = vy[r] - vy[a], v2z = vz[r] - vz[a];
+        float v1x = vx[b] - vx[a], v1y = vy[b] - vy[a], v1z = vz[b] - vz[a];
+        float cx = v1y * v2z - v1z * v2y;
+        float cy = v1z * v2x - v1x * v2z;
+        float cz = v1x * v2y - v1y * v2x;
+        float l = sqrtf(cx * cx + cy * cy + cz * cz);
+        nx = cx / l;
+        ny = cy / l;
+        nz = cz / l;
+    }
+    const size_t idx = (size_t)y * width + x;
+    N[idx * 3 + 0] = nx;
+    N[idx * 3 + 1] = ny;
+    N[idx * 3 + 2] = nz;
+}
+
 __global__ __launch_bounds__(256) void popcount_kernel(const unsigned int *__restrict__ words, size_t n,
                                                        unsigned long long *__restrict__ counter) {
     unsigned long long c = 0;
@@ -1469,6 +1529,17 @@ int tsdf_merge_hits_device(const float *device_hits_all, uint32_t n_slabs, uint3
     hipLaunchKernelGGL(merge_hits_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream,
                        reinterpret_cast<const float4 *>(device_hits_all), n_slabs, n, device_vertices);
     TSDF_HIP(hipGetLastError(), "merge hits failed");
+    return TSDF_OK;
+}
+
+int tsdf_merge_hits_normals_device(const float *device_hits_all, uint32_t n_slabs, uint32_t width, uint32_t height,
+                                   float *device_vertices, float *device_normals, void *hip_stream) {
+    TSDF_REQUIRE(device_hits_all && device_vertices && device_normals && n_slabs > 0 && width > 0 && height > 0,
+                 "tsdf_merge_hits_normals: bad argument");
+    hipLaunchKernelGGL(merge_hits_normals_kernel, dim3((width + 15) / 16, (height + 15) / 16), dim3(kResolveThreads), 0,
+                       (hipStream_t)hip_stream, reinterpret_cast<const float4 *>(device_hits_all), n_slabs, width, height, device_vertices,
+                       device_normals);
+    TSDF_HIP(hipGetLastError(), "merge hits + normals failed");
     return TSDF_OK;
 }
 
