@@ -342,6 +342,7 @@ np.savez(sys.argv[1], V=V, N=N, D=gv.get_distance_data())
     {"TSDF_RAY_SEGMENTS": "3", "TSDF_RAY_TRIP_BUDGET": "2", "TSDF_RAY_TAIL_LANES": "4", "TSDF_RAY_TAIL_GRID": "7"},
     {"TSDF_RAY_SEGMENTS": "16", "TSDF_RAY_TRIP_BUDGET": "100000"},                             # nothing in the tail kernel
     {"TSDF_RAY_SEGMENTS": "64", "TSDF_RAY_TRIP_BUDGET": "5", "TSDF_RAY_TAIL_LANES": "8"},
+    {"TSDF_INT_GRID_PER_CU": "3"},                                                             # integrate: resident grid walking the brick list
     {"TSDF_OCC_REBUILD_PERIOD": "0"},                                                          # sticky flags only
     {"TSDF_OCC_REBUILD_PERIOD": "1"},                                                          # flags rebuilt every frame
 ])
@@ -359,6 +360,15 @@ def test_schedule_knobs_do_not_change_a_bit(oracle, tmp_path, env):
     got = np.load(out)
     n = 96
     ov = oracle.Volume((n, n, n), (3000, 3000, 3000))
+    if "TSDF_INT_GRID_PER_CU" in env:                   # the integrate knob: the distances themselves against the oracle
+        oi = oracle.Volume((n, n, n), (3000, 3000, 3000))
+        ob = oracle.BilateralFilter(30.0, 4.5) if hasattr(oracle, "BilateralFilter") else None
+        bil = tsdf_amd.BilateralFilter(30.0, 4.5)
+        for i in range(3):
+            d, c = synth.depth_frame(i, 4, seed=0x5EED0002)
+            f = d.copy(); bil.filter(f, synth.WIDTH, synth.HEIGHT)      # (the filter's parity is covered elsewhere)
+            oi.integrate(f, synth.WIDTH, synth.HEIGHT, c.inverse_pose(), c.k(), c.kinv(), nthreads=oracle.max_threads())
+        assert_same_floats(got["D"], oi.dist, "distances with %s" % env)
     ov.set_distance_data(got["D"])                      # (integrate parity is covered elsewhere)
     _, cam = synth.depth_frame(0, 4, seed=0x5EED0002)
     Vo, No = ov.raycast(W, H, cam.pose(), cam.kinv(), nthreads=oracle.max_threads())
