@@ -129,7 +129,7 @@ __device__ inline int float2int_rn(float f) {
 // Reduction::operator() (Cuda/estimate.cu:139-209): projective association of the current frame's vertices into the
 // model, distance / angle gates, the 27 upper-triangular products of the row (n, v x n, n.(v_prev - v)) + inlier count.
 // The pose is read from the device state (T as doubles, narrowed to float like `rotationMatrix().cast<float>()`).
-__device__ inline void icp_finish_step(const float *partial, int n_blocks, const double *state_in, int update, double *pose_out,
+__device__ __forceinline__ void icp_finish_step(const float *partial, int n_blocks, const double *state_in, int update, double *pose_out,
                                        double *state_out);
 
 // One Gauss-Newton step's sums.  `pending` != 0: the previous launch left its per-workgroup sums in partial_prev and the
@@ -245,7 +245,7 @@ __device__ inline void swap_if(bool c, double &a, double &b) {
 // healthy ICP step it needs no row exchanges; returns false (result unused) when a pivot is not safely positive, and the
 // pivoted version above/below takes over.  ~250 dependent flops instead of ~4000 predicated moves.
 __device__ inline bool ldlt_solve6_unpivoted(const float *A_in, const float *b_in, double *x) {
-    double A[6][6], L[6][6], D[6], y[6];
+    double A[6][6], L[6][6], D[6], Dinv[6], y[6];
     double dmax = 0.0;
 #pragma unroll
     for (int i = 0; i < 6; i++) {
@@ -260,6 +260,7 @@ __device__ inline bool ldlt_solve6_unpivoted(const float *A_in, const float *b_i
         D[k] = A[k][k];
         ok = ok && D[k] > 1.0e-9 * dmax;
         const double inv = 1.0 / D[k];
+        Dinv[k] = inv;
 #pragma unroll
         for (int i = k + 1; i < 6; i++) L[i][k] = A[i][k] * inv;
 #pragma unroll
@@ -275,7 +276,7 @@ __device__ inline bool ldlt_solve6_unpivoted(const float *A_in, const float *b_i
 #pragma unroll
         for (int j = 0; j < i; j++) y[i] -= L[i][j] * y[j];
 #pragma unroll
-    for (int i = 0; i < 6; i++) y[i] = y[i] / D[i];
+    for (int i = 0; i < 6; i++) y[i] = y[i] * Dinv[i];   // (the pivots' reciprocals again: six divisions fewer on the critical path)
 #pragma unroll
     for (int i = 5; i >= 0; i--) {
 #pragma unroll
@@ -367,12 +368,13 @@ __device__ inline void se3_exp(const double *a, double *E) {
     double A, B, C;  // sin th / th, (1 - cos th) / th^2, (th - sin th) / th^3
     if (th2 < 0.0625) {
         // |th| < 1/4 (every step of a converging ICP): the three entire functions by their power series in th^2, summed
-        // from the smallest term (Horner); the first omitted terms are < 1e-19 relative.  One lane evaluates this on the
+        // from the smallest term (Horner, constant reciprocals: a double division costs this lane ~25 dependent instructions);
+        // the first omitted terms are < 1e-19 relative.  One lane evaluates this on the
         // critical path of every iteration, and the library's double sin / cos cost several microseconds there.
         const double t = th2;
-        A = 1.0 - t / 6.0 * (1.0 - t / 20.0 * (1.0 - t / 42.0 * (1.0 - t / 72.0 * (1.0 - t / 110.0 * (1.0 - t / 156.0 * (1.0 - t / 210.0))))));
-        B = 0.5 * (1.0 - t / 12.0 * (1.0 - t / 30.0 * (1.0 - t / 56.0 * (1.0 - t / 90.0 * (1.0 - t / 132.0 * (1.0 - t / 182.0 * (1.0 - t / 240.0)))))));
-        C = 1.0 / 6.0 * (1.0 - t / 20.0 * (1.0 - t / 42.0 * (1.0 - t / 72.0 * (1.0 - t / 110.0 * (1.0 - t / 156.0 * (1.0 - t / 210.0 * (1.0 - t / 272.0)))))));
+        A = 1.0 - t * (1.0 / 6.0) * (1.0 - t * (1.0 / 20.0) * (1.0 - t * (1.0 / 42.0) * (1.0 - t * (1.0 / 72.0) * (1.0 - t * (1.0 / 110.0) * (1.0 - t * (1.0 / 156.0) * (1.0 - t * (1.0 / 210.0)))))));
+        B = 0.5 * (1.0 - t * (1.0 / 12.0) * (1.0 - t * (1.0 / 30.0) * (1.0 - t * (1.0 / 56.0) * (1.0 - t * (1.0 / 90.0) * (1.0 - t * (1.0 / 132.0) * (1.0 - t * (1.0 / 182.0) * (1.0 - t * (1.0 / 240.0))))))));
+        C = 1.0 / 6.0 * (1.0 - t * (1.0 / 20.0) * (1.0 - t * (1.0 / 42.0) * (1.0 - t * (1.0 / 72.0) * (1.0 - t * (1.0 / 110.0) * (1.0 - t * (1.0 / 156.0) * (1.0 - t * (1.0 / 210.0) * (1.0 - t * (1.0 / 272.0))))))));
     } else {
         A = sin(th) / th;
         B = (1.0 - cos(th)) / th2;
@@ -395,7 +397,7 @@ __device__ inline void se3_exp(const double *a, double *E) {
 // getIncrementalTransformation: A, b, residual, inliers; when `update` != 0 also x = A^-1 b and T <- exp(x) * T.
 // Run by all 256 threads of a workgroup; the pose after the step goes to pose_out (shared memory, for the caller's
 // __syncthreads), the whole state to state_out when that is not null.  The sums were written by the previous launch.
-__device__ inline void icp_finish_step(const float *partial, int n_blocks, const double *state_in, int update, double *pose_out,
+__device__ __forceinline__ void icp_finish_step(const float *partial, int n_blocks, const double *state_in, int update, double *pose_out,
                                        double *state_out) {
     // 29 entries x 8 groups of blocks: thread (entry, group) adds its 32 blocks in order (loads issued together), then
     // one thread per entry adds the 8 group sums in order -- a fixed tree, in double
