@@ -404,6 +404,13 @@ __device__ __forceinline__ void icp_finish_step(const float *partial, int n_bloc
     __shared__ double group_sum[8][32];
     __shared__ float total[32];
     const int entry = threadIdx.x & 31, group = threadIdx.x >> 5;
+    // (the pose the sums were taken at: requested now, with the sums, not after them -- one memory round trip less on the
+    // path every iteration waits for)
+    double T[16];
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) T[i] = state_in[i];
+    }
     if (entry < 29) {
         float v[32];
 #pragma unroll
@@ -439,8 +446,8 @@ __device__ __forceinline__ void icp_finish_step(const float *partial, int n_bloc
         for (int i = 0; i < 36; i++) state_out[18 + i] = A[i];
         for (int i = 0; i < 6; i++) state_out[54 + i] = b[i];
     }
-    double T[16], out[16];
-    for (int i = 0; i < 16; i++) T[i] = out[i] = state_in[i];
+    double out[16];
+    for (int i = 0; i < 16; i++) out[i] = T[i];
     if (update) {
         double x[6], E[16];
         if (!ldlt_solve6_unpivoted(A, b, x)) ldlt_solve6(A, b, x);
