@@ -7,7 +7,7 @@ ARCH     ?= gfx950
 # -ffp-contract=off: every fp32 op rounds on its own, in the reference's order (parity contract)
 HIPFLAGS  = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Iinclude -Itsdf_amd/csrc -Wall -Wno-unused-function
 CSRC      = tsdf_amd/csrc
-HIP_SRCS  = $(CSRC)/volume.hip $(CSRC)/integrate.hip $(CSRC)/raycast.hip $(CSRC)/bilateral.hip $(CSRC)/icp.hip
+HIP_SRCS  = $(CSRC)/volume.hip $(CSRC)/integrate.hip $(CSRC)/raycast.hip $(CSRC)/bilateral.hip $(CSRC)/icp.hip $(CSRC)/mcubes.hip
 HIP_OBJS  = $(HIP_SRCS:.hip=.o)
 LIBDIR    = tsdf_amd/lib
 

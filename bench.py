@@ -399,15 +399,17 @@ def tracking_loop(tsdf_amd, synth, n, physical, stream_frames, n_frames=24):
         worst_r = max(worst_r, float(np.arccos(np.clip(c, -1.0, 1.0))))
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 1e3 / (n_frames - 4)
-    # ... and the mesh of the tracked model: extract_surface = distances to the host + host marching cubes (north_star
-    # keeps src/MarchingCubes on the host)
+    # ... and the mesh of the tracked model: extract_surface = marching cubes on the device (vertices to the host), beside
+    # the host implementation on the downloaded distances (the same vertices, bit for bit: tests/test_parity_marching_cubes.py)
     t1 = time.perf_counter()
+    mesh_dev = vol.extract_surface()
+    t1b = time.perf_counter()
     dist_host = vol.get_distance_data()
     t2 = time.perf_counter()
     mesh = tsdf_amd.marching_cubes(dist_host, (n, n, n), (physical / n,) * 3)
     t3 = time.perf_counter()
     return {"ms_per_frame": round(ms, 4),
-            "mesh": {"download_s": round(t2 - t1, 3), "marching_cubes_s": round(t3 - t2, 3), "triangles": int(mesh.shape[0] // 3)}, "frames": n_frames, "max_translation_error_mm": round(worst_t, 3),
+            "mesh": {"extract_surface_device_s": round(t1b - t1, 4), "same_as_host": bool(mesh_dev.shape == mesh.shape and np.array_equal(mesh_dev.view(np.uint32), mesh.view(np.uint32))), "host_download_s": round(t2 - t1b, 3), "host_marching_cubes_s": round(t3 - t2, 3), "triangles": int(mesh.shape[0] // 3)}, "frames": n_frames, "max_translation_error_mm": round(worst_t, 3),
             "max_rotation_error_rad": round(worst_r, 6),
             "what": "bilateral + raycast(prev pose) + render depth + ICP (3 levels, 19 iterations) + integrate per frame"}
 

@@ -191,6 +191,15 @@ int tsdf_volume_occupancy(const tsdf_volume *volume, uint64_t *occupied_bricks, 
 int tsdf_volume_get_occupancy_data(const tsdf_volume *volume, int force_rebuild, uint8_t *host_fine, uint8_t *host_cell,
                                    uint8_t *host_reach);
 
+/* Replaces the device part of extract_surface (src/MarchingCubes/MarkAndSweepMC.cu:506-555): marching cubes over the
+ * volume's distance array on the GPU.  Cubes in the reference's order (x fastest, then y, then z), its corner / edge
+ * numbering (:9-36, :80-97), sign rule (:110-124) and interpolate() arithmetic (:47-63); three consecutive vertices per
+ * triangle (the caller wires them (i, i+2, i+1), :549).  table = 256 x 32 edge numbers, three per triangle, -1
+ * terminated (the host library generates it: tsdf_host_mc_table).  *n_vertices receives the vertex count; when
+ * host_vertices is not NULL and capacity (in vertices) suffices, it receives 3 floats per vertex.  Whole volumes only. */
+int tsdf_volume_marching_cubes(const tsdf_volume *volume, const int8_t *table, uint64_t *n_vertices, float *host_vertices,
+                               uint64_t capacity);
+
 /* Multi-GPU raycast: a slab evaluates only the samples whose lower trilinear
  * tap plane it owns and writes one 16-byte record per pixel {k, x, y, z}: k = index of the
  * first owned sample with tsdf <= 0 (+inf if none).  After an all-gather of the records,

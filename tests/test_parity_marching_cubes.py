@@ -1,0 +1,53 @@
+"""GPU: extract_surface on the device (tsdf_volume_marching_cubes) returns exactly what the host marching cubes returns
+on the downloaded distances -- the same vertices in the same order, bit for bit."""
+import numpy as np
+import pytest
+
+import tsdf_amd
+from tests.helpers import assert_same_floats
+from tsdf_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def both(gv, size):
+    dev = gv.extract_surface()
+    vs = gv.voxel_size()
+    host = tsdf_amd.marching_cubes(gv.get_distance_data(), size, vs, gv.offset())
+    return dev, host
+
+
+@pytest.mark.parametrize("size", [(2, 2, 2), (3, 2, 5), (17, 9, 11), (64, 64, 64), (65, 33, 70), (130, 20, 7)])
+def test_random_fields_of_odd_sizes(size):
+    rng = np.random.default_rng(size[0] * 1000 + size[1] * 10 + size[2])
+    gv = tsdf_amd.TSDFVolume(size, (size[0] * 10.0, size[1] * 12.5, size[2] * 9.0))
+    gv.offset(100.0, -50.0, 25.0)
+    n = size[0] * size[1] * size[2]
+    D = rng.uniform(-1.0, 1.0, n).astype(np.float32)
+    D[rng.random(n) < 0.6] = 1.0                       # mostly outside, so that every configuration turns up
+    D[rng.integers(0, n, 3)] = [0.0, -0.0, np.nan]     # zeros are "not negative", a NaN neither
+    gv.set_distance_data(D)
+    dev, host = both(gv, size)
+    assert dev.shape == host.shape and dev.shape[0] % 3 == 0 and (size == (2, 2, 2) or dev.shape[0] > 0)
+    assert_same_floats(dev, host, "marching cubes %s" % (size,))
+
+
+def test_integrated_scene_and_empty_volume():
+    n = 96
+    gv = tsdf_amd.TSDFVolume((n, n, n), (3000.0,) * 3)
+    dev, host = both(gv, (n, n, n))
+    assert dev.shape == (0, 3) and host.shape == (0, 3)          # cleared: the distance is +trunc everywhere
+    bil = tsdf_amd.BilateralFilter(30.0, 4.5)
+    for i in range(3):
+        d, cam = synth.depth_frame(i, 4, seed=0x5EED0002)
+        f = d.copy(); bil.filter(f, synth.WIDTH, synth.HEIGHT)
+        gv.integrate(f, synth.WIDTH, synth.HEIGHT, cam)
+    dev, host = both(gv, (n, n, n))
+    assert dev.shape[0] > 10000
+    assert_same_floats(dev, host, "mesh of the integrated scene")
+
+
+def test_slabs_are_refused():
+    s = tsdf_amd.TSDFVolume((16, 16, 16), (100.0,) * 3, slab=(0, 8))
+    with pytest.raises(Exception, match="whole volume"):
+        s.extract_surface()

@@ -145,6 +145,17 @@ class TSDFVolume:
         a = self._host(nodes, 6)
         check(lib.tsdf_volume_set_deformation(self._h, a.ctypes.data))
 
+    def extract_surface(self):
+        """extract_surface on the device (tsdf_volume_marching_cubes): (3*T, 3) float32 vertices, triangle t = rows 3t,
+        3t+1, 3t+2, cubes in the reference's order -- the same array as marching_cubes() on the downloaded distances."""
+        table = marching_cubes_table()
+        n = C.c_uint64(0)
+        check(lib.tsdf_volume_marching_cubes(self._h, table.ctypes.data, C.byref(n), None, 0))
+        out = np.empty((n.value, 3), np.float32)
+        if n.value:
+            check(lib.tsdf_volume_marching_cubes(self._h, table.ctypes.data, C.byref(n), out.ctypes.data, n.value))
+        return out
+
     def deform_mesh(self, points):
         """TSDFVolume::deform_mesh (src/TSDF/TSDFVolume.cu:265-291): points (n,3) float32 -> deformed copy."""
         p = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3).copy()

@@ -1,4 +1,4 @@
-// Host-side iso-surface extraction: marching cubes over the distance array, as the reference's extract_surface
+// Iso-surface extraction: marching cubes over the distance array, as the reference's extract_surface
 // (src/MarchingCubes/MarkAndSweepMC.cu:506-555) -- same cube order, corner and edge numbering (:9-36, :80-97), sign
 // classification (:110-124), edge interpolation (:47-63), triangle soup with winding (i, i+2, i+1) (:549).
 //
@@ -190,14 +190,16 @@ const int8_t *tsdf_host_mc_triangle_table() { return &tables().tri[0][0]; }
 void extract_surface(const TSDFVolume *volume, std::vector<float3> &vertices, std::vector<int3> &triangles) {
     vertices.clear();
     triangles.clear();
-    const TSDFVolume::UInt3 size = volume->size();
-    const TSDFVolume::Float3 vs = volume->voxel_size();
-    const TSDFVolume::Float3 off = volume->offset();
-    const size_t n = (size_t)size.x * size.y * size.z;
-    std::vector<float> dist(n);
-    tsdf_host::check(tsdf_volume_get_distance_data(volume->handle(), dist.data()), "Couldn't read distance data");
-    const float vsa[3] = {vs.x, vs.y, vs.z}, offa[3] = {off.x, off.y, off.z};
-    tsdf_host_marching_cubes(dist.data(), size.x, size.y, size.z, vsa, offa, vertices);
+    // on the device (the reference extracts on the GPU too); the table is the one generated above
+    uint64_t n_vertices = 0;
+    tsdf_host::check(tsdf_volume_marching_cubes(volume->handle(), tsdf_host_mc_triangle_table(), &n_vertices, nullptr, 0),
+                     "Couldn't extract the surface");
+    vertices.resize((size_t)n_vertices);
+    if (n_vertices != 0)
+        tsdf_host::check(tsdf_volume_marching_cubes(volume->handle(), tsdf_host_mc_triangle_table(), &n_vertices,
+                                                    reinterpret_cast<float *>(vertices.data()), n_vertices),
+                         "Couldn't extract the surface");
+
     // triangles are implicit, three consecutive vertices each, wired (i, i+2, i+1) like the reference (:549)
     for (size_t i = 0; i + 2 < vertices.size(); i += 3) triangles.push_back(int3{(int)i, (int)i + 2, (int)i + 1});
 }
