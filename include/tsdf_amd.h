@@ -196,7 +196,8 @@ int tsdf_volume_get_occupancy_data(const tsdf_volume *volume, int force_rebuild,
  * numbering (:9-36, :80-97), sign rule (:110-124) and interpolate() arithmetic (:47-63); three consecutive vertices per
  * triangle (the caller wires them (i, i+2, i+1), :549).  table = 256 x 32 edge numbers, three per triangle, -1
  * terminated (the host library generates it: tsdf_host_mc_table).  *n_vertices receives the vertex count; when
- * host_vertices is not NULL and capacity (in vertices) suffices, it receives 3 floats per vertex.  Whole volumes only. */
+ * host_vertices is not NULL and capacity (in vertices) suffices, it receives 3 floats per vertex.  A Z-slab marches the cube layers
+ * rooted in its own planes: the slabs' arrays concatenated in slab order are the whole volume's. */
 int tsdf_volume_marching_cubes(const tsdf_volume *volume, const int8_t *table, uint64_t *n_vertices, float *host_vertices,
                                uint64_t capacity);
 

@@ -47,7 +47,20 @@ def test_integrated_scene_and_empty_volume():
     assert_same_floats(dev, host, "mesh of the integrated scene")
 
 
-def test_slabs_are_refused():
-    s = tsdf_amd.TSDFVolume((16, 16, 16), (100.0,) * 3, slab=(0, 8))
-    with pytest.raises(Exception, match="whole volume"):
-        s.extract_surface()
+def test_slabs_concatenate_to_the_whole_volume():
+    size, phys = (40, 24, 50), (400.0, 240.0, 500.0)
+    rng = np.random.default_rng(7)
+    D = rng.uniform(-1.0, 1.0, size[0] * size[1] * size[2]).astype(np.float32)
+    D[rng.random(D.size) < 0.5] = 1.0
+    whole = tsdf_amd.TSDFVolume(size, phys)
+    whole.set_distance_data(D)
+    ref = whole.extract_surface()
+    planes = D.reshape(size[2], -1)
+    for bounds in ((0, 17, 18, 49, 50), (0, 1, 25, 50), (0, 50)):
+        parts = []
+        for zb, ze in zip(bounds[:-1], bounds[1:]):
+            s = tsdf_amd.TSDFVolume(size, phys, slab=(zb, ze))
+            lo, hi = s.resident_planes()
+            s.set_distance_data(planes[lo:hi].ravel())
+            parts.append(s.extract_surface())
+        assert_same_floats(np.concatenate(parts), ref, "slabs %s" % (bounds,))

@@ -40,16 +40,17 @@ __device__ inline int cube_type(const float *__restrict__ dist, size_t base, siz
 
 // EMIT = false: row_count[row] = vertices of the row.  EMIT = true: writes them at row_offset[row].
 template <bool EMIT>
-__global__ __launch_bounds__(256) void mc_rows_kernel(const float *__restrict__ dist, uint32_t X, uint32_t Y, uint32_t Z, F3 vs, F3 offset,
+__global__ __launch_bounds__(256) void mc_rows_kernel(const float *__restrict__ dist, uint32_t X, uint32_t Y, uint32_t z_first, uint32_t n_layers,
+                                                      uint32_t z_stored, F3 vs, F3 offset,
                                                       const McTable *__restrict__ table, uint32_t *__restrict__ row_count,
                                                       const uint64_t *__restrict__ row_offset, float *__restrict__ out) {
     __shared__ uint8_t count[256];
     count[threadIdx.x] = table->count[threadIdx.x];
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63u, n_rows = (Y - 1) * (Z - 1);
+    const uint32_t lane = threadIdx.x & 63u, n_rows = (Y - 1) * n_layers;
     const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n_rows) return;
-    const uint32_t y = row % (Y - 1), z = row / (Y - 1);
+    const uint32_t y = row % (Y - 1), z = z_first + row / (Y - 1);   // (z: the grid's plane; z - z_stored: where it is stored)
     const size_t dy = X, dz = (size_t)X * Y;
     uint64_t running = EMIT ? row_offset[row] : 0;   // vertices of the row so far (EMIT: absolute position)
     for (uint32_t x0 = 0; x0 + 1 < X; x0 += 64) {
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void mc_rows_kernel(const float *__restrict__ 
         const bool valid = x + 1 < X;
         float w[8];
         int type = 0;
-        if (valid) type = cube_type(dist, (size_t)x + y * dy + z * dz, dy, dz, w);
+        if (valid) type = cube_type(dist, (size_t)x + y * dy + (z - z_stored) * dz, dy, dz, w);
         const uint32_t n = valid ? count[type] : 0u;
         uint32_t incl = n;   // inclusive prefix over the wave
         for (int o = 1; o < 64; o <<= 1) {
@@ -131,9 +132,13 @@ extern "C" int tsdf_volume_marching_cubes(const tsdf_volume *cv, const int8_t *t
     TSDF_REQUIRE(cv && table && n_vertices, "tsdf_volume_marching_cubes: null argument");
     tsdf_volume *v = const_cast<tsdf_volume *>(cv);
     const Geom &g = v->g;
-    TSDF_REQUIRE(v->z_begin == 0 && v->z_end == g.Z, "tsdf_volume_marching_cubes needs a whole volume (gather the slabs first)");
     *n_vertices = 0;
     if (g.X < 2 || g.Y < 2 || g.Z < 2) return TSDF_OK;
+    // a Z-slab marches the cube layers rooted in the planes it owns (the layer above its last plane reads the halo plane
+    // it stores): concatenated in slab order the slabs' vertices are the whole volume's
+    const uint32_t z_first = v->z_begin, z_last = v->z_end < g.Z - 1 ? v->z_end : g.Z - 1;   // cube layers [z_first, z_last)
+    if (z_last <= z_first) return TSDF_OK;
+    const uint32_t n_layers = z_last - z_first;
     McTable t;
     memset(&t, 0, sizeof(t));
     for (int c = 0; c < 256; c++) {
@@ -147,7 +152,7 @@ extern "C" int tsdf_volume_marching_cubes(const tsdf_volume *cv, const int8_t *t
         for (int i = n; i < 32; i++) t.tri[c][i] = -1;
         t.count[c] = (uint8_t)n;
     }
-    const uint32_t n_rows = (g.Y - 1) * (g.Z - 1);
+    const uint32_t n_rows = (g.Y - 1) * n_layers;
     McTable *d_table = nullptr;
     uint32_t *d_count = nullptr;
     uint64_t *d_offset = nullptr;
@@ -160,7 +165,7 @@ extern "C" int tsdf_volume_marching_cubes(const tsdf_volume *cv, const int8_t *t
     uint64_t total = 0;
     if (e == hipSuccess) {
         const dim3 grid((n_rows + 3) / 4);
-        hipLaunchKernelGGL((mc_rows_kernel<false>), grid, dim3(256), 0, v->stream, v->dist, g.X, g.Y, g.Z, g.vs, g.offset, d_table, d_count,
+        hipLaunchKernelGGL((mc_rows_kernel<false>), grid, dim3(256), 0, v->stream, v->dist, g.X, g.Y, z_first, n_layers, g.z_store_begin, g.vs, g.offset, d_table, d_count,
                            (const uint64_t *)nullptr, (float *)nullptr);
         hipLaunchKernelGGL(mc_scan_kernel, dim3(1), dim3(1024), 0, v->stream, d_count, n_rows, d_offset);
         e = hipGetLastError();
@@ -175,7 +180,7 @@ extern "C" int tsdf_volume_marching_cubes(const tsdf_volume *cv, const int8_t *t
             } else {
                 e = hipMalloc((void **)&d_out, total * 3 * sizeof(float));
                 if (e == hipSuccess) {
-                    hipLaunchKernelGGL((mc_rows_kernel<true>), grid, dim3(256), 0, v->stream, v->dist, g.X, g.Y, g.Z, g.vs, g.offset, d_table,
+                    hipLaunchKernelGGL((mc_rows_kernel<true>), grid, dim3(256), 0, v->stream, v->dist, g.X, g.Y, z_first, n_layers, g.z_store_begin, g.vs, g.offset, d_table,
                                        (uint32_t *)nullptr, d_offset, d_out);
                     e = hipGetLastError();
                 }
