@@ -51,6 +51,7 @@ def parse():
 
 def main():
     args = parse()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (before the HIP runtime starts: RCCL's IPC needs it on this host driver)
     import torch
     import torch.distributed as dist
 
@@ -68,7 +69,6 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if share:
             dist.init_process_group("gloo")
         else:
