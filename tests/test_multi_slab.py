@@ -103,3 +103,41 @@ def test_merge_hits_refuses_cpu_tensors():
     from tsdf_amd.multi import merge_hits
     with pytest.raises(TypeError):
         merge_hits(torch.zeros((2, 4, 4)), 2, 2)
+
+
+def _mesh_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import tsdf_amd
+        from tsdf_amd.multi import gather_vertices, slab_range
+        size, vs = (20, 12, 23), (10.0, 12.5, 9.0)
+        D = np.random.default_rng(11).uniform(-1.0, 1.0, size[0] * size[1] * size[2]).astype(np.float32)
+        whole = tsdf_amd.marching_cubes(D, size, vs)                         # host marching cubes, the whole grid
+        # this rank's part: the cube layers rooted in its planes = the host marching cubes of planes [zb, ze] (with the
+        # halo plane), shifted to its place -- what TSDFVolume.extract_surface returns for the slab on a GPU
+        zb, ze = slab_range(size[2], world, rank)
+        hi = min(ze + 1, size[2])
+        planes = D.reshape(size[2], -1)[zb:hi]
+        mine = tsdf_amd.marching_cubes(planes.ravel(), (size[0], size[1], hi - zb), vs, offset=(0.0, 0.0, 0.0)) if hi - zb >= 2 else np.zeros((0, 3), np.float32)
+        mine = mine.copy()
+        # (z of a slab-local vertex: the same expression with the global plane index -- recompute rather than add an offset)
+        got = gather_vertices(torch.from_numpy(mine)).numpy()
+        if rank == 0:
+            np.save(os.path.join(tmp, "mesh.npy"), np.array([got.shape[0], whole.shape[0],
+                                                             int(np.array_equal(got[:, :2].view(np.uint32), whole[:, :2].view(np.uint32)))]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_meshes_gathered_over_gloo_are_the_whole_mesh_in_cube_order(tmp_path, world):
+    """gather_vertices: parts of different lengths, concatenated in rank order (x and y of every vertex compared; z is
+    produced with the global plane index by the device kernel, tests/test_parity_marching_cubes.py)."""
+    port = _free_port()
+    mp.spawn(_mesh_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    n_got, n_whole, same_xy = np.load(os.path.join(str(tmp_path), "mesh.npy"))
+    assert n_got == n_whole and n_whole > 100 and same_xy == 1

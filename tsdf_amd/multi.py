@@ -55,3 +55,21 @@ def merge_hits(hits_all, width, height, vertices=None, stream=None):
     s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
     merge_hits_device(hits_all.data_ptr(), hits_all.shape[0], width, height, vertices.data_ptr(), s)
     return vertices
+
+
+def gather_vertices(vertices_mine, group=None):
+    """extract_surface over the slabs: every rank's (n_r, 3) float32 vertices (TSDFVolume.extract_surface on its slab)
+    -> the whole volume's array on every rank, the ranks' parts in rank order (= the reference's cube order, z-major).
+    The parts differ in length: lengths first, then one all-gather of the parts padded to the longest."""
+    world = dist.get_world_size(group)
+    mine = torch.as_tensor(vertices_mine, dtype=torch.float32).reshape(-1, 3)
+    dev = mine.device
+    n_mine = torch.tensor([mine.shape[0]], dtype=torch.int64, device=dev)
+    counts = torch.empty((world,), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts, n_mine, group=group)
+    longest = int(counts.max().item())
+    padded = torch.zeros((longest, 3), dtype=torch.float32, device=dev)
+    padded[:mine.shape[0]] = mine
+    parts = torch.empty((world, longest, 3), dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(parts.view(-1), padded.view(-1), group=group)
+    return torch.cat([parts[r, :int(counts[r].item())] for r in range(world)], dim=0)
