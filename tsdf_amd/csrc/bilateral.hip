@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void bilateral_kernel(const PIX *__restrict__ 
         const float *krow = kernel + (cx - fx) * ny;
         for (int cy = fy; cy <= ly_; cy++) {
             int conv = col[(cy - ty0) * span];
-            int delta = abs(conv - current);
+            const unsigned delta = __builtin_amdgcn_sad_u16((unsigned)conv, (unsigned)current, 0u);   // |conv - current| in one instruction (both are 0..65535: the high halves are 0)
             const float weight = krow[cy - fy] * similarity[delta];   // the float product the reference widens (:99)
             sum = (float)((double)sum + ((double)weight * col_d[(cy - ty0) * span]));
             // total_weight + weight evaluated in double and narrowed (:102) == the fp32 sum: both operands are floats, so
