@@ -64,3 +64,21 @@ def test_slabs_concatenate_to_the_whole_volume():
             s.set_distance_data(planes[lo:hi].ravel())
             parts.append(s.extract_surface())
         assert_same_floats(np.concatenate(parts), ref, "slabs %s" % (bounds,))
+
+
+def test_a_buffer_that_is_too_small_is_refused_and_a_bad_table_too():
+    import ctypes as C
+    from tsdf_amd import _capi
+    gv = tsdf_amd.TSDFVolume((8, 8, 8), (80.0,) * 3)
+    D = np.ones(512, np.float32); D[200] = -1.0
+    gv.set_distance_data(D)
+    table = tsdf_amd.marching_cubes_table()
+    n = C.c_uint64(0)
+    assert _capi.lib.tsdf_volume_marching_cubes(gv._h, table.ctypes.data, C.byref(n), None, 0) == 0 and n.value > 0
+    small = np.zeros((n.value - 1, 3), np.float32)
+    rc = _capi.lib.tsdf_volume_marching_cubes(gv._h, table.ctypes.data, C.byref(n), small.ctypes.data, n.value - 1)
+    assert rc != 0 and b"do not fit" in _capi.lib.tsdf_last_error()
+    bad = table.copy(); bad[1, 0] = 12                      # no such edge
+    assert _capi.lib.tsdf_volume_marching_cubes(gv._h, bad.ctypes.data, C.byref(n), None, 0) != 0
+    bad = table.copy(); bad[1, 3] = 0                       # four vertices: not whole triangles
+    assert _capi.lib.tsdf_volume_marching_cubes(gv._h, bad.ctypes.data, C.byref(n), None, 0) != 0
