@@ -3,7 +3,7 @@ TUMDataLoader / extract_surface ...) on the GPU.
 
   * build/test_surface (tests/cpp/test_surface.cpp) drives the classes the way the reference's kinfu.cpp does and
     dumps raw results; they must be bit-identical to what the oracle computes from the same inputs.
-  * when oracle/_ref/kinfu exists (the REFERENCE's unchanged src/Tools/kinfu.cpp compiled against this repo's
+  * when build/linkcheck/bin/kinfu exists (the REFERENCE's unchanged src/Tools/kinfu.cpp compiled against this repo's
     headers by tools/linkcheck.sh), it is run end to end on a synthetic TUM-layout directory.
 """
 import os
@@ -17,7 +17,7 @@ from tsdf_amd import synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "build", "test_surface")
-KINFU = os.path.join(ROOT, "oracle", "_ref", "kinfu")
+KINFU = os.path.join(ROOT, "build", "linkcheck", "bin", "kinfu")
 
 
 def test_headers_of_the_class_surface_compile_standalone():
@@ -69,9 +69,9 @@ int main(int argc, char **argv) {
 def test_reference_tsdf_view_writes_its_slice_images(tmp_path):
     """src/Tools/tsdf_view.cpp of the reference, compiled unchanged against this repo's PNG utilities (no GPU needed): it
     reads dims + 3 floats + a cubic distance array and writes three tiled colour PNGs into the working directory."""
-    tool = os.path.join(ROOT, "oracle", "_ref", "tsdf_view")
+    tool = os.path.join(ROOT, "build", "linkcheck", "bin", "tsdf_view")
     if not os.path.exists(tool):
-        pytest.skip("oracle/_ref/tsdf_view not built (needs the reference tree at build time)")
+        pytest.skip("build/linkcheck/bin/tsdf_view not built (needs the reference tree at build time)")
     n = 8
     rng = np.random.default_rng(1)
     with open(tmp_path / "v.bin", "wb") as f:
@@ -101,9 +101,9 @@ def test_reference_tsdf_view_writes_its_slice_images(tmp_path):
 def test_reference_pgm2png_converts_a_depth_map(tmp_path):
     """src/Tools/pgm2png.cpp of the reference, compiled unchanged: read_nyu_depth_map (16-bit PGM, bytes of every sample
     swapped after the read, src/Utilities/DepthMapUtilities.cpp:29-31) + save_png_to_file (16-bit greyscale PNG)."""
-    tool = os.path.join(ROOT, "oracle", "_ref", "pgm2png")
+    tool = os.path.join(ROOT, "build", "linkcheck", "bin", "pgm2png")
     if not os.path.exists(tool):
-        pytest.skip("oracle/_ref/pgm2png not built (needs the reference tree at build time)")
+        pytest.skip("build/linkcheck/bin/pgm2png not built (needs the reference tree at build time)")
     w, h = 7, 5
     img = (np.arange(w * h, dtype=np.uint32) * 1234 % 65536).astype(np.uint16).reshape(h, w)
     with open(tmp_path / "d.pgm", "wb") as f:
@@ -190,7 +190,7 @@ def test_cpp_surface_matches_the_oracle(tmp_path, oracle):
 @pytest.mark.gpu
 def test_reference_kinfu_runs_end_to_end_against_this_library(tmp_path):
     if not os.path.exists(KINFU):
-        pytest.skip("oracle/_ref/kinfu not built (needs the reference tree at build time)")
+        pytest.skip("build/linkcheck/bin/kinfu not built (needs the reference tree at build time)")
     d = tmp_path / "tum"
     synth.write_tum_directory(str(d), 3, seed=0x5EED0002)
     r = subprocess.run([KINFU, "-m", "3", "-d", str(d)], capture_output=True, text=True, timeout=300)
@@ -208,9 +208,9 @@ def test_reference_kinfu_runs_end_to_end_against_this_library(tmp_path):
 def test_reference_tsdf_icp_runs_against_this_library(tmp_path):
     """src/Tools/tsdf_icp.cpp of the reference, compiled unchanged (tools/linkcheck.sh): loads a .tsdf volume and a depth
     PNG, renders the volume from the pose stored in it and runs ICPOdometry between the two images."""
-    tool = os.path.join(ROOT, "oracle", "_ref", "tsdf_icp")
+    tool = os.path.join(ROOT, "build", "linkcheck", "bin", "tsdf_icp")
     if not os.path.exists(tool) or not os.path.exists(BIN):
-        pytest.skip("oracle/_ref/tsdf_icp not built (needs the reference tree at build time)")
+        pytest.skip("build/linkcheck/bin/tsdf_icp not built (needs the reference tree at build time)")
     # a volume file written by the class surface (test_surface saves <out>/volume.tsdf) ...
     depth, cam = synth.depth_frame(2, 30, seed=0x5EED0001)
     depth.tofile(str(tmp_path / "depth.u16"))
