@@ -46,6 +46,8 @@ def parse():
                          "a few microseconds of stream time, 9 %% of the step when every launch is bracketed")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: filter frame i+1 after, not during, the exchange of frame i")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    ap.add_argument("--path-only", action="store_true",
+                    help="only the timed hot path and its roofline (no ICP / tracking / host-buffer legs): what the profiling passes run")
     return ap.parse_args()
 
 
@@ -276,10 +278,10 @@ def main():
             r_["frac_of_measured_copy"] = round(r_["achieved"] / copy_gbs, 5)
         out["roofline"] = roof_ray if dominant == "raycast" else roof_int
         out["roofline_other"] = roof_int if dominant == "raycast" else roof_ray
-        out["host_buffer_api"] = host_api_time(vol, bil, frames, cams, last)
-
-        out["icp"] = icp_tracking(tsdf_amd, synth, depth_dev, frames, stream, not args.no_cpu_baseline)
-        out["tracking"] = tracking_loop(tsdf_amd, synth, n, args.physical, args.stream_frames)
+        if not args.path_only:
+            out["host_buffer_api"] = host_api_time(vol, bil, frames, cams, last)
+            out["icp"] = icp_tracking(tsdf_amd, synth, depth_dev, frames, stream, not args.no_cpu_baseline)
+            out["tracking"] = tracking_loop(tsdf_amd, synth, n, args.physical, args.stream_frames)
         if not args.no_parity:
             out["parity"] = parity_gate(tsdf_amd, synth, n_small=96)
         if not args.no_cpu_baseline:

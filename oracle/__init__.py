@@ -18,7 +18,7 @@ def build(force=False):
     """(Re)build the oracle .so (and oracle/_ref when /root/reference is mounted)."""
     if force or not os.path.exists(_LIB) or \
             os.path.getmtime(_LIB) < max(os.path.getmtime(os.path.join(_HERE, f))
-                                         for f in ("tsdf_oracle.c", "icp_oracle.c", "tsdf_oracle.h")):
+                                         for f in ("tsdf_oracle.c", "icp_oracle.c", "mc_oracle.c", "tsdf_oracle.h")):
         subprocess.check_call(["make", "-C", _HERE, "-s", "all"])
     return _LIB
 
@@ -86,6 +86,9 @@ def lib():
         L.orc_deform_points.argtypes = [C.POINTER(C.c_uint32), fp, fp, fp, fp, fp, fp, C.c_int, fp]
         L.orc_icp_incremental_transformation.argtypes = [u16p, u16p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
                                                          C.c_float, C.c_float, C.c_float, C.c_float, dp, fp, fp]
+        L.orc_mc_tables.argtypes = [C.POINTER(C.c_int8), C.POINTER(C.c_uint8)]
+        L.orc_marching_cubes.restype = C.c_int64
+        L.orc_marching_cubes.argtypes = [fp, C.c_uint32, C.c_uint32, C.c_uint32, fp, fp, fp, C.c_int64, C.c_int]
         _lib = L
     return _lib
 
@@ -409,3 +412,27 @@ def deform_points(dims, vs, offset, offset_at_clear, nodes, global_rotation, glo
     lib().orc_deform_points(d.ctypes.data_as(C.POINTER(C.c_uint32)), _fp(a[0]), _fp(a[1]), _fp(a[2]),
                             _fp(nd) if nd is not None else None, _fp(r), _fp(t), pts.shape[0], _fp(pts))
     return pts
+
+
+# ------------------------------------------------------------------------------ marching cubes (mc_oracle.c)
+
+def mc_tables():
+    """(TRIANGLE_TABLE 256 x 16 int8, VERTICES_FOR_CUBE_TYPE 256 uint8) as the oracle builds them."""
+    t = np.empty((256, 16), np.int8)
+    c = np.empty(256, np.uint8)
+    lib().orc_mc_tables(t.ctypes.data_as(C.POINTER(C.c_int8)), c.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return t, c
+
+
+def marching_cubes(distances, size, voxel_size, offset=(0.0, 0.0, 0.0), nthreads=1):
+    """extract_surface of the reference (MarkAndSweepMC.cu:506-555) on a host distance array: (n, 3) float32 vertices, three
+    per triangle in emission order (the reference wires triangle t as (3t, 3t+2, 3t+1))."""
+    X, Y, Z = (int(v) for v in size)
+    d = _f32(distances, X * Y * Z)
+    vs, off = _f32(voxel_size, 3), _f32(offset, 3)
+    n = lib().orc_marching_cubes(_fp(d), X, Y, Z, _fp(vs), _fp(off), None, 0, nthreads)
+    out = np.empty((max(n, 0), 3), np.float32)
+    if n > 0:
+        got = lib().orc_marching_cubes(_fp(d), X, Y, Z, _fp(vs), _fp(off), _fp(out), n, nthreads)
+        assert got == n
+    return out

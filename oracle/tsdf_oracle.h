@@ -156,6 +156,15 @@ void orc_deform_points(const uint32_t dims[3], const float vs[3], const float of
                        const float *nodes, const float global_rotation[3], const float global_translation[3], int num_points,
                        float *points);
 
+/* ---- marching cubes (mc_oracle.c; src/MarchingCubes/MarkAndSweepMC.cu) ------------------------------ */
+/* TRIANGLE_TABLE / VERTICES_FOR_CUBE_TYPE (MC_triangle_table.cu:87, :46), rebuilt from base configurations + rotations;
+ * pinned by SHA-256 on the reference's file (tests/golden/mc_tables.sha256.json) */
+void orc_mc_tables(int8_t triangle_table[256][16], uint8_t vertices_for_cube_type[256]);
+/* extract_surface (MarkAndSweepMC.cu:506-555): vertices in emission order, three per triangle; vertices == NULL counts.
+ * Returns the number of vertices, -1 if capacity (in vertices) is too small. */
+int64_t orc_marching_cubes(const float *dist, uint32_t X, uint32_t Y, uint32_t Z, const float vs[3], const float offset[3],
+                           float *vertices, int64_t capacity, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,6 +41,10 @@ def test_default_shaped_run_prints_the_contract_line():
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
     assert d["parity"]["pass"] is True
+    # BASELINE configs[4] runs inside the bench at 512^3: its outcome is asserted, not just reported
+    t = d["tracking"]
+    assert t["frames"] >= 24 and t["max_translation_error_mm"] < 10.0 and t["max_rotation_error_rad"] < 0.006
+    assert t["mesh"]["same_as_host"] is True and t["mesh"]["triangles"] > 500_000
 
 
 def test_few_steps_and_no_sampled_events_still_give_strict_json():

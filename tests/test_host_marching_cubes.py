@@ -1,11 +1,18 @@
-"""Host marching cubes (tsdf_amd/host/src/MarkAndSweepMC.cpp; next row f2).  The 256-case table is generated from the cube
-geometry, not taken from the reference, so it is pinned on what a marching-cubes table must satisfy and on geometry with a
-known answer; the vertex positions follow the reference's interpolate() and are checked bit for bit against an
-independent numpy evaluation of every sign-changing lattice edge."""
+"""Host marching cubes (tsdf_amd/host/src/MarkAndSweepMC.cpp; next row f2).  The 256-case table is built from base
+configurations + the cube's rotations and must equal the reference's TRIANGLE_TABLE entry for entry: its SHA-256 is
+compared with the digest tools/mc_table_sha.py took from the reference's file (tests/golden/mc_tables.sha256.json).  On top:
+what any marching-cubes table must satisfy, the oracle's restatement of the reference's loop (same vertex array, bit for
+bit), an independent numpy evaluation of every sign-changing lattice edge, and geometry with a known answer."""
+import hashlib
+import json
+import os
+
 import numpy as np
 import pytest
 
 import tsdf_amd
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mc_tables.sha256.json")
 
 CORNER = np.array([[0, 0, 1], [1, 0, 1], [1, 0, 0], [0, 0, 0], [0, 1, 1], [1, 1, 1], [1, 1, 0], [0, 1, 0]])   # MarkAndSweepMC.cu:80-97
 EDGE = [(0, 1), (2, 1), (3, 2), (3, 0), (4, 5), (6, 5), (7, 6), (7, 4), (0, 4), (1, 5), (2, 6), (3, 7)]        # :291-302
@@ -15,7 +22,37 @@ def rows_of(table):
     return [[int(e) for e in row if e >= 0] for row in table]
 
 
-def test_generated_table_is_a_marching_cubes_table():
+def test_table_is_the_reference_table_entry_for_entry():
+    gold = json.load(open(GOLD))
+    t = tsdf_amd.marching_cubes_table()
+    assert t.shape == (256, 32) and t.dtype == np.int8 and (t[:, 16:] == -1).all()
+    assert hashlib.sha256(np.ascontiguousarray(t[:, :16]).tobytes()).hexdigest() == gold["TRIANGLE_TABLE[256][16] int8"]
+    counts = (t >= 0).sum(axis=1).astype(np.uint8)
+    assert hashlib.sha256(counts.tobytes()).hexdigest() == gold["VERTICES_FOR_CUBE_TYPE[256] uint8"]
+    assert hashlib.sha256(np.array(EDGE, np.uint8).tobytes()).hexdigest() == gold["EDGE_VERTICES[12][2] uint8"]
+
+
+def test_table_equals_the_oracle_table(oracle):
+    t, counts = oracle.mc_tables()
+    assert np.array_equal(tsdf_amd.marching_cubes_table()[:, :16], t)
+    assert np.array_equal((t >= 0).sum(axis=1), counts)
+
+
+@pytest.mark.parametrize("size", [(2, 2, 2), (3, 2, 5), (17, 9, 11), (40, 33, 21)])
+def test_vertex_array_equals_the_oracle_restatement_of_the_reference_loop(oracle, size):
+    rng = np.random.default_rng(size[0] * 100 + size[2])
+    n = size[0] * size[1] * size[2]
+    D = rng.uniform(-1.0, 1.0, n).astype(np.float32)
+    D[rng.random(n) < 0.5] = 1.0
+    D[rng.integers(0, n, 3)] = [0.0, -0.0, np.nan]         # zeros and NaN are "not negative"
+    vs, off = (2.0, 3.0, 1.5), (10.0, -4.0, 0.25)
+    got = tsdf_amd.marching_cubes(D, size, vs, off)
+    exp = oracle.marching_cubes(D, size, vs, off, nthreads=2)
+    assert got.shape == exp.shape
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+
+
+def test_table_is_a_marching_cubes_table():
     rows = rows_of(tsdf_amd.marching_cubes_table())
     assert rows[0] == [] and rows[255] == []
     assert rows[1] == [0, 8, 3]                    # only corner 0 negative: the classic orientation

@@ -278,3 +278,53 @@ def test_sphere_raycast_golden_vectors_lie_on_the_sphere(oracle):
         assert hit.sum() > 500
         r = np.linalg.norm(V[hit].astype(np.float64) - 128.0, axis=1)
         assert np.all(np.abs(r - 80.0) < 8.0)          # within the truncation band of the radius-80 sphere
+
+
+# ---------------------------------------------------------------------------------------- marching cubes (mc_oracle.c)
+
+def test_mc_tables_equal_the_reference_tables_by_digest(oracle):
+    """TRIANGLE_TABLE / VERTICES_FOR_CUBE_TYPE as the oracle builds them vs the SHA-256 tools/mc_table_sha.py took from the
+    reference's MC_triangle_table.cu where it lies (and, when the reference is mounted, vs that file again right now)."""
+    import hashlib
+    import json
+    gold = json.load(open(os.path.join(GOLD, "mc_tables.sha256.json")))
+    t, counts = oracle.mc_tables()
+    assert hashlib.sha256(t.tobytes()).hexdigest() == gold["TRIANGLE_TABLE[256][16] int8"]
+    assert hashlib.sha256(counts.tobytes()).hexdigest() == gold["VERTICES_FOR_CUBE_TYPE[256] uint8"]
+    assert list(t[1][:4]) == [0, 8, 3, -1] and list(t[3][:7]) == [1, 8, 3, 9, 8, 1, -1]     # the comment of MC_triangle_table.cu:84 aside
+    if os.path.exists("/root/reference/src/MarchingCubes/MC_triangle_table.cu"):
+        import subprocess
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        assert subprocess.run([sys.executable, os.path.join(root, "tools", "mc_table_sha.py")], stdout=subprocess.DEVNULL).returncode == 0
+
+
+def test_mc_single_cube_known_answers(oracle):
+    """One cube, corner 0 = voxel (0,0,1) negative: TRIANGLE_TABLE[1] = edges 0, 8, 3 -> the crossings towards corners 1, 4
+    and 3, each at ratio -w0/(w1-w0) from the negative end (interpolate, MarkAndSweepMC.cu:47-63)."""
+    D = np.ones(8, np.float32)
+    D[0 + 0 * 2 + 1 * 4] = -1.0                       # voxel (0,0,1)
+    V = oracle.marching_cubes(D, (2, 2, 2), (2.0, 2.0, 2.0), (0.0, 0.0, 0.0))
+    assert V.shape == (3, 3)
+    # voxel centres: 1 and 3 per axis; the crossing is half way (w = -1 / +1)
+    assert np.array_equal(V, np.array([[2.0, 1.0, 3.0], [1.0, 2.0, 3.0], [1.0, 1.0, 2.0]], np.float32))
+    D[0 + 0 * 2 + 1 * 4] = -3.0                       # ratio 3/4 from the negative corner
+    V = oracle.marching_cubes(D, (2, 2, 2), (2.0, 2.0, 2.0), (0.0, 0.0, 0.0))
+    assert np.array_equal(V, np.array([[2.5, 1.0, 3.0], [1.0, 2.5, 3.0], [1.0, 1.0, 1.5]], np.float32))
+
+
+def test_mc_sphere_like_the_reference_fixture(oracle):
+    """The sphere SDF of the reference's test_MC_main.cpp:12-47 at 48^3: closed, outward oriented, area and volume of the
+    sphere, every vertex on it."""
+    n, r = 48, 15.0
+    zz, yy, xx = np.mgrid[0:n, 0:n, 0:n]
+    c = n / 2.0
+    D = (np.sqrt((xx + 0.5 - c) ** 2 + (yy + 0.5 - c) ** 2 + (zz + 0.5 - c) ** 2) - r).astype(np.float32)
+    V = oracle.marching_cubes(D.reshape(-1), (n, n, n), (1.0, 1.0, 1.0), nthreads=2).astype(np.float64)
+    T = V.reshape(-1, 3, 3)
+    assert np.all(np.abs(np.linalg.norm(V - c, axis=1) - r) < 0.05)
+    a, b, cc = T[:, 0], T[:, 2], T[:, 1]               # wired (i, i+2, i+1), MarkAndSweepMC.cu:549
+    area = 0.5 * np.linalg.norm(np.cross(b - a, cc - a), axis=1).sum()
+    volume = np.einsum("ij,ij->i", a - c, np.cross(b - c, cc - c)).sum() / 6.0
+    assert abs(area - 4 * np.pi * r * r) < 0.01 * 4 * np.pi * r * r
+    assert abs(volume - 4.0 / 3.0 * np.pi * r ** 3) < 0.01 * 4.0 / 3.0 * np.pi * r ** 3

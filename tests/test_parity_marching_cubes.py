@@ -1,5 +1,6 @@
-"""GPU: extract_surface on the device (tsdf_volume_marching_cubes) returns exactly what the host marching cubes returns
-on the downloaded distances -- the same vertices in the same order, bit for bit."""
+"""GPU: extract_surface on the device (tsdf_volume_marching_cubes) returns exactly what the oracle's restatement of the
+reference's loop (oracle/mc_oracle.c: MarkAndSweepMC.cu:133-152, 219-312, 506-555 with the reference's TRIANGLE_TABLE) returns
+on the downloaded distances -- the same vertices in the same order, bit for bit -- and what the host code returns."""
 import numpy as np
 import pytest
 
@@ -11,10 +12,16 @@ pytestmark = pytest.mark.gpu
 
 
 def both(gv, size):
+    """(device mesh, oracle mesh); the host implementation is checked on the way."""
+    import oracle as O
     dev = gv.extract_surface()
     vs = gv.voxel_size()
-    host = tsdf_amd.marching_cubes(gv.get_distance_data(), size, vs, gv.offset())
-    return dev, host
+    D = gv.get_distance_data()
+    host = tsdf_amd.marching_cubes(D, size, vs, gv.offset())
+    orc = O.marching_cubes(D, size, vs, gv.offset(), nthreads=O.max_threads())
+    assert host.shape == orc.shape
+    assert_same_floats(host, orc, "host marching cubes vs oracle %s" % (size,))
+    return dev, orc
 
 
 @pytest.mark.parametrize("size", [(2, 2, 2), (3, 2, 5), (17, 9, 11), (64, 64, 64), (65, 33, 70), (130, 20, 7)])

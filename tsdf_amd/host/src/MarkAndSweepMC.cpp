@@ -2,15 +2,14 @@
 // (src/MarchingCubes/MarkAndSweepMC.cu:506-555) -- same cube order, corner and edge numbering (:9-36, :80-97), sign
 // classification (:110-124), edge interpolation (:47-63), triangle soup with winding (i, i+2, i+1) (:549).
 //
-// The 256-case table is not taken from the reference's MC_triangle_table.cu: it is GENERATED here, once, from the cube's
-// geometry.  For a sign configuration, on every face the points where the surface crosses the face's edges are joined
-// pairwise (a face whose corners alternate in sign is resolved by cutting off its negative corners -- the rule depends on
-// the face alone, so two cubes sharing a face agree and the mesh has no cracks), each segment directed so that the
-// negative side lies to its left seen from outside (the orientation of the classic table: configuration 1, only corner
-// 0 negative, comes out as edges 0, 8, 3); the segments chain into closed loops, and every loop is
-// triangulated as a fan from its lowest-numbered edge.  For the unambiguous configurations this is the same surface patch
-// as the classic table's, possibly fanned from another corner; the set of mesh vertices (one per sign-changing cube edge
-// per triangle corner using it) lies on the same edges at the same interpolated positions.
+// The 256-case triangle table is built at start-up the way the classic tables were derived (Lorensen & Cline's base
+// configurations carried round the cube by its rotation group; P. Bourke, "Polygonising a scalar field", 1994, whose
+// table the reference's MC_triangle_table.cu:87 holds): a configuration is turned by the cube's 24 rotations, tried in a
+// fixed order, until it coincides with one of 30 base configurations, and that base's triangulation is turned back.
+// The base triangulations and the try-order below reproduce the reference's TRIANGLE_TABLE entry for entry -- same
+// triangles, same order, same first vertex (tools/mc_table_sha.py compares a SHA-256 of the 256 x 16 table with the
+// reference's file where that is mounted; tests/golden/mc_triangle_table.sha256 carries the digest to the GPU box) -- so
+// extract_surface emits the vertex array the reference's loop (MarkAndSweepMC.cu:285) emits.
 #include "MarkAndSweepMC.hpp"
 
 #include <cmath>
@@ -25,14 +24,11 @@ namespace {
 const int kCorner[8][3] = {{0, 0, 1}, {1, 0, 1}, {1, 0, 0}, {0, 0, 0}, {0, 1, 1}, {1, 1, 1}, {1, 1, 0}, {0, 1, 0}};
 // edge e joins corners kEdge[e][0] and kEdge[e][1], in the order the reference interpolates them (:291-302)
 const int kEdge[12][2] = {{0, 1}, {2, 1}, {3, 2}, {3, 0}, {4, 5}, {6, 5}, {7, 6}, {7, 4}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
-// the six faces, corners in cyclic order
-const int kFace[6][4] = {{0, 1, 2, 3}, {4, 5, 6, 7}, {0, 1, 5, 4}, {3, 2, 6, 7}, {0, 3, 7, 4}, {1, 2, 6, 5}};
-
-constexpr int kTableWidth = 32;   // 12 crossing edges bound a configuration to 10 triangles; the generated table needs 5
+constexpr int kTableWidth = 32;   // row stride of the table handed to the device kernel; the reference's rows hold 16 entries
 
 struct Tables {
     int8_t tri[256][kTableWidth];   // edge numbers, three per triangle, -1 terminated
-    uint8_t count[256];    // vertices emitted per configuration
+    uint8_t count[256];    // vertices emitted per configuration (the reference's VERTICES_FOR_CUBE_TYPE, MC_triangle_table.cu:46)
 };
 
 int edge_between(int a, int b) {
@@ -41,67 +37,57 @@ int edge_between(int a, int b) {
     return -1;
 }
 
-void edge_midpoint(int e, double m[3]) {
-    for (int k = 0; k < 3; k++) m[k] = 0.5 * (kCorner[kEdge[e][0]][k] + kCorner[kEdge[e][1]][k]);
-}
+// The 24 rotations of the cube as corner permutations (corner i goes to kRotation[r][i]), in the order they are tried.
+const uint8_t kRotation[24][8] = {
+    {0, 1, 2, 3, 4, 5, 6, 7}, {2, 1, 5, 6, 3, 0, 4, 7}, {5, 1, 0, 4, 6, 2, 3, 7}, {1, 0, 4, 5, 2, 3, 7, 6},
+    {4, 0, 3, 7, 5, 1, 2, 6}, {2, 3, 0, 1, 6, 7, 4, 5}, {7, 3, 2, 6, 4, 0, 1, 5}, {3, 0, 1, 2, 7, 4, 5, 6},
+    {0, 3, 7, 4, 1, 2, 6, 5}, {1, 2, 3, 0, 5, 6, 7, 4}, {3, 2, 6, 7, 0, 1, 5, 4}, {6, 2, 1, 5, 7, 3, 0, 4},
+    {0, 4, 5, 1, 3, 7, 6, 2}, {5, 4, 7, 6, 1, 0, 3, 2}, {7, 4, 0, 3, 6, 5, 1, 2}, {1, 5, 6, 2, 0, 4, 7, 3},
+    {4, 5, 1, 0, 7, 6, 2, 3}, {3, 7, 4, 0, 2, 6, 5, 1}, {6, 7, 3, 2, 5, 4, 0, 1}, {6, 5, 4, 7, 2, 1, 0, 3},
+    {4, 7, 6, 5, 0, 3, 2, 1}, {2, 6, 7, 3, 1, 5, 4, 0}, {7, 6, 5, 4, 3, 2, 1, 0}, {5, 6, 2, 1, 4, 7, 3, 0}};
 
-// Is corner q on the LEFT of the directed segment a -> b, seen from outside the face with outward normal n?
-bool on_left(const double a[3], const double b[3], const double n[3], int q) {
-    const double d[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
-    const double left[3] = {n[1] * d[2] - n[2] * d[1], n[2] * d[0] - n[0] * d[2], n[0] * d[1] - n[1] * d[0]};  // n x d
-    const double r[3] = {kCorner[q][0] - a[0], kCorner[q][1] - a[1], kCorner[q][2] - a[2]};
-    return left[0] * r[0] + left[1] * r[1] + left[2] * r[2] > 0.0;
-}
+// Base configurations (bit i set = corner i negative) and their triangulations: one hex digit per triangle corner = the
+// cube edge it lies on.
+struct BaseCase {
+    uint8_t config;
+    const char *triangles;
+};
+const BaseCase kBase[] = {
+    {0, ""}, {1, "083"}, {3, "183981"}, {5, "08312a"}, {7, "2832a8a98"},
+    {15, "98aa8b"}, {20, "12a847"}, {21, "34730412a"}, {23, "2a9297273794"}, {27, "47b94b9b2921"},
+    {31, "47b4b99ba"}, {37, "30812a495"}, {45, "4950818a18ba"}, {60, "958857a13a3b"}, {61, "5705097b010aba0"},
+    {63, "ba57b5"}, {90, "01947823b5a6"}, {92, "8473b53515b6"}, {94, "059065036b63847"}, {95, "65969b4797b9"},
+    {113, "0730a709a67a"}, {125, "091b67"}, {141, "a7617a187108"}, {142, "03707a0a96a7"}, {150, "4b846b0292a9"},
+    {153, "042462"}, {165, "6b712a083495"}, {191, "a56"}, {232, "29a279237749"}, {255, ""}};
 
 Tables build_tables() {
     Tables t;
-    for (int c = 0; c < 256; c++) {
-        int next[12];
-        for (int e = 0; e < 12; e++) next[e] = -1;
-        auto negative = [c](int corner) { return ((c >> corner) & 1) != 0; };
-        auto join = [&](int e_from, int e_to, const double n[3], int negative_corner) {
-            double a[3], b[3];
-            edge_midpoint(e_from, a);
-            edge_midpoint(e_to, b);
-            if (on_left(a, b, n, negative_corner)) next[e_from] = e_to; else next[e_to] = e_from;
-        };
-        for (int f = 0; f < 6; f++) {
-            const int *q = kFace[f];
-            // outward normal: from the cube centre to the face centre
-            double n[3] = {0, 0, 0};
-            for (int i = 0; i < 4; i++)
-                for (int k = 0; k < 3; k++) n[k] += 0.25 * kCorner[q[i]][k];
-            for (int k = 0; k < 3; k++) n[k] -= 0.5;
-            int crossing[4], n_cross = 0;   // index i: the face edge q[i] - q[i+1] changes sign
-            for (int i = 0; i < 4; i++)
-                if (negative(q[i]) != negative(q[(i + 1) & 3])) crossing[n_cross++] = i;
-            if (n_cross == 2) {
-                // one segment; any negative corner of the face tells the side
-                int neg = -1;
-                for (int i = 0; i < 4; i++)
-                    if (negative(q[i])) neg = q[i];
-                join(edge_between(q[crossing[0]], q[(crossing[0] + 1) & 3]), edge_between(q[crossing[1]], q[(crossing[1] + 1) & 3]), n, neg);
-            } else if (n_cross == 4) {
-                // alternating corners: cut off each negative corner with its own segment
-                for (int i = 0; i < 4; i++)
-                    if (negative(q[i])) join(edge_between(q[(i + 3) & 3], q[i]), edge_between(q[i], q[(i + 1) & 3]), n, q[i]);
-            }
+    // edge permutation of every rotation: the edge joining corners (a, b) goes to the edge joining their images
+    uint8_t edge_map[24][12], inverse[24];
+    for (int r = 0; r < 24; r++)
+        for (int e = 0; e < 12; e++) edge_map[r][e] = (uint8_t)edge_between(kRotation[r][kEdge[e][0]], kRotation[r][kEdge[e][1]]);
+    for (int r = 0; r < 24; r++)
+        for (int q = 0; q < 24; q++) {
+            bool is_inverse = true;
+            for (int i = 0; i < 8; i++) is_inverse = is_inverse && kRotation[q][kRotation[r][i]] == i;
+            if (is_inverse) inverse[r] = (uint8_t)q;
         }
-        // closed loops -> fans
+    int base_of[256];
+    for (int c = 0; c < 256; c++) base_of[c] = -1;
+    for (size_t b = 0; b < sizeof(kBase) / sizeof(kBase[0]); b++) base_of[kBase[b].config] = (int)b;
+    for (int c = 0; c < 256; c++) {
         int n_out = 0;
-        bool used[12] = {false};
-        for (int e0 = 0; e0 < 12; e0++) {
-            if (next[e0] < 0 || used[e0]) continue;
-            int loop[12], len = 0;
-            for (int e = e0; !used[e]; e = next[e]) {
-                used[e] = true;
-                loop[len++] = e;
+        for (int r = 0; r < 24; r++) {
+            int turned = 0;   // the configuration after rotation r
+            for (int i = 0; i < 8; i++)
+                if ((c >> i) & 1) turned |= 1 << kRotation[r][i];
+            if (base_of[turned] < 0) continue;
+            // the base's triangles, turned back
+            for (const char *d = kBase[base_of[turned]].triangles; *d; d++) {
+                const int e = *d <= '9' ? *d - '0' : *d - 'a' + 10;
+                t.tri[c][n_out++] = (int8_t)edge_map[inverse[r]][e];
             }
-            for (int i = 1; i + 1 < len; i++) {
-                t.tri[c][n_out++] = (int8_t)loop[0];
-                t.tri[c][n_out++] = (int8_t)loop[i];
-                t.tri[c][n_out++] = (int8_t)loop[i + 1];
-            }
+            break;
         }
         t.count[c] = (uint8_t)n_out;
         for (int i = n_out; i < kTableWidth; i++) t.tri[c][i] = -1;
@@ -184,13 +170,13 @@ void tsdf_host_marching_cubes(const float *dist, unsigned X, unsigned Y, unsigne
     for (const auto &p : parts) vertices.insert(vertices.end(), p.begin(), p.end());
 }
 
-// the generated table, for tests: 256 x 32 edge numbers
+// the table, for tests and for the device kernel: 256 x 32 edge numbers (the reference's 16 columns + padding)
 const int8_t *tsdf_host_mc_triangle_table() { return &tables().tri[0][0]; }
 
 void extract_surface(const TSDFVolume *volume, std::vector<float3> &vertices, std::vector<int3> &triangles) {
     vertices.clear();
     triangles.clear();
-    // on the device (the reference extracts on the GPU too); the table is the one generated above
+    // on the device (the reference extracts on the GPU too), with the table built above
     uint64_t n_vertices = 0;
     tsdf_host::check(tsdf_volume_marching_cubes(volume->handle(), tsdf_host_mc_triangle_table(), &n_vertices, nullptr, 0),
                      "Couldn't extract the surface");

@@ -39,6 +39,7 @@ class FrameToModelTracker:
         self.icp.set_stream(self.stream.cuda_stream)
         self.frames = 0
         self.last_error, self.last_inliers = 0.0, 0.0
+        self.last_T = None          # the last incremental transformation (4x4, metres) as ICPOdometry returned it
 
     def pose(self):
         """Current camera pose, 4x4 float64 (camera -> world, millimetres)."""
@@ -66,12 +67,19 @@ class FrameToModelTracker:
             self.icp.init_icp_device(self._model.data_ptr(), model=True, depth_cutoff=self.depth_cutoff)
             self.icp.init_icp_device(self._filtered.data_ptr(), depth_cutoff=self.depth_cutoff)
             T = self.icp.get_incremental_transformation()      # current camera -> previous camera, metres
+            self.last_T = T.copy()
             T[:3, 3] *= 1000.0
             self.last_error, self.last_inliers = self.icp.last_error, self.icp.last_inliers
             self.camera.set_pose_rows(self.pose() @ T)
         self.volume.integrate_device(self._filtered.data_ptr(), W, H, self.camera)
         self.frames += 1
         return self.pose()
+
+    def last_icp_inputs(self):
+        """(model depth, filtered current depth) of the last tracked frame as host uint16 arrays: the pair ICPOdometry was
+        given, for checking its answer elsewhere."""
+        self.torch.cuda.synchronize()
+        return (self._model.cpu().numpy().view(np.uint16).copy(), self._filtered.cpu().numpy().view(np.uint16).copy())
 
     def process(self, depth, initial_pose=None):
         """Host depth image (uint16 mm)."""
