@@ -132,6 +132,16 @@ int tsdf_volume_deform_points_device(const tsdf_volume *volume, int num_points, 
 /* Blocking D2H of every resident voxel (what save_to_file does, src/TSDF/TSDFVolume.cu:911-1027). */
 int tsdf_volume_get_distance_data(const tsdf_volume *volume, float *host);
 int tsdf_volume_get_weight_data(const tsdf_volume *volume, float *host);
+/* The deformation nodes of resident planes [plane_begin, plane_begin + plane_count) (plane 0 = the first resident one), X*Y
+ * nodes each, as save_to_file writes m_deformation_nodes (src/TSDF/TSDFVolume.cu:1003-1018): the device array when it has been
+ * materialised (deformation() / set_deformation()), otherwise the regular grid initialise_deformation would have written
+ * (src/TSDF/TSDFVolume.cu:783-785: voxel centre + the offset at the last clear(), rotation 0) -- without materialising it. */
+int tsdf_volume_get_deformation_planes(const tsdf_volume *volume, uint32_t plane_begin, uint32_t plane_count,
+                                       tsdf_deformation_node *host);
+/* File constructor (src/TSDF/TSDFVolume.cu:463-664): a saved volume's node block is loaded verbatim.  When that block is the
+ * regular grid of some constant offset (what clear() wrote, Q1) the nodes can stay implicit; this tells the volume which offset
+ * they carry.  Refused once the node array is materialised. */
+int tsdf_volume_set_offset_at_clear(tsdf_volume *volume, const float offset_at_clear[3]);
 
 /* ---- integrate -------------------------------------------------------------------------- */
 /* Replaces TSDFVolume::integrate + integrate_kernel (src/TSDF/TSDFVolume.cu:861-902, 308-392).

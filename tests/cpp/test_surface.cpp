@@ -122,6 +122,55 @@ int main(int argc, char **argv) {
         }
     }
 
+    // Checkpoints of volumes that are not in the state the constructor leaves them in:
+    // (a) offset() then clear(): the node grid carries that offset (Q1, src/TSDF/TSDFVolume.cu:783-785 + :343); after
+    //     save -> load an integrate must see the same voxel centres as the original volume does;
+    // (b) edited deformation nodes survive save -> load verbatim (the reference writes and reads m_deformation_nodes as is).
+    {
+        const unsigned m = 32;
+        TSDFVolume a(TSDFVolume::UInt3{m, m, m}, TSDFVolume::Float3{3000.0f, 3000.0f, 3000.0f});
+        a.offset(37.5f, -20.25f, 11.0f);
+        a.clear();
+        a.offset(-3.0f, 4.5f, 0.75f);              // changed again after the clear: both offsets are live now
+        if (!a.save_to_file(out + "/offset.tsdf")) return 10;
+        TSDFVolume b(out + "/offset.tsdf");
+        tsdf_volume_info ia, ib;
+        if (tsdf_volume_get_info(a.handle(), &ia) != 0 || tsdf_volume_get_info(b.handle(), &ib) != 0) return 11;
+        if (ib.deformation_materialised != 0) return 12;          // a regular grid stays implicit ...
+        for (int k = 0; k < 3; k++)
+            if (ib.offset_at_clear[k] != ia.offset_at_clear[k] || ib.offset[k] != ia.offset[k]) return 13;   // ... with both offsets
+        a.integrate(filtered.data(), W, H, *camera);
+        b.integrate(filtered.data(), W, H, *camera);
+        std::vector<float> da((size_t)m * m * m), db(da.size());
+        if (tsdf_volume_get_distance_data(a.handle(), da.data()) != 0 || tsdf_volume_get_distance_data(b.handle(), db.data()) != 0) return 14;
+        dump(out + "/offset_dist_original.f32", da.data(), da.size() * sizeof(float));
+        dump(out + "/offset_dist_loaded.f32", db.data(), db.size() * sizeof(float));
+
+        const unsigned q = 12;
+        TSDFVolume c(TSDFVolume::UInt3{q, q, q}, TSDFVolume::Float3{1200.0f, 1200.0f, 1200.0f});
+        std::vector<TSDFVolume::DeformationNode> nodes((size_t)q * q * q);
+        if (tsdf_volume_get_deformation_planes(c.handle(), 0, q, reinterpret_cast<tsdf_deformation_node *>(nodes.data())) != 0) return 15;
+        for (size_t i = 0; i < nodes.size(); i++) {          // a warp: shift and a rotation entry
+            nodes[i].translation.x += 0.125f * (float)(i % 7);
+            nodes[i].translation.z -= 0.5f * (float)(i % 3);
+            nodes[i].rotation.y = 0.01f * (float)(i % 5);
+        }
+        c.set_deformation(nodes.data());
+        if (!c.save_to_file(out + "/warped.tsdf")) return 16;
+        TSDFVolume d(out + "/warped.tsdf");
+        std::vector<TSDFVolume::DeformationNode> back(nodes.size());
+        if (tsdf_volume_get_deformation_planes(d.handle(), 0, q, reinterpret_cast<tsdf_deformation_node *>(back.data())) != 0) return 17;
+        dump(out + "/warp_nodes_set.f32", nodes.data(), nodes.size() * sizeof(nodes[0]));
+        dump(out + "/warp_nodes_loaded.f32", back.data(), back.size() * sizeof(back[0]));
+        // and the file itself carries them (last block of the file)
+        std::ifstream f(out + "/warped.tsdf", std::ios::binary);
+        f.seekg((std::streamoff)(68 + (size_t)q * q * q * (4 + 4 + 3)));
+        std::vector<TSDFVolume::DeformationNode> in_file(nodes.size());
+        f.read((char *)in_file.data(), (std::streamsize)(in_file.size() * sizeof(in_file[0])));
+        if (!f) return 18;
+        dump(out + "/warp_nodes_in_file.f32", in_file.data(), in_file.size() * sizeof(in_file[0]));
+    }
+
     delete loaded;
     delete camera;
     delete volume;

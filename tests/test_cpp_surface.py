@@ -167,6 +167,23 @@ def test_cpp_surface_matches_the_oracle(tmp_path, oracle):
     assert os.path.getsize(str(tmp_path / "volume.tsdf")) == 68 + n ** 3 * (4 + 4 + 3 + 24)
     hdr = np.fromfile(str(tmp_path / "volume.tsdf"), np.uint32, 3)
     assert tuple(hdr) == (n, n, n)
+    # checkpoints of volumes that left the constructor's state: (a) offset() + clear() + offset() -- the loaded volume keeps
+    # both offsets (Q1) and integrates like the original, which integrates like the oracle
+    da = np.fromfile(str(tmp_path / "offset_dist_original.f32"), np.float32)
+    db = np.fromfile(str(tmp_path / "offset_dist_loaded.f32"), np.float32)
+    assert_same_floats(db, da, "integrate after save/load of a volume cleared under an offset")
+    oq = oracle.Volume((32, 32, 32), (3000, 3000, 3000))
+    oq.offset(37.5, -20.25, 11.0)
+    oq.clear()
+    oq.offset(-3.0, 4.5, 0.75)
+    oq.integrate(exp_f, W, H, cam.inverse_pose(), cam.k(), cam.kinv(), nthreads=oracle.max_threads())
+    assert_same_floats(da, oq.dist, "integrate under both offsets vs oracle")
+    assert (da != da[0]).any()
+    # (b) edited deformation nodes are written and read back verbatim
+    ns = np.fromfile(str(tmp_path / "warp_nodes_set.f32"), np.float32)
+    assert ns.size == 12 ** 3 * 6
+    assert np.array_equal(ns, np.fromfile(str(tmp_path / "warp_nodes_in_file.f32"), np.float32))
+    assert np.array_equal(ns, np.fromfile(str(tmp_path / "warp_nodes_loaded.f32"), np.float32))
     # render_to_depth_image: camera-space z of the vertices, rounded (misses -> 0)
     rd = np.fromfile(str(tmp_path / "rendered_depth.u16"), np.uint16)
     hit = ~np.isnan(Vo[:, 0])

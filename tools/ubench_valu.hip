@@ -108,6 +108,33 @@ struct Result {
 // same selects with vcc written once before the loop by a scalar move
 #define A_CND1(i) "v_cndmask_b32 %" #i ", %" #i ", %8, vcc\n"
 #define A_CMP1CND8_0(i) "v_cmp_lt_f32 vcc, %0, %8\nv_cndmask_b32 %0, %0, %8, vcc\n"
+
+// v_cndmask_b32 reading vcc: how far behind the compare may it sit?  Each block: one compare, K unrelated adds, one select.
+#define CND_GAP_KERNEL(NAME, BLOCK)                                                                             \
+    __global__ __launch_bounds__(64) void NAME(Result *out, int iters, float seed) {                           \
+        float r0 = seed, r1 = seed + 1, r2 = seed + 2, r3 = seed + 3, r4 = seed + 4, r5 = seed + 5, r6 = seed + 6, r7 = seed + 7, b = seed + 9; \
+        const unsigned long long c0 = __builtin_readcyclecounter();                                             \
+        const unsigned long long t0 = wall_clock64();                                                           \
+        for (int i = 0; i < iters; i++) {                                                                       \
+            _Pragma("unroll") for (int u = 0; u < 8; u++)                                                       \
+                asm volatile(BLOCK : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(b) : "vcc", "s10", "s11"); \
+        }                                                                                                       \
+        const unsigned long long c1 = __builtin_readcyclecounter();                                             \
+        const unsigned long long t1 = wall_clock64();                                                           \
+        float s = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7;                                                        \
+        if (threadIdx.x == 0) { out[blockIdx.x].cycles = c1 - c0; out[blockIdx.x].ticks = t1 - t0; }           \
+        if (s == 123.456f) out[blockIdx.x].cycles = 0;                                                          \
+    }
+CND_GAP_KERNEL(k_cnd_gap0, "v_cmp_lt_f32 vcc, %0, %8\nv_cndmask_b32 %1, %1, %8, vcc\nv_add_f32 %2, %2, %8\nv_add_f32 %3, %3, %8\nv_add_f32 %4, %4, %8\nv_add_f32 %5, %5, %8\n")
+CND_GAP_KERNEL(k_cnd_gap1, "v_cmp_lt_f32 vcc, %0, %8\nv_add_f32 %2, %2, %8\nv_cndmask_b32 %1, %1, %8, vcc\nv_add_f32 %3, %3, %8\nv_add_f32 %4, %4, %8\nv_add_f32 %5, %5, %8\n")
+CND_GAP_KERNEL(k_cnd_gap2, "v_cmp_lt_f32 vcc, %0, %8\nv_add_f32 %2, %2, %8\nv_add_f32 %3, %3, %8\nv_cndmask_b32 %1, %1, %8, vcc\nv_add_f32 %4, %4, %8\nv_add_f32 %5, %5, %8\n")
+CND_GAP_KERNEL(k_cnd_gap4, "v_cmp_lt_f32 vcc, %0, %8\nv_add_f32 %2, %2, %8\nv_add_f32 %3, %3, %8\nv_add_f32 %4, %4, %8\nv_add_f32 %5, %5, %8\nv_cndmask_b32 %1, %1, %8, vcc\n")
+CND_GAP_KERNEL(k_cnd_2nd, "v_cmp_lt_f32 vcc, %0, %8\nv_cndmask_b32 %1, %1, %8, vcc\nv_cndmask_b32 %2, %2, %8, vcc\nv_add_f32 %3, %3, %8\nv_add_f32 %4, %4, %8\nv_add_f32 %5, %5, %8\n")
+CND_GAP_KERNEL(k_cnd_e64_vcc, "v_cndmask_b32_e64 %0, %0, %8, vcc\nv_cndmask_b32_e64 %1, %1, %8, vcc\nv_cndmask_b32_e64 %2, %2, %8, vcc\nv_cndmask_b32_e64 %3, %3, %8, vcc\nv_cndmask_b32_e64 %4, %4, %8, vcc\nv_cndmask_b32_e64 %5, %5, %8, vcc\n")
+CND_GAP_KERNEL(k_cnd_e64_gap4, "v_cmp_lt_f32_e64 s[10:11], %0, %8\nv_add_f32 %2, %2, %8\nv_add_f32 %3, %3, %8\nv_add_f32 %4, %4, %8\nv_add_f32 %5, %5, %8\nv_cndmask_b32_e64 %1, %1, %8, s[10:11]\n")
+CND_GAP_KERNEL(k_cnd_smov, "s_mov_b64 vcc, s[10:11]\nv_cndmask_b32 %1, %1, %8, vcc\nv_add_f32 %2, %2, %8\nv_add_f32 %3, %3, %8\nv_add_f32 %4, %4, %8\nv_add_f32 %5, %5, %8\n")
+CND_GAP_KERNEL(k_addc_vcc, "v_addc_co_u32 %0, vcc, %0, %8, vcc\nv_addc_co_u32 %1, vcc, %1, %8, vcc\nv_addc_co_u32 %2, vcc, %2, %8, vcc\nv_addc_co_u32 %3, vcc, %3, %8, vcc\nv_addc_co_u32 %4, vcc, %4, %8, vcc\nv_addc_co_u32 %5, vcc, %5, %8, vcc\n")
+CND_GAP_KERNEL(k_divfmas_vcc, "v_div_fmas_f32 %0, %0, %8, %8\nv_div_fmas_f32 %1, %1, %8, %8\nv_div_fmas_f32 %2, %2, %8, %8\nv_div_fmas_f32 %3, %3, %8, %8\nv_div_fmas_f32 %4, %4, %8, %8\nv_div_fmas_f32 %5, %5, %8, %8\n")
 KERNEL(k_sub, float, INITF, A_SUB)
 __global__ __launch_bounds__(64) void k_cmp1_cnd8(Result *out, int iters, float seed) {
     float r0 = seed, r1 = seed + 1, r2 = seed + 2, r3 = seed + 3, r4 = seed + 4, r5 = seed + 5, r6 = seed + 6, r7 = seed + 7, b = seed + 9;
@@ -273,7 +300,11 @@ int main(int argc, char **argv) {
         {"v_cvt_f32_u32", k_cvtfu, 64}, {"v_rndne_f32", k_rndne, 64}, {"v_fract_f32", k_fract, 64}, {"v_bfe_u32", k_bfe, 64},
         {"v_mul_u32_u24", k_mul24, 64}, {"v_sad_u16", k_sad, 64}, {"v_exp_f32", k_exp, 64}, {"v_add3_u32", k_add3, 64}, {"v_min3_f32", k_min3, 64},
         {"v_cndmask_b32 e64 sgpr mask", k_cnd_sgpr, 64}, {"v_cndmask_b32 vcc (src swapped)", k_cnd_swapped, 64},
-        {"v_cmp+v_cndmask (2 instr)", k_cmp_cnd, 128}, {"1 v_cmp + 8 v_cndmask vcc", k_cmp1_cnd8, 72}, {"v_cndmask vcc after s_mov vcc", k_cnd_vcc_smov, 64}, {"v_cmp_lt_f32_e64 -> sgpr", k_cmp_sgpr, 64}, {"v_cmp_class_f32", k_cmp_class, 64},
+        {"v_cmp+v_cndmask (2 instr)", k_cmp_cnd, 128}, {"1 v_cmp + 8 v_cndmask vcc", k_cmp1_cnd8, 72}, {"v_cndmask vcc after s_mov vcc", k_cnd_vcc_smov, 64},
+        {"cmp,CND,4 add (6 instr)", k_cnd_gap0, 48}, {"cmp,add,CND,3 add", k_cnd_gap1, 48}, {"cmp,2 add,CND,2 add", k_cnd_gap2, 48},
+        {"cmp,4 add,CND", k_cnd_gap4, 48}, {"cmp,CND,CND,3 add", k_cnd_2nd, 48}, {"6 v_cndmask_e64 on vcc", k_cnd_e64_vcc, 48},
+        {"cmp_e64 s,4 add,CND_e64 s", k_cnd_e64_gap4, 48}, {"s_mov vcc,CND,4 add", k_cnd_smov, 48}, {"6 v_addc_co_u32 (vcc in+out)", k_addc_vcc, 48},
+        {"6 v_div_fmas (reads vcc)", k_divfmas_vcc, 48}, {"v_cmp_lt_f32_e64 -> sgpr", k_cmp_sgpr, 64}, {"v_cmp_class_f32", k_cmp_class, 64},
         {"v_div_scale_f32", k_divscale, 64}, {"v_div_fmas_f32", k_divfmas, 64},
         {"v_mul+v_add (2 instr)", k_muladd, 128}, {"v_mul+v_fma (2 instr)", k_mulfma, 128},
         {"v_mul_f32 sgpr operand", k_mulsgpr, 64}, {"v_mul_f32 literal operand", k_mullit, 64}, {"v_add_f32 dpp quad_perm", k_dpp, 64},

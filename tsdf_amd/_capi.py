@@ -66,6 +66,8 @@ _SIGS = {
     "tsdf_volume_set_deformation": (_i, [_vp, _vp]),
     "tsdf_volume_get_distance_data": (_i, [_vp, _vp]),
     "tsdf_volume_get_weight_data": (_i, [_vp, _vp]),
+    "tsdf_volume_get_deformation_planes": (_i, [_vp, C.c_uint32, C.c_uint32, _vp]),
+    "tsdf_volume_set_offset_at_clear": (_i, [_vp, _vp]),
     "tsdf_integrate": (_i, [_vp, _vp, _u32, _u32, _fp, _fp, _fp, _fp]),
     "tsdf_integrate_device": (_i, [_vp, _vp, _u32, _u32, _fp, _fp, _fp, _fp]),
     "tsdf_volume_set_timing": (_i, [_vp, _i]),

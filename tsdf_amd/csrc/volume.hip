@@ -816,6 +816,39 @@ int tsdf_volume_get_weight_data(const tsdf_volume *v, float *host) {
     return copy_out(v, host, v->weight, v->resident_voxels() * sizeof(float), "Couldn't read weight data");
 }
 
+int tsdf_volume_get_deformation_planes(const tsdf_volume *v, uint32_t plane_begin, uint32_t plane_count,
+                                       tsdf_deformation_node *host) {
+    TSDF_REQUIRE(v && host, "null argument");
+    const Geom &g = v->g;
+    const uint32_t planes = g.z_store_end - g.z_store_begin;
+    TSDF_REQUIRE(plane_begin <= planes && plane_count <= planes - plane_begin, "planes [%u, +%u) are not resident (%u planes)",
+                 plane_begin, plane_count, planes);
+    const size_t per_plane = (size_t)g.X * g.Y;
+    if (v->nodes)
+        return copy_out(v, host, v->nodes + per_plane * plane_begin, per_plane * plane_count * sizeof(tsdf_deformation_node),
+                        "Couldn't read deformation data");
+    // implicit grid: the expression of init_nodes_kernel / initialise_deformation with the offset of the last clear()
+    for (uint32_t p = 0; p < plane_count; p++) {
+        const uint32_t z = g.z_store_begin + plane_begin + p;
+        tsdf_deformation_node *out = host + per_plane * p;
+        for (uint32_t y = 0; y < g.Y; y++)
+            for (uint32_t x = 0; x < g.X; x++, out++) {
+                out->translation[0] = (((int)x + 0.5f) * g.vs.x) + g.offset_clear.x;
+                out->translation[1] = (((int)y + 0.5f) * g.vs.y) + g.offset_clear.y;
+                out->translation[2] = (((int)z + 0.5f) * g.vs.z) + g.offset_clear.z;
+                out->rotation[0] = out->rotation[1] = out->rotation[2] = 0.0f;
+            }
+    }
+    return TSDF_OK;
+}
+
+int tsdf_volume_set_offset_at_clear(tsdf_volume *v, const float oc[3]) {
+    TSDF_REQUIRE(v && oc, "null argument");
+    TSDF_REQUIRE(!v->nodes, "the deformation nodes are materialised: their translations are what they are");
+    v->g.offset_clear = {oc[0], oc[1], oc[2]};
+    return TSDF_OK;
+}
+
 int tsdf_volume_set_timing(tsdf_volume *v, int enabled) {
     TSDF_REQUIRE(v, "null volume");
     v->timing = enabled > 0 ? enabled : 0;

@@ -3,6 +3,7 @@
 #include "TSDFVolume.hpp"
 
 #include <cassert>
+#include <cmath>
 #include <fstream>
 #include <stdexcept>
 
@@ -182,20 +183,16 @@ bool TSDFVolume::save_to_file(const std::string &file_name) const {
         std::vector<unsigned char> zeros((size_t)m_size.x * m_size.y * 3, 0);
         for (unsigned z = 0; z < m_size.z; z++) ofs.write((const char *)zeros.data(), zeros.size());
     }
-    // deformation nodes: the device array if a caller materialised it, else the regular grid
-    tsdf_volume_info info;
-    if (tsdf_volume_get_info(m_handle, &info) != TSDF_OK) return false;
+    // deformation nodes, as the reference writes m_deformation_nodes (src/TSDF/TSDFVolume.cu:1003-1018): the device array when
+    // a caller has touched it (deformation() / set_deformation()), else the regular grid clear() would have written --
+    // tsdf_volume_get_deformation_planes hands out either, plane by plane
     {
         std::vector<DeformationNode> plane((size_t)m_size.x * m_size.y);
         for (unsigned z = 0; z < m_size.z; z++) {
-            size_t i = 0;
-            for (unsigned y = 0; y < m_size.y; y++)
-                for (unsigned x = 0; x < m_size.x; x++, i++) {
-                    plane[i].translation = float3{(((int)x + 0.5f) * m_voxel_size.x) + info.offset_at_clear[0],
-                                                  (((int)y + 0.5f) * m_voxel_size.y) + info.offset_at_clear[1],
-                                                  (((int)z + 0.5f) * m_voxel_size.z) + info.offset_at_clear[2]};
-                    plane[i].rotation = float3{0.0f, 0.0f, 0.0f};
-                }
+            if (tsdf_volume_get_deformation_planes(m_handle, z, 1, reinterpret_cast<tsdf_deformation_node *>(plane.data())) != TSDF_OK) {
+                std::cout << "Failed to copy deformation data from device memory [" << tsdf_last_error() << "] " << std::endl;
+                return false;
+            }
             ofs.write((const char *)plane.data(), plane.size() * sizeof(DeformationNode));
         }
     }
@@ -245,24 +242,52 @@ TSDFVolume::TSDFVolume(const std::string &file_name) : m_handle{nullptr}, m_offs
             if (!ifs.read((char *)nodes.data(), n * sizeof(DeformationNode))) {
                 why = "Failed to read deformation data";
             } else {
-                bool regular = true;
+                // The reference keeps the block verbatim.  When it is the regular grid clear() wrote for some constant offset oc
+                // (node = ((v + 0.5) * vs) + oc, src/TSDF/TSDFVolume.cu:783-785; oc = the offset current at that clear(), Q1)
+                // the nodes stay implicit and the volume is told oc.  oc is read off node 0 and its fp32 neighbours are tried
+                // too: 0.5*vs + oc was rounded, so node0 - 0.5*vs need not give oc back, while any oc that reproduces every node
+                // bit for bit is as good as the original (the kernels only ever form these sums).
                 const float3 vs = float3{phys.x / (float)size.x, phys.y / (float)size.y, phys.z / (float)size.z};
-                // the saved grid carries the offset that was current when it was last cleared; accept
-                // any constant offset by reading it off node 0
-                const float3 oc = float3{nodes[0].translation.x - (0.5f * vs.x), nodes[0].translation.y - (0.5f * vs.y),
-                                         nodes[0].translation.z - (0.5f * vs.z)};
+                const size_t stride[3] = {1, (size_t)size.x, (size_t)size.x * size.y};
+                const unsigned count[3] = {size.x, size.y, size.z};
+                const float vsa[3] = {vs.x, vs.y, vs.z};
+                float oc[3] = {0.0f, 0.0f, 0.0f};
+                bool regular = true;
+                auto component = [](const DeformationNode &nd, int axis) {
+                    return axis == 0 ? nd.translation.x : axis == 1 ? nd.translation.y : nd.translation.z;
+                };
+                for (int axis = 0; axis < 3 && regular; axis++) {
+                    const float first = component(nodes[0], axis);
+                    const float centre = first - (0.5f * vsa[axis]);
+                    bool found = false;
+                    for (int k = 0; k < 9 && !found; k++) {          // 0, +1, -1, +2, -2, ... ulps: the nearest fit wins
+                        float guess = centre;
+                        for (int step = 0; step < (k + 1) / 2; step++) guess = std::nextafter(guess, (k & 1) ? INFINITY : -INFINITY);
+                        bool ok = true;
+                        for (unsigned i = 0; i < count[axis] && ok; i++)
+                            ok = component(nodes[i * stride[axis]], axis) == (((int)i + 0.5f) * vsa[axis]) + guess;
+                        if (ok) {
+                            oc[axis] = guess;
+                            found = true;
+                        }
+                    }
+                    regular = found;
+                }
+                // the three axis sequences fit: now every node (translations that do not vary across the grid, rotations zero)
                 size_t i = 0;
                 for (unsigned z = 0; z < size.z && regular; z++)
                     for (unsigned y = 0; y < size.y && regular; y++)
                         for (unsigned x = 0; x < size.x; x++, i++) {
                             const DeformationNode &nd = nodes[i];
-                            if (nd.translation.x != (((int)x + 0.5f) * vs.x) + oc.x ||
-                                nd.translation.y != (((int)y + 0.5f) * vs.y) + oc.y ||
-                                nd.translation.z != (((int)z + 0.5f) * vs.z) + oc.z) {
+                            if (nd.translation.x != (((int)x + 0.5f) * vs.x) + oc[0] ||
+                                nd.translation.y != (((int)y + 0.5f) * vs.y) + oc[1] ||
+                                nd.translation.z != (((int)z + 0.5f) * vs.z) + oc[2] ||
+                                nd.rotation.x != 0.0f || nd.rotation.y != 0.0f || nd.rotation.z != 0.0f) {
                                 regular = false;
                                 break;
                             }
                         }
+                if (regular && tsdf_volume_set_offset_at_clear(m_handle, oc) != TSDF_OK) why = "Failed to restore the node offset";
                 if (!regular &&
                     tsdf_volume_set_deformation(m_handle, reinterpret_cast<const tsdf_deformation_node *>(nodes.data())) != TSDF_OK)
                     why = "Failed to copy deformation data to device";
