@@ -117,7 +117,7 @@ struct Result {
         const unsigned long long t0 = wall_clock64();                                                           \
         for (int i = 0; i < iters; i++) {                                                                       \
             _Pragma("unroll") for (int u = 0; u < 8; u++)                                                       \
-                asm volatile(BLOCK : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(b) : "vcc", "s10", "s11"); \
+                asm volatile(BLOCK : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(b) : "vcc", "s10", "s11", "v100", "v101", "v102", "v103", "v104", "v105"); \
         }                                                                                                       \
         const unsigned long long c1 = __builtin_readcyclecounter();                                             \
         const unsigned long long t1 = wall_clock64();                                                           \
@@ -125,6 +125,13 @@ struct Result {
         if (threadIdx.x == 0) { out[blockIdx.x].cycles = c1 - c0; out[blockIdx.x].ticks = t1 - t0; }           \
         if (s == 123.456f) out[blockIdx.x].cycles = 0;                                                          \
     }
+// dependent chains (one register feeding the next instruction): latency, not throughput
+CND_GAP_KERNEL(k_dep_bilateral, "v_cvt_f64_f32 v[100:101], %0\nv_fma_f64 v[100:101], v[102:103], v[104:105], v[100:101]\nv_cvt_f32_f64 %0, v[100:101]\nv_cvt_f64_f32 v[100:101], %0\nv_fma_f64 v[100:101], v[102:103], v[104:105], v[100:101]\nv_cvt_f32_f64 %0, v[100:101]\n")
+CND_GAP_KERNEL(k_dep_add, "v_add_f32 %0, %0, %8\nv_add_f32 %0, %0, %8\nv_add_f32 %0, %0, %8\nv_add_f32 %0, %0, %8\nv_add_f32 %0, %0, %8\nv_add_f32 %0, %0, %8\n")
+CND_GAP_KERNEL(k_dep_fma, "v_fma_f32 %0, %0, %8, %8\nv_fma_f32 %0, %0, %8, %8\nv_fma_f32 %0, %0, %8, %8\nv_fma_f32 %0, %0, %8, %8\nv_fma_f32 %0, %0, %8, %8\nv_fma_f32 %0, %0, %8, %8\n")
+CND_GAP_KERNEL(k_dep_fma64, "v_fma_f64 v[100:101], v[102:103], v[104:105], v[100:101]\nv_fma_f64 v[100:101], v[102:103], v[104:105], v[100:101]\nv_fma_f64 v[100:101], v[102:103], v[104:105], v[100:101]\nv_fma_f64 v[100:101], v[102:103], v[104:105], v[100:101]\nv_fma_f64 v[100:101], v[102:103], v[104:105], v[100:101]\nv_fma_f64 v[100:101], v[102:103], v[104:105], v[100:101]\n")
+CND_GAP_KERNEL(k_dep_cvt, "v_cvt_f64_f32 v[100:101], %0\nv_cvt_f32_f64 %0, v[100:101]\nv_cvt_f64_f32 v[100:101], %0\nv_cvt_f32_f64 %0, v[100:101]\nv_cvt_f64_f32 v[100:101], %0\nv_cvt_f32_f64 %0, v[100:101]\n")
+CND_GAP_KERNEL(k_dep_rcp, "v_rcp_f32 %0, %0\nv_rcp_f32 %0, %0\nv_rcp_f32 %0, %0\nv_rcp_f32 %0, %0\nv_rcp_f32 %0, %0\nv_rcp_f32 %0, %0\n")
 CND_GAP_KERNEL(k_cnd_gap0, "v_cmp_lt_f32 vcc, %0, %8\nv_cndmask_b32 %1, %1, %8, vcc\nv_add_f32 %2, %2, %8\nv_add_f32 %3, %3, %8\nv_add_f32 %4, %4, %8\nv_add_f32 %5, %5, %8\n")
 CND_GAP_KERNEL(k_cnd_gap1, "v_cmp_lt_f32 vcc, %0, %8\nv_add_f32 %2, %2, %8\nv_cndmask_b32 %1, %1, %8, vcc\nv_add_f32 %3, %3, %8\nv_add_f32 %4, %4, %8\nv_add_f32 %5, %5, %8\n")
 CND_GAP_KERNEL(k_cnd_gap2, "v_cmp_lt_f32 vcc, %0, %8\nv_add_f32 %2, %2, %8\nv_add_f32 %3, %3, %8\nv_cndmask_b32 %1, %1, %8, vcc\nv_add_f32 %4, %4, %8\nv_add_f32 %5, %5, %8\n")
@@ -301,6 +308,8 @@ int main(int argc, char **argv) {
         {"v_mul_u32_u24", k_mul24, 64}, {"v_sad_u16", k_sad, 64}, {"v_exp_f32", k_exp, 64}, {"v_add3_u32", k_add3, 64}, {"v_min3_f32", k_min3, 64},
         {"v_cndmask_b32 e64 sgpr mask", k_cnd_sgpr, 64}, {"v_cndmask_b32 vcc (src swapped)", k_cnd_swapped, 64},
         {"v_cmp+v_cndmask (2 instr)", k_cmp_cnd, 128}, {"1 v_cmp + 8 v_cndmask vcc", k_cmp1_cnd8, 72}, {"v_cndmask vcc after s_mov vcc", k_cnd_vcc_smov, 64},
+        {"DEP cvt,fma64,cvt chain", k_dep_bilateral, 48}, {"DEP v_add_f32 chain", k_dep_add, 48}, {"DEP v_fma_f32 chain", k_dep_fma, 48},
+        {"DEP v_fma_f64 chain", k_dep_fma64, 48}, {"DEP cvt f32<->f64 chain", k_dep_cvt, 48}, {"DEP v_rcp_f32 chain", k_dep_rcp, 48},
         {"cmp,CND,4 add (6 instr)", k_cnd_gap0, 48}, {"cmp,add,CND,3 add", k_cnd_gap1, 48}, {"cmp,2 add,CND,2 add", k_cnd_gap2, 48},
         {"cmp,4 add,CND", k_cnd_gap4, 48}, {"cmp,CND,CND,3 add", k_cnd_2nd, 48}, {"6 v_cndmask_e64 on vcc", k_cnd_e64_vcc, 48},
         {"cmp_e64 s,4 add,CND_e64 s", k_cnd_e64_gap4, 48}, {"s_mov vcc,CND,4 add", k_cnd_smov, 48}, {"6 v_addc_co_u32 (vcc in+out)", k_addc_vcc, 48},

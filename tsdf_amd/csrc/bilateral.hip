@@ -16,7 +16,9 @@
 // semantics here: similarity(d) = exp(-d / sigma_colour^2) for every d in 0..65535
 // (a 65536-entry table whose first 256 entries are the reference's), 16-bit store per pixel.
 #include <cmath>
+#include <cstdlib>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "common.hpp"
@@ -24,68 +26,203 @@
 namespace tsdf {
 
 constexpr int kBTile = 16;
-constexpr int kMaxRadius = 24;  // LDS tile (16+2*24)^2 * 10 B = 40 KiB
+constexpr int kMaxRadius = 24;  // LDS tile (16+2*24)^2 * 12 B = 48 KiB
 
-template <typename PIX>
+constexpr int kSimLds = 4096;   // similarity entries staged in LDS (intensity differences below this; the rest stay in global memory)
+
+// One tap of the reference's accumulation (src/BilateralFilter.cpp:99-102):
+//     double conv_weight = kernel * similarity;          the float product, widened
+//     sum          += conv_weight * intensity;           (float)((double)sum + conv_weight * (double)intensity)
+//     total_weight += conv_weight;                       (float)((double)total_weight + conv_weight)
+// The double product has at most 24 + 16 significant bits, so it is exact and mul-then-add in double equals ONE fused
+// multiply-add in double (same single rounding).  total_weight + weight evaluated in double and narrowed equals the fp32 sum:
+// both operands are floats, so the double sum is exact unless the smaller is below 2^-29 of the larger, and then both
+// roundings return the larger operand (weights are >= 0).
+__device__ inline void bilateral_tap(float weight, double intensity, float &sum, float &total_weight) {
+    sum = (float)__builtin_fma((double)weight, intensity, (double)sum);
+    total_weight = total_weight + weight;
+}
+
+// |a - b| of two unsigned words in one instruction
+__device__ inline unsigned sad_u32(unsigned a, unsigned b) {
+    unsigned d;
+    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
+// R > 0: the radius is known at compile time (the tap rows unroll, LDS offsets become immediates) and the similarity table's
+// head is staged in LDS; R == 0: run-time radius, plain loops.
+//
+// LDS: the tile as doubles (the widened operand of the reference's product, converted once per pixel instead of once per tap)
+// and as 4 * intensity in 32-bit words (|4a - 4b| is the byte offset of similarity[|a - b|]); the spatial kernel; the head of
+// the similarity table.
+//
+// The accumulation is one serial chain per pixel (every tap rounds the running sum to float, :101), and a chain that also waits
+// for its own look-ups spends ~400 cycles per tap (measured in round 2: the kernel took exactly as long as ONE wave's 225
+// dependent taps, whatever the instruction count -- 51 us).  A tap's weight does not depend on the sum, so the weights of
+// tap column i + 1 are looked up (LDS reads only: the waits can be counted) while the chain works through column i.
+template <typename PIX, int R>
 __global__ __launch_bounds__(256) void bilateral_kernel(const PIX *__restrict__ in, PIX *__restrict__ out,
-                                                        int width, int height, int radius,
+                                                        int width, int height, int radius_arg,
                                                         const float *__restrict__ kernel,
-                                                        const float *__restrict__ similarity) {
-    // the tile twice: as doubles (the widened operand of the reference's product, converted once per pixel here instead of
-    // once per tap) and as 16-bit integers (for the intensity difference)
+                                                        const float *__restrict__ similarity, const int debug_skip) {
+    constexpr bool STAGED = R > 0;
     extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int radius = R > 0 ? R : radius_arg;
+    const int n = 2 * radius + 1;
     const int span = kBTile + 2 * radius;
     double *tile_d = reinterpret_cast<double *>(smem_raw);
-    uint16_t *tile = reinterpret_cast<uint16_t *>(tile_d + span * span);
+    float *kern_lds = reinterpret_cast<float *>(tile_d + span * span);
+    float *sim_lds = kern_lds + n * n;
+    uint32_t *tile4 = reinterpret_cast<uint32_t *>(sim_lds + (STAGED ? kSimLds : 0));
     const int tx0 = blockIdx.x * kBTile - radius;
     const int ty0 = blockIdx.y * kBTile - radius;
     for (int i = threadIdx.x; i < span * span; i += 256) {
         int ly = i / span, lx = i - ly * span;
         int gx = tx0 + lx, gy = ty0 + ly;
-        uint16_t v = 0;
+        unsigned v = 0;
         if (gx >= 0 && gx < width && gy >= 0 && gy < height) v = in[(size_t)gy * width + gx];
-        tile[i] = v;
+        tile4[i] = v * 4u;
         tile_d[i] = (double)(int)v;
+    }
+    for (int i = threadIdx.x; i < n * n; i += 256) kern_lds[i] = kernel[i];
+    if (STAGED) {
+        const int n_sim = sizeof(PIX) == 1 ? 256 : kSimLds;
+        for (int i = threadIdx.x; i < n_sim; i += 256) sim_lds[i] = similarity[i];
     }
     __syncthreads();
 
-    const int x = blockIdx.x * kBTile + (threadIdx.x & 15);
-    const int y = blockIdx.y * kBTile + (threadIdx.x >> 4);
-    if (x >= width || y >= height) return;
-
-    const int current = tile[(y - ty0) * span + (x - tx0)];
-    // in-image tap ranges and the reference's running kernel index (Q12)
-    const int fx = max(x - radius, 0), lx_ = min(x + radius, width - 1);
-    const int fy = max(y - radius, 0), ly_ = min(y + radius, height - 1);
-    const int ny = ly_ - fy + 1;
-
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int x = blockIdx.x * kBTile + lx;
+    const int y = blockIdx.y * kBTile + ly;
+    const uint32_t *t0 = tile4 + ly * span + lx;      // tap (0, 0) of this lane's window
+    const double *d0 = tile_d + ly * span + lx;
+    const unsigned current4 = t0[radius * span + radius];
     float total_weight = 0;
     float sum = 0;
-    for (int cx = fx; cx <= lx_; cx++) {
-        const uint16_t *col = tile + (cx - tx0);
-        const double *col_d = tile_d + (cx - tx0);
-        const float *krow = kernel + (cx - fx) * ny;
-        for (int cy = fy; cy <= ly_; cy++) {
-            int conv = col[(cy - ty0) * span];
-            const unsigned delta = __builtin_amdgcn_sad_u16((unsigned)conv, (unsigned)current, 0u);   // |conv - current| in one instruction (both are 0..65535: the high halves are 0)
-            const float weight = krow[cy - fy] * similarity[delta];   // the float product the reference widens (:99)
-            sum = (float)((double)sum + ((double)weight * col_d[(cy - ty0) * span]));
-            // total_weight + weight evaluated in double and narrowed (:102) == the fp32 sum: both operands are floats, so
-            // the double sum is exact unless the smaller is below 2^-29 of the larger, and then both roundings return the
-            // larger operand (weights are >= 0).  One fp32 add instead of two conversions and a double add.
-            total_weight = total_weight + weight;
+    // A wave is a 16 x 4 strip of pixels.  Waves whose every tap lies inside the image (all but the frame's rim): the
+    // reference's running kernel index is the plain (column, row) of the tap, the same for every lane.
+    // Rim: the reference advances its kernel index only for in-image taps (Q12), so a pixel with in-image tap columns
+    // [i0, i1] and rows [j0, j1] uses kernel[(i - i0) * (j1 - j0 + 1) + (j - j0)] for tap (i, j) -- a per-lane index.  Every
+    // lane walks the whole window; a tap outside the image (or of a lane outside it) gets weight 0, which leaves both
+    // accumulators exactly as they are (sum + 0 * 0 and total + 0 are exact).
+    const int wy0 = (blockIdx.y * kBTile + (ly & ~3)) - radius;      // first tap row of the wave's first pixel row
+    const bool interior = tx0 >= 0 && tx0 + span <= width && wy0 >= 0 && wy0 + 4 + 2 * radius <= height;
+    if (debug_skip && (debug_skip == 1) == !interior) return;   // (timing experiments only: 1 = rim waves leave, 2 = interior waves leave)
+    const bool inside = x < width && y < height;
+    const int i0 = max(0, radius - x), i1 = inside ? min(n - 1, width - 1 - x + radius) : -1;
+    const int j0 = max(0, radius - y), j1 = inside ? min(n - 1, height - 1 - y + radius) : -1;
+    const int nyv = j1 - j0 + 1;
+
+    if (STAGED) {
+        constexpr int N = 2 * (R > 0 ? R : 1) + 1;
+        constexpr int SPAN = kBTile + 2 * (R > 0 ? R : 1);
+        constexpr unsigned kStagedBytes = (sizeof(PIX) == 1 ? 256u : (unsigned)kSimLds) * 4u;
+        // A column is handled as two halves (rows 0..7 and 8..14 for N = 15): half a column of look-ups in flight is enough to
+        // cover the chain's other half, and a whole column's worth of registers would cost the fifth wave per SIMD that
+        // the 4 800 waves of a 640 x 480 frame need to be resident together.
+        constexpr int NA = (N + 1) / 2, NB = N - NA;
+        float w_a[NA], w_b[NB > 0 ? NB : 1];
+        auto fetch = [&](const int i, auto first_row, auto count, float *w, const auto rim) {
+            constexpr int J0 = decltype(first_row)::value, CNT = decltype(count)::value;
+            unsigned delta4[CNT];
+#pragma unroll
+            for (int j = 0; j < CNT; j++) delta4[j] = sad_u32(t0[(J0 + j) * SPAN + i], current4);     // 4 * |conv - current|
+#pragma unroll
+            for (int j = 0; j < CNT; j++)
+                w[j] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(sim_lds) + (delta4[j] & (kStagedBytes - 1u)));
+            if (sizeof(PIX) != 1) {
+                // differences beyond the staged head (kSimLds mm and more): one test per half column; the entries come through
+                // a load the compiler cannot fold with the LDS read into a generic-address load
+                unsigned big = delta4[0];
+#pragma unroll
+                for (int j = 1; j < CNT; j++) big = max(big, delta4[j]);
+                if (__builtin_expect(big >= kStagedBytes, 0)) {
+#pragma unroll
+                    for (int j = 0; j < CNT; j++)
+                        if (delta4[j] >= kStagedBytes) {
+                            const char *p = reinterpret_cast<const char *>(similarity) + delta4[j];
+                            asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(w[j]) : "v"(p) : "memory");
+                        }
+                }
+            }
+            if (!decltype(rim)::value) {
+#pragma unroll
+                for (int j = 0; j < CNT; j++) w[j] = kern_lds[i * N + J0 + j] * w[j];     // the float product the reference widens (:99)
+            } else {
+                const bool col_ok = i >= i0 && i <= i1;
+                const int base = (i - i0) * nyv - j0;
+#pragma unroll
+                for (int j = 0; j < CNT; j++) {
+                    const bool ok = col_ok && J0 + j >= j0 && J0 + j <= j1;
+                    // (selects, not branches: the table read is unconditional at a safe index, the weight is masked)
+                    const float k = kern_lds[(base + J0 + j) & (ok ? 255 : 0)];
+                    w[j] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, k * w[j]) & (ok ? 0xffffffffu : 0u));
+                }
+            }
+        };
+        auto chain = [&](const int i, auto first_row, auto count, const float *w) {
+            constexpr int J0 = decltype(first_row)::value, CNT = decltype(count)::value;
+#pragma unroll
+            for (int j = 0; j < CNT; j++) bilateral_tap(w[j], d0[(J0 + j) * SPAN + i], sum, total_weight);
+        };
+        using Lo = std::integral_constant<int, 0>;
+        using Hi = std::integral_constant<int, NA>;
+        using CntA = std::integral_constant<int, NA>;
+        using CntB = std::integral_constant<int, NB>;
+        auto run = [&](const auto rim) {
+            fetch(0, Lo{}, CntA{}, w_a, rim);
+#pragma unroll 1
+            for (int i = 0; i + 1 < N; i++) {              // conv_x: outer loop of the reference
+                fetch(i, Hi{}, CntB{}, w_b, rim);
+                chain(i, Lo{}, CntA{}, w_a);
+                fetch(i + 1, Lo{}, CntA{}, w_a, rim);
+                chain(i, Hi{}, CntB{}, w_b);
+            }
+            fetch(N - 1, Hi{}, CntB{}, w_b, rim);          // the last column, nothing left to prefetch
+            chain(N - 1, Lo{}, CntA{}, w_a);
+            chain(N - 1, Hi{}, CntB{}, w_b);
+        };
+        if (interior) {
+            run(std::false_type{});
+        } else {
+            __builtin_amdgcn_s_setprio(3);                 // the few rim waves do more per tap: let them run ahead of their SIMD's other waves
+            run(std::true_type{});
+        }
+    } else {
+#pragma unroll 1
+        for (int i = 0; i < n; i++) {                      // conv_x: outer loop of the reference
+            const bool col_ok = i >= i0 && i <= i1;
+            const int base = (i - i0) * nyv - j0;
+#pragma unroll 1
+            for (int j = 0; j < n; j++) {                  // conv_y
+                const int o = j * span + i;
+                const bool ok = col_ok && j >= j0 && j <= j1;
+                const unsigned delta = sad_u32(t0[o], current4) >> 2;     // |conv - current|
+                const float k = kern_lds[ok ? base + j : 0];
+                const float weight = ok ? k * similarity[delta] : 0.0f;  // the float product the reference widens (:99)
+                bilateral_tap(weight, d0[o], sum, total_weight);
+            }
         }
     }
-    out[(size_t)y * width + x] = (PIX)(int)floorf(sum / total_weight);
+    if (inside) out[(size_t)y * width + x] = (PIX)(int)floorf(sum / total_weight);
 }
 
 template <typename PIX>
 static int launch_bilateral(const tsdf_bilateral *f, const PIX *in, PIX *out, int width, int height, hipStream_t s) {
     dim3 grid((width + kBTile - 1) / kBTile, (height + kBTile - 1) / kBTile);
-    int span = kBTile + 2 * f->radius;
-    size_t smem = (size_t)span * span * (sizeof(double) + sizeof(uint16_t));
-    hipLaunchKernelGGL((bilateral_kernel<PIX>), grid, dim3(256), smem, s, in, out, width, height, f->radius,
-                       f->kernel_dev, f->similarity_dev);
+    const int span = kBTile + 2 * f->radius, n = 2 * f->radius + 1;
+    static const int variant = [] { const char *e = getenv("TSDF_BIL_VARIANT"); return e ? atoi(e) : 1; }();   // tuning aid: 0 = plain loops
+    static const int debug_skip = [] { const char *e = getenv("TSDF_BIL_DEBUG_SKIP"); return e ? atoi(e) : 0; }();
+    const bool staged = f->radius == 7 && variant >= 1;      // the depth filter of the pipeline: sigma_space 4.5 -> 15 x 15 taps
+    size_t smem = (size_t)span * span * (sizeof(double) + sizeof(uint32_t)) + (size_t)n * n * sizeof(float) +
+                  (staged ? kSimLds * sizeof(float) : 0);
+    if (staged)
+        hipLaunchKernelGGL((bilateral_kernel<PIX, 7>), grid, dim3(256), smem, s, in, out, width, height, f->radius, f->kernel_dev,
+                           f->similarity_dev, debug_skip);
+    else
+        hipLaunchKernelGGL((bilateral_kernel<PIX, 0>), grid, dim3(256), smem, s, in, out, width, height, f->radius, f->kernel_dev,
+                           f->similarity_dev, debug_skip);
     TSDF_HIP(hipGetLastError(), "bilateral filter kernel failed");
     return TSDF_OK;
 }
@@ -153,6 +290,7 @@ int tsdf_bilateral_create(float sigma_colour, float sigma_space, tsdf_bilateral 
     hipError_t e = hipGetDevice(&f->device);
     if (e == hipSuccess) e = hipMalloc((void **)&f->kernel_dev, kernel.size() * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&f->similarity_dev, similarity.size() * sizeof(float));
+
     if (e == hipSuccess) e = hipMemcpy(f->kernel_dev, kernel.data(), kernel.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(f->similarity_dev, similarity.data(), similarity.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
