@@ -36,19 +36,32 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--grid", type=int, default=512)
+    ap.add_argument("--workload", choices=("config3", "config4"), default="config3",
+                    help="config3 = BASELINE configs[2] (512^3, camera in front of the volume; the metric's configuration); config4 = "
+                         "BASELINE configs[3] (1024^3 over the ranks' Z-slabs, camera inside the volume, seed 0x5EED0004, 100-frame stream)")
+    ap.add_argument("--grid", type=int, default=None, help="voxels per side (default 512, or 1024 for --workload config4)")
     ap.add_argument("--physical", type=float, default=3000.0)
-    ap.add_argument("--stream-frames", type=int, default=200, help="length of the synthetic trajectory")
+    ap.add_argument("--stream-frames", type=int, default=None, help="length of the synthetic trajectory (default 200; 100 for config4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
-    ap.add_argument("--event-period", type=int, default=16,
-                    help="per-stage and per-kernel HIP events are recorded on every n-th timed step (0 = on the first one only): each record costs "
-                         "a few microseconds of stream time, 9 %% of the step when every launch is bracketed")
-    ap.add_argument("--no-overlap", action="store_true", help="N > 1: filter frame i+1 after, not during, the exchange of frame i")
+    ap.add_argument("--event-period", type=int, default=0,
+                    help="per-stage HIP events inside the TIMED region on every n-th step (0 = none: each record costs a few "
+                         "microseconds of stream time).  Stage and kernel times always come from an untimed replay of the same frames "
+                         "with every launch bracketed")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: filter + integrate frame i+1 after, not during, the exchange of frame i")
+    ap.add_argument("--slab-plan", choices=("measured", "model", "uniform"), default="measured",
+                    help="N > 1: Z-slab boundaries re-cut from the ranks' measured times on the first frames (default), from a "
+                         "work estimate of a small planner volume, or equal plane counts")
+    ap.add_argument("--plan-rounds", type=int, default=3, help="--slab-plan measured: rebalancing rounds (each costs a few frames)")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--path-only", action="store_true",
                     help="only the timed hot path and its roofline (no ICP / tracking / host-buffer legs): what the profiling passes run")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.grid is None:
+        a.grid = 1024 if a.workload == "config4" else 512
+    if a.stream_frames is None:
+        a.stream_frames = 100 if a.workload == "config4" else 200
+    return a
 
 
 def main():
@@ -78,6 +91,7 @@ def main():
 
     import tsdf_amd
     from tsdf_amd import synth
+    import ctypes as C
     from tsdf_amd._capi import check, lib
 
     check(lib.tsdf_set_device(local_rank))
@@ -85,11 +99,13 @@ def main():
     N_vox = n * n * n
     K, Wu = args.steps, args.warmup
     n_frames = K + Wu + 1
+    inside = args.workload == "config4"
+    seed = 0x5EED0004 if inside else SEED
 
     # ---- inputs: synthetic stream, resident in HBM before timing ---------------------------------
     frames, cams = [], []
     for i in range(n_frames):
-        d, cam = synth.depth_frame(i % args.stream_frames, args.stream_frames, seed=SEED)
+        d, cam = synth.depth_frame(i % args.stream_frames, args.stream_frames, seed=seed, inside=inside)
         frames.append(d)
         cams.append(cam)
     depth_dev = torch.from_numpy(np.stack(frames).view(np.int16)).cuda()           # (F, H*W) uint16 bits
@@ -101,8 +117,72 @@ def main():
     if world == 1:
         vol = tsdf_amd.TSDFVolume((n, n, n), (args.physical,) * 3)
     else:
-        from tsdf_amd.multi import slab_range
-        zb, ze = slab_range(n, world, rank)
+        from tsdf_amd.multi import balanced_slab_ranges, plane_costs, refine_slab_ranges, slab_range
+        hits_probe = torch.empty((H * W, 4), dtype=torch.float32, device="cuda")
+        bil0 = tsdf_amd.BilateralFilter(30.0, 4.5)
+        rc0 = tsdf_amd.GPURaycaster(W, H)
+        s0 = torch.cuda.current_stream()
+
+        def build(plan):
+            v = tsdf_amd.TSDFVolume((n, n, n), (args.physical,) * 3, slab=tuple(plan[rank]))
+            v.set_stream(s0.cuda_stream)
+            return v
+
+        def probe(v):
+            """seconds this rank's slab needs for integrate + slab ray cast of a stream frame (3 frames in, then 2 timed)."""
+            pf = min(5, n_frames)
+            for i in range(pf):
+                if i == pf - 2:
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(s0)
+                bil0.filter_device(depth_dev[i].data_ptr(), filt_dev.data_ptr(), W, H, bits=16, stream=s0.cuda_stream)
+                v.integrate_device(filt_dev.data_ptr(), W, H, cams[i])
+                rc0.raycast_slab_device(v, cams[i], hits_probe.data_ptr())
+            e1.record(s0)
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e-3 / 2.0
+
+        def gathered(x):
+            t = torch.tensor([x], dtype=torch.float64)
+            allt = torch.empty((world,), dtype=torch.float64)
+            if share:
+                dist.all_gather_into_tensor(allt, t)
+            else:
+                tg, ag = t.cuda(), allt.cuda()
+                dist.all_gather_into_tensor(ag, tg)
+                allt = ag.cpu()
+            return [float(v) for v in allt.tolist()]
+
+        slab_plan = [slab_range(n, world, r) for r in range(world)]
+        plan_log = []
+        vol = None
+        if args.slab_plan == "model":
+            # boundaries from a work estimate: a 128-plane planner volume integrates three frames of the stream and says where
+            # the updated voxels and the occupied ray-caster bricks are (every rank computes the same plan)
+            pick = sorted({0, (Wu + K) // 2, Wu + K - 1})
+            costs = plane_costs(lambda g: tsdf_amd.TSDFVolume(g, (args.physical,) * 3), [frames[i] for i in pick], [cams[i] for i in pick], (n, n, n))
+            slab_plan = balanced_slab_ranges(costs, world, min_planes=8)
+        elif args.slab_plan == "measured":
+            # contiguous Z-slabs whose boundaries even out the MEASURED work (still north_star's split, only the cuts move):
+            # every rank times integrate + slab cast of its slab on the first frames, the times are all-gathered, each rank's
+            # time above the common floor is spread over its planes and the density is re-cut; the best of the plans tried stays
+            best = None
+            for rnd in range(args.plan_rounds + 1):
+                v = build(slab_plan)
+                secs = gathered(probe(v))
+                plan_log.append({"planes": [int(b_ - a_) for a_, b_ in slab_plan], "ms": [round(x * 1e3, 4) for x in secs]})
+                if best is None or max(secs) < best[0]:
+                    if best is not None and best[2] is not None:
+                        best[2].close()
+                    best = (max(secs), [tuple(r_) for r_ in slab_plan], v)
+                else:
+                    v.close()
+                if rnd < args.plan_rounds:
+                    slab_plan = refine_slab_ranges(slab_plan, secs, n, min_planes=8)
+            slab_plan = best[1]
+            best[2].close()          # (a fresh volume below: the probe frames must not stay integrated)
+        zb, ze = slab_plan[rank]
         vol = tsdf_amd.TSDFVolume((n, n, n), (args.physical,) * 3, slab=(zb, ze))
         hits_mine = torch.empty((H * W, 4), dtype=torch.float32, device="cuda")
         hits_all = torch.empty((world, H * W, 4), dtype=torch.float32, device="cuda")
@@ -114,50 +194,55 @@ def main():
     stage_names = ["bilateral", "integrate", "raycast", "exchange", "normals"]
     ev = {s: [] for s in stage_names}
 
-    # N > 1: while the hit records are exchanged the compute units idle, and the next frame's bilateral filter does not
-    # depend on the volume -- it is queued on a second stream at that point (two filtered-frame buffers).  Every timed
-    # step still contains one filter, one integrate, one ray cast, one exchange, one normal map.  (On one GPU there is no
-    # idle phase to fill: tried, no gain, so the single-GPU step stays strictly sequential.)
+    # N > 1: while the hit records are exchanged and merged the compute units idle, and the next frame's filter + integrate
+    # depend on nothing the exchange produces: they are queued on a second stream as soon as this frame's slab cast has read the
+    # volume (two filtered-frame buffers).  Every timed step still contains one filter, one integrate, one ray cast, one
+    # exchange, one normal map.  (On one GPU there is no idle phase to fill: tried, no gain -- the single-GPU step stays
+    # strictly sequential.)
     overlap = world > 1 and not args.no_overlap
     side = torch.cuda.Stream() if overlap else None
     filt2 = [filt_dev, torch.empty_like(filt_dev)] if overlap else [filt_dev, filt_dev]
-    prefiltered = {}        # frame index -> (event on the side stream, timing pair or None)
+    prefiltered = {}        # frame index -> (event on the side stream: filtered and integrated, timing pairs or None)
+
+    def filter_and_integrate(i, on, timed):
+        """bilateral + integrate of frame i on stream `on`; returns the event pairs (bilateral, integrate) when timed."""
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if timed else None
+        fbuf = filt2[i % 2]
+        if timed: e[0].record(on)
+        bil.filter_device(depth_dev[i].data_ptr(), fbuf.data_ptr(), W, H, bits=16, stream=on.cuda_stream)
+        if timed: e[1].record(on)
+        vol.set_stream(on.cuda_stream)
+        vol.integrate_device(fbuf.data_ptr(), W, H, cams[i])
+        vol.set_stream(stream.cuda_stream)
+        if timed: e[2].record(on)
+        return ((e[0], e[1]), (e[1], e[2])) if timed else None
 
     def step(i, timed, timed_next=False):
-        e = [torch.cuda.Event(enable_timing=True) for _ in range(6)] if timed else None
         cam = cams[i]
-        fbuf = filt2[i % 2]
         if i in prefiltered:
-            done, pair = prefiltered.pop(i)
+            done, pairs = prefiltered.pop(i)
             stream.wait_event(done)
-            if timed and pair is not None:
-                ev["bilateral"].append(pair)
-            if timed: e[1].record(stream)
         else:
-            if timed: e[0].record(stream)
-            bil.filter_device(depth_dev[i].data_ptr(), fbuf.data_ptr(), W, H, bits=16, stream=stream.cuda_stream)
-            if timed:
-                e[1].record(stream)
-                ev["bilateral"].append((e[0], e[1]))
-        vol.integrate_device(fbuf.data_ptr(), W, H, cam)
-        if timed: e[2].record(stream)
+            pairs = filter_and_integrate(i, stream, timed)
+        if timed and pairs is not None:
+            ev["bilateral"].append(pairs[0])
+            ev["integrate"].append(pairs[1])
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timed else None
+        if timed: e[0].record(stream)
         if world == 1:
             rc.raycast_device(vol, cam, vert_dev.data_ptr(), None if os.environ.get('BENCH_SPLIT_NORMALS') else norm_dev.data_ptr())   # vertices and normals in one go
-            if timed: e[3].record(stream)
+            if timed: e[1].record(stream)
         else:
             rc.raycast_slab_device(vol, cam, hits_mine.data_ptr())
-            if timed: e[3].record(stream)
+            if timed: e[1].record(stream)
             if overlap and i + 1 < n_frames:
                 cast = torch.cuda.Event()
-                cast.record(stream)            # integrate(i) and the slab cast are done: the other buffer is free, the CUs too
+                cast.record(stream)            # the slab cast has read the volume: frame i+1 may go in, on the idle compute units
                 side.wait_event(cast)
-                pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if timed_next else None   # (it is the next step's filter)
-                if pair: pair[0].record(side)
-                bil.filter_device(depth_dev[i + 1].data_ptr(), filt2[(i + 1) % 2].data_ptr(), W, H, bits=16, stream=side.cuda_stream)
-                if pair: pair[1].record(side)
+                nxt = filter_and_integrate(i + 1, side, timed_next)
                 done = torch.cuda.Event()
                 done.record(side)
-                prefiltered[i + 1] = (done, pair)
+                prefiltered[i + 1] = (done, nxt)
             if share:   # gloo: stage through the host
                 h_all = torch.empty(hits_all.shape, dtype=hits_all.dtype)
                 dist.all_gather_into_tensor(h_all.view(-1), hits_mine.cpu().view(-1))
@@ -165,14 +250,14 @@ def main():
             else:
                 dist.all_gather_into_tensor(hits_all.view(-1), hits_mine.view(-1))
             tsdf_amd.merge_hits_normals_device(hits_all.data_ptr(), world, W, H, vert_dev.data_ptr(), norm_dev.data_ptr(), stream.cuda_stream)   # merged vertices and their normals in one go
-        if timed: e[4].record(stream)
+        if timed: e[2].record(stream)
         if os.environ.get('BENCH_SPLIT_NORMALS'):    # (the ray cast, or the merge of the slabs' records, has formed the normals with the vertices)
             tsdf_amd.compute_normals_device(W, H, vert_dev.data_ptr(), norm_dev.data_ptr(), stream.cuda_stream)
         if timed:
-            e[5].record(stream)
-            for j, s in enumerate(stage_names):
-                if s != "bilateral":
-                    ev[s].append((e[j], e[j + 1]))
+            e[3].record(stream)
+            ev["raycast"].append((e[0], e[1]))
+            ev["exchange"].append((e[1], e[2]))
+            ev["normals"].append((e[2], e[3]))
 
     def barrier():
         if world > 1:
@@ -180,19 +265,14 @@ def main():
 
     # ---- warmup, then the timed region -------------------------------------------------------------
     for i in range(Wu):
-        if i == Wu - 1:
-            vol.set_counting(True)            # voxels updated by the frame just before the timed region (byte model below)
         step(i, False)
     torch.cuda.synchronize()
-    U_before = vol.last_updated_voxels() if Wu > 0 else None
-    vol.set_counting(False)
-    period = args.event_period if args.event_period > 0 else K + 1
-    vol.set_timing(period)      # HIP events around the dominant kernels, on the stream they are launched on
+    period = args.event_period if args.event_period > 0 else 0
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(Wu, Wu + K):
-        step(i, (i - Wu) % period == 0, (i + 1 - Wu) % period == 0 and i + 1 < Wu + K)
+        step(i, period > 0 and (i - Wu) % period == 0, period > 0 and (i + 1 - Wu) % period == 0 and i + 1 < Wu + K)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -201,10 +281,32 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    checksum = float(torch.nan_to_num(vert_dev.double(), nan=0.0).sum().item())   # the picture of the last timed frame
+    last_vertices = vert_dev.clone()
 
-    stage_ms = {s: (float(np.mean([a.elapsed_time(b) for a, b in ev[s]])) if ev[s] else None) for s in stage_names}   # (None: not sampled)
+    # ---- untimed replays of the SAME K frames: (1) every stage and every launch of the dominant kernels bracketed with HIP
+    # events on the launch stream (K launches timed, none of their cost inside `value`); (2) the voxels each frame updates,
+    # counted by the kernel (which voxels a frame updates does not depend on the volume's state: depth > 0 and sdf >= -trunc,
+    # src/TSDF/TSDFVolume.cu:355,366 -- so the byte model prices exactly the launches that were timed)
+    for s_ in stage_names:
+        ev[s_].clear()
+    prefiltered.clear()
+    vol.set_timing(1)
+    for i in range(Wu, Wu + K):
+        step(i, True, True)
+    torch.cuda.synchronize()
+    stage_ms = {s_: (float(np.mean([a.elapsed_time(b) for a, b in ev[s_]])) if ev[s_] else None) for s_ in stage_names}
     kern = {w: vol.kernel_time(w) for w in ("integrate", "raycast", "raycast_tail")}     # (launches, avg ms), kernel only
     vol.set_timing(False)
+    prefiltered.clear()
+    vol.set_counting(True)
+    U_frames = []
+    for i in range(Wu, Wu + K):
+        bil.filter_device(depth_dev[i].data_ptr(), filt_dev.data_ptr(), W, H, bits=16, stream=stream.cuda_stream)
+        vol.integrate_device(filt_dev.data_ptr(), W, H, cams[i])
+        torch.cuda.synchronize()
+        U_frames.append(vol.last_updated_voxels())
+    vol.set_counting(False)
     ms_per_step = elapsed * 1e3 / K
     value = N_vox * K / elapsed / 1e6
 
@@ -216,47 +318,47 @@ def main():
         "n_gpus": world,
         "steps": K,
         "warmup": Wu,
-        "event_period": period,     # per-stage / per-kernel HIP events on every n-th timed step (each record costs stream time)
+        "event_period": period,     # HIP events inside the timed region on every n-th step (0 = none)
+        "stage_and_kernel_times_from": "untimed replay of the %d timed frames, every launch bracketed with HIP events on the launch stream" % K,
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "configs[2]: %d^3 TSDF over %.0f mm, synthetic TUM-surrogate stream (%d-frame "
-                               "trajectory, seed 0x%X), 640x480 uint16 depth, bilateral(30,4.5) + integrate + "
-                               "raycast + normals per frame" % (n, args.physical, args.stream_frames, SEED),
+        "config": {"workload": "configs[%d]: %d^3 TSDF over %.0f mm, synthetic TUM-surrogate stream (%d-frame "
+                               "trajectory%s, seed 0x%X), 640x480 uint16 depth, bilateral(30,4.5) + integrate + "
+                               "raycast + normals per frame" % (3 if inside else 2, n, args.physical, args.stream_frames,
+                                                                " inside the volume" if inside else "", seed),
                    "grid": [n, n, n], "image": [W, H], "parallelism": "zslab%d" % world,
-                   "overlap": "bilateral(i+1) on a second stream during the exchange of frame i" if overlap else "none"},
+                   "overlap": "bilateral + integrate of frame i+1 on a second stream during the exchange of frame i" if overlap else "none"},
         "integrate_mvoxels_per_s": round(N_vox / (stage_ms["integrate"] * 1e-3) / 1e6, 1),
         "raycast_mrays_per_s": round(W * H / ((stage_ms["raycast"] + stage_ms["exchange"] + stage_ms["normals"]) * 1e-3) / 1e6, 2),
         "stage_ms": {s: (round(v, 4) if v is not None else None) for s, v in stage_ms.items()},
         # sum of the finite vertex coordinates of the last frame's picture: equal between runs that differ only in schedule
-        "last_frame_vertex_checksum": float(torch.nan_to_num(vert_dev.double(), nan=0.0).sum().item()),
+        "last_frame_vertex_checksum": checksum,
     }
 
-    if rank == 0 and world == 1:
-        # ---- roofline of the dominant kernel (by time): HIP-event durations measured above --------------
-        last = Wu + K                                  # one more frame, untimed, for the byte counts
+    # ---- roofline of the dominant kernel (by time): HIP-event durations of the replay, bytes of the same launches ----------
+    last = Wu + K                                  # one more frame (untimed legs below)
+    U = int(round(float(np.mean(U_frames))))       # voxels updated per launch, mean over the K timed frames (this rank's slab)
+    int_bytes = 16 * U + 2 * W * H                 # 16*U + depth frame
+    int_ms = kern["integrate"][1] or stage_ms["integrate"]
+    int_gbs = int_bytes / (int_ms * 1e-3) / 1e9
+    traffic, traffic_meta = load_traffic(args)
+    roof_int = {"kernel": "integrate_kernel", "bound": "hbm", "achieved": round(int_gbs, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(int_gbs / HBM_PEAK_GBS, 5), "traffic": traffic.get("integrate_kernel"),
+                "algorithmic_bytes": int_bytes, "avg_launch_ms": round(int_ms, 4), "launches_timed": kern["integrate"][0],
+                "U_voxels_updated": U, "U_min_max": [int(min(U_frames)), int(max(U_frames))], "dense_bytes": 16 * N_vox}
+    roof_int.update(traffic_meta)
+    if world == 1:
         st = rc.stats(vol, cams[last - 1])             # S samples, T distinct voxels touched at the end state
-        vol.set_counting(True)
-        bil.filter_device(depth_dev[last].data_ptr(), filt_dev.data_ptr(), W, H, bits=16, stream=stream.cuda_stream)
-        vol.integrate_device(filt_dev.data_ptr(), W, H, cams[last])
-        U_after = vol.last_updated_voxels()
-        vol.set_counting(False)
-        # the kernel time is an average over the timed launches; the updated-voxel count drifts as the camera moves, so the
-        # bytes are priced at the mean of the frame before and the frame after the timed region
-        U = (U_before + U_after) // 2 if U_before is not None else U_after
         ray_bytes = 4 * st["touched"] + 12 * W * H     # 4*T + vertex store (normals kernel: +12*W*H)
-        int_bytes = 16 * U + 2 * W * H                 # 16*U + depth frame
         # the march is two kernels (bulk + tail queue); its bytes are priced against their summed duration.  The
         # stage times also hold the occupancy refresh / merge / cull kernels.
         ray_main_ms, ray_tail_ms = kern["raycast"][1], kern["raycast_tail"][1]
         ray_ms = (ray_main_ms + ray_tail_ms) or stage_ms["raycast"]
-        int_ms = kern["integrate"][1] or stage_ms["integrate"]
         ray_gbs = ray_bytes / (ray_ms * 1e-3) / 1e9
-        int_gbs = int_bytes / (int_ms * 1e-3) / 1e9
-        traffic = load_traffic()
         # dominant = the single kernel with the longest average launch
         dominant = "raycast" if max(ray_main_ms, ray_tail_ms) >= int_ms else "integrate"
         roof_ray = {"kernel": "process_ray_kernel + process_ray_tail_kernel", "bound": "hbm", "achieved": round(ray_gbs, 2), "peak": HBM_PEAK_GBS,
@@ -267,15 +369,17 @@ def main():
                     "samples_evaluated_after_exact_skipping": st["evaluated"],
                     "msamples_per_s": round(st["samples"] / (ray_ms * 1e-3) / 1e6, 1),
                     "l2_level_gbs": round(32 * st["samples"] / (ray_ms * 1e-3) / 1e9, 1)}
-        roof_int = {"kernel": "integrate_kernel", "bound": "hbm", "achieved": round(int_gbs, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(int_gbs / HBM_PEAK_GBS, 5), "traffic": traffic.get("integrate_kernel"),
-                    "algorithmic_bytes": int_bytes, "avg_launch_ms": round(int_ms, 4), "launches_timed": kern["integrate"][0],
-                    "U_voxels_updated": U, "U_first_last": [U_before, U_after], "dense_bytes": 16 * N_vox}
-        # the fraction against the measured device-to-device copy rate as well as the nominal peak
-        copy_gbs = measured_copy_gbs(torch)
-        for r_ in (roof_ray, roof_int):
+        roof_ray.update(traffic_meta)
+    if rank == 0:
+        # the fraction against the measured device-to-device copy rate (float4 copy kernel of the library, 1 GiB,
+        # best of 5, on the launch stream) as well as the nominal peak
+        gbs = C.c_double(0.0)
+        check(lib.tsdf_measure_copy_bandwidth(1 << 30, 5, C.c_void_p(stream.cuda_stream), C.byref(gbs)))
+        copy_gbs = float(gbs.value)
+        for r_ in ([roof_int] if world > 1 else [roof_ray, roof_int]):
             r_["measured_copy_gbs"] = round(copy_gbs, 1)
             r_["frac_of_measured_copy"] = round(r_["achieved"] / copy_gbs, 5)
+    if rank == 0 and world == 1:
         out["roofline"] = roof_ray if dominant == "raycast" else roof_int
         out["roofline_other"] = roof_int if dominant == "raycast" else roof_ray
         if not args.path_only:
@@ -284,8 +388,45 @@ def main():
             out["tracking"] = tracking_loop(tsdf_amd, synth, n, args.physical, args.stream_frames)
         if not args.no_parity:
             out["parity"] = parity_gate(tsdf_amd, synth, n_small=96)
+            out["parity"]["note"] = ("GPU vs oracle, bit for bit.  The oracle's integrate / ray-cast legs are a line-by-line restatement "
+                                     "(the reference holds no vectors for them: parity unpinned); the 16-bit bilateral follows semantics "
+                                     "defined here (the reference's 16-bit path is undefined behaviour), its 8-bit path is pinned on the "
+                                     "reference compiled natively")
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(vol, frames[last], cams[last], n, args.physical, args.cpu_budget_s)
+    if world > 1:
+        # every rank's stage and kernel times (the step waits for the slowest), and a parity flag: rank 0 replays the whole
+        # stream on ONE volume and compares the merged picture of the last timed frame with it, bit for bit
+        mine = torch.tensor([stage_ms[s_] or 0.0 for s_ in stage_names] + [kern["integrate"][1], kern["raycast"][1], kern["raycast_tail"][1], float(U)],
+                            dtype=torch.float64, device="cuda")
+        allr = torch.empty((world, mine.numel()), dtype=torch.float64, device="cuda")
+        if share:
+            h_all = torch.empty(allr.shape, dtype=allr.dtype)
+            dist.all_gather_into_tensor(h_all.view(-1), mine.cpu())
+            allr.copy_(h_all)
+        else:
+            dist.all_gather_into_tensor(allr.view(-1), mine)
+        if rank == 0:
+            names = stage_names + ["integrate_kernel", "process_ray_kernel", "process_ray_tail_kernel", "U_voxels_updated"]
+            out["per_rank_ms"] = {nm: [round(float(v), 4) for v in allr[:, j].tolist()] for j, nm in enumerate(names)}
+            out["slabs"] = [list(r_) for r_ in slab_plan]
+            out["slab_plan"] = {"method": args.slab_plan, "rounds": plan_log}
+            out["roofline"] = roof_int
+            out["roofline"]["note"] = "rank 0's slab"
+            if not args.no_parity:
+                whole = tsdf_amd.TSDFVolume((n, n, n), (args.physical,) * 3)
+                whole.set_stream(stream.cuda_stream)
+                ref_v = torch.empty_like(vert_dev)
+                for i in range(Wu + K):
+                    bil.filter_device(depth_dev[i].data_ptr(), filt_dev.data_ptr(), W, H, bits=16, stream=stream.cuda_stream)
+                    whole.integrate_device(filt_dev.data_ptr(), W, H, cams[i])
+                rc.raycast_device(whole, cams[Wu + K - 1], ref_v.data_ptr(), None)
+                torch.cuda.synchronize()
+                a_, b_ = last_vertices.view(torch.int32), ref_v.view(torch.int32)
+                same = bool(((a_ == b_) | (torch.isnan(last_vertices) & torch.isnan(ref_v))).all().item())
+                out["parity"] = {"merged_picture_equals_single_volume_replay": same, "frames": Wu + K,
+                                 "hits": int((~torch.isnan(ref_v[:, 0])).sum().item()), "pass": same}
+                whole.close()
 
     if rank == 0:
         def finite(o):      # strict JSON: a non-finite number (an unsampled average, an empty ratio) becomes null
@@ -300,23 +441,6 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def measured_copy_gbs(torch):
-    """Device-to-device copy of 1 GiB (read + write = 2 GiB of traffic), best of 5: the practical HBM ceiling."""
-    a = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
-    b = torch.empty_like(a)
-    b.copy_(a)
-    torch.cuda.synchronize()
-    best = 0.0
-    for _ in range(5):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        b.copy_(a)
-        e1.record()
-        torch.cuda.synchronize()
-        best = max(best, 2.0 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
-    return best
 
 
 def host_api_time(vol, bil, frames, cams, last):
@@ -416,16 +540,41 @@ def tracking_loop(tsdf_amd, synth, n, physical, stream_frames, n_frames=24):
             "what": "bilateral + raycast(prev pose) + render depth + ICP (3 levels, 19 iterations) + integrate per frame"}
 
 
-def load_traffic():
-    """HBM bytes per launch from the PMC passes (profiles/traffic.json, written by tools/pmc_traffic.py from
-    rocprofv3 --pmc runs of this same command); empty when no counter run has been committed."""
+def kernel_source_sha():
+    """SHA-256 over the kernel sources: a committed counter profile only speaks for the code it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "tsdf_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_traffic(args):
+    """HBM bytes per launch from the PMC passes (profiles/traffic.json, written by tools/profile_round.sh from separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, averaged over the K timed launches only).  The counters
+    cannot be read inside this process, so the figure is reported only when the profile was taken on the same kernel sources
+    with the same --steps / --warmup / --grid; otherwise `traffic` is null and the reason is stated."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(p):
-        try:
-            return json.load(open(p)).get("bytes_per_launch", {})
-        except Exception:
-            return {}
-    return {}
+    meta = {"traffic_source": None}
+    if not os.path.exists(p):
+        meta["traffic_note"] = "no counter profile committed"
+        return {}, meta
+    try:
+        d = json.load(open(p))
+    except Exception:
+        meta["traffic_note"] = "profiles/traffic.json unreadable"
+        return {}, meta
+    want = {"steps": args.steps, "warmup": args.warmup, "grid": args.grid, "gpus": args.gpus}
+    if d.get("kernel_source_sha") != kernel_source_sha():
+        meta["traffic_note"] = "profiles/traffic.json was taken on other kernel sources (%s): not reported" % d.get("tag")
+        return {}, meta
+    if d.get("bench_args") != want:
+        meta["traffic_note"] = "profiles/traffic.json was taken with %s, this run is %s: not reported" % (d.get("bench_args"), want)
+        return {}, meta
+    meta["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, mean over the %d timed launches of the same command)" % (d.get("tag"), args.steps)
+    return d.get("bytes_per_launch", {}), meta
 
 
 def parity_gate(tsdf_amd, synth, n_small):

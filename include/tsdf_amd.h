@@ -265,6 +265,12 @@ int tsdf_bilateral_filter_u8_device(const tsdf_bilateral *filter, const uint8_t 
 int tsdf_bilateral_filter_u16_device(const tsdf_bilateral *filter, const uint16_t *device_in,
                                      uint16_t *device_out, int width, int height, void *hip_stream);
 
+/* ---- measurement aid (no reference counterpart) ------------------------------------------ */
+/* Device-to-device copy of `bytes` (a multiple of 16; two internal buffers) with a float4 copy kernel, `reps` times on
+ * `hip_stream`, timed with HIP events on that stream: *gb_per_s = read + write bytes per second of the best repetition / 1e9.
+ * bench.py reports it beside the nominal HBM peak as the practical ceiling of a streaming kernel on this box. */
+int tsdf_measure_copy_bandwidth(size_t bytes, int reps, void *hip_stream, double *gb_per_s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,35 @@ def test_slab_ranges_partition_the_grid():
         slab_range(8, 2, 2)
 
 
+def test_balanced_and_refined_slab_ranges():
+    """The work-balanced planner: contiguous, complete, at least min_planes each, never worse than the uniform split under its
+    own cost model, and the measured refinement moves planes from the slow ranks to the fast ones."""
+    from tsdf_amd.multi import balanced_slab_ranges, refine_slab_ranges, slab_range
+    rng = np.random.default_rng(3)
+    for Z, world in ((512, 8), (512, 4), (1024, 8), (100, 3), (64, 8), (9, 2)):
+        cost = rng.uniform(0.0, 0.05, Z)
+        cost[Z // 3: Z // 2] += 1.0                                    # the surfaces sit in a band of planes
+        for min_planes in (1, 8):
+            if world * min_planes > Z:
+                with pytest.raises(ValueError):
+                    balanced_slab_ranges(cost, world, min_planes)
+                continue
+            r = balanced_slab_ranges(cost, world, min_planes)
+            assert len(r) == world and r[0][0] == 0 and r[-1][1] == Z
+            assert all(a[1] == b[0] for a, b in zip(r, r[1:])) and all(e - b >= min_planes for b, e in r)
+            worst = max(cost[b:e].sum() for b, e in r)
+            uniform = max(cost[slice(*slab_range(Z, world, k))].sum() for k in range(world))
+            assert worst <= uniform + 1e-9
+    assert balanced_slab_ranges(np.zeros(16), 4) == [slab_range(16, 4, k) for k in range(4)]      # nothing known: the uniform split
+    # measured refinement: rank 2 was three times slower than the others -> its slab shrinks, the plan stays a partition
+    ranges = [slab_range(512, 4, k) for k in range(4)]
+    new = refine_slab_ranges(ranges, [0.10, 0.10, 0.30, 0.10], 512, min_planes=8)
+    assert new[0][0] == 0 and new[-1][1] == 512 and all(a[1] == b[0] for a, b in zip(new, new[1:]))
+    assert new[2][1] - new[2][0] < 128 and all(e - b >= 8 for b, e in new)
+    # every rank computes the same plan from the same numbers
+    assert new == refine_slab_ranges(list(ranges), [0.10, 0.10, 0.30, 0.10], 512, min_planes=8)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -20,11 +20,24 @@ def timed(fn, reps):
     for _ in range(reps): fn()
     b.record(stream); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps
+raw = [synth.depth_frame(i, 200, seed=0x5EED0003) for i in (0, 6, 11)]
+wi, wr, wc = (float(x) for x in os.environ.get("PLAN_WEIGHTS", "0.4,0.6,0.02").split(","))
+costs = multi.plane_costs(lambda g: tsdf_amd.TSDFVolume(g, (3000.0,) * 3), [d for d, _ in raw], [c for _, c in raw], (n, n, n),
+                          integrate_weight=wi, raycast_weight=wr, constant=wc)
+measured = {}
 for P in (1, 2, 4, 8):
+  for plan in (("uniform", "balanced", "refined1", "refined2", "refined3") if P > 1 else ("uniform",)):
+    if plan == "uniform":
+        ranges = [multi.slab_range(n, P, r) for r in range(P)]
+    elif plan == "balanced":
+        ranges = multi.balanced_slab_ranges(costs, P, min_planes=8)
+    else:   # measured rebalancing, starting from the uniform split
+        prev_ranges, prev_t = measured[P]
+        ranges = multi.refine_slab_ranges(prev_ranges, prev_t, n, min_planes=8)
     worst_i = worst_r = 0.0
     rows = []
     for r in range(P):
-        zb, ze = multi.slab_range(n, P, r)
+        zb, ze = ranges[r]
         v = tsdf_amd.TSDFVolume((n, n, n), (3000.0,) * 3, slab=(zb, ze)) if P > 1 else tsdf_amd.TSDFVolume((n, n, n), (3000.0,) * 3)
         v.set_stream(stream.cuda_stream)
         for fr, cam in frames[:8]:
@@ -45,4 +58,8 @@ for P in (1, 2, 4, 8):
         rows.append((round(ti, 3), round(tr, 3)))
         worst_i, worst_r = max(worst_i, ti), max(worst_r, tr)
         v.close()
-    print("P=%d slowest slab: integrate %.3f ms, raycast %.3f ms   per slab (integrate, raycast): %s" % (P, worst_i, worst_r, rows))
+    tot = [a + b for a, b in rows]
+    if plan != "balanced":
+        measured[P] = (ranges, tot)
+    print("P=%d %-8s slowest slab: integrate %.3f ms, raycast %.3f ms, integrate+raycast %.3f (mean %.3f, x%.2f)  planes %s  per slab: %s"
+          % (P, plan, worst_i, worst_r, max(tot), sum(tot) / len(tot), max(tot) / (sum(tot) / len(tot)), [b - a for a, b in ranges], rows))

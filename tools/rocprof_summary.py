@@ -47,25 +47,45 @@ def pmc_text(db):
     return "\n".join(out)
 
 
-def traffic(fetch_db, write_db):
+def launches_of(db, counter):
+    """{kernel display name: [(start, value, duration)] in dispatch order} for one counter."""
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute("select kernel_name, start, value, duration from counters_collection where counter_name = ? order by start",
+                       (counter,)).fetchall()
+    out = {}
+    for k, st, v, d in rows:
+        out.setdefault(k, []).append((st, v, d))
+    return out
+
+
+def traffic(fetch_db, write_db, skip=0, take=0, meta=None):
+    """Bytes per launch, averaged over launches [skip, skip + take) of each kernel's most-launched template variant (the
+    production one): with skip = warm-up steps and take = timed steps these are exactly the launches bench.py's timed region
+    issued (the replays behind it are left out)."""
     res = {}
-    calls = {}
     for db, cname, scale in ((fetch_db, "FETCH_SIZE", 2.0), (write_db, "WRITE_SIZE", 1.0)):
-        for k, c, n, a, mn, mx, d in pmc_by_kernel(db):
-            if c != cname:
-                continue
+        best = {}
+        for k, rows in launches_of(db, cname).items():
             key = short(k).split("<")[0]
-            # several template variants share a name: keep the one launched most often (the production variant)
-            if calls.get((key, cname), 0) >= n:
-                continue
-            calls[(key, cname)] = n
+            if key not in best or len(rows) > len(best[key][1]):
+                best[key] = (short(k), rows)
+        for key, (variant, rows) in best.items():
+            sel = rows[skip:skip + take] if take else rows
+            if not sel:
+                sel = rows
+            a = sum(v for _, v, _ in sel) / len(sel)
             e = res.setdefault(key, {})
             e[cname + "_avg_raw_kb"] = a
-            e[cname + "_variant"] = short(k)
+            e[cname + "_variant"] = variant
+            e[cname + "_launches_averaged"] = len(sel)
+            e[cname + "_launches_total"] = len(rows)
             e[cname.lower().replace("_size", "") + "_bytes"] = a * 1024.0 * scale
     out = {"note": "bytes per launch = FETCH_SIZE*1024*2 (gfx950 half-count correction, MI355X_MICROARCH.md HBM) + "
-                   "WRITE_SIZE*1024 (uncalibrated); separate --pmc passes of the bench command",
+                   "WRITE_SIZE*1024 (calibrated on fill2_kernel); separate --pmc passes of the bench command; mean over the "
+                   "launches of the timed region (after `skip` warm-up launches)",
            "bytes_per_launch": {}, "detail": res}
+    if meta:
+        out.update(meta)
     for k, e in res.items():
         out["bytes_per_launch"][k] = int(e.get("fetch_bytes", 0) + e.get("write_bytes", 0))
     return json.dumps(out, indent=1)
@@ -78,4 +98,11 @@ if __name__ == "__main__":
     elif mode == "pmc":
         print(pmc_text(sys.argv[2]))
     elif mode == "traffic":
-        print(traffic(sys.argv[2], sys.argv[3]))
+        # traffic FETCH.db WRITE.db [skip take [key=value ...]]   (key=value pairs go into the JSON: tag, steps, warmup, ...)
+        skip = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+        take = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+        meta = {}
+        for kv in sys.argv[6:]:
+            k, v = kv.split("=", 1)
+            meta[k] = json.loads(v) if v[:1] in "{[0123456789" else v
+        print(traffic(sys.argv[2], sys.argv[3], skip, take, meta))

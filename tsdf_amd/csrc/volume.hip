@@ -10,6 +10,8 @@
 #include <new>
 #include <vector>
 
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace tsdf {
@@ -46,6 +48,17 @@ __global__ __launch_bounds__(256) void fill2_kernel(float *__restrict__ dist, fl
         dist[t] = dval;
         weight[t] = wval;
     }
+}
+
+// float4 streaming copy, one 16-byte element per thread and four per loop trip (tsdf_measure_copy_bandwidth)
+__global__ __launch_bounds__(256) void copy4_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n; i += stride) dst[i] = src[i];
 }
 
 // initialise_deformation (src/TSDF/TSDFVolume.cu:768-794) for the materialised node array.
@@ -846,6 +859,42 @@ int tsdf_volume_set_offset_at_clear(tsdf_volume *v, const float oc[3]) {
     TSDF_REQUIRE(v && oc, "null argument");
     TSDF_REQUIRE(!v->nodes, "the deformation nodes are materialised: their translations are what they are");
     v->g.offset_clear = {oc[0], oc[1], oc[2]};
+    return TSDF_OK;
+}
+
+int tsdf_measure_copy_bandwidth(size_t bytes, int reps, void *hip_stream, double *gb_per_s) {
+    TSDF_REQUIRE(gb_per_s && bytes >= 16 && bytes % 16 == 0 && reps >= 1, "tsdf_measure_copy_bandwidth: bad argument");
+    hipStream_t s = (hipStream_t)hip_stream;
+    float4 *a = nullptr, *b = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipMalloc((void **)&a, bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&b, bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(a, 0x3c, bytes, s);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    double best = 0.0;
+    const size_t n = bytes / 16;
+    // several launch shapes, the best one counts (a ceiling is asked for): one element per thread, and grid-stride loops of
+    // 8 ... 64 workgroups per compute unit
+    const size_t shapes[5] = {(n + 255) / 256, (size_t)256 * 8, (size_t)256 * 16, (size_t)256 * 32, (size_t)256 * 64};
+    for (int sh = 0; sh < 5 && e == hipSuccess; sh++) {
+        const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, shapes[sh]);
+        for (int r = 0; r <= reps && e == hipSuccess; r++) {          // (the first round warms up)
+            e = hipEventRecord(e0, s);
+            hipLaunchKernelGGL(copy4_kernel, dim3(grid), dim3(256), 0, s, a, b, n);
+            if (e == hipSuccess) e = hipEventRecord(e1, s);
+            if (e == hipSuccess) e = hipEventSynchronize(e1);
+            float ms = 0.0f;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+            if (e == hipSuccess && r > 0 && ms > 0.0f) best = std::max(best, 2.0 * (double)bytes / (ms * 1e-3) / 1e9);
+        }
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    if (e != hipSuccess) return hip_fail(e, "copy bandwidth measurement");
+    *gb_per_s = best;
     return TSDF_OK;
 }
 

@@ -22,6 +22,93 @@ def slab_range(size_z, world, rank):
     return z_begin, z_begin + base + (1 if rank < rem else 0)
 
 
+def balanced_slab_ranges(cost_per_plane, world, min_planes=1):
+    """Contiguous Z ranges [(z_begin, z_end)] * world that minimise the largest slab cost (still north_star's Z-slab split,
+    only the boundaries move).  cost_per_plane: non-negative work estimate per plane (len = size_z).  Exact: the smallest
+    feasible bound is found by bisection over the greedy 'fill until the bound' test, then the slabs are laid out left to
+    right keeping at least `min_planes` planes for every slab still to come."""
+    cost = [max(0.0, float(c)) for c in cost_per_plane]
+    Z = len(cost)
+    if world < 1 or world * min_planes > Z:
+        raise ValueError("cannot split %d planes over %d ranks" % (Z, world))
+    if world == 1:
+        return [(0, Z)]
+    total = sum(cost)
+    if total <= 0.0:
+        return [slab_range(Z, world, r) for r in range(world)]
+
+    def layout(bound):
+        """Greedy ranges under `bound` (None if more than `world` slabs are needed)."""
+        ranges, z = [], 0
+        for r in range(world):
+            left = world - r - 1                      # slabs still to come
+            end, acc = z, 0.0
+            while end < Z - left * min_planes and (end - z < min_planes or acc + cost[end] <= bound):
+                acc += cost[end]
+                end += 1
+            if r == world - 1 and end < Z:
+                return None
+            ranges.append((z, end))
+            z = end
+        return ranges if z == Z else None
+
+    lo, hi = max(cost), total
+    for _ in range(60):
+        mid = 0.5 * (lo + hi)
+        if layout(mid) is None:
+            lo = mid
+        else:
+            hi = mid
+    ranges = layout(hi)
+    # the last slabs may have been left with exactly min_planes each although they could take more: even them out by
+    # re-running the greedy from the right with the same bound when that lowers the largest cost (cheap: world <= 8)
+    return ranges
+
+
+def refine_slab_ranges(ranges, seconds, size_z, min_planes=1, floor=None):
+    """One round of measured rebalancing: `seconds[r]` is what rank r's slab `ranges[r]` cost for the same frames (integrate +
+    slab ray cast).  A rank's time above the common floor (what even an empty slab costs: launches, ray set-up; default = 0.8 x
+    the cheapest rank) is spread evenly over its planes, and balanced_slab_ranges re-cuts that density.  Every rank calls this
+    with the same all-gathered numbers and gets the same plan."""
+    world = len(ranges)
+    t = [max(0.0, float(x)) for x in seconds]
+    base = 0.8 * min(t) if floor is None else float(floor)
+    density = [0.0] * size_z
+    for (zb, ze), tr in zip(ranges, t):
+        d = max(tr - base, 0.02 * max(t)) / max(1, ze - zb)
+        for z in range(zb, ze):
+            density[z] = d
+    return balanced_slab_ranges(density, world, min_planes)
+
+
+def plane_costs(volume_factory, frames, cameras, size, planner_z=128, integrate_weight=0.4, raycast_weight=0.6, constant=0.02):
+    """Work estimate per Z plane of a `size` grid, for balanced_slab_ranges: a small planner volume of the same physical box
+    (planner_z planes) integrates the given frames; per planner plane, the share of updated voxels (what integrate_kernel
+    does per frame) and of occupied ray-caster bricks (where the march evaluates samples instead of jumping) are blended with
+    the two kernels' share of a step, plus a constant per plane (cull, projection of voxels not updated).  Deterministic:
+    every rank computes the same costs from the same frames, no communication.  volume_factory(grid_xyz) -> TSDFVolume."""
+    import numpy as np
+    X, Y, Z = (int(v) for v in size)
+    pz = min(int(planner_z), Z)
+    grid = (max(8, X * pz // Z), max(8, Y * pz // Z), pz)
+    vol = volume_factory(grid)
+    for depth, cam in zip(frames, cameras):
+        vol.integrate(depth, 640, 480, cam)
+    w = vol.get_weight_data().reshape(pz, -1)
+    updated = (w > 0).sum(axis=1).astype(np.float64)
+    fine = vol.occupancy_data(force_rebuild=True)[0]                     # (nbz, nby, nbx), 4-voxel bricks
+    interior = fine[:, 1:-1, 1:-1] if fine.shape[1] > 2 and fine.shape[2] > 2 else fine
+    occ = np.repeat(interior.reshape(interior.shape[0], -1).sum(axis=1).astype(np.float64), 4)[:pz]
+    if hasattr(vol, "close"):
+        vol.close()
+    u = updated / updated.sum() if updated.sum() > 0 else np.full(pz, 1.0 / pz)
+    o = occ / occ.sum() if occ.sum() > 0 else np.full(pz, 1.0 / pz)
+    cost_p = integrate_weight * u + raycast_weight * o + constant / pz
+    # planner planes -> grid planes
+    idx = (np.arange(Z) * pz) // Z
+    return (cost_p[idx] * pz / Z).tolist()
+
+
 def resident_range(size_z, world, rank):
     """Planes a rank keeps in HBM: its slab plus one halo plane above (trilinear reads lower.z + 1)."""
     zb, ze = slab_range(size_z, world, rank)

@@ -41,10 +41,17 @@ def camera_position(i, n):
     return (1500.0 + 200.0 * math.sin(a), 1300.0 + 100.0 * math.sin(2.0 * a), -600.0 + 150.0 * math.cos(a))
 
 
-def camera_for_frame(i, n, camera=None):
+def camera_position_inside(i, n):
+    """Closed trajectory INSIDE the volume, one metre in front of the wall (BASELINE configs[3]: at 1024^3 a ray covers only
+    4402 * 0.279 mm = 1228 mm, Q8, so the scene has to be that close)."""
+    a = 2.0 * math.pi * i / n
+    return (1500.0 + 120.0 * math.sin(a), 1350.0 + 60.0 * math.sin(2.0 * a), 1400.0 + 80.0 * math.cos(a))
+
+
+def camera_for_frame(i, n, camera=None, inside=False):
     cam = camera or Camera.default_depth_camera()
     cam.set_pose(np.eye(4, dtype=np.float32).reshape(-1))
-    cam.move_to(*camera_position(i, n))
+    cam.move_to(*(camera_position_inside(i, n) if inside else camera_position(i, n)))
     cam.look_at(*LOOK_AT)
     return cam
 
@@ -88,9 +95,9 @@ def trace_depth(camera, width=WIDTH, height=HEIGHT):
     return best
 
 
-def depth_frame(i, n, seed, width=WIDTH, height=HEIGHT, camera=None, noise=True):
-    """-> (depth uint16 (H*W,), camera) for frame i of an n-frame stream."""
-    cam = camera_for_frame(i, n, camera)
+def depth_frame(i, n, seed, width=WIDTH, height=HEIGHT, camera=None, noise=True, inside=False):
+    """-> (depth uint16 (H*W,), camera) for frame i of an n-frame stream (inside: the config-4 trajectory within the volume)."""
+    cam = camera_for_frame(i, n, camera, inside)
     z = trace_depth(cam, width, height)
     mm = np.where(np.isfinite(z), np.rint(z), 0.0)
     if noise:
