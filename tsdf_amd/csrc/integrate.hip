@@ -222,8 +222,9 @@ __global__ __launch_bounds__(256) void brick_cull_kernel(const Geom g, const Bri
 // the divisions by 1.
 // rx = roundf(a1 / b), ry = roundf(a2 / b) exactly as the reference's IEEE divisions + round() give them
 // (src/Utilities/cuda_coordinate_transforms.cu:25-26), at a fraction of the cost.  The quotients are first formed with
-// the hardware reciprocal (relative error < 2.4e-7 against the correctly rounded quotient) and rounded as
-// floor(q + 1/2); h = 1/2 - |q - floor(q + 1/2)| is the distance of q to the nearest rounding boundary (x.5).
+// the hardware reciprocal (relative error < 2.4e-7 against the correctly rounded quotient) and rounded to the nearest
+// integer r (v_rndne; round 1 used floor(q + 1/2), the same number wherever the fast path is kept);
+// h = 1/2 - |q - r| is the distance of q to the nearest rounding boundary (x.5).
 //   * |q| <= L = max(width, height) + 2 and h > thr = 4e-7 * L: the IEEE quotient lies on the same side of the same
 //     boundaries, and away from a boundary floor(q + 1/2) == roundf(q) for either sign (the addition q + 1/2 is exact
 //     or errs by less than thr), so the result is the reference's;
@@ -231,18 +232,28 @@ __global__ __launch_bounds__(256) void brick_cull_kernel(const Geom g, const Bri
 //     two round to fails the reference's frustum test alike;
 //   * otherwise (also NaN / infinite quotients, zero or denormal divisors: h is NaN or <= thr) the lane redoes the IEEE
 //     division and roundf, and maps NaN to 0 as the target's float -> int conversion does.
-__device__ inline void round_quotients(float a1, float a2, float b, float thr, float &rx, float &ry) {
+__device__ inline void round_quotients(float a1, float a2, float b, float near_half, float &rx, float &ry) {
     const float rc = __builtin_amdgcn_rcpf(b);
     const float q1 = a1 * rc, q2 = a2 * rc;
-    rx = floorf(q1 + 0.5f);
-    ry = floorf(q2 + 0.5f);
-    const float h1 = 0.5f - fabsf(q1 - rx), h2 = 0.5f - fabsf(q2 - ry);
-    if (!(h1 > thr) || !(h2 > thr)) {
+    // nearest integer (ties to even): equals floor(q + 1/2) wherever the test below lets the fast path stand -- the two differ
+    // only on ties and where q + 1/2 itself rounds across an integer, and both leave |q - r| within thr of 1/2
+    rx = __builtin_rintf(q1);
+    ry = __builtin_rintf(q2);
+    // h > thr  <=>  |q - r| < 1/2 - thr; near_half is the float just BELOW fl(1/2 - thr) (host), so the comparison can only
+    // send more lanes to the exact path than the bound in the comment above asks for.  NaN compares false -> exact path.
+    if (!(fabsf(q1 - rx) < near_half) || !(fabsf(q2 - ry) < near_half)) {
         rx = roundf(a1 / b);
         ry = roundf(a2 / b);
         if (rx != rx) rx = 0.0f;
         if (ry != ry) ry = 0.0f;
     }
+}
+
+// float -> int as the hardware converts: saturating, NaN -> 0 (defined for every float, unlike the C cast)
+__device__ inline int cvt_i32_sat(float f) {
+    int i;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(i) : "v"(f));
+    return i;
 }
 
 // Per z plane, the terms of the projection that depend on z only (the same fp32 products the reference forms per voxel):
@@ -269,7 +280,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     const size_t plane = (size_t)g.X * g.Y;
     const float neg_trunc = -g.trunc;
     const float fwidth = (float)width, fheight = (float)height;
-    const float round_thr = 4.0e-7f * ((float)max(width, height) + 2.0f);  // see round_quotients
+    // see round_quotients: thr = 4e-7 * (max(width, height) + 2); the float just below 1/2 - thr
+    const float round_near_half = __uint_as_float(__float_as_uint(0.5f - 4.0e-7f * ((float)max(width, height) + 2.0f)) - 1u);   // (positive: one ulp down)
     uint32_t updated = 0;
 
     for (uint32_t i = blockIdx.x; i < n_active; i += gridDim.x) {
@@ -372,10 +384,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                 // pixel = (int)round(q) with the target's conversion (NaN -> 0, saturating); the frustum test (:349) is
                 // done on the rounded floats, which order exactly like the saturated ints
                 float rx, ry;
-                round_quotients(imx, imy, imz, round_thr, rx, ry);
-                // (clamped before the conversion so that it is defined for any float; -1 and 65536 are off the image)
-                px_[j] = (int)__builtin_amdgcn_fmed3f(rx, -1.0f, 65536.0f);
-                py_[j] = (int)__builtin_amdgcn_fmed3f(ry, -1.0f, 65536.0f);
+                round_quotients(imx, imy, imz, round_near_half, rx, ry);
+                // (the hardware conversion saturates: anything beyond the int range is off the image either way)
+                px_[j] = cvt_i32_sat(rx);
+                py_[j] = cvt_i32_sat(ry);
                 // The brick's pixel box (cull kernel) holds every pixel a voxel of this brick can map to, and it lies
                 // inside the image: a pixel in the box passes the frustum test.  The LDS read is unconditional (a slot
                 // holding 0 when outside) and the global gather a separate, rare branch, so that neither turns into a generic
@@ -411,11 +423,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                 // (sdf > 0) ? min(sdf, trunc) : sdf  ==  sdf < trunc ? sdf : trunc   (trunc > 0)
                 tsdf_[j] = update ? (sdf < g.trunc ? sdf : g.trunc) : NAN;
                 pw_[j] = pd_[j] = 0.f;
+#ifndef TSDF_DEBUG_NOMEM
                 if (update) {
                     const size_t pb = brick_base + plane * (size_t)(zb - z0 + j);
                     pw_[j] = (weight + pb)[lane_off];
                     pd_[j] = (dist + pb)[lane_off];
                 }
+#endif
             }
         };
         auto blend_and_store = [&](const uint32_t zb, const float (&tsdf_)[kBatchZ], const float (&pw_)[kBatchZ], const float (&pd_)[kBatchZ]) {
@@ -425,8 +439,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                     const float new_weight = pw_[j] + 1.0f;
                     const float new_distance = ((pd_[j] * pw_[j]) + (tsdf_[j] * 1.0f)) / new_weight;
                     const size_t pb = brick_base + plane * (size_t)(zb - z0 + j);
+#ifndef TSDF_DEBUG_NOMEM
                     (weight + pb)[lane_off] = new_weight;
                     (dist + pb)[lane_off] = new_distance;
+#else
+                    if (new_weight == -123.0f && new_distance == 77.0f) (dist + pb)[lane_off] = new_distance;   // (keeps the arithmetic alive)
+#endif
                     if (!(new_distance > occ.tau)) mark_occupied(occ, vx, vy, zb + j);
                     if (COUNT) updated++;
                 }
