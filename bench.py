@@ -376,9 +376,15 @@ def main():
         gbs = C.c_double(0.0)
         check(lib.tsdf_measure_copy_bandwidth(1 << 30, 5, C.c_void_p(stream.cuda_stream), C.byref(gbs)))
         copy_gbs = float(gbs.value)
+        # ... and against what integrate's own memory walk reaches when it does nothing but the in-place update of every voxel
+        # (read-modify-write of both arrays, brick by brick, no projection): the ceiling of the access shape
+        check(lib.tsdf_measure_update_bandwidth(5, C.c_void_p(stream.cuda_stream), C.byref(gbs)))
+        update_gbs = float(gbs.value)
         for r_ in ([roof_int] if world > 1 else [roof_ray, roof_int]):
             r_["measured_copy_gbs"] = round(copy_gbs, 1)
             r_["frac_of_measured_copy"] = round(r_["achieved"] / copy_gbs, 5)
+        roof_int["measured_inplace_update_gbs"] = round(update_gbs, 1)
+        roof_int["frac_of_inplace_update"] = round(roof_int["achieved"] / update_gbs, 5)
     if rank == 0 and world == 1:
         out["roofline"] = roof_ray if dominant == "raycast" else roof_int
         out["roofline_other"] = roof_int if dominant == "raycast" else roof_ray

@@ -270,6 +270,11 @@ int tsdf_bilateral_filter_u16_device(const tsdf_bilateral *filter, const uint16_
  * `hip_stream`, timed with HIP events on that stream: *gb_per_s = read + write bytes per second of the best repetition / 1e9.
  * bench.py reports it beside the nominal HBM peak as the practical ceiling of a streaming kernel on this box. */
 int tsdf_measure_copy_bandwidth(size_t bytes, int reps, void *hip_stream, double *gb_per_s);
+/* The same for the access shape of integrate: two arrays of a 512^3 float grid updated IN PLACE (read, modify, write back)
+ * brick by brick -- workgroups of 4 waves walking 32 planes of a 64 x 4 x 32 voxel brick, a wave per 256-byte row segment, 4
+ * planes in flight -- with no projection work at all: *gb_per_s = (read + write bytes of both arrays) per second / 1e9, best of
+ * `reps`.  The ceiling an in-place update of every voxel could reach with integrate's memory walk. */
+int tsdf_measure_update_bandwidth(int reps, void *hip_stream, double *gb_per_s);
 
 #ifdef __cplusplus
 }

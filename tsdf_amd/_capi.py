@@ -66,6 +66,7 @@ _SIGS = {
     "tsdf_volume_set_deformation": (_i, [_vp, _vp]),
     "tsdf_volume_get_distance_data": (_i, [_vp, _vp]),
     "tsdf_measure_copy_bandwidth": (_i, [C.c_size_t, _i, _vp, C.POINTER(C.c_double)]),
+    "tsdf_measure_update_bandwidth": (_i, [_i, _vp, C.POINTER(C.c_double)]),
     "tsdf_volume_get_weight_data": (_i, [_vp, _vp]),
     "tsdf_volume_get_deformation_planes": (_i, [_vp, C.c_uint32, C.c_uint32, _vp]),
     "tsdf_volume_set_offset_at_clear": (_i, [_vp, _vp]),

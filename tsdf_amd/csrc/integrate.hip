@@ -419,16 +419,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                 }
                 const float sdf = surf_z - voxel_cam_z;
                 // depth > 0 (:355; also false for planes past the brick and pixels off the image) and sdf >= -trunc (:366)
+#ifdef TSDF_DEBUG_ALLUPDATE
+                const bool update = act[j];     // (experiment, DESIGN.md 3.1: every voxel of a surviving brick takes the memory path)
+#else
                 const bool update = d_[j] != 0 && sdf >= neg_trunc;
+#endif
                 // (sdf > 0) ? min(sdf, trunc) : sdf  ==  sdf < trunc ? sdf : trunc   (trunc > 0)
                 tsdf_[j] = update ? (sdf < g.trunc ? sdf : g.trunc) : NAN;
                 pw_[j] = pd_[j] = 0.f;
 #ifndef TSDF_DEBUG_NOMEM
+#ifndef TSDF_DEBUG_NOMEM     // (experiment, DESIGN.md 3.1: the kernel without its HBM loads and stores)
                 if (update) {
                     const size_t pb = brick_base + plane * (size_t)(zb - z0 + j);
                     pw_[j] = (weight + pb)[lane_off];
                     pd_[j] = (dist + pb)[lane_off];
                 }
+#endif
 #endif
             }
         };

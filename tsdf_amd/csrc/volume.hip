@@ -61,6 +61,26 @@ __global__ __launch_bounds__(256) void copy4_kernel(const float4 *__restrict__ s
     for (; i < n; i += stride) dst[i] = src[i];
 }
 
+// In-place update of two 512^3 float arrays in integrate_kernel's walk (tsdf_measure_update_bandwidth): one workgroup per
+// 64 x 4 x 32 brick, lane <-> x, 4 planes in flight, the running-mean arithmetic but no projection.
+__global__ __launch_bounds__(256) void update_walk_kernel(float *__restrict__ d, float *__restrict__ w) {
+    const unsigned b = blockIdx.x, bx = b % 8, by = (b / 8) % 128, bz = b / (8 * 128);
+    const size_t plane = (size_t)512 * 512;
+    const size_t idx = (size_t)bz * 32 * plane + (size_t)(by * 4 + threadIdx.y) * 512 + bx * 64 + threadIdx.x;
+#pragma unroll 1
+    for (int z = 0; z < 32; z += 4) {
+        float pd[4], pw[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { pd[j] = d[idx + (z + j) * plane]; pw[j] = w[idx + (z + j) * plane]; }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float nw = pw[j] + 1.0f;
+            d[idx + (z + j) * plane] = (pd[j] * pw[j] + 3.0f) / nw;
+            w[idx + (z + j) * plane] = nw;
+        }
+    }
+}
+
 // initialise_deformation (src/TSDF/TSDFVolume.cu:768-794) for the materialised node array.
 __global__ __launch_bounds__(256) void init_nodes_kernel(tsdf_deformation_node *nodes, Geom g) {
     uint32_t vx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -894,6 +914,37 @@ int tsdf_measure_copy_bandwidth(size_t bytes, int reps, void *hip_stream, double
     if (a) (void)hipFree(a);
     if (b) (void)hipFree(b);
     if (e != hipSuccess) return hip_fail(e, "copy bandwidth measurement");
+    *gb_per_s = best;
+    return TSDF_OK;
+}
+
+int tsdf_measure_update_bandwidth(int reps, void *hip_stream, double *gb_per_s) {
+    TSDF_REQUIRE(gb_per_s && reps >= 1, "tsdf_measure_update_bandwidth: bad argument");
+    hipStream_t s = (hipStream_t)hip_stream;
+    const size_t bytes = (size_t)512 * 512 * 512 * sizeof(float);
+    float *a = nullptr, *b = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipMalloc((void **)&a, bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&b, bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(a, 0, bytes, s);
+    if (e == hipSuccess) e = hipMemsetAsync(b, 0, bytes, s);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    double best = 0.0;
+    for (int r = 0; r <= reps && e == hipSuccess; r++) {          // (the first round warms up)
+        e = hipEventRecord(e0, s);
+        hipLaunchKernelGGL(update_walk_kernel, dim3(8 * 128 * 16), dim3(64, 4), 0, s, a, b);
+        if (e == hipSuccess) e = hipEventRecord(e1, s);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0.0f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e == hipSuccess && r > 0 && ms > 0.0f) best = std::max(best, 4.0 * (double)bytes / (ms * 1e-3) / 1e9);
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    if (e != hipSuccess) return hip_fail(e, "update bandwidth measurement");
     *gb_per_s = best;
     return TSDF_OK;
 }
