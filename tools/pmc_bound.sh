@@ -14,6 +14,7 @@ run() {  # name, counters...
   timeout 300 rocprofv3 --kernel-trace --pmc "$@" -d $out/prof_$name -o bench -- $cmd > $out/prof_$name.log 2>&1
   db=$(find $out/prof_$name -name "*.db" | head -1)
   if [ -n "$db" ]; then (cd $root; python tools/rocprof_summary.py pmc $db > $out/profiles_$tag/${tag}_pmc_$name.txt); else echo "pass $name produced no database"; tail -5 $out/prof_$name.log; fi
+  rm -rf $out/prof_$name   # raw database: scratch (gpurun copies back at most 64 MiB)
 }
 run clock GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES
 run insts SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS

@@ -18,4 +18,5 @@ for p in "$@"; do
   db=$(find $out/prof_$name -name "*.db" | head -1)
   if [ -n "$db" ]; then (cd $root; python tools/rocprof_summary.py pmc $db > $out/profiles_$tag/${tag}_pmc_$name.txt); echo "== $name"; grep -i "$filt" $out/profiles_$tag/${tag}_pmc_$name.txt | cut -c1-175
   else echo "pass $name produced no database"; tail -5 $out/prof_$name.log; fi
+  rm -rf $out/prof_$name
 done

@@ -25,3 +25,5 @@ python tools/rocprof_summary.py traffic $(f prof_fetch) $(f prof_write) $warmup 
     "bench_args={\"steps\": $steps, \"warmup\": $warmup, \"grid\": 512, \"gpus\": 1}" > $out/profiles_$tag/${tag}_traffic.json
 timeout 600 python bench.py --steps $steps --warmup $warmup > $out/profiles_$tag/${tag}_bench.json 2> $out/bench.err
 tail -c 600 $out/profiles_$tag/${tag}_kernel_stats.txt
+# the raw databases are scratch (gpurun copies back at most 64 MiB): keep only the summaries
+rm -rf $out/prof_stats $out/prof_fetch $out/prof_write
