@@ -104,5 +104,8 @@ if __name__ == "__main__":
         meta = {}
         for kv in sys.argv[6:]:
             k, v = kv.split("=", 1)
-            meta[k] = json.loads(v) if v[:1] in "{[0123456789" else v
+            try:
+                meta[k] = json.loads(v) if v[:1] in "{[0123456789" else v
+            except ValueError:      # (a hex digest that starts with a digit)
+                meta[k] = v
         print(traffic(sys.argv[2], sys.argv[3], skip, take, meta))

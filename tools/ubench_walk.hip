@@ -43,6 +43,48 @@ __global__ __launch_bounds__(256) void walk(typename V<LF>::T *__restrict__ d, t
     }
 }
 
+// general shape: a workgroup covers LF * 64 x, YR rows, ZP planes; its 4 waves take the (row, plane) slots in turn, rows fastest
+// (ROWFAST) or planes fastest, 4 slots in flight per wave
+template <int LF, int YR, int ZP, bool ROWFAST>
+__global__ __launch_bounds__(256) void walk2(typename V<LF>::T *__restrict__ d, typename V<LF>::T *__restrict__ w) {
+    typedef typename V<LF>::T T;
+    constexpr unsigned NBX = 512 / (64 * LF), NBY = 512 / YR;
+    const unsigned b = blockIdx.x;
+    const unsigned bx = b % NBX, by = (b / NBX) % NBY, bz = b / (NBX * NBY);
+    const size_t row = 512 / LF, plane = row * 512;
+    const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t base = (size_t)(bz * ZP) * plane + (size_t)(by * YR) * row + bx * 64 + lane;
+#pragma unroll 1
+    for (unsigned s0 = wave * 4; s0 < YR * ZP; s0 += 16) {
+        T pd[4], pw[4];
+        size_t idx[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned sl = s0 + j, y = ROWFAST ? sl % YR : sl / ZP, z = ROWFAST ? sl / YR : sl % ZP;
+            idx[j] = base + z * plane + y * row;
+            pd[j] = d[idx[j]]; pw[j] = w[idx[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) { d[idx[j]] = inc(pd[j]); w[idx[j]] = inc(pw[j]); }
+    }
+}
+template <int LF, int YR, int ZP, bool ROWFAST>
+static void run2(void *a, void *b, const char *what) {
+    typedef typename V<LF>::T T;
+    const unsigned n = (512 / (64 * LF)) * (512 / YR) * (512 / ZP);
+    const double bb = 4.0 * 512.0 * 512 * 512 * 4;
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    double best = 0;
+    for (int r = 0; r < 6; r++) {
+        (void)hipEventRecord(e0, 0);
+        hipLaunchKernelGGL((walk2<LF, YR, ZP, ROWFAST>), dim3(n), dim3(256), 0, 0, (T *)a, (T *)b);
+        (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+        float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+        if (r > 0 && bb / (ms * 1e-3) / 1e9 > best) best = bb / (ms * 1e-3) / 1e9;
+    }
+    printf("%-58s %7.1f GB/s\n", what, best);
+}
+
 // the product's update_walk_kernel (volume.hip), for reference
 __global__ __launch_bounds__(256) void update_walk_ref(float *__restrict__ d, float *__restrict__ w) {
     const unsigned b = blockIdx.x, bx = b % 8, by = (b / 8) % 128, bz = b / (8 * 128);
@@ -109,6 +151,14 @@ int main() {
     run<1, false, false, 1, 32>(a, b, "4 B/lane, 1 row x 32 planes (waves split z)");
     run<1, true, false, 1, 32>(a, b, "4 B/lane, 1 row x 32 planes, XCD-contiguous");
     run<2, true, false, 1, 32>(a, b, "8 B/lane, 1 row x 32 planes, XCD-contiguous");
+    run2<1, 4, 32, true>(a, b, "walk2 4 B/lane 4 rows x 32 planes, rows fastest");
+    run2<1, 4, 32, false>(a, b, "walk2 4 B/lane 4 rows x 32 planes, planes fastest");
+    run2<1, 32, 4, true>(a, b, "walk2 4 B/lane 32 rows x 4 planes, rows fastest");
+    run2<1, 128, 1, true>(a, b, "walk2 4 B/lane 128 rows x 1 plane");
+    run2<1, 16, 8, true>(a, b, "walk2 4 B/lane 16 rows x 8 planes, rows fastest");
+    run2<2, 32, 4, true>(a, b, "walk2 8 B/lane 32 rows x 4 planes, rows fastest");
+    run2<2, 4, 32, true>(a, b, "walk2 8 B/lane 4 rows x 32 planes, rows fastest");
+    run2<4, 32, 4, true>(a, b, "walk2 16 B/lane 32 rows x 4 planes, rows fastest");
     run<1, false, false, 4, 16>(a, b, "4 B/lane, 4 rows x 16 planes");
     run<1, true, false, 4, 16>(a, b, "4 B/lane, 4 rows x 16 planes, XCD-contiguous");
     return 0;
