@@ -125,6 +125,7 @@ struct BrickGrid {
     uint32_t nx, ny, nz;  // bricks per axis over the resident planes
     uint32_t z_extra;     // planes (<= kBatchZ) appended to the bricks of the last z layer: a slab's halo plane, which would
                           // otherwise cost a whole layer of bricks that project 32 planes to update one
+    uint32_t pair_loads;  // 1 = the image has an even width and a 4-byte aligned base: pixel boxes are made even and staged two pixels per lane
 };
 
 // One thread per 64x4x32 brick: decide whether any voxel of it can be updated by this frame (see the header).
@@ -190,6 +191,11 @@ __global__ __launch_bounds__(256) void brick_cull_kernel(const Geom g, const Bri
         const float fy0 = fmaxf(qy_lo - 1.0f, 0.0f), fy1 = fminf(qy_hi + 1.0f, (float)(height - 1));
         if (keep && fx0 <= fx1 && fy0 <= fy1) {  // (false for NaN: box stays unknown)
             box = make_uint4((uint32_t)fx0, (uint32_t)fy0, (uint32_t)fx1 - (uint32_t)fx0 + 1, (uint32_t)fy1 - (uint32_t)fy0 + 1);
+            if (bg.pair_loads) {   // grown to even columns (any superset inside the image will do; the width is even)
+                const uint32_t xa = box.x & ~1u, xe = (box.x + box.z + 1u) & ~1u;
+                box.x = xa;
+                box.z = xe - xa;
+            }
             if (depth_test) {
                 const uint32_t tx0 = (uint32_t)fx0 / kDepthTile, tx1 = (uint32_t)fx1 / kDepthTile;
                 const uint32_t ty0 = (uint32_t)fy0 / kDepthTile, ty1 = (uint32_t)fy1 / kDepthTile;
@@ -304,9 +310,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         }
         if (tid == 0) tile[kTilePixels] = 0;
         if (staged) {
-            for (uint32_t p = tid; p < pitch * box.w; p += kTileX * kTileY) {
-                const uint32_t ty = p / pitch, tx = p - ty * pitch;
-                tile[p] = (tx < box.z) ? depth[(size_t)(box.y + ty) * width + (box.x + tx)] : (uint16_t)0;
+            // kStageBatch look-ups are requested before the first is waited for (a loop of single look-ups is one memory round
+            // trip after the other: ~16 of them per brick).  No branch inside a batch: slots past the end re-read the last pixel
+            // and are not written.
+            constexpr uint32_t kStageBatch = 8;
+            const uint32_t total = pitch * box.w;
+            if (bg.pair_loads) {
+                // (even image width, 4-byte aligned image: the cull kernel has made box.x and box.z even, a lane takes two pixels)
+                const uint32_t half = pitch >> 1, total2 = half * box.w;
+                const uint32_t *depth2 = reinterpret_cast<const uint32_t *>(depth);
+                uint32_t *tile2 = reinterpret_cast<uint32_t *>(tile);
+                for (uint32_t p0 = tid; p0 < total2; p0 += kTileX * kTileY * kStageBatch) {
+                    uint32_t px[kStageBatch];
+#pragma unroll
+                    for (uint32_t u = 0; u < kStageBatch; u++) {
+                        const uint32_t p = min(p0 + u * (kTileX * kTileY), total2 - 1u);
+                        const uint32_t ty = p / half, tx2 = p - ty * half;
+                        px[u] = depth2[(((size_t)(box.y + ty) * width + box.x) >> 1) + tx2];
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < kStageBatch; u++) {
+                        const uint32_t p = p0 + u * (kTileX * kTileY);
+                        if (p < total2) tile2[p] = px[u];
+                    }
+                }
+            } else
+            for (uint32_t p0 = tid; p0 < total; p0 += kTileX * kTileY * kStageBatch) {
+                uint16_t px[kStageBatch];
+#pragma unroll
+                for (uint32_t u = 0; u < kStageBatch; u++) {
+                    const uint32_t p = min(p0 + u * (kTileX * kTileY), total - 1u);
+                    const uint32_t ty = p / pitch, tx = min(p - ty * pitch, box.z - 1u);
+                    px[u] = depth[(size_t)(box.y + ty) * width + (box.x + tx)];
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < kStageBatch; u++) {
+                    const uint32_t p = p0 + u * (kTileX * kTileY);
+                    const uint32_t ty = p / pitch, tx = p - ty * pitch;
+                    if (p < total) tile[p] = (tx < box.z) ? px[u] : (uint16_t)0;
+                }
             }
         }
         __syncthreads();
@@ -496,6 +538,7 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
         bg.nz = append ? full : (planes + kChunkZ - 1) / kChunkZ;
         bg.z_extra = append ? rest : 0;
     }
+    bg.pair_loads = (width % 2 == 0 && (reinterpret_cast<uintptr_t>(d_depth) & 3u) == 0) ? 1u : 0u;
     const size_t n_bricks = (size_t)bg.nx * bg.ny * bg.nz;
     TSDF_REQUIRE(n_bricks < 0xFFFFFFFFull, "volume too large for the brick list");
 
