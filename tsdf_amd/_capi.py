@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtsdf_hip.so")
+# (TSDF_HIP_LIB: another build of the same library, for A/B timing of kernel variants on one box -- tools/ab_variants.sh)
+LIB_PATH = os.environ.get("TSDF_HIP_LIB") or os.path.join(_HERE, "lib", "libtsdf_hip.so")
 
 TSDF_OK, TSDF_ERR_INVALID, TSDF_ERR_DEVICE, TSDF_ERR_NOMEM = 0, 1, 2, 3
 

@@ -8,7 +8,7 @@
 //
 // Three launches per frame:
 //   1. depth_tile_max_kernel: max depth of every 16x16 pixel tile (1200 tiles at 640x480).
-//   2. brick_cull_kernel (one thread per brick): exact, conservative culling.  The 8 corner voxel centres are
+//   2. brick_cull_kernel (eight lanes per brick, one per corner): exact, conservative culling.  The 8 corner voxel centres are
 //      projected with running error bounds.  A projective map sends the convex brick into the convex hull of
 //      the projected corners as long as the homogeneous divisor keeps one sign over the brick, so
 //        (a) if all corners fall off the same side of the depth image no voxel passes the reference's
@@ -96,6 +96,7 @@ __device__ inline void mark_occupied(const OccGrid &occ, uint32_t vx, uint32_t v
 }
 
 constexpr int kDepthTile = 16;  // pixels per side of a depth tile
+constexpr int kCullTilesLds = 4096;  // tile maxima brick_cull_kernel keeps in LDS (1200 at 640x480)
 
 static uint32_t occupancy_rebuild_period() {
     static const uint32_t n = [] {
@@ -128,93 +129,130 @@ struct BrickGrid {
     uint32_t pair_loads;  // 1 = the image has an even width and a 4-byte aligned base: pixel boxes are made even and staged two pixels per lane
 };
 
-// One thread per 64x4x32 brick: decide whether any voxel of it can be updated by this frame (see the header).
+// Eight lanes per 64x4x32 brick: decide whether any voxel of it can be updated by this frame (see the header).
 __global__ __launch_bounds__(256) void brick_cull_kernel(const Geom g, const BrickGrid bg, const Mat44 ip, const Mat33 k,
                                                          const uint32_t width, const uint32_t height,
                                                          const uint16_t *__restrict__ tile_max, const uint32_t tiles_x,
                                                          const int depth_test, uint32_t *__restrict__ list,
                                                          uint4 *__restrict__ boxes, uint32_t *__restrict__ count,
                                                          float4 *__restrict__ plane_const, const uint32_t n_plane_const) {
-    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    // One lane per corner: 8 consecutive lanes share a brick and combine their corners with 3 butterfly steps (a thread per brick
+    // walked its 8 corners one after the other on a quarter of the chip's compute units: 12 us of dependent arithmetic).
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     // side job: the per-plane constants of integrate_kernel (see there)
-    for (uint32_t p = b; p < n_plane_const; p += gridDim.x * 256) {
+    for (uint32_t p = t; p < n_plane_const; p += gridDim.x * 256) {
         const uint32_t vz = g.z_store_begin + p;
         const float cz = ((((int)vz + 0.5f) * g.vs.z) + g.offset_clear.z) + g.offset.z;
         plane_const[p] = make_float4(cz, ip.m13 * cz, ip.m23 * cz, ip.m33 * cz);
     }
-    if (b >= bg.nx * bg.ny * bg.nz) return;
-    const uint32_t bx = b % bg.nx, by = (b / bg.nx) % bg.ny, bz = b / (bg.nx * bg.ny);
+    // the tile maxima in LDS (when they fit): the depth test below reads up to 256 of them per brick
+    __shared__ uint16_t tmax_lds[kCullTilesLds];
+    __shared__ uint32_t wave_count[4], wg_base;   // survivors per wave of this workgroup, the workgroup's first slot in the list
+    const uint32_t n_tiles = tiles_x * ((height + kDepthTile - 1) / kDepthTile);
+    const bool tiles_in_lds = depth_test && n_tiles <= (uint32_t)kCullTilesLds;
+    if (tiles_in_lds)
+        for (uint32_t i = threadIdx.x; i < n_tiles; i += 256) tmax_lds[i] = tile_max[i];
+    __syncthreads();
+    // Groups of 8 lanes take the bricks column by column: all rows (y, then z) of x-brick 0, then of x-brick 1, ...  The list
+    // keeps roughly that order, and workgroup i of integrate_kernel (on XCD i % 8) takes entry i: bricks in flight together are
+    // then rows apart, never neighbours along x.  Neighbours along x share every 2 KiB row of the volume they touch, and with it
+    // the memory channel: listed next to each other (index order) they cost integrate_kernel 0.130 ms against 0.121 ms in this
+    // order and 0.133 ms in a scattered one (same box, host-sorted lists, round 2).
+    const uint32_t g8 = t >> 3, c = t & 7u;
+    const uint32_t n_bricks = bg.nx * bg.ny * bg.nz, n_rows = bg.ny * bg.nz;
+    const bool live = g8 < n_bricks;   // (whole groups of 8 lanes; dead groups compute on brick 0 and append nothing)
+    const uint32_t bx = live ? g8 / n_rows : 0u, row = live ? g8 % n_rows : 0u;
+    const uint32_t by = row % bg.ny, bz = row / bg.ny;
+    const uint32_t b = bx + bg.nx * row;
     const uint32_t x0 = bx * kTileX, x1 = min(x0 + kTileX, g.X) - 1;
     const uint32_t y0 = by * kTileY, y1 = min(y0 + kTileY, g.Y) - 1;
     const uint32_t z0 = g.z_store_begin + bz * kChunkZ, z1 = min(z0 + kChunkZ + (bz + 1 == bg.nz ? bg.z_extra : 0u), g.z_store_end) - 1;
 
-    bool all_pos = true, all_neg = true;
-    bool left = true, right = true, top = true, bottom = true;
-    float qx_lo = INFINITY, qx_hi = -INFINITY, qy_lo = INFINITY, qy_hi = -INFINITY;
-    float camz_lo = INFINITY, ecz_max = 0.0f;
-    for (int c = 0; c < 8; c++) {
-        const uint32_t vx = (c & 1) ? x1 : x0, vy = (c & 2) ? y1 : y0, vz = (c & 4) ? z1 : z0;
-        const float px = ((((int)vx + 0.5f) * g.vs.x) + g.offset_clear.x) + g.offset.x;
-        const float py = ((((int)vy + 0.5f) * g.vs.y) + g.offset_clear.y) + g.offset.y;
-        const float pz = ((((int)vz + 0.5f) * g.vs.z) + g.offset_clear.z) + g.offset.z;
-        // voxel centres inside the brick deviate from the exact lattice spanned by the corners by a few ulps of
-        // the coordinate; that is folded into the error bounds
-        const Projected p = project_with_bounds(px, py, pz, ip, k);
-        const float aiz = fabsf(p.iz);
-        const bool sign_ok = aiz > 8.0f * p.ez + 1.0e-3f;  // divisor reliably away from zero
-        all_pos = all_pos && sign_ok && p.iz > 0.0f;
-        all_neg = all_neg && sign_ok && p.iz < 0.0f;
-        // (bounds only: the hardware reciprocal instead of four IEEE divisions per corner; its error, a few 1e-7 relative,
-        // goes into the margins)
-        const float riz = __builtin_amdgcn_rcpf(p.iz), raiz = fabsf(riz);
-        const float qx = p.ix * riz, qy = p.iy * riz;
-        // error of the quotient (first order, doubled)
-        const float mqx = 2.0f * (p.ex + fabsf(qx) * p.ez) * raiz + 1.0e-3f + 1.0e-6f * fabsf(qx);
-        const float mqy = 2.0f * (p.ey + fabsf(qy) * p.ez) * raiz + 1.0e-3f + 1.0e-6f * fabsf(qy);
-        // a voxel passes the frustum test iff round(q) in [0, W-1]  <=>  q in [-0.5, W-0.5)
-        left = left && (qx + mqx < -1.0f);
-        right = right && (qx - mqx > (float)width);
-        top = top && (qy + mqy < -1.0f);
-        bottom = bottom && (qy - mqy > (float)height);
-        qx_lo = fminf(qx_lo, qx - mqx); qx_hi = fmaxf(qx_hi, qx + mqx);
-        qy_lo = fminf(qy_lo, qy - mqy); qy_hi = fmaxf(qy_hi, qy + mqy);
-        camz_lo = fminf(camz_lo, p.cam_z - p.ecz);
-        ecz_max = fmaxf(ecz_max, p.ecz);
+    const uint32_t vx = (c & 1) ? x1 : x0, vy = (c & 2) ? y1 : y0, vz = (c & 4) ? z1 : z0;
+    const float px = ((((int)vx + 0.5f) * g.vs.x) + g.offset_clear.x) + g.offset.x;
+    const float py = ((((int)vy + 0.5f) * g.vs.y) + g.offset_clear.y) + g.offset.y;
+    const float pz = ((((int)vz + 0.5f) * g.vs.z) + g.offset_clear.z) + g.offset.z;
+    // voxel centres inside the brick deviate from the exact lattice spanned by the corners by a few ulps of
+    // the coordinate; that is folded into the error bounds
+    const Projected p = project_with_bounds(px, py, pz, ip, k);
+    const float aiz = fabsf(p.iz);
+    const bool sign_ok = aiz > 8.0f * p.ez + 1.0e-3f;  // divisor reliably away from zero
+    // (bounds only: the hardware reciprocal instead of four IEEE divisions per corner; its error, a few 1e-7 relative,
+    // goes into the margins)
+    const float riz = __builtin_amdgcn_rcpf(p.iz), raiz = fabsf(riz);
+    const float qx = p.ix * riz, qy = p.iy * riz;
+    // error of the quotient (first order, doubled)
+    const float mqx = 2.0f * (p.ex + fabsf(qx) * p.ez) * raiz + 1.0e-3f + 1.0e-6f * fabsf(qx);
+    const float mqy = 2.0f * (p.ey + fabsf(qy) * p.ez) * raiz + 1.0e-3f + 1.0e-6f * fabsf(qy);
+    // a voxel passes the frustum test iff round(q) in [0, W-1]  <=>  q in [-0.5, W-0.5)
+    // bits that must hold for ALL corners: 0 divisor positive, 1 divisor negative, 2 left of the image, 3 right, 4 above, 5 below
+    uint32_t all = ((sign_ok && p.iz > 0.0f) ? 1u : 0u) | ((sign_ok && p.iz < 0.0f) ? 2u : 0u) | ((qx + mqx < -1.0f) ? 4u : 0u) |
+                   ((qx - mqx > (float)width) ? 8u : 0u) | ((qy + mqy < -1.0f) ? 16u : 0u) | ((qy - mqy > (float)height) ? 32u : 0u);
+    float qx_lo = qx - mqx, qx_hi = qx + mqx, qy_lo = qy - mqy, qy_hi = qy + mqy;
+    float camz_lo = p.cam_z - p.ecz, ecz_max = p.ecz;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {   // (fminf / fmaxf drop a NaN, as the serial loop's did)
+        all &= (uint32_t)__shfl_xor((int)all, o);
+        qx_lo = fminf(qx_lo, __shfl_xor(qx_lo, o)); qx_hi = fmaxf(qx_hi, __shfl_xor(qx_hi, o));
+        qy_lo = fminf(qy_lo, __shfl_xor(qy_lo, o)); qy_hi = fmaxf(qy_hi, __shfl_xor(qy_hi, o));
+        camz_lo = fminf(camz_lo, __shfl_xor(camz_lo, o));
+        ecz_max = fmaxf(ecz_max, __shfl_xor(ecz_max, o));
     }
     bool keep = true;
     // pixel box that contains the pixel of every voxel of the brick that passes the frustum test; 0 x 0 = unknown
     uint4 box = make_uint4(0, 0, 0, 0);  // x0, y0, width, height
-    if (all_pos || all_neg) {
-        if (left || right || top || bottom) keep = false;
+    if (all & 3u) {   // the divisor keeps one sign over the brick
+        if (all & 60u) keep = false;
         // pixels any voxel of the brick can round to: the hull's bounding box grown by 1 px
         const float fx0 = fmaxf(qx_lo - 1.0f, 0.0f), fx1 = fminf(qx_hi + 1.0f, (float)(width - 1));
         const float fy0 = fmaxf(qy_lo - 1.0f, 0.0f), fy1 = fminf(qy_hi + 1.0f, (float)(height - 1));
-        if (keep && fx0 <= fx1 && fy0 <= fy1) {  // (false for NaN: box stays unknown)
+        const bool boxed = keep && fx0 <= fx1 && fy0 <= fy1;  // (false for NaN: box stays unknown)
+        if (boxed) {
             box = make_uint4((uint32_t)fx0, (uint32_t)fy0, (uint32_t)fx1 - (uint32_t)fx0 + 1, (uint32_t)fy1 - (uint32_t)fy0 + 1);
             if (bg.pair_loads) {   // grown to even columns (any superset inside the image will do; the width is even)
                 const uint32_t xa = box.x & ~1u, xe = (box.x + box.z + 1u) & ~1u;
                 box.x = xa;
                 box.z = xe - xa;
             }
-            if (depth_test) {
-                const uint32_t tx0 = (uint32_t)fx0 / kDepthTile, tx1 = (uint32_t)fx1 / kDepthTile;
-                const uint32_t ty0 = (uint32_t)fy0 / kDepthTile, ty1 = (uint32_t)fy1 / kDepthTile;
-                if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) <= 256u) {
-                    uint32_t dmax = 0;
-                    for (uint32_t ty = ty0; ty <= ty1; ty++)
-                        for (uint32_t tx = tx0; tx <= tx1; tx++) dmax = max(dmax, (uint32_t)tile_max[ty * tiles_x + tx]);
-                    // (b) nothing but invalid depth in reach; (c) the whole brick lies more than trunc behind the
-                    // farthest surface in reach: sdf = depth - cam_z < -trunc for every voxel
-                    if (dmax == 0) keep = false;
-                    // (a voxel's own cam_z carries the same kind of rounding error as a corner's: 2 * ecz_max more)
-                    else if (camz_lo - (float)dmax > g.trunc * 1.0001f + 1.0e-3f + 1.0e-5f * fabsf(camz_lo) + 2.0f * ecz_max)
-                        keep = false;
-                }
+        }
+        // (every lane of the group holds the same box; the group's 8 lanes share the tiles)
+        const uint32_t tx0 = boxed ? (uint32_t)fx0 / kDepthTile : 0u, tx1 = boxed ? (uint32_t)fx1 / kDepthTile : 0u;
+        const uint32_t ty0 = boxed ? (uint32_t)fy0 / kDepthTile : 0u, ty1 = boxed ? (uint32_t)fy1 / kDepthTile : 0u;
+        const uint32_t tw = tx1 - tx0 + 1, n_box_tiles = tw * (ty1 - ty0 + 1);
+        const bool tested = boxed && depth_test && n_box_tiles <= 256u;
+        uint32_t dmax = 0;
+        if (tested)
+            for (uint32_t i = c; i < n_box_tiles; i += 8) {
+                const uint32_t ty = ty0 + i / tw, tx = tx0 + i % tw;
+                dmax = max(dmax, (uint32_t)(tiles_in_lds ? tmax_lds[ty * tiles_x + tx] : tile_max[ty * tiles_x + tx]));
             }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, o));
+        if (tested) {
+            // (b) nothing but invalid depth in reach; (c) the whole brick lies more than trunc behind the
+            // farthest surface in reach: sdf = depth - cam_z < -trunc for every voxel
+            if (dmax == 0) keep = false;
+            // (a voxel's own cam_z carries the same kind of rounding error as a corner's: 2 * ecz_max more)
+            else if (camz_lo - (float)dmax > g.trunc * 1.0001f + 1.0e-3f + 1.0e-5f * fabsf(camz_lo) + 2.0f * ecz_max)
+                keep = false;
         }
     }
-    if (keep) {
-        const uint32_t slot = atomicAdd(count, 1u);
+    // One atomic on the list's length per workgroup (a few thousand of them on one address, from 8 XCDs, were most of this
+    // kernel's time), the workgroup's survivors in brick order behind it: neighbouring bricks stay neighbours in the list, so
+    // that they are in flight together in integrate_kernel (rows of the volume they share stay open in memory).
+    const bool append = keep && live && c == 0;
+    const uint64_t mask = __ballot(append);
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    if (lane == 0) wave_count[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t n = wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+        wg_base = n ? atomicAdd(count, n) : 0u;
+    }
+    __syncthreads();
+    if (append) {
+        uint32_t slot = wg_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        for (uint32_t w = 0; w < wave; w++) slot += wave_count[w];
         list[slot] = b;
         boxes[slot] = box;
     }
@@ -578,8 +616,41 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
                                 mkinv.m31 == 0.0f && mkinv.m32 == 0.0f && mkinv.m33 == 1.0f) ? 1 : 0;
         hipLaunchKernelGGL(depth_tile_max_kernel, dim3(tiles_x, tiles_y), dim3(64), 0, v->stream, d_depth, width, height,
                            tiles_x, v->tile_max, count);
-        hipLaunchKernelGGL(brick_cull_kernel, dim3((unsigned)((n_bricks + 255) / 256)), dim3(256), 0, v->stream, g, bg, ip, mk,
+        hipLaunchKernelGGL(brick_cull_kernel, dim3((unsigned)((8 * n_bricks + 255) / 256)), dim3(256), 0, v->stream, g, bg, ip, mk,
                            width, height, v->tile_max, tiles_x, depth_test, v->brick_list, boxes, count, plane_const, n_plane_const);
+    }
+    if (!v->nodes) {   // diagnostics, TSDF_DEBUG_SORT = 1..8: the list reordered on the host (synchronises), to time integrate_kernel on other orders --
+                       // 1 index order, 2 scattered, 3 position in the layer then layer, 4 x / z / y (what the cull kernel produces), 5 x / y / z, 6 x then
+                       // scattered rows, 7 z / x / y, 8 even rows first
+        static const int sort_mode = [] { const char *e = getenv("TSDF_DEBUG_SORT"); return e ? atoi(e) : 0; }();
+        if (sort_mode) {
+            (void)hipStreamSynchronize(v->stream);
+            uint32_t n = 0;
+            (void)hipMemcpy(&n, count, sizeof(n), hipMemcpyDeviceToHost);
+            std::vector<uint32_t> l(n), idx(n);
+            std::vector<uint4> bx(n), bx2(n);
+            (void)hipMemcpy(l.data(), v->brick_list, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(bx.data(), boxes, n * sizeof(uint4), hipMemcpyDeviceToHost);
+            for (uint32_t i = 0; i < n; i++) idx[i] = i;
+            const uint32_t layer = bg.nx * bg.ny;
+            auto key = [&](uint32_t i) -> uint64_t {
+                const uint32_t b = l[i];
+                if (sort_mode == 1) return b;
+                if (sort_mode == 2) return ((uint64_t)b * 2654435761u) & 0xffffffffu;
+                if (sort_mode == 3) return ((uint64_t)(b % layer) << 8) | (b / layer);           // position in the layer, then the layer
+                if (sort_mode == 4) return ((uint64_t)(b % bg.nx) << 32) | (b / bg.nx);             // x, then the row
+                const uint32_t bxx = b % bg.nx, byy = (b / bg.nx) % bg.ny, bzz = b / layer;
+                if (sort_mode == 5) return ((uint64_t)bxx << 32) | ((uint64_t)byy << 16) | bzz;      // x, y, then the layer
+                if (sort_mode == 6) return ((uint64_t)bxx << 32) | (((uint64_t)(b / bg.nx) * 2654435761u) & 0xffffffffu);   // x, rows scattered
+                if (sort_mode == 7) return ((uint64_t)bzz << 32) | ((uint64_t)bxx << 16) | byy;      // layer, x, y
+                return ((uint64_t)(byy & 1u) << 48) | ((uint64_t)bxx << 32) | (b / bg.nx);          // even rows first, x, row
+            };
+            std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t c) { return key(a) < key(c); });
+            std::vector<uint32_t> l2(n);
+            for (uint32_t i = 0; i < n; i++) { l2[i] = l[idx[i]]; bx2[i] = bx[idx[i]]; }
+            (void)hipMemcpy(v->brick_list, l2.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice);
+            (void)hipMemcpy(boxes, bx2.data(), n * sizeof(uint4), hipMemcpyHostToDevice);
+        }
     }
     dim3 block(kTileX, kTileY, 1);
     // One workgroup per brick of the grid; those beyond the list's length leave at once.  The dispatcher hands the next brick to
@@ -612,6 +683,15 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
         uint32_t n_active = 0;
         (void)hipMemcpy(&n_active, count, sizeof(n_active), hipMemcpyDeviceToHost);
         fprintf(stderr, "tsdf: %u of %zu bricks active (%.1f M voxels processed)\n", n_active, n_bricks, n_active * 4096.0 / 1e6);
+        if (atoi(getenv("TSDF_DEBUG_BRICKS")) > 1) {   // the order of the list: its first entries, and how long its runs of consecutive bricks are
+            std::vector<uint32_t> l(n_active);
+            (void)hipMemcpy(l.data(), v->brick_list, n_active * sizeof(uint32_t), hipMemcpyDeviceToHost);
+            fprintf(stderr, "tsdf: list starts");
+            for (uint32_t i = 0; i < std::min(n_active, 40u); i++) fprintf(stderr, " %u", l[i]);
+            size_t runs = 1, same_row = 0;
+            for (uint32_t i = 1; i < n_active; i++) { runs += l[i] != l[i - 1] + 1; same_row += (l[i] / bg.nx == l[i - 1] / bg.nx); }
+            fprintf(stderr, "\ntsdf: %zu runs of consecutive bricks (mean length %.1f), %zu neighbours in the same row\n", runs, (double)n_active / runs, same_row);
+        }
     }
     v->reach_dirty = 1;  // bricks may have been flagged
     // The kernel only sets occupancy flags.  A voxel that was low when first seen (sensor dropouts smeared by the
