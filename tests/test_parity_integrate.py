@@ -237,3 +237,53 @@ def test_non_standard_intrinsics_and_projective_pose_take_the_general_path(oracl
     gv, ov, up = run_both(oracle, (64, 64, 64), (3000, 3000, 3000), [(d, proj)])
     check(gv, ov, up, "projective inverse pose")
     assert up[0][1] > 0
+
+
+def _cropped(depth, width, height, new_w, new_h):
+    """Top-left new_w x new_h window of a width x height depth image (same intrinsics: the principal point stays where it was)."""
+    return np.ascontiguousarray(depth.reshape(height, width)[:new_h, :new_w]).reshape(-1)
+
+
+@pytest.mark.parametrize("size", [(639, 480), (321, 241), (638, 479)])
+def test_odd_image_widths_take_the_single_pixel_staging(oracle, size):
+    """The brick's pixel box is staged two pixels per lane only for an even image width (integrate.hip: pair_loads); an odd
+    width, and an even one with odd boxes at the right edge, must give the same bits."""
+    w, h = size
+    frames = []
+    for i in (1, 4):
+        d, cam = synth.depth_frame(i, 8, seed=9)
+        frames.append((_cropped(d, W, H, w, h), cam))
+    gv, ov, up = run_both(oracle, (80, 72, 64), (3000, 2700, 2400), frames, width=w, height=h)
+    check(gv, ov, up, "%dx%d image" % (w, h))
+    assert up[0][1] > 0
+
+
+def test_depth_pointer_that_is_not_4_byte_aligned(oracle):
+    """integrate_device accepts any device pointer to uint16: one that sits 2 bytes into a buffer takes the single-pixel staging."""
+    import torch
+    d, cam = synth.depth_frame(3, 8, seed=11)
+    buf = torch.zeros(W * H + 1, dtype=torch.int16, device="cuda")
+    buf[1:] = torch.from_numpy(d.view(np.int16)).cuda()
+    assert (buf.data_ptr() + 2) % 4 == 2
+    gv = tsdf_amd.TSDFVolume((96, 96, 96), (3000.0,) * 3)
+    ov = oracle.Volume((96, 96, 96), (3000.0,) * 3)
+    gv.integrate_device(buf.data_ptr() + 2, W, H, cam)
+    torch.cuda.synchronize()
+    ov.integrate(d, W, H, cam.inverse_pose(), cam.k(), cam.kinv(), nthreads=oracle.max_threads())
+    assert_same_floats(gv.get_weight_data(), ov.weight, "misaligned depth weights")
+    assert_same_floats(gv.get_distance_data(), ov.dist, "misaligned depth distances")
+
+
+def test_image_with_more_tiles_than_the_cull_kernel_keeps_in_lds(oracle):
+    """1600 x 1200 pixels are 7 500 depth tiles; brick_cull_kernel stages at most 4 096 maxima in LDS and reads the rest from memory."""
+    w, h = 1600, 1200
+    cam = camera_at((1500, 1500, -800))
+    k = cam.k().copy(); k[0] *= 2.5; k[4] *= 2.5; k[6] = w / 2.0; k[7] = h / 2.0
+    from tests.helpers import Cam
+    big = Cam(cam.pose(), cam.inverse_pose(), k, oracle.mat3_inverse(k))
+    rng = np.random.default_rng(5)
+    depth = (2200 + 60 * np.sin(np.arange(w * h) * 1e-3) + rng.integers(-3, 4, size=w * h)).astype(np.uint16)
+    depth[rng.random(w * h) < 0.02] = 0
+    gv, ov, up = run_both(oracle, (64, 64, 64), (3000, 3000, 3000), [(depth, big)], width=w, height=h)
+    check(gv, ov, up, "1600x1200 image")
+    assert up[0][1] > 0
