@@ -50,3 +50,22 @@ def test_default_shaped_run_prints_the_contract_line():
 def test_few_steps_and_no_sampled_events_still_give_strict_json():
     d = run_bench("--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-parity", "--event-period", "0")
     assert d["steps"] == 3 and d["value"] > 0
+
+
+def test_two_ranks_on_one_gpu_walk_the_sharded_path_and_agree_with_one_volume():
+    """N > 1 cannot run over RCCL on a one-GPU box; TSDF_BENCH_SHARE_GPU=1 puts both ranks on device 0 and exchanges over gloo.
+    Everything else is the N = 2 path: measured slab plan, slab integrate + slab ray cast, all-gather of the hit records,
+    min-k merge, next frame's filter + integrate overlapped with the exchange, and rank 0's parity replay against ONE volume."""
+    env = dict(os.environ, TSDF_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29617", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--plan-rounds", "1"]
+    p = subprocess.run(cmd, cwd=ROOT, timeout=900, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly one JSON line, got %d" % len(lines)
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["parallelism"] == "zslab2"
+    assert d["parity"]["pass"] is True and d["parity"]["merged_picture_equals_single_volume_replay"] is True
+    assert len(d["slabs"]) == 2 and d["slabs"][0][0] == 0 and d["slabs"][0][1] == d["slabs"][1][0] and d["slabs"][1][1] == 512
+    for name in ("integrate", "raycast", "exchange", "integrate_kernel", "process_ray_kernel"):
+        assert len(d["per_rank_ms"][name]) == 2 and all(x > 0 for x in d["per_rank_ms"][name]), name
