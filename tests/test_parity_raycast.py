@@ -342,6 +342,10 @@ np.savez(sys.argv[1], V=V, N=N, D=gv.get_distance_data())
     {"TSDF_RAY_SEGMENTS": "3", "TSDF_RAY_TRIP_BUDGET": "2", "TSDF_RAY_TAIL_LANES": "4", "TSDF_RAY_TAIL_GRID": "7"},
     {"TSDF_RAY_SEGMENTS": "16", "TSDF_RAY_TRIP_BUDGET": "100000"},                             # nothing in the tail kernel
     {"TSDF_RAY_SEGMENTS": "64", "TSDF_RAY_TRIP_BUDGET": "5", "TSDF_RAY_TAIL_LANES": "8"},
+    {"TSDF_RAY_RANGE_ORDER": "0"},                                                             # sample ranges dispatched near to far (round 1)
+    {"TSDF_RAY_RANGE_ORDER": "2", "TSDF_RAY_SEGMENTS": "5"},                                   # ... last, first, then far to near
+    {"TSDF_DEBUG_SORT": "1"},                                                                  # integrate: brick list in index order
+    {"TSDF_DEBUG_SORT": "2"},                                                                  # ... scattered
     {"TSDF_INT_GRID_PER_CU": "3"},                                                             # integrate: resident grid walking the brick list
     {"TSDF_OCC_REBUILD_PERIOD": "0"},                                                          # sticky flags only
     {"TSDF_OCC_REBUILD_PERIOD": "1"},                                                          # flags rebuilt every frame
