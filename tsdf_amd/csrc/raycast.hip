@@ -249,12 +249,12 @@ constexpr int kDone = 0x7fffffff;
 // the APPROXIMATE location used at brick level.
 constexpr float kCellPositive = 1.0e-30f;
 constexpr int kTailLanesDefault = 4;        // lanes per queue entry in the tail kernel
-constexpr int kRaySegmentsDefault = 6;      // sample ranges a ray's march is split into
+constexpr int kRaySegmentsDefault = 5;   // sample ranges of a whole-volume march (round 2: 5 ranges / 24 passes, re-tuned with the ranges dispatched far to near; round 1: 6 / 18)
 constexpr int kTailGridDefault = 256 * 10;   // workgroups of the tail kernel (5 fit a CU at 86 VGPRs: two rounds)
 // What is left of a ray's range when the pass budget runs out is queued in up to kTailPieces pieces of at least
 // kTailPieceMin samples, so that a long stretch is marched by several groups of the tail kernel at once.
 constexpr int kTailPieces = 16, kTailPieceMin = 64;
-constexpr int kTripBudgetDefault = 18;      // passes of the first kernel's loop before unfinished rays go to the tail kernel
+constexpr int kTripBudgetDefault = 24;   // passes of the marching loop before a wave hands over to the tail kernel
 static int ray_segments() {
     static const int n = [] {
         const char *e = getenv("TSDF_RAY_SEGMENTS");  // tuning aid
@@ -735,6 +735,7 @@ struct TailQueue {
     uint32_t lanes;        // lanes per ray in the tail kernel (power of two, 4..64)
     uint32_t *best;        // per pixel: smallest sample index found <= 0 so far (kNoHit = none)
     int piece_min;         // shortest piece a handed-over stretch is cut into
+    unsigned long long *wave_log;   // diagnostics (TSDF_DEBUG_WAVES): per wave of the tail kernel {batches << 32 | rounds, start, end}
 };
 constexpr uint32_t kNoHit = 0xffffffffu;
 
@@ -970,7 +971,7 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
 // robin until none is left (persistent workgroups); every pass of the loop is uniform across the wave.
 //   LANES: lanes per queue entry fixed at compile time (the group reductions become DPP operations), 0 = tail.lanes.
 template <bool SLAB, bool FASTDIV, int LANES>
-__global__ __launch_bounds__(256) void process_ray_tail_kernel(const float *__restrict__ dist, const Geom g, const RayParams rp,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void process_ray_tail_kernel(const float *__restrict__ dist, const Geom g, const RayParams rp,
                                                                const OccGrid occ, const float *__restrict__ t_table,
                                                                const TailQueue tail) {
     __shared__ float T[kTableLen];
@@ -988,7 +989,10 @@ __global__ __launch_bounds__(256) void process_ray_tail_kernel(const float *__re
     // sample range: alike in length), works on them until all are finished, then takes the next batch: waves round robin.
     const uint32_t groups_per_wave = 64 / lanes_per_ray;
     const uint32_t n_waves = gridDim.x * 4, wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const unsigned long long dbg_t0 = tail.wave_log ? wall_clock64() : 0ull;
+    uint32_t dbg_batches = 0, dbg_rounds = 0;
     for (uint32_t batch = wave_id * groups_per_wave; batch < n_entries; batch += n_waves * groups_per_wave) {
+        dbg_batches++;
         RayState ray = {0, 0, 0, 0, 0, 0};
         int k = kDone, k_end = 0;   // the group's stretch (all its lanes hold the same values); kDone: none
         uint32_t *best = tail.best;
@@ -1004,6 +1008,7 @@ __global__ __launch_bounds__(256) void process_ray_tail_kernel(const float *__re
         }
         while (true) {
             if (__ballot(k != kDone) == 0ull) break;
+            dbg_rounds++;
             const int kk = k + j;
             int adv = 0;
             bool hit = false;
@@ -1039,6 +1044,11 @@ __global__ __launch_bounds__(256) void process_ray_tail_kernel(const float *__re
                 }
             }
         }
+    }
+    if (tail.wave_log && lane == 0) {
+        tail.wave_log[3 * wave_id + 0] = ((unsigned long long)dbg_batches << 32) | dbg_rounds;
+        tail.wave_log[3 * wave_id + 1] = dbg_t0;
+        tail.wave_log[3 * wave_id + 2] = wall_clock64();
     }
 }
 
@@ -1347,7 +1357,7 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
         TSDF_HIP(hipMemsetAsync(v->tail_count, 0, 2 * sizeof(uint32_t), v->stream), "ray tail counter reset");
     }
     v->ray_best_dirty = 1;
-    TailQueue tail = {reinterpret_cast<uint2 *>(v->tail_entries), v->tail_count, (uint32_t)trip_budget(), (uint32_t)tail_lanes(), v->ray_best + (size_t)v->ray_best_side * v->ray_best_cap, tail_piece_min()};
+    TailQueue tail = {reinterpret_cast<uint2 *>(v->tail_entries), v->tail_count, (uint32_t)trip_budget(), (uint32_t)tail_lanes(), v->ray_best + (size_t)v->ray_best_side * v->ray_best_cap, tail_piece_min(), nullptr};
     uint32_t *best_next = v->ray_best + (size_t)(1 - v->ray_best_side) * v->ray_best_cap;
     rp.seg_len = (kMaxSamples + n_segments - 1) / n_segments;
     rp.slab_ranges = SLAB ? (uint32_t)n_segments : 0u;
@@ -1390,6 +1400,13 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
             fprintf(stderr, "tsdf:   range %u: %zu waves, %.1f passes, %zu full, %.1f / %.1f us, last end %.1f\n", r, n, n ? passes / n : 0.0, full, n ? dur / n : 0.0, dmax, last);
         }
     }
+    unsigned long long *tail_log = nullptr;
+    const size_t n_tail_waves = (size_t)tail_grid() * 4;
+    if (debug_waves) {
+        (void)hipMalloc((void **)&tail_log, 3 * n_tail_waves * sizeof(unsigned long long));
+        (void)hipMemset(tail_log, 0, 3 * n_tail_waves * sizeof(unsigned long long));
+        tail.wave_log = tail_log;
+    }
     // persistent workgroups: groups of 16 lanes, fetching queue entries until none is left
     timing_begin(v, 2);
     // (the default group width is compiled in; another one, a tuning aid, takes the variant that reads it at run time)
@@ -1405,6 +1422,27 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
         hipLaunchKernelGGL((process_ray_tail_kernel<SLAB, false, 0>), tgrid_, dim3(256), 0, v->stream, v->dist, v->g, rp, v->occ, v->t_table, tail);
     timing_end(v, 2);
     TSDF_HIP(hipGetLastError(), "process_ray (tail) failed");
+    if (debug_waves) {   // diagnostics (synchronises): the tail kernel's waves
+        (void)hipStreamSynchronize(v->stream);
+        std::vector<unsigned long long> log(3 * n_tail_waves);
+        (void)hipMemcpy(log.data(), tail_log, log.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        (void)hipFree(tail_log);
+        unsigned long long t0 = ~0ull, t1 = 0;
+        size_t n = 0, alive[16] = {};
+        double rounds = 0, rmax = 0, batches = 0, dur = 0, dmax = 0, dmin = 1e18;
+        for (size_t w = 0; w < n_tail_waves; w++) if (log[3 * w + 1]) { t0 = std::min(t0, log[3 * w + 1]); t1 = std::max(t1, log[3 * w + 2]); }
+        for (size_t w = 0; w < n_tail_waves; w++) {
+            if (!log[3 * w + 1]) continue;
+            const double b0 = (double)(log[3 * w + 1] - t0) / 100.0, e0 = (double)(log[3 * w + 2] - t0) / 100.0;
+            n++; rounds += (uint32_t)log[3 * w]; rmax = std::max(rmax, (double)(uint32_t)log[3 * w]); batches += (double)(log[3 * w] >> 32);
+            dur += e0 - b0; dmax = std::max(dmax, e0 - b0); dmin = std::min(dmin, e0 - b0);
+            for (int q = 0; q < 16; q++) { const double tq = (q + 0.5) / 16.0 * (double)(t1 - t0) / 100.0; if (b0 <= tq && tq < e0) alive[q]++; }
+        }
+        fprintf(stderr, "tsdf: tail ray kernel %.1f us after the table: %zu waves with work, %.1f batches and %.0f rounds a wave (most %.0f), wave time mean %.1f, %.1f .. %.1f us; alive per sixteenth:",
+                (t1 - t0) / 100.0, n, n ? batches / n : 0.0, n ? rounds / n : 0.0, rmax, n ? dur / n : 0.0, dmin, dmax);
+        for (int q = 0; q < 16; q++) fprintf(stderr, " %zu", alive[q]);
+        fprintf(stderr, "\n");
+    }
     if (getenv("TSDF_DEBUG_RAYS")) {   // diagnostics: how much went through the tail queue (synchronises)
         uint32_t n_tail = 0;
         (void)hipMemcpy(&n_tail, v->tail_count, sizeof(n_tail), hipMemcpyDeviceToHost);
