@@ -95,6 +95,55 @@ __device__ inline void mark_occupied(const OccGrid &occ, uint32_t vx, uint32_t v
             for (uint32_t bx = cx0; bx <= cx1; bx++) occ.cell[((size_t)bz * occ.nby + by) * occ.nbx + bx] = 1;
 }
 
+// Occupancy marks of integrate_kernel.  Each lane keeps one bit per plane of its brick ("my voxel of that plane got a new
+// distance that is not safely positive"); when the brick is done, mark_low_voxels() turns the bits of a wave row (64 voxels along x
+// from voxel 4 * bx0, at vy, planes z0 .. z0 + 63 at most) into exactly the bricks mark_occupied() flags voxel by voxel: per layer
+// of bricks along z, the ballot of the lanes with a bit among the planes that reach the layer, grown along x with scalar mask
+// arithmetic, written by at most 18 lanes.  Called by the whole wave.
+__device__ inline uint64_t plane_range_mask(int lo, int hi) {   // bits lo .. hi (any ints) of a 64-bit mask
+    lo = max(lo, 0);
+    hi = min(hi, 63);
+    return hi < lo ? 0ull : ((~0ull >> (63 - hi)) & (~0ull << lo));
+}
+__device__ inline void mark_low_voxels(const OccGrid &occ, const uint32_t bits_lo, const uint32_t bits_hi, const uint32_t bx0,
+                                       const uint32_t vy, const uint32_t z0, const uint32_t z_first, const uint32_t z_last, const uint32_t lane) {
+    const int bxl = (int)bx0 - 1 + (int)lane;   // lane l looks after brick bx0 - 1 + l
+    const bool in_grid = bxl >= 0 && bxl < (int)occ.nbx && lane < 18u;
+    const uint32_t sh = 4u * ((lane - 1u) & 15u);
+    // y: the row's voxels reach the bricks holding vy-2 .. vy+2 (fine) and vy / 4, plus the one before when vy is a multiple of 4 (cell)
+    const uint32_t by0 = (max(vy, (uint32_t)kBrickGrow) - kBrickGrow) >> kBrickShift, by1 = min((vy + kBrickGrow) >> kBrickShift, occ.nby - 1);
+    const uint32_t cy1 = vy >> kBrickShift, cy0 = ((vy & (kBrick - 1)) == 0 && cy1 > 0) ? cy1 - 1 : cy1;
+    const uint32_t zb_first = (max(z_first, (uint32_t)kBrickGrow) - kBrickGrow) >> kBrickShift, zb_last = min((z_last + kBrickGrow) >> kBrickShift, occ.nbz - 1);
+#pragma unroll 1
+    for (uint32_t zb = zb_first; zb <= zb_last; zb++) {
+        // fine[zb] takes voxels with (z-2)/4 <= zb <= (z+2)/4, i.e. z in [4 zb - 2, 4 zb + 5]; cell[zb] those with z / 4 == zb or
+        // z == 4 (zb + 1), i.e. z in [4 zb, 4 zb + 4]  (mark_occupied's ranges, solved for the brick)
+        const int rel = (int)(zb << kBrickShift) - (int)z0;
+        const uint64_t zf = plane_range_mask(rel - 2, rel + 5), zc = plane_range_mask(rel, rel + 4);
+        const uint64_t low = __ballot(((bits_lo & (uint32_t)zf) | (bits_hi & (uint32_t)(zf >> 32))) != 0u);
+        if (low) {
+            // x, fine: the bricks holding v-2 .. v+2.  Inside the row that is the mask grown by two lanes either way, nibble by
+            // nibble; lanes 0, 1 also reach the brick before the row, lanes 62, 63 the one after it
+            const uint64_t grown = low | (low << 1) | (low << 2) | (low >> 1) | (low >> 2);
+            const bool f_fine = in_grid && (lane == 0u ? (low & 3ull) != 0 : lane == 17u ? (low >> 62) != 0 : ((grown >> sh) & 15ull) != 0);
+            if (f_fine) {   // (by1 - by0 is 0 or 1: two stores, possibly to the same byte)
+                occ.fine[((size_t)zb * occ.nby + by0) * occ.nbx + bxl] = 1;
+                occ.fine[((size_t)zb * occ.nby + by1) * occ.nbx + bxl] = 1;
+            }
+        }
+        const uint64_t lowc = __ballot(((bits_lo & (uint32_t)zc) | (bits_hi & (uint32_t)(zc >> 32))) != 0u);
+        if (lowc) {
+            // x, cell: brick v / 4, and the one before it when v is a multiple of 4
+            const uint64_t with_prev = lowc | ((lowc & 0x1111111111111111ull) >> 1);
+            const bool f_cell = in_grid && lane < 17u && (lane == 0u ? (lowc & 1ull) != 0 : ((with_prev >> sh) & 15ull) != 0);
+            if (f_cell) {
+                occ.cell[((size_t)zb * occ.nby + cy0) * occ.nbx + bxl] = 1;
+                occ.cell[((size_t)zb * occ.nby + cy1) * occ.nbx + bxl] = 1;
+            }
+        }
+    }
+}
+
 constexpr int kDepthTile = 16;  // pixels per side of a depth tile
 constexpr int kCullTilesLds = 4096;  // tile maxima brick_cull_kernel keeps in LDS (1200 at 640x480)
 
@@ -329,6 +378,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     uint32_t updated = 0;
 
     for (uint32_t i = blockIdx.x; i < n_active; i += gridDim.x) {
+        const unsigned long long dbg_t0 = (!COUNT && counter) ? wall_clock64() : 0ull;   // (diagnostics, TSDF_DEBUG_BRICKS=3: per-brick clocks)
         const uint32_t b = DEFORM ? i : list[i];
         const uint32_t bx = b % bg.nx, by = (b / bg.nx) % bg.ny, bz = b / (bg.nx * bg.ny);
         const uint32_t vx = bx * kTileX + threadIdx.x;
@@ -390,7 +440,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             }
         }
         __syncthreads();
-        if (vx >= g.X || vy >= g.Y) continue;
+        if (vy >= g.Y) continue;   // (a whole wave)
+        const bool lane_ok = vx < g.X;   // lanes past the grid's x edge stay in (the marks at the end of the brick are made by the wave's first lanes): they update nothing
 
         size_t idx = plane * (z0 - g.z_store_begin) + (size_t)g.X * vy + vx;  // (custom nodes only)
         // distance / weight addressing: a wave-uniform base per plane (scalar registers) + one 32-bit lane offset that
@@ -404,6 +455,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         // partial row sums of inv_pose * (c,1): the reference evaluates ((m_i1*x + m_i2*y) + m_i3*z) + m_i4
         float r1 = 0.f, r2 = 0.f, r3 = 0.f, r4 = 0.f;
         float r4_[kBatchZ] = {};
+        uint32_t low_lo = 0, low_hi = 0;   // bit o: my voxel of plane z0 + o got a distance that is not safely positive
         if (!DEFORM) {
             cx = ((((int)vx + 0.5f) * g.vs.x) + g.offset_clear.x) + g.offset.x;
             cy = ((((int)vy + 0.5f) * g.vs.y) + g.offset_clear.y) + g.offset.y;
@@ -427,7 +479,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 #pragma unroll
             for (int j = 0; j < kBatchZ; j++) {
                 const uint32_t vz = zb + j;
-                act[j] = vz < z1;
+                act[j] = vz < z1 && lane_ok;
                 float cz = 0.f;
                 if (DEFORM) {
                     // (custom nodes: x/y parts differ per voxel)
@@ -531,7 +583,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 #else
                     if (new_weight == -123.0f && new_distance == 77.0f) (dist + pb)[lane_off] = new_distance;   // (keeps the arithmetic alive)
 #endif
-                    if (!(new_distance > occ.tau)) mark_occupied(occ, vx, vy, zb + j);
+                    if (!(new_distance > occ.tau)) {   // not safely positive: remember the plane, the bricks are marked when this one is done
+                        const uint32_t o_ = zb + j - z0;
+                        if (o_ < 32u) low_lo |= 1u << o_; else low_hi |= 1u << (o_ - 32u);
+                    }
                     if (COUNT) updated++;
                 }
             }
@@ -551,6 +606,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             project_and_load(z0 + kChunkZ, tsdf_a, pw_a, pd_a);
             blend_and_store(z0 + kChunkZ, tsdf_a, pw_a, pd_a);
         }
+        if (__any((low_lo | low_hi) != 0u))
+            mark_low_voxels(occ, low_lo, low_hi, (bx * kTileX) >> kBrickShift, __builtin_amdgcn_readfirstlane(vy), z0, z0, z1 - 1u, threadIdx.x);
+        if (!COUNT && counter && tid == 0) { counter[2 * i] = dbg_t0; counter[2 * i + 1] = wall_clock64(); }
     }
     if (COUNT) {
         // wave reduction then one atomic per wave
@@ -665,9 +723,16 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
     const bool std_camera = finite && ip.m41 == 0.0f && ip.m42 == 0.0f && ip.m43 == 0.0f && ip.m44 == 1.0f &&
                             mk.m21 == 0.0f && mk.m31 == 0.0f && mk.m12 == 0.0f && mk.m32 == 0.0f && mk.m33 == 1.0f &&
                             mkinv.m31 == 0.0f && mkinv.m32 == 0.0f && mkinv.m33 == 1.0f;
+    static const int debug_clocks = [] { const char *e = getenv("TSDF_DEBUG_BRICKS"); return e && atoi(e) >= 3; }();
+    unsigned long long *brick_log = nullptr;
+    if (debug_clocks && !v->counting && !v->nodes) {
+        (void)hipMalloc((void **)&brick_log, 2 * n_bricks * sizeof(unsigned long long));
+        (void)hipMemset(brick_log, 0, 2 * n_bricks * sizeof(unsigned long long));
+    }
+    unsigned long long *counter_arg = brick_log ? brick_log : (v->counting ? v->counter_dev : nullptr);
 #define LAUNCH(DEF, CNT, STDC)                                                                                       \
     hipLaunchKernelGGL((integrate_kernel<DEF, CNT, STDC>), grid, block, 0, v->stream, v->dist, v->weight, v->nodes, \
-                       g, bg, ip, mk, mkinv, width, height, d_depth, v->counter_dev, v->occ, v->brick_list, boxes, count, plane_const)
+                       g, bg, ip, mk, mkinv, width, height, d_depth, counter_arg, v->occ, v->brick_list, boxes, count, plane_const)
     timing_begin(v, 0);
     if (v->nodes) {
         if (v->counting) LAUNCH(true, true, false); else LAUNCH(true, false, false);
@@ -679,6 +744,42 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
 #undef LAUNCH
     timing_end(v, 0);
     TSDF_HIP(hipGetLastError(), "Integrate kernel failed");
+    if (brick_log) {   // diagnostics (synchronises): the launch's bricks over time
+        (void)hipStreamSynchronize(v->stream);
+        uint32_t n = 0;
+        (void)hipMemcpy(&n, count, sizeof(n), hipMemcpyDeviceToHost);
+        std::vector<unsigned long long> log(2 * (size_t)n);
+        (void)hipMemcpy(log.data(), brick_log, log.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        (void)hipFree(brick_log);
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (uint32_t e = 0; e < n; e++) if (log[2 * e]) { t0 = std::min(t0, log[2 * e]); t1 = std::max(t1, log[2 * e + 1]); }
+        size_t alive[16] = {};
+        double dur = 0, dmax = 0, dmin = 1e18, last_start = 0;
+        for (uint32_t e = 0; e < n; e++) {
+            const double b0 = (double)(log[2 * e] - t0) / 100.0, e0 = (double)(log[2 * e + 1] - t0) / 100.0;
+            dur += e0 - b0; dmax = std::max(dmax, e0 - b0); dmin = std::min(dmin, e0 - b0); last_start = std::max(last_start, b0);
+            for (int q = 0; q < 16; q++) { const double tq = (q + 0.5) / 16.0 * (double)(t1 - t0) / 100.0; if (b0 <= tq && tq < e0) alive[q]++; }
+        }
+        fprintf(stderr, "tsdf: integrate_kernel %.1f us (100 MHz clock): %u bricks, %.1f us each (%.1f .. %.1f), last start %.1f; alive per sixteenth:", (t1 - t0) / 100.0, n,
+                n ? dur / n : 0.0, dmin, dmax, last_start);
+        for (int q = 0; q < 16; q++) fprintf(stderr, " %zu", alive[q]);
+        fprintf(stderr, "\n");
+        {   // the bricks that end last, and the longest ones: start, duration, pixel box
+            std::vector<uint4> bx(n);
+            (void)hipMemcpy(bx.data(), boxes, n * sizeof(uint4), hipMemcpyDeviceToHost);
+            std::vector<uint32_t> idx(n);
+            for (uint32_t e = 0; e < n; e++) idx[e] = e;
+            std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t c) { return log[2 * a + 1] > log[2 * c + 1]; });
+            fprintf(stderr, "tsdf:   last to end (entry: start + duration us, box):");
+            for (uint32_t r = 0; r < std::min(n, 6u); r++) { const uint32_t e = idx[r]; fprintf(stderr, " %u: %.0f + %.0f, %ux%u;", e, (log[2 * e] - t0) / 100.0, (log[2 * e + 1] - log[2 * e]) / 100.0, bx[e].z, bx[e].w); }
+            std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t c) { return log[2 * a + 1] - log[2 * a] > log[2 * c + 1] - log[2 * c]; });
+            fprintf(stderr, "\ntsdf:   longest:");
+            for (uint32_t r = 0; r < std::min(n, 6u); r++) { const uint32_t e = idx[r]; fprintf(stderr, " %u: %.0f + %.0f, %ux%u;", e, (log[2 * e] - t0) / 100.0, (log[2 * e + 1] - log[2 * e]) / 100.0, bx[e].z, bx[e].w); }
+            size_t n_unstaged = 0; double d_unstaged = 0, d_staged = 0;
+            for (uint32_t e = 0; e < n; e++) { const bool st = bx[e].z != 0 && ((bx[e].z + 1u) & ~1u) * bx[e].w <= (uint32_t)kTilePixels; const double d = (log[2 * e + 1] - log[2 * e]) / 100.0; if (st) d_staged += d; else { d_unstaged += d; n_unstaged++; } }
+            fprintf(stderr, "\ntsdf:   %zu bricks without a tile: %.1f us each; the others %.1f us\n", n_unstaged, n_unstaged ? d_unstaged / n_unstaged : 0.0, n > n_unstaged ? d_staged / (n - n_unstaged) : 0.0);
+        }
+    }
     if (getenv("TSDF_DEBUG_BRICKS") && !v->nodes) {   // diagnostics: how many bricks survived the cull
         uint32_t n_active = 0;
         (void)hipMemcpy(&n_active, count, sizeof(n_active), hipMemcpyDeviceToHost);
