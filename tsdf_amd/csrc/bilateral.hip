@@ -123,11 +123,15 @@ __global__ __launch_bounds__(256) void bilateral_kernel(const PIX *__restrict__ 
         // the 4 800 waves of a 640 x 480 frame need to be resident together.
         constexpr int NA = (N + 1) / 2, NB = N - NA;
         float w_a[NA], w_b[NB > 0 ? NB : 1];
-        auto fetch = [&](const int i, auto first_row, auto count, float *w, const auto rim) {
+        unsigned v_a[NA], v_b[NB > 0 ? NB : 1];   // 4 * intensity of the taps (the chain widens it itself: one LDS read per pixel and tap less)
+        auto fetch = [&](const int i, auto first_row, auto count, float *w, unsigned *v4, const auto rim) {
             constexpr int J0 = decltype(first_row)::value, CNT = decltype(count)::value;
             unsigned delta4[CNT];
 #pragma unroll
-            for (int j = 0; j < CNT; j++) delta4[j] = sad_u32(t0[(J0 + j) * SPAN + i], current4);     // 4 * |conv - current|
+            for (int j = 0; j < CNT; j++) {
+                v4[j] = t0[(J0 + j) * SPAN + i];
+                delta4[j] = sad_u32(v4[j], current4);     // 4 * |conv - current|
+            }
 #pragma unroll
             for (int j = 0; j < CNT; j++)
                 w[j] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(sim_lds) + (delta4[j] & (kStagedBytes - 1u)));
@@ -147,8 +151,9 @@ __global__ __launch_bounds__(256) void bilateral_kernel(const PIX *__restrict__ 
                 }
             }
             if (!decltype(rim)::value) {
+                // (the tap's spatial weight is the same for every lane: a scalar load from the table in memory, not an LDS read)
 #pragma unroll
-                for (int j = 0; j < CNT; j++) w[j] = kern_lds[i * N + J0 + j] * w[j];     // the float product the reference widens (:99)
+                for (int j = 0; j < CNT; j++) w[j] = kernel[i * N + J0 + j] * w[j];     // the float product the reference widens (:99)
             } else {
                 const bool col_ok = i >= i0 && i <= i1;
                 const int base = (i - i0) * nyv - j0;
@@ -161,27 +166,28 @@ __global__ __launch_bounds__(256) void bilateral_kernel(const PIX *__restrict__ 
                 }
             }
         };
-        auto chain = [&](const int i, auto first_row, auto count, const float *w) {
-            constexpr int J0 = decltype(first_row)::value, CNT = decltype(count)::value;
+        auto chain = [&](const int i, auto first_row, auto count, const float *w, const unsigned *v4) {
+            constexpr int CNT = decltype(count)::value;
+            (void)i;
 #pragma unroll
-            for (int j = 0; j < CNT; j++) bilateral_tap(w[j], d0[(J0 + j) * SPAN + i], sum, total_weight);
+            for (int j = 0; j < CNT; j++) bilateral_tap(w[j], (double)(v4[j] >> 2), sum, total_weight);
         };
         using Lo = std::integral_constant<int, 0>;
         using Hi = std::integral_constant<int, NA>;
         using CntA = std::integral_constant<int, NA>;
         using CntB = std::integral_constant<int, NB>;
         auto run = [&](const auto rim) {
-            fetch(0, Lo{}, CntA{}, w_a, rim);
+            fetch(0, Lo{}, CntA{}, w_a, v_a, rim);
 #pragma unroll 1
             for (int i = 0; i + 1 < N; i++) {              // conv_x: outer loop of the reference
-                fetch(i, Hi{}, CntB{}, w_b, rim);
-                chain(i, Lo{}, CntA{}, w_a);
-                fetch(i + 1, Lo{}, CntA{}, w_a, rim);
-                chain(i, Hi{}, CntB{}, w_b);
+                fetch(i, Hi{}, CntB{}, w_b, v_b, rim);
+                chain(i, Lo{}, CntA{}, w_a, v_a);
+                fetch(i + 1, Lo{}, CntA{}, w_a, v_a, rim);
+                chain(i, Hi{}, CntB{}, w_b, v_b);
             }
-            fetch(N - 1, Hi{}, CntB{}, w_b, rim);          // the last column, nothing left to prefetch
-            chain(N - 1, Lo{}, CntA{}, w_a);
-            chain(N - 1, Hi{}, CntB{}, w_b);
+            fetch(N - 1, Hi{}, CntB{}, w_b, v_b, rim);     // the last column, nothing left to prefetch
+            chain(N - 1, Lo{}, CntA{}, w_a, v_a);
+            chain(N - 1, Hi{}, CntB{}, w_b, v_b);
         };
         if (interior) {
             run(std::false_type{});
