@@ -75,6 +75,8 @@ __device__ inline Projected project_with_bounds(float px, float py, float pz, co
 
 // A voxel whose new distance is not safely positive flags every brick whose grown region
 // (brick +- kBrickGrow voxels) contains it: the bricks holding voxel v-2 .. v+2 on each axis.
+// (The definition, voxel by voxel: what integrate_kernel did up to round 2.  It now makes the same marks once per brick,
+// mark_low_voxels below; this function is kept as the statement of which bricks a low voxel marks.)
 __device__ inline void mark_occupied(const OccGrid &occ, uint32_t vx, uint32_t vy, uint32_t vz) {
     const uint32_t bx0 = (max(vx, (uint32_t)kBrickGrow) - kBrickGrow) >> kBrickShift;
     const uint32_t by0 = (max(vy, (uint32_t)kBrickGrow) - kBrickGrow) >> kBrickShift;
