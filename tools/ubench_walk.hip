@@ -57,6 +57,24 @@ static void run_cm(void *a, void *b, const char *what) {
     printf("%-58s %7.1f GB/s\n", what, best);
 }
 
+// two x-adjacent 64-wide bricks per workgroup of 8 waves (4 B per lane): waves 0-3 the left brick's rows, 4-7 the right one's
+__global__ __launch_bounds__(512) void walk_pair(float *__restrict__ d, float *__restrict__ w) {
+    const unsigned b = blockIdx.x;                      // 4 x-pairs, 128 rows, 16 layers; column by column
+    const unsigned ROWS = 128 * 16;
+    const unsigned bxp = b / ROWS, r = b % ROWS, by = r % 128, bz = r / 128;
+    const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t plane = 512 * 512;
+    size_t idx = (size_t)(bz * 32) * plane + (size_t)(by * 4 + (wave & 3)) * 512 + (bxp * 2 + (wave >> 2)) * 64 + lane;
+#pragma unroll 1
+    for (unsigned z = 0; z < 32; z += 4) {
+        float pd[4], pw[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { pd[j] = d[idx + (z + j) * plane]; pw[j] = w[idx + (z + j) * plane]; }
+#pragma unroll
+        for (int j = 0; j < 4; j++) { d[idx + (z + j) * plane] = pd[j] + 1.0f; w[idx + (z + j) * plane] = pw[j] + 1.0f; }
+    }
+}
+
 template <int LF, bool REMAP, bool NT, int YROWS, int ZPLANES>
 __global__ __launch_bounds__(256) void walk(typename V<LF>::T *__restrict__ d, typename V<LF>::T *__restrict__ w) {
     typedef typename V<LF>::T T;
@@ -176,6 +194,7 @@ int main() {
     printf("%-58s %7.1f GB/s\n", "update_walk_kernel of the product (64 x 4 block)", timed([&] { hipLaunchKernelGGL(update_walk_ref, dim3(16384), dim3(64, 4), 0, 0, (float *)a, (float *)b); }, bb));
     run<1, false, false, 4, 32>(a, b, "4 B/lane, 4 rows x 32 planes (integrate's walk)");
     printf("%-58s %7.1f GB/s\n", "update_walk_kernel of the product (64 x 4 block)", timed([&] { hipLaunchKernelGGL(update_walk_ref, dim3(16384), dim3(64, 4), 0, 0, (float *)a, (float *)b); }, bb));
+    printf("%-58s %7.1f GB/s\n", "two x-adjacent bricks per workgroup of 8 waves", timed([&] { hipLaunchKernelGGL(walk_pair, dim3(4 * 128 * 16), dim3(512), 0, 0, (float *)a, (float *)b); }, bb));
     run_cm<1, 4, 32, 0>(a, b, "4 B/lane, 4 rows x 32 planes, column by column");
     run_cm<1, 4, 32, 1>(a, b, "4 B/lane, 4 rows x 32 planes, 8 rows then next column");
     run_cm<2, 4, 32, 0>(a, b, "8 B/lane, 4 rows x 32 planes, column by column");
