@@ -451,8 +451,9 @@ class Camera:
         return Camera(591.1, 590.1, 331.0, 234.6)   # Camera.hpp:41-44
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            _capi.host.tsdf_camera_destroy(self._h)
+        host = getattr(_capi, "host", None) if _capi is not None else None   # (None during interpreter shutdown)
+        if getattr(self, "_h", None) and host is not None:
+            host.tsdf_camera_destroy(self._h)
             self._h = None
 
     def _refresh(self):

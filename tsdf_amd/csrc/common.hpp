@@ -5,6 +5,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstdint>
@@ -24,9 +25,24 @@ int hip_fail(hipError_t e, const char *what);
 int occupancy_rebuild(struct ::tsdf_volume *v);  // volume.hip
 int occupancy_refresh(struct ::tsdf_volume *v);  // volume.hip: bring fine + reach up to date
 int build_t_table(struct ::tsdf_volume *v);      // volume.hip
-// timing helpers (volume.hip): bracket one launch of kernel `which` with events when timing is on
+// timing helpers (volume.hip).  When timing is on, a launch of kernel `which` carries a start and a stop event that take the
+// dispatch's own begin / end timestamps (hipExtLaunchKernel: what rocprofv3's kernel trace reads), TSDF_LAUNCH_TIMED below.
+// (Up to round 2h the launch was bracketed with two hipEventRecord calls: that interval also holds the two barrier packets and
+// the dispatch latency, 8-10 us more than the kernel at 0.11 ms.  TSDF_TIMING_BRACKET=1 brings the brackets back.)
+bool timing_pair(struct ::tsdf_volume *v, int which, hipEvent_t *start, hipEvent_t *stop);
 void timing_begin(struct ::tsdf_volume *v, int which);
 void timing_end(struct ::tsdf_volume *v, int which);
+#define TSDF_LAUNCH_TIMED(v, which, kernel, grid, block, ...)                                              \
+    do {                                                                                                   \
+        hipEvent_t ts0__ = nullptr, ts1__ = nullptr;                                                       \
+        if (tsdf::timing_pair(v, which, &ts0__, &ts1__))                                                   \
+            hipExtLaunchKernelGGL(kernel, grid, block, 0, (v)->stream, ts0__, ts1__, 0, __VA_ARGS__);      \
+        else {                                                                                             \
+            tsdf::timing_begin(v, which);                                                                  \
+            hipLaunchKernelGGL(kernel, grid, block, 0, (v)->stream, __VA_ARGS__);                          \
+            tsdf::timing_end(v, which);                                                                    \
+        }                                                                                                  \
+    } while (0)
 int verify_fast_division(struct ::tsdf_volume *v);  // volume.hip
 
 #define TSDF_HIP(call, what)                                  \

@@ -28,6 +28,7 @@
 #include <cmath>
 
 #include <cstdlib>
+#include <unordered_map>
 
 #include "common.hpp"
 
@@ -148,6 +149,8 @@ __device__ inline void mark_low_voxels(const OccGrid &occ, const uint32_t bits_l
 
 constexpr int kDepthTile = 16;  // pixels per side of a depth tile
 constexpr int kCullTilesLds = 4096;  // tile maxima brick_cull_kernel keeps in LDS (1200 at 640x480)
+
+static std::unordered_map<uint32_t, float> g_prev_brick_us;   // diagnostics (TSDF_DEBUG_SORT=9/10): brick -> microseconds in the previous launch
 
 static uint32_t occupancy_rebuild_period() {
     static const uint32_t n = [] {
@@ -683,7 +686,32 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
                        // 1 index order, 2 scattered, 3 position in the layer then layer, 4 x / z / y (what the cull kernel produces), 5 x / y / z, 6 x then
                        // scattered rows, 7 z / x / y, 8 even rows first
         static const int sort_mode = [] { const char *e = getenv("TSDF_DEBUG_SORT"); return e ? atoi(e) : 0; }();
-        if (sort_mode) {
+        // 9 / 10 (with TSDF_DEBUG_BRICKS=3): bricks that took long in the previous launch first, in 2 / 3 classes, each class column by column
+        if (sort_mode >= 9 && !g_prev_brick_us.empty()) {
+            (void)hipStreamSynchronize(v->stream);
+            uint32_t n = 0;
+            (void)hipMemcpy(&n, count, sizeof(n), hipMemcpyDeviceToHost);
+            std::vector<uint32_t> l(n), idx(n), l2(n);
+            std::vector<uint4> bx(n), bx2(n);
+            (void)hipMemcpy(l.data(), v->brick_list, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(bx.data(), boxes, n * sizeof(uint4), hipMemcpyDeviceToHost);
+            std::vector<float> known;
+            for (uint32_t i = 0; i < n; i++) { idx[i] = i; auto it = g_prev_brick_us.find(l[i]); if (it != g_prev_brick_us.end()) known.push_back(it->second); }
+            std::sort(known.begin(), known.end());
+            const int classes = sort_mode == 9 ? 2 : 3;
+            auto cls = [&](uint32_t i) -> uint64_t {
+                auto it = g_prev_brick_us.find(l[i]);
+                if (it == g_prev_brick_us.end() || known.empty()) return 0;   // unknown: with the expensive ones
+                const size_t rank = std::lower_bound(known.begin(), known.end(), it->second) - known.begin();
+                return (uint64_t)(classes - 1 - std::min<size_t>(classes - 1, rank * classes / known.size()));
+            };
+            std::vector<uint64_t> key(n);
+            for (uint32_t i = 0; i < n; i++) key[i] = (cls(i) << 56) | ((uint64_t)(l[i] % bg.nx) << 32) | (l[i] / bg.nx);
+            std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t c) { return key[a] < key[c]; });
+            for (uint32_t i = 0; i < n; i++) { l2[i] = l[idx[i]]; bx2[i] = bx[idx[i]]; }
+            (void)hipMemcpy(v->brick_list, l2.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice);
+            (void)hipMemcpy(boxes, bx2.data(), n * sizeof(uint4), hipMemcpyHostToDevice);
+        } else if (sort_mode && sort_mode < 9) {
             (void)hipStreamSynchronize(v->stream);
             uint32_t n = 0;
             (void)hipMemcpy(&n, count, sizeof(n), hipMemcpyDeviceToHost);
@@ -733,9 +761,8 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
     }
     unsigned long long *counter_arg = brick_log ? brick_log : (v->counting ? v->counter_dev : nullptr);
 #define LAUNCH(DEF, CNT, STDC)                                                                                       \
-    hipLaunchKernelGGL((integrate_kernel<DEF, CNT, STDC>), grid, block, 0, v->stream, v->dist, v->weight, v->nodes, \
-                       g, bg, ip, mk, mkinv, width, height, d_depth, counter_arg, v->occ, v->brick_list, boxes, count, plane_const)
-    timing_begin(v, 0);
+    TSDF_LAUNCH_TIMED(v, 0, (integrate_kernel<DEF, CNT, STDC>), grid, block, v->dist, v->weight, v->nodes,          \
+                      g, bg, ip, mk, mkinv, width, height, d_depth, counter_arg, v->occ, v->brick_list, boxes, count, plane_const)
     if (v->nodes) {
         if (v->counting) LAUNCH(true, true, false); else LAUNCH(true, false, false);
     } else if (std_camera) {
@@ -744,7 +771,6 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
         if (v->counting) LAUNCH(false, true, false); else LAUNCH(false, false, false);
     }
 #undef LAUNCH
-    timing_end(v, 0);
     TSDF_HIP(hipGetLastError(), "Integrate kernel failed");
     if (brick_log) {   // diagnostics (synchronises): the launch's bricks over time
         (void)hipStreamSynchronize(v->stream);
@@ -755,6 +781,12 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
         (void)hipFree(brick_log);
         unsigned long long t0 = ~0ull, t1 = 0;
         for (uint32_t e = 0; e < n; e++) if (log[2 * e]) { t0 = std::min(t0, log[2 * e]); t1 = std::max(t1, log[2 * e + 1]); }
+        {
+            std::vector<uint32_t> lst(n);
+            (void)hipMemcpy(lst.data(), v->brick_list, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+            g_prev_brick_us.clear();
+            for (uint32_t e = 0; e < n; e++) g_prev_brick_us[lst[e]] = (float)((double)(log[2 * e + 1] - log[2 * e]) / 100.0);
+        }
         size_t alive[16] = {};
         double dur = 0, dmax = 0, dmin = 1e18, last_start = 0;
         for (uint32_t e = 0; e < n; e++) {

@@ -1370,14 +1370,12 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
         (void)hipMalloc((void **)&wave_log, 3 * n_waves_log * sizeof(unsigned long long));
         (void)hipMemset(wave_log, 0, 3 * n_waves_log * sizeof(unsigned long long));
     }
-    timing_begin(v, 1);
     if (v->fast_div)
-        hipLaunchKernelGGL((process_ray_kernel<SLAB, false, true, true, true, true>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp,
-                           (float *)nullptr, wave_log, (unsigned int *)nullptr, v->occ, v->t_table, tail);
+        TSDF_LAUNCH_TIMED(v, 1, (process_ray_kernel<SLAB, false, true, true, true, true>), grid, dim3(256), v->dist, v->g, rp,
+                          (float *)nullptr, wave_log, (unsigned int *)nullptr, v->occ, v->t_table, tail);
     else
-        hipLaunchKernelGGL((process_ray_kernel<SLAB, false, true, false, true, true>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp,
-                           (float *)nullptr, (unsigned long long *)nullptr, (unsigned int *)nullptr, v->occ, v->t_table, tail);
-    timing_end(v, 1);
+        TSDF_LAUNCH_TIMED(v, 1, (process_ray_kernel<SLAB, false, true, false, true, true>), grid, dim3(256), v->dist, v->g, rp,
+                          (float *)nullptr, (unsigned long long *)nullptr, (unsigned int *)nullptr, v->occ, v->t_table, tail);
     TSDF_HIP(hipGetLastError(), "process_ray failed");
     if (debug_waves) {   // diagnostics (synchronises): the bulk kernel's waves by sample range
         (void)hipStreamSynchronize(v->stream);
@@ -1408,19 +1406,17 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
         tail.wave_log = tail_log;
     }
     // persistent workgroups: groups of 16 lanes, fetching queue entries until none is left
-    timing_begin(v, 2);
     // (the default group width is compiled in; another one, a tuning aid, takes the variant that reads it at run time)
     const bool fixed_lanes = tail_lanes() == kTailLanesDefault;
     const dim3 tgrid_(tail_grid());
     if (v->fast_div && fixed_lanes)
-        hipLaunchKernelGGL((process_ray_tail_kernel<SLAB, true, kTailLanesDefault>), tgrid_, dim3(256), 0, v->stream, v->dist, v->g, rp, v->occ, v->t_table, tail);
+        TSDF_LAUNCH_TIMED(v, 2, (process_ray_tail_kernel<SLAB, true, kTailLanesDefault>), tgrid_, dim3(256), v->dist, v->g, rp, v->occ, v->t_table, tail);
     else if (v->fast_div)
-        hipLaunchKernelGGL((process_ray_tail_kernel<SLAB, true, 0>), tgrid_, dim3(256), 0, v->stream, v->dist, v->g, rp, v->occ, v->t_table, tail);
+        TSDF_LAUNCH_TIMED(v, 2, (process_ray_tail_kernel<SLAB, true, 0>), tgrid_, dim3(256), v->dist, v->g, rp, v->occ, v->t_table, tail);
     else if (fixed_lanes)
-        hipLaunchKernelGGL((process_ray_tail_kernel<SLAB, false, kTailLanesDefault>), tgrid_, dim3(256), 0, v->stream, v->dist, v->g, rp, v->occ, v->t_table, tail);
+        TSDF_LAUNCH_TIMED(v, 2, (process_ray_tail_kernel<SLAB, false, kTailLanesDefault>), tgrid_, dim3(256), v->dist, v->g, rp, v->occ, v->t_table, tail);
     else
-        hipLaunchKernelGGL((process_ray_tail_kernel<SLAB, false, 0>), tgrid_, dim3(256), 0, v->stream, v->dist, v->g, rp, v->occ, v->t_table, tail);
-    timing_end(v, 2);
+        TSDF_LAUNCH_TIMED(v, 2, (process_ray_tail_kernel<SLAB, false, 0>), tgrid_, dim3(256), v->dist, v->g, rp, v->occ, v->t_table, tail);
     TSDF_HIP(hipGetLastError(), "process_ray (tail) failed");
     if (debug_waves) {   // diagnostics (synchronises): the tail kernel's waves
         (void)hipStreamSynchronize(v->stream);

@@ -376,8 +376,29 @@ int verify_fast_division(tsdf_volume *v) {
     return TSDF_OK;
 }
 
+static bool timing_brackets() {
+    static const bool b = [] { const char *e = getenv("TSDF_TIMING_BRACKET"); return e && atoi(e) != 0; }();
+    return b;
+}
+
+// Start / stop events for the next launch of kernel `which` (filled by hipExtLaunchKernel with the dispatch's timestamps);
+// false when this launch is not to be timed, or when the brackets are asked for.
+bool timing_pair(tsdf_volume *v, int which, hipEvent_t *start, hipEvent_t *stop) {
+    if (!v->timing || timing_brackets()) return false;
+    if (v->timing_launches[which]++ % (uint32_t)v->timing != 0) return false;
+    if (!v->tev[which]) v->tev[which] = new std::vector<hipEvent_t>();
+    if (hipEventCreate(start) != hipSuccess) return false;
+    if (hipEventCreate(stop) != hipSuccess) {
+        (void)hipEventDestroy(*start);
+        return false;
+    }
+    v->tev[which]->push_back(*start);
+    v->tev[which]->push_back(*stop);
+    return true;
+}
+
 void timing_begin(tsdf_volume *v, int which) {
-    if (!v->timing) return;
+    if (!v->timing || !timing_brackets()) return;
     if (v->timing_launches[which]++ % (uint32_t)v->timing != 0) return;   // every timing-th launch is bracketed
     if (!v->tev[which]) v->tev[which] = new std::vector<hipEvent_t>();
     hipEvent_t e;
@@ -387,7 +408,7 @@ void timing_begin(tsdf_volume *v, int which) {
 }
 
 void timing_end(tsdf_volume *v, int which) {
-    if (!v->timing || !v->tev[which] || (v->tev[which]->size() & 1) == 0) return;
+    if (!v->timing || !timing_brackets() || !v->tev[which] || (v->tev[which]->size() & 1) == 0) return;
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) {
         (void)hipEventDestroy(v->tev[which]->back());
