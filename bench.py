@@ -53,6 +53,9 @@ def parse():
                     help="N > 1: Z-slab boundaries re-cut from the ranks' measured times on the first frames (default), from a "
                          "work estimate of a small planner volume, or equal plane counts")
     ap.add_argument("--plan-rounds", type=int, default=3, help="--slab-plan measured: rebalancing rounds (each costs a few frames)")
+    ap.add_argument("--separate-tile-max", action="store_true",
+                    help="integrate computes the depth tile maxima in a launch of its own (tsdf_integrate_device) instead of taking "
+                         "them from the bilateral filter's launch (tsdf_bilateral_filter_u16_device_tiles + tsdf_integrate_device_tiles)")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--path-only", action="store_true",
                     help="only the timed hot path and its roofline (no ICP / tracking / host-buffer legs): what the profiling passes run")
@@ -110,6 +113,11 @@ def main():
         cams.append(cam)
     depth_dev = torch.from_numpy(np.stack(frames).view(np.int16)).cuda()           # (F, H*W) uint16 bits
     filt_dev = torch.empty((H * W,), dtype=torch.int16, device="cuda")
+    # the bilateral filter leaves the 16 x 16 tile maxima of its output for integrate's brick culling (one launch fewer per frame;
+    # --separate-tile-max: integrate computes them itself from the filtered image, as tsdf_integrate_device does)
+    n_tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    tmax_dev = [torch.empty((n_tiles,), dtype=torch.int16, device="cuda") for _ in range(2)]
+    tiles_of = (lambda j: None) if args.separate_tile_max else (lambda j: tmax_dev[j % 2].data_ptr())
     vert_dev = torch.empty((H * W, 3), dtype=torch.float32, device="cuda")
     norm_dev = torch.empty((H * W, 3), dtype=torch.float32, device="cuda")
 
@@ -136,8 +144,8 @@ def main():
                     torch.cuda.synchronize()
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(s0)
-                bil0.filter_device(depth_dev[i].data_ptr(), filt_dev.data_ptr(), W, H, bits=16, stream=s0.cuda_stream)
-                v.integrate_device(filt_dev.data_ptr(), W, H, cams[i])
+                bil0.filter_device(depth_dev[i].data_ptr(), filt_dev.data_ptr(), W, H, bits=16, stream=s0.cuda_stream, tile_max_ptr=tiles_of(0))
+                v.integrate_device(filt_dev.data_ptr(), W, H, cams[i], tile_max_ptr=tiles_of(0))
                 rc0.raycast_slab_device(v, cams[i], hits_probe.data_ptr())
             e1.record(s0)
             torch.cuda.synchronize()
@@ -209,10 +217,10 @@ def main():
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if timed else None
         fbuf = filt2[i % 2]
         if timed: e[0].record(on)
-        bil.filter_device(depth_dev[i].data_ptr(), fbuf.data_ptr(), W, H, bits=16, stream=on.cuda_stream)
+        bil.filter_device(depth_dev[i].data_ptr(), fbuf.data_ptr(), W, H, bits=16, stream=on.cuda_stream, tile_max_ptr=tiles_of(i))
         if timed: e[1].record(on)
         vol.set_stream(on.cuda_stream)
-        vol.integrate_device(fbuf.data_ptr(), W, H, cams[i])
+        vol.integrate_device(fbuf.data_ptr(), W, H, cams[i], tile_max_ptr=tiles_of(i))
         vol.set_stream(stream.cuda_stream)
         if timed: e[2].record(on)
         return ((e[0], e[1]), (e[1], e[2])) if timed else None
@@ -263,6 +271,15 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # The replays below record ~13 events per step; the HIP runtime grows its pool of signals in steps of a few hundred events, and
+    # the step that triggers a growth waits ~25 ms for it (seen as one 24.8 ms ray cast among 0.19 ms ones at --steps 40).  Grow it
+    # now, outside every measured interval.
+    pool = [torch.cuda.Event(enable_timing=True) for _ in range(max(1024, 20 * (K + Wu)))]
+    for e_ in pool:
+        e_.record(stream)
+    torch.cuda.synchronize()
+    del pool
+
     # ---- warmup, then the timed region -------------------------------------------------------------
     for i in range(Wu):
         step(i, False)
@@ -296,14 +313,16 @@ def main():
         step(i, True, True)
     torch.cuda.synchronize()
     stage_ms = {s_: (float(np.mean([a.elapsed_time(b) for a, b in ev[s_]])) if ev[s_] else None) for s_ in stage_names}
+    if os.environ.get("BENCH_DEBUG_STAGES"):
+        print("raycast stage per step:", [round(a.elapsed_time(b), 3) for a, b in ev["raycast"]], file=sys.stderr)
     kern = {w: vol.kernel_time(w) for w in ("integrate", "raycast", "raycast_tail")}     # (launches, avg ms), kernel only
     vol.set_timing(False)
     prefiltered.clear()
     vol.set_counting(True)
     U_frames = []
     for i in range(Wu, Wu + K):
-        bil.filter_device(depth_dev[i].data_ptr(), filt_dev.data_ptr(), W, H, bits=16, stream=stream.cuda_stream)
-        vol.integrate_device(filt_dev.data_ptr(), W, H, cams[i])
+        bil.filter_device(depth_dev[i].data_ptr(), filt_dev.data_ptr(), W, H, bits=16, stream=stream.cuda_stream, tile_max_ptr=tiles_of(0))
+        vol.integrate_device(filt_dev.data_ptr(), W, H, cams[i], tile_max_ptr=tiles_of(0))
         torch.cuda.synchronize()
         U_frames.append(vol.last_updated_voxels())
     vol.set_counting(False)
@@ -331,7 +350,8 @@ def main():
                                "raycast + normals per frame" % (3 if inside else 2, n, args.physical, args.stream_frames,
                                                                 " inside the volume" if inside else "", seed),
                    "grid": [n, n, n], "image": [W, H], "parallelism": "zslab%d" % world,
-                   "overlap": "bilateral + integrate of frame i+1 on a second stream during the exchange of frame i" if overlap else "none"},
+                   "overlap": "bilateral + integrate of frame i+1 on a second stream during the exchange of frame i" if overlap else "none",
+                   "depth_tile_maxima": "integrate's own launch" if args.separate_tile_max else "left by the bilateral filter's launch"},
         "integrate_mvoxels_per_s": round(N_vox / (stage_ms["integrate"] * 1e-3) / 1e6, 1),
         "raycast_mrays_per_s": round(W * H / ((stage_ms["raycast"] + stage_ms["exchange"] + stage_ms["normals"]) * 1e-3) / 1e6, 2),
         "stage_ms": {s: (round(v, 4) if v is not None else None) for s, v in stage_ms.items()},

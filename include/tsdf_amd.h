@@ -152,6 +152,13 @@ int tsdf_integrate(tsdf_volume *volume, const uint16_t *host_depth, uint32_t wid
 int tsdf_integrate_device(tsdf_volume *volume, const uint16_t *device_depth, uint32_t width,
                           uint32_t height, const float pose[16], const float inv_pose[16],
                           const float k[9], const float kinv[9]);
+/* tsdf_integrate_device for a depth image whose tile maxima the caller already holds in HBM (written by
+ * tsdf_bilateral_filter_u16_device_tiles for this very image, earlier on the same stream): same result, one launch fewer.
+ * device_tile_max[ty * ceil(width / TSDF_DEPTH_TILE) + tx] must be >= every pixel of tile (tx, ty) and 0 only if all of
+ * them are 0; a wrong array makes the culling drop bricks the frame updates. */
+int tsdf_integrate_device_tiles(tsdf_volume *volume, const uint16_t *device_depth, uint32_t width,
+                                uint32_t height, const float pose[16], const float inv_pose[16],
+                                const float k[9], const float kinv[9], const uint16_t *device_tile_max);
 /* Optional kernel timing for roofline reports: when enabled, every launch of integrate_kernel (which = 0) and of
  * process_ray_kernel (which = 1) and process_ray_tail_kernel (which = 2) is bracketed by HIP events on the volume's stream; tsdf_volume_kernel_time
  * synchronises the stream and returns the number of bracketed launches and their average duration since timing was
@@ -264,6 +271,14 @@ int tsdf_bilateral_filter_u8_device(const tsdf_bilateral *filter, const uint8_t 
                                     uint8_t *device_out, int width, int height, void *hip_stream);
 int tsdf_bilateral_filter_u16_device(const tsdf_bilateral *filter, const uint16_t *device_in,
                                      uint16_t *device_out, int width, int height, void *hip_stream);
+/* The same filter; each workgroup also leaves the largest filtered value of its TSDF_DEPTH_TILE x TSDF_DEPTH_TILE pixel
+ * tile in device_tile_max[tile_y * ceil(width / TSDF_DEPTH_TILE) + tile_x] (0 = the tile holds no valid depth).  Hand the
+ * array to tsdf_integrate_device_tiles with the filtered image: integrate's culling then skips its own pass over the image.
+ * (No reference counterpart: the reference filters on the host and integrates every voxel.) */
+#define TSDF_DEPTH_TILE 16
+int tsdf_bilateral_filter_u16_device_tiles(const tsdf_bilateral *filter, const uint16_t *device_in,
+                                           uint16_t *device_out, int width, int height,
+                                           uint16_t *device_tile_max, void *hip_stream);
 
 /* ---- measurement aid (no reference counterpart) ------------------------------------------ */
 /* Device-to-device copy of `bytes` (a multiple of 16; two internal buffers) with a float4 copy kernel, `reps` times on

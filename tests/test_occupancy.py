@@ -52,7 +52,8 @@ def _expected_reach(fine):
     return reach
 
 
-@pytest.mark.parametrize("dims", [(48, 40, 44), (37, 30, 41), (72, 72, 72)])
+# (brick counts that are multiples of 16 on every axis take reach_mip_wave_kernel, the others reach_mip_kernel)
+@pytest.mark.parametrize("dims", [(48, 40, 44), (37, 30, 41), (72, 72, 72), (128, 64, 64), (64, 128, 192)])
 def test_rebuilt_flags_equal_their_definition(dims):
     X, Y, Z = dims
     rng = np.random.default_rng(X * 1000 + Y)

@@ -66,3 +66,31 @@ def test_device_variant_matches_host_variant():
                     stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert np.array_equal(dst.cpu().numpy().view(np.uint16), host)
+
+
+@pytest.mark.parametrize("shape", [(640, 480), (53, 37), (16, 16), (641, 479)])
+def test_tile_maxima_of_the_filtered_image(shape):
+    """tsdf_bilateral_filter_u16_device_tiles: the same filtered image, plus the largest filtered value of every 16 x 16 tile
+    (what integrate's depth_tile_max_kernel computes from it)."""
+    import torch
+    w, h = shape
+    d, _ = synth.depth_frame(2, 10, seed=7)
+    img = np.ascontiguousarray(d.reshape(480, 640)[:h, :w]) if (w <= 640 and h <= 480) else None
+    if img is None:
+        img = np.random.RandomState(3).randint(0, 4000, (h, w)).astype(np.uint16)
+    f = tsdf_amd.BilateralFilter(30.0, 4.5)
+    src = torch.from_numpy(img.view(np.int16).copy()).cuda()
+    plain, tiled = torch.empty_like(src), torch.empty_like(src)
+    tx, ty = (w + 15) // 16, (h + 15) // 16
+    tmax = torch.full((ty * tx,), -1, dtype=torch.int16, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    f.filter_device(src.data_ptr(), plain.data_ptr(), w, h, bits=16, stream=s)
+    f.filter_device(src.data_ptr(), tiled.data_ptr(), w, h, bits=16, stream=s, tile_max_ptr=tmax.data_ptr())
+    torch.cuda.synchronize()
+    out = plain.cpu().numpy().view(np.uint16).reshape(h, w)
+    assert np.array_equal(tiled.cpu().numpy().view(np.uint16).reshape(h, w), out)
+    exp = np.zeros((ty, tx), np.uint16)
+    for j in range(ty):
+        for i in range(tx):
+            exp[j, i] = out[j * 16:(j + 1) * 16, i * 16:(i + 1) * 16].max()
+    assert np.array_equal(tmax.cpu().numpy().view(np.uint16).reshape(ty, tx), exp)

@@ -287,3 +287,46 @@ def test_image_with_more_tiles_than_the_cull_kernel_keeps_in_lds(oracle):
     gv, ov, up = run_both(oracle, (64, 64, 64), (3000, 3000, 3000), [(depth, big)], width=w, height=h)
     check(gv, ov, up, "1600x1200 image")
     assert up[0][1] > 0
+
+
+def test_tile_maxima_brought_by_the_caller_give_the_same_volume(oracle):
+    """tsdf_integrate_device_tiles skips depth_tile_max_kernel and culls on the maxima the bilateral filter left; calls with and
+    without them alternate on one volume (the brick list's two length words change sides every integration)."""
+    import torch
+    s = torch.cuda.current_stream().cuda_stream
+    bil = tsdf_amd.BilateralFilter(30.0, 4.5)
+    gv = tsdf_amd.TSDFVolume((96, 96, 96), (3000.0,) * 3)
+    gv.set_stream(s)
+    ov = oracle.Volume((96, 96, 96), (3000.0,) * 3)
+    tmax = torch.empty((30 * 40,), dtype=torch.int16, device="cuda")
+    for n, with_tiles in enumerate((True, True, False, True, False, False, True)):
+        d, cam = synth.depth_frame(n, 12, seed=21)
+        src = torch.from_numpy(d.view(np.int16).copy()).cuda()
+        dst = torch.empty_like(src)
+        bil.filter_device(src.data_ptr(), dst.data_ptr(), W, H, bits=16, stream=s, tile_max_ptr=tmax.data_ptr() if with_tiles else None)
+        gv.integrate_device(dst.data_ptr(), W, H, cam, tile_max_ptr=tmax.data_ptr() if with_tiles else None)
+        torch.cuda.synchronize()
+        filt = dst.cpu().numpy().view(np.uint16)
+        ov.integrate(filt, W, H, cam.inverse_pose(), cam.k(), cam.kinv(), nthreads=oracle.max_threads())
+        assert_same_floats(gv.get_weight_data(), ov.weight, "frame %d weights" % n)
+        assert_same_floats(gv.get_distance_data(), ov.dist, "frame %d distances" % n)
+
+
+def test_slab_with_caller_tile_maxima(oracle):
+    import torch
+    s = torch.cuda.current_stream().cuda_stream
+    bil = tsdf_amd.BilateralFilter(30.0, 4.5)
+    whole = tsdf_amd.TSDFVolume((64, 64, 96), (2000.0, 2000.0, 3000.0))
+    slab = tsdf_amd.TSDFVolume((64, 64, 96), (2000.0, 2000.0, 3000.0), slab=(30, 71))
+    tmax = torch.empty((30 * 40,), dtype=torch.int16, device="cuda")
+    for n in range(3):
+        d, cam = synth.depth_frame(n, 12, seed=22)
+        src = torch.from_numpy(d.view(np.int16).copy()).cuda()
+        dst = torch.empty_like(src)
+        bil.filter_device(src.data_ptr(), dst.data_ptr(), W, H, bits=16, stream=s, tile_max_ptr=tmax.data_ptr())
+        whole.integrate_device(dst.data_ptr(), W, H, cam)
+        slab.integrate_device(dst.data_ptr(), W, H, cam, tile_max_ptr=tmax.data_ptr())
+        torch.cuda.synchronize()
+    a, b = whole.get_distance_data().reshape(96, 64, 64), slab.get_distance_data().reshape(-1, 64, 64)
+    z0 = 30
+    assert_same_floats(a[z0:z0 + b.shape[0]].reshape(-1), b.reshape(-1), "slab distances")

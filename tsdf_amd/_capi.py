@@ -73,6 +73,7 @@ _SIGS = {
     "tsdf_volume_set_offset_at_clear": (_i, [_vp, _vp]),
     "tsdf_integrate": (_i, [_vp, _vp, _u32, _u32, _fp, _fp, _fp, _fp]),
     "tsdf_integrate_device": (_i, [_vp, _vp, _u32, _u32, _fp, _fp, _fp, _fp]),
+    "tsdf_integrate_device_tiles": (_i, [_vp, _vp, _u32, _u32, _fp, _fp, _fp, _fp, _vp]),
     "tsdf_volume_set_timing": (_i, [_vp, _i]),
     "tsdf_volume_kernel_time": (_i, [_vp, _i, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]),
     "tsdf_volume_set_counting": (_i, [_vp, _i]),
@@ -107,6 +108,7 @@ _SIGS = {
     "tsdf_bilateral_filter_u16": (_i, [_vp, _vp, _i, _i]),
     "tsdf_bilateral_filter_u8_device": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "tsdf_bilateral_filter_u16_device": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "tsdf_bilateral_filter_u16_device_tiles": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
 }
 #: every symbol include/tsdf_amd.h declares
 EXPORTS = tuple(_SIGS)

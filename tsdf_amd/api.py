@@ -183,11 +183,16 @@ class TSDFVolume:
         pose, ipose, k, kinv = _camera_matrices(camera)
         check(lib.tsdf_integrate(self._h, d.ctypes.data, width, height, _fp(pose), _fp(ipose), _fp(k), _fp(kinv)))
 
-    def integrate_device(self, depth_ptr, width, height, camera):
-        """Asynchronous on the volume's stream; depth_ptr is a device pointer to width*height uint16."""
+    def integrate_device(self, depth_ptr, width, height, camera, tile_max_ptr=None):
+        """Asynchronous on the volume's stream; depth_ptr is a device pointer to width*height uint16.  tile_max_ptr: the
+        16 x 16 pixel tile maxima of that image when the caller holds them (BilateralFilter.filter_device(tile_max_ptr=...))."""
         pose, ipose, k, kinv = _camera_matrices(camera)
-        check(lib.tsdf_integrate_device(self._h, C.c_void_p(int(depth_ptr)), width, height, _fp(pose), _fp(ipose),
-                                        _fp(k), _fp(kinv)))
+        if tile_max_ptr:
+            check(lib.tsdf_integrate_device_tiles(self._h, C.c_void_p(int(depth_ptr)), width, height, _fp(pose), _fp(ipose),
+                                                  _fp(k), _fp(kinv), C.c_void_p(int(tile_max_ptr))))
+        else:
+            check(lib.tsdf_integrate_device(self._h, C.c_void_p(int(depth_ptr)), width, height, _fp(pose), _fp(ipose),
+                                            _fp(k), _fp(kinv)))
 
     def occupancy(self):
         """(occupied, total) bricks of the ray caster's empty-space summary."""
@@ -324,7 +329,15 @@ class BilateralFilter:
         fn = lib.tsdf_bilateral_filter_u8 if image.dtype == np.uint8 else lib.tsdf_bilateral_filter_u16
         check(fn(self._h, image.ctypes.data, width, height))
 
-    def filter_device(self, in_ptr, out_ptr, width, height, bits=16, stream=0):
+    def filter_device(self, in_ptr, out_ptr, width, height, bits=16, stream=0, tile_max_ptr=None):
+        """tile_max_ptr (16 bit only): device array of ceil(width / 16) * ceil(height / 16) uint16 that receives the largest
+        filtered value of every 16 x 16 pixel tile, for TSDFVolume.integrate_device(tile_max_ptr=...)."""
+        if tile_max_ptr:
+            if bits != 16:
+                raise ValueError("tile maxima are produced by the 16-bit filter only")
+            check(lib.tsdf_bilateral_filter_u16_device_tiles(self._h, C.c_void_p(int(in_ptr)), C.c_void_p(int(out_ptr)), width, height,
+                                                             C.c_void_p(int(tile_max_ptr)), C.c_void_p(int(stream) if stream else 0)))
+            return
         fn = lib.tsdf_bilateral_filter_u8_device if bits == 8 else lib.tsdf_bilateral_filter_u16_device
         check(fn(self._h, C.c_void_p(int(in_ptr)), C.c_void_p(int(out_ptr)), width, height,
                  C.c_void_p(int(stream) if stream else 0)))

@@ -65,8 +65,13 @@ template <typename PIX, int R>
 __global__ __launch_bounds__(256) void bilateral_kernel(const PIX *__restrict__ in, PIX *__restrict__ out,
                                                         int width, int height, int radius_arg,
                                                         const float *__restrict__ kernel,
-                                                        const float *__restrict__ similarity, const int debug_skip) {
+                                                        const float *__restrict__ similarity, const int debug_skip,
+                                                        uint16_t *__restrict__ tile_max) {
     constexpr bool STAGED = R > 0;
+    // tile_max != nullptr: the workgroup also leaves the largest value of its 16 x 16 output tile in tile_max[tile] -- what
+    // integrate's depth_tile_max_kernel would compute from the filtered image in a launch of its own (tsdf_integrate_device_tiles)
+    __shared__ unsigned wg_max;
+    if (threadIdx.x == 0) wg_max = 0u;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int radius = R > 0 ? R : radius_arg;
     const int n = 2 * radius + 1;
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(256) void bilateral_kernel(const PIX *__restrict__ 
     // accumulators exactly as they are (sum + 0 * 0 and total + 0 are exact).
     const int wy0 = (blockIdx.y * kBTile + (ly & ~3)) - radius;      // first tap row of the wave's first pixel row
     const bool interior = tx0 >= 0 && tx0 + span <= width && wy0 >= 0 && wy0 + 4 + 2 * radius <= height;
-    if (debug_skip && (debug_skip == 1) == !interior) return;   // (timing experiments only: 1 = rim waves leave, 2 = interior waves leave)
+    if (debug_skip && !tile_max && (debug_skip == 1) == !interior) return;   // (timing experiments only: 1 = rim waves leave, 2 = interior waves leave)
     const bool inside = x < width && y < height;
     const int i0 = max(0, radius - x), i1 = inside ? min(n - 1, width - 1 - x + radius) : -1;
     const int j0 = max(0, radius - y), j1 = inside ? min(n - 1, height - 1 - y + radius) : -1;
@@ -211,11 +216,20 @@ __global__ __launch_bounds__(256) void bilateral_kernel(const PIX *__restrict__ 
             }
         }
     }
-    if (inside) out[(size_t)y * width + x] = (PIX)(int)floorf(sum / total_weight);
+    const PIX filtered = inside ? (PIX)(int)floorf(sum / total_weight) : (PIX)0;
+    if (inside) out[(size_t)y * width + x] = filtered;
+    if (tile_max) {   // (uniform)
+        unsigned m = (unsigned)filtered;
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_down((int)m, o));
+        if ((threadIdx.x & 63) == 0 && m) atomicMax(&wg_max, m);
+        __syncthreads();
+        if (threadIdx.x == 0) tile_max[blockIdx.y * gridDim.x + blockIdx.x] = (uint16_t)wg_max;
+    }
 }
 
 template <typename PIX>
-static int launch_bilateral(const tsdf_bilateral *f, const PIX *in, PIX *out, int width, int height, hipStream_t s) {
+static int launch_bilateral(const tsdf_bilateral *f, const PIX *in, PIX *out, int width, int height, hipStream_t s,
+                            uint16_t *tile_max = nullptr) {
     dim3 grid((width + kBTile - 1) / kBTile, (height + kBTile - 1) / kBTile);
     const int span = kBTile + 2 * f->radius, n = 2 * f->radius + 1;
     static const int variant = [] { const char *e = getenv("TSDF_BIL_VARIANT"); return e ? atoi(e) : 1; }();   // tuning aid: 0 = plain loops
@@ -225,10 +239,10 @@ static int launch_bilateral(const tsdf_bilateral *f, const PIX *in, PIX *out, in
                   (staged ? kSimLds * sizeof(float) : 0);
     if (staged)
         hipLaunchKernelGGL((bilateral_kernel<PIX, 7>), grid, dim3(256), smem, s, in, out, width, height, f->radius, f->kernel_dev,
-                           f->similarity_dev, debug_skip);
+                           f->similarity_dev, debug_skip, tile_max);
     else
         hipLaunchKernelGGL((bilateral_kernel<PIX, 0>), grid, dim3(256), smem, s, in, out, width, height, f->radius, f->kernel_dev,
-                           f->similarity_dev, debug_skip);
+                           f->similarity_dev, debug_skip, tile_max);
     TSDF_HIP(hipGetLastError(), "bilateral filter kernel failed");
     return TSDF_OK;
 }
@@ -336,6 +350,13 @@ int tsdf_bilateral_filter_u16_device(const tsdf_bilateral *f, const uint16_t *in
                                      int height, void *hip_stream) {
     TSDF_REQUIRE(f && in && out && in != out && width > 0 && height > 0, "tsdf_bilateral_filter: bad argument");
     return launch_bilateral<uint16_t>(f, in, out, width, height, (hipStream_t)hip_stream);
+}
+
+int tsdf_bilateral_filter_u16_device_tiles(const tsdf_bilateral *f, const uint16_t *in, uint16_t *out, int width,
+                                           int height, uint16_t *tile_max, void *hip_stream) {
+    TSDF_REQUIRE(f && in && out && in != out && tile_max && width > 0 && height > 0, "tsdf_bilateral_filter: bad argument");
+    static_assert(kBTile == TSDF_DEPTH_TILE, "the filter's workgroup tile is the depth tile of integrate's culling");
+    return launch_bilateral<uint16_t>(f, in, out, width, height, (hipStream_t)hip_stream, tile_max);
 }
 
 }  // extern "C"

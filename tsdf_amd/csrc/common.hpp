@@ -179,6 +179,7 @@ struct tsdf_volume {
     // integrate scratch: compact list of bricks a frame can touch (+ its counter), depth tile maxima
     uint32_t *brick_list;
     size_t brick_list_cap;
+    uint32_t brick_count_side;    // which of the list's two length words the next integration appends behind (integrate.hip)
     uint32_t *brick_boxes;   // uint4 per active brick: pixel box of the brick's projection
     size_t brick_box_cap;
     uint16_t *tile_max;

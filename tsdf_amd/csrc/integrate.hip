@@ -147,7 +147,7 @@ __device__ inline void mark_low_voxels(const OccGrid &occ, const uint32_t bits_l
     }
 }
 
-constexpr int kDepthTile = 16;  // pixels per side of a depth tile
+constexpr int kDepthTile = TSDF_DEPTH_TILE;  // pixels per side of a depth tile (16)
 constexpr int kCullTilesLds = 4096;  // tile maxima brick_cull_kernel keeps in LDS (1200 at 640x480)
 
 static std::unordered_map<uint32_t, float> g_prev_brick_us;   // diagnostics (TSDF_DEBUG_SORT=9/10): brick -> microseconds in the previous launch
@@ -164,9 +164,8 @@ static uint32_t occupancy_rebuild_period() {
 // Max depth per 16x16 pixel tile (0 = the tile holds no valid depth).  One wave per tile.
 __global__ __launch_bounds__(64) void depth_tile_max_kernel(const uint16_t *__restrict__ depth, uint32_t width,
                                                             uint32_t height, uint32_t tiles_x,
-                                                            uint16_t *__restrict__ tile_max, uint32_t *__restrict__ brick_count) {
+                                                            uint16_t *__restrict__ tile_max) {
     const uint32_t tx = blockIdx.x, ty = blockIdx.y;
-    if (tx == 0 && ty == 0 && threadIdx.x == 0) *brick_count = 0;  // for brick_cull_kernel, the next launch on the stream
     uint32_t m = 0;
     for (uint32_t i = threadIdx.x; i < kDepthTile * kDepthTile; i += 64) {
         uint32_t x = tx * kDepthTile + (i & (kDepthTile - 1)), y = ty * kDepthTile + (i / kDepthTile);
@@ -189,10 +188,16 @@ __global__ __launch_bounds__(256) void brick_cull_kernel(const Geom g, const Bri
                                                          const uint16_t *__restrict__ tile_max, const uint32_t tiles_x,
                                                          const int depth_test, uint32_t *__restrict__ list,
                                                          uint4 *__restrict__ boxes, uint32_t *__restrict__ count,
+                                                         uint32_t *__restrict__ count_next,
                                                          float4 *__restrict__ plane_const, const uint32_t n_plane_const) {
     // One lane per corner: 8 consecutive lanes share a brick and combine their corners with 3 butterfly steps (a thread per brick
     // walked its 8 corners one after the other on a quarter of the chip's compute units: 12 us of dependent arithmetic).
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    // The list's length lives in two words used alternately: this launch appends behind *count and zeroes the word of the NEXT
+    // integration (nothing reads that one before the next brick_cull_kernel, which comes after this frame's integrate_kernel in
+    // stream order).  Up to round 2h depth_tile_max_kernel reset the one word; that launch is skipped when the caller brings the
+    // tile maxima (tsdf_integrate_device_tiles).
+    if (t == 0) *count_next = 0;
     // side job: the per-plane constants of integrate_kernel (see there)
     for (uint32_t p = t; p < n_plane_const; p += gridDim.x * 256) {
         const uint32_t vz = g.z_store_begin + p;
@@ -623,7 +628,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 }
 
 static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t width, uint32_t height,
-                            const float inv_pose[16], const float k[9], const float kinv[9]) {
+                            const float inv_pose[16], const float k[9], const float kinv[9], const uint16_t *caller_tile_max = nullptr) {
     Mat44 ip;
     Mat33 mk, mkinv;
     memcpy(&ip, inv_pose, sizeof(ip));
@@ -645,12 +650,14 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
 
     // scratch: brick list + counter, depth tile maxima
     const uint32_t tiles_x = (width + kDepthTile - 1) / kDepthTile, tiles_y = (height + kDepthTile - 1) / kDepthTile;
-    if (v->brick_list_cap < n_bricks + 1) {
+    if (v->brick_list_cap < n_bricks + 2) {
         if (v->brick_list) (void)hipFree(v->brick_list);
         v->brick_list = nullptr;
         v->brick_list_cap = 0;
-        TSDF_HIP(hipMalloc((void **)&v->brick_list, (n_bricks + 1) * sizeof(uint32_t)), "brick list alloc");
-        v->brick_list_cap = n_bricks + 1;
+        TSDF_HIP(hipMalloc((void **)&v->brick_list, (n_bricks + 2) * sizeof(uint32_t)), "brick list alloc");
+        TSDF_HIP(hipMemsetAsync(v->brick_list + n_bricks, 0, 2 * sizeof(uint32_t), v->stream), "brick list alloc");   // both length words
+        v->brick_list_cap = n_bricks + 2;
+        v->brick_count_side = 0;
     }
     if (v->tile_max_cap < (size_t)tiles_x * tiles_y) {
         if (v->tile_max) (void)hipFree(v->tile_max);
@@ -659,7 +666,8 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
         TSDF_HIP(hipMalloc((void **)&v->tile_max, (size_t)tiles_x * tiles_y * sizeof(uint16_t)), "depth tile alloc");
         v->tile_max_cap = (size_t)tiles_x * tiles_y;
     }
-    uint32_t *count = v->brick_list + n_bricks;  // last slot
+    // the list's length: the last two slots, used alternately (see brick_cull_kernel)
+    uint32_t *count = v->brick_list + n_bricks + v->brick_count_side, *count_next = v->brick_list + n_bricks + (1u - v->brick_count_side);
     if (v->brick_box_cap < n_bricks) {
         if (v->brick_boxes) (void)hipFree(v->brick_boxes);
         v->brick_boxes = nullptr;
@@ -677,10 +685,13 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
         // the depth tests need surface z == depth and w == 1 exactly (rigid pose, standard intrinsics)
         const int depth_test = (ip.m41 == 0.0f && ip.m42 == 0.0f && ip.m43 == 0.0f && ip.m44 == 1.0f &&
                                 mkinv.m31 == 0.0f && mkinv.m32 == 0.0f && mkinv.m33 == 1.0f) ? 1 : 0;
-        hipLaunchKernelGGL(depth_tile_max_kernel, dim3(tiles_x, tiles_y), dim3(64), 0, v->stream, d_depth, width, height,
-                           tiles_x, v->tile_max, count);
+        if (!caller_tile_max)
+            hipLaunchKernelGGL(depth_tile_max_kernel, dim3(tiles_x, tiles_y), dim3(64), 0, v->stream, d_depth, width, height,
+                               tiles_x, v->tile_max);
         hipLaunchKernelGGL(brick_cull_kernel, dim3((unsigned)((8 * n_bricks + 255) / 256)), dim3(256), 0, v->stream, g, bg, ip, mk,
-                           width, height, v->tile_max, tiles_x, depth_test, v->brick_list, boxes, count, plane_const, n_plane_const);
+                           width, height, caller_tile_max ? caller_tile_max : v->tile_max, tiles_x, depth_test, v->brick_list, boxes, count,
+                           count_next, plane_const, n_plane_const);
+        v->brick_count_side = 1u - v->brick_count_side;
     }
     if (!v->nodes) {   // diagnostics, TSDF_DEBUG_SORT = 1..8: the list reordered on the host (synchronises), to time integrate_kernel on other orders --
                        // 1 index order, 2 scattered, 3 position in the layer then layer, 4 x / z / y (what the cull kernel produces), 5 x / y / z, 6 x then
@@ -855,6 +866,15 @@ int tsdf_integrate_device(tsdf_volume *v, const uint16_t *device_depth, uint32_t
     TSDF_REQUIRE(width > 0 && height > 0, "tsdf_integrate: empty depth map");
     (void)pose;  // the reference passes pose to its kernel but never reads it (src/TSDF/TSDFVolume.cu:316)
     return launch_integrate(v, device_depth, width, height, inv_pose, k, kinv);
+}
+
+int tsdf_integrate_device_tiles(tsdf_volume *v, const uint16_t *device_depth, uint32_t width, uint32_t height,
+                                const float pose[16], const float inv_pose[16], const float k[9], const float kinv[9],
+                                const uint16_t *device_tile_max) {
+    TSDF_REQUIRE(v && device_depth && inv_pose && k && kinv && device_tile_max, "tsdf_integrate: null argument");
+    TSDF_REQUIRE(width > 0 && height > 0, "tsdf_integrate: empty depth map");
+    (void)pose;
+    return launch_integrate(v, device_depth, width, height, inv_pose, k, kinv, device_tile_max);
 }
 
 int tsdf_integrate(tsdf_volume *v, const uint16_t *host_depth, uint32_t width, uint32_t height,

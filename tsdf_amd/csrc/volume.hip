@@ -282,6 +282,46 @@ __global__ __launch_bounds__(256) void reach_mip_kernel(OccGrid occ) {
     }
 }
 
+// The same summary for grids whose brick counts are multiples of 16 on every axis (every super block whole), one WAVE per super
+// block and no LDS, no barrier: lane = (y, zg) holds the 4 rows z = 4 zg .. 4 zg + 3 of 16 flag bytes each (0 / 1, the only
+// values the writers store); the OR over an aligned block is built in the byte domain along x (shifts inside the words), along
+// z inside the lane and across lanes 16 / 32 apart, along y across neighbouring lanes.  Flagged-ness grows with the block (a
+// flagged brick flags every block that holds it), so the level is 5 minus the number of flagged blocks among {brick, 2-, 4-, 8-,
+// 16-block}: a byte-wise sum.  reach_mip_kernel above: 512 workgroups at 512^3 that spend their 9.5 us in five barriers.
+__device__ inline uint32_t or_x2(uint32_t w) { const uint32_t a = (w | (w >> 8)) & 0x00ff00ffu; return a | (a << 8); }   // byte pairs (x, x ^ 1)
+__device__ inline uint32_t or_x4(uint32_t w) { const uint32_t a = (w | (w >> 16)) & 0x0000ffffu; return a | (a << 16); }   // (of a pair-uniform word)
+__device__ inline uint32_t or_lanes(uint32_t v, int mask) { return v | (uint32_t)__shfl_xor((int)v, mask); }
+__global__ __launch_bounds__(64) void reach_mip_wave_kernel(OccGrid occ) {
+    const uint32_t lane = threadIdx.x, y = blockIdx.y * kSuper + (lane & 15u), z0 = blockIdx.z * kSuper + (lane >> 4) * 4u;
+    const size_t row0 = ((size_t)z0 * occ.nby + y) * occ.nbx + (size_t)blockIdx.x * kSuper, zstride = (size_t)occ.nby * occ.nbx;
+    uint32_t f[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint4 r = *reinterpret_cast<const uint4 *>(occ.fine + row0 + j * zstride);
+        f[j][0] = r.x; f[j][1] = r.y; f[j][2] = r.z; f[j][3] = r.w;
+    }
+    uint32_t l1[2][4], l2[4], l3[2], l4;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        // 2-blocks: x pair, z pair (rows 2 jp, 2 jp + 1), y pair (lane ^ 1)
+#pragma unroll
+        for (int jp = 0; jp < 2; jp++) l1[jp][k] = or_lanes(or_x2(f[2 * jp][k]) | or_x2(f[2 * jp + 1][k]), 1);
+        // 4-blocks: x quad, the lane's 4 rows, y quad (the pair's neighbour pair: lane ^ 2)
+        l2[k] = or_lanes(or_x4(l1[0][k]) | or_x4(l1[1][k]), 2);
+    }
+    // 8-blocks: two words along x, lanes y ^ 4, the neighbouring z group (lane ^ 16)
+#pragma unroll
+    for (int h = 0; h < 2; h++) l3[h] = or_lanes(or_lanes(l2[2 * h] | l2[2 * h + 1], 4), 16);
+    l4 = or_lanes(or_lanes(l3[0] | l3[1], 8), 32);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) o[k] = 0x05050505u - (f[j][k] + l1[j >> 1][k] + l2[k] + l3[k >> 1] + l4);
+        *reinterpret_cast<uint4 *>(occ.reach + row0 + j * zstride) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 static int occupancy_reset(tsdf_volume *v) {
     size_t n = v->occ.fine_count();
     hipLaunchKernelGGL(occupancy_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, v->stream, v->occ, v->g.X, v->g.Y, v->g.Z);
@@ -312,7 +352,13 @@ int occupancy_refresh(tsdf_volume *v) {
     }
     if (v->reach_dirty) {
         dim3 grid((v->occ.nbx + kSuper - 1) / kSuper, (v->occ.nby + kSuper - 1) / kSuper, (v->occ.nbz + kSuper - 1) / kSuper);
-        hipLaunchKernelGGL(reach_mip_kernel, grid, dim3(256), 0, v->stream, v->occ);
+        static const bool lds_variant = [] { const char *e = getenv("TSDF_REACH_LDS"); return e && atoi(e) != 0; }();   // tuning aid: the workgroup variant always
+        const bool whole_blocks = v->occ.nbx % kSuper == 0 && v->occ.nby % kSuper == 0 && v->occ.nbz % kSuper == 0 &&
+                                  (reinterpret_cast<uintptr_t>(v->occ.fine) & 15u) == 0 && (reinterpret_cast<uintptr_t>(v->occ.reach) & 15u) == 0;
+        if (whole_blocks && !lds_variant)
+            hipLaunchKernelGGL(reach_mip_wave_kernel, grid, dim3(64), 0, v->stream, v->occ);
+        else
+            hipLaunchKernelGGL(reach_mip_kernel, grid, dim3(256), 0, v->stream, v->occ);
         TSDF_HIP(hipGetLastError(), "occupancy summary");
         v->reach_dirty = 0;
     }
