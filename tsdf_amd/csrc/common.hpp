@@ -32,17 +32,18 @@ int build_t_table(struct ::tsdf_volume *v);      // volume.hip
 bool timing_pair(struct ::tsdf_volume *v, int which, hipEvent_t *start, hipEvent_t *stop);
 void timing_begin(struct ::tsdf_volume *v, int which);
 void timing_end(struct ::tsdf_volume *v, int which);
-#define TSDF_LAUNCH_TIMED(v, which, kernel, grid, block, ...)                                              \
-    do {                                                                                                   \
-        hipEvent_t ts0__ = nullptr, ts1__ = nullptr;                                                       \
-        if (tsdf::timing_pair(v, which, &ts0__, &ts1__))                                                   \
-            hipExtLaunchKernelGGL(kernel, grid, block, 0, (v)->stream, ts0__, ts1__, 0, __VA_ARGS__);      \
-        else {                                                                                             \
-            tsdf::timing_begin(v, which);                                                                  \
-            hipLaunchKernelGGL(kernel, grid, block, 0, (v)->stream, __VA_ARGS__);                          \
-            tsdf::timing_end(v, which);                                                                    \
-        }                                                                                                  \
+#define TSDF_LAUNCH_TIMED_LDS(v, which, kernel, grid, block, lds_bytes, ...)                                            \
+    do {                                                                                                                \
+        hipEvent_t ts0__ = nullptr, ts1__ = nullptr;                                                                    \
+        if (tsdf::timing_pair(v, which, &ts0__, &ts1__))                                                                \
+            hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)(lds_bytes), (v)->stream, ts0__, ts1__, 0, __VA_ARGS__); \
+        else {                                                                                                          \
+            tsdf::timing_begin(v, which);                                                                               \
+            hipLaunchKernelGGL(kernel, grid, block, (uint32_t)(lds_bytes), (v)->stream, __VA_ARGS__);                   \
+            tsdf::timing_end(v, which);                                                                                 \
+        }                                                                                                               \
     } while (0)
+#define TSDF_LAUNCH_TIMED(v, which, kernel, grid, block, ...) TSDF_LAUNCH_TIMED_LDS(v, which, kernel, grid, block, 0, __VA_ARGS__)
 int verify_fast_division(struct ::tsdf_volume *v);  // volume.hip
 
 #define TSDF_HIP(call, what)                                  \

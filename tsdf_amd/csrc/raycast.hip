@@ -659,8 +659,10 @@ __device__ inline bool ray_geometry(int imx, int imy, bool in_image, const RayPa
 }
 
 template <bool SLAB>
-__device__ inline void setup_ray(int imx, int imy, bool in_image, int k_lo, int k_hi, const float *T, const RayParams &rp,
+__device__ inline void setup_ray(int imx, int imy, bool in_image, int k_lo, int k_hi, const float *Ts, const int t_off, const RayParams &rp,
                                  const Geom &g, float step_size, RayState &ray, int &k_first, int &k_end) {
+    // Ts[k + t_off] = T[k] for k_lo <= k <= k_hi (the staged part of the table)
+    auto T = [&](int k) { return Ts[k + t_off]; };
     float max_t;
     const bool intersects = ray_geometry(imx, imy, in_image, rp, ray, max_t);
     const float sz = ray.sz;
@@ -678,7 +680,7 @@ __device__ inline void setup_ray(int imx, int imy, bool in_image, int k_lo, int 
         {
             const int c = f2i_sat(max_t * __builtin_amdgcn_rcpf(step_size));
             const int a = max(lo, min(hi, c - 4)), b = min(hi, max(lo, c + 4));
-            const bool below = a == lo || T[a - 1] < max_t, above = b == hi || T[b] >= max_t;
+            const bool below = a == lo || T(a - 1) < max_t, above = b == hi || T(b) >= max_t;
             if (below && above) {
                 lo = a;
                 hi = b;
@@ -686,11 +688,11 @@ __device__ inline void setup_ray(int imx, int imy, bool in_image, int k_lo, int 
         }
         while (lo < hi) {
             int mid = (lo + hi) >> 1;
-            if (T[mid] >= max_t) hi = mid; else lo = mid + 1;
+            if (T(mid) >= max_t) hi = mid; else lo = mid + 1;
         }
         k_end = lo;
         // the range starts beyond the ray's last sample (k_lo >= 1 and T[k_lo] >= max_t): nothing to do
-        if (k_lo >= 1 && T[k_lo] >= max_t) k_end = 0;
+        if (k_lo >= 1 && T(k_lo) >= max_t) k_end = 0;
     }
 
     // A slab only ever evaluates samples whose lower tap plane it owns; along a ray those occupy one interval
@@ -782,11 +784,16 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
     const uint32_t range = rp.range_order == 0 ? bz_ : rp.range_order == 1 ? nz - 1u - bz_ : (bz_ == 0 ? nz - 1u : bz_ == 1 ? 0u : nz - bz_);
     const int k_lo = per_ray_ranges ? 0 : (int)(range * rp.seg_len);
     const int k_hi = (rp.seg_len && !per_ray_ranges) ? min(kMaxSamples, k_lo + (int)rp.seg_len) : kMaxSamples;
-    __shared__ float T[kTableLen];
-    // T[1] (the step) plus the part of the table this range reads: T[k_lo .. k_hi]
-    for (int i = k_lo + (int)threadIdx.x; i <= k_hi; i += 256) T[i] = t_table[i];
-    if (threadIdx.x < 2) T[threadIdx.x] = t_table[threadIdx.x];
+    const unsigned long long dbg_entry = (TAIL && !STATS && counters) ? wall_clock64() : 0ull;   // (diagnostics, TSDF_DEBUG_WAVES)
+    // T[0], T[1] (the step) and the part of the table this range reads, T[k_lo .. k_hi], at Ts[2 ..]: 3.5 KB of LDS for a fifth of
+    // the table (dynamic allocation, ray_table_lds_bytes) instead of 17.6 KB for all of it.  (Workgroup residency is not what
+    // limits this kernel: 9 -> 16 workgroups per compute unit by LDS left the launch at 0.091 ms.)
+    extern __shared__ float Ts[];
+    for (int i = (int)threadIdx.x; i <= k_hi - k_lo; i += 256) Ts[2 + i] = t_table[k_lo + i];
+    if (threadIdx.x < 2) Ts[threadIdx.x] = t_table[threadIdx.x];
     __syncthreads();
+    const int t_off = 2 - k_lo;
+    auto T = [&](int k_) { return Ts[k_ + t_off]; };
 
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     // Workgroups are dealt to the 8 XCDs round robin in launch order; remap the linear tile index so that each XCD (own
@@ -808,11 +815,11 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
     static_assert(SEG || !(SLAB || TAIL), "slabs and the tail queue go with sample ranges");
     float ix = NAN, iy = NAN, iz = NAN;
     const float previous_tsdf = g.trunc;  // Q7
-    const float step_size = T[1];         // = (float)((double)trunc * 0.05), :324
+    const float step_size = Ts[1];         // = (float)((double)trunc * 0.05), :324
 
     RayState ray;
     int k_first, k_end;
-    setup_ray<SLAB>(imx, imy, in_image, k_lo, k_hi, T, rp, g, step_size, ray, k_first, k_end);
+    setup_ray<SLAB>(imx, imy, in_image, k_lo, k_hi, Ts, t_off, rp, g, step_size, ray, k_first, k_end);
     if (per_ray_ranges && k_end > k_first) {
         // part blockIdx.z of rp.slab_ranges equal parts of this ray's stretch [k_first, k_end) through the slab
         const int len = k_end - k_first, a = k_first + (int)(((long long)len * range) / rp.slab_ranges);
@@ -828,6 +835,7 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
     if (SEG && range > 0 && k != kDone && load_best(&tail.best[idx]) <= (uint32_t)k_first) k = kDone;
     BrickCache bc = {0, 0, false};
     SampleWork work = {0, 0, 0, 0};
+    const unsigned long long dbg_setup = (TAIL && !STATS && counters) ? wall_clock64() : 0ull;
 
     // Lead-in: most (tile, range) pairs start in empty space and many never leave it.  Jumping from block to block needs
     // only the brick look-up, so it gets a loop of its own -- a fraction of the instructions of the full pass below --
@@ -837,7 +845,7 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
             const bool hopping = k != kDone && sc.skip_ok && k >= bc.k_brick_end;
             if (__ballot(hopping) == 0ull) break;
             if (hopping) {
-                const float t = T[k];
+                const float t = T(k);
                 const float fx = ((t * ray.dx) + ray.sx) * sc.inv_vx, fy = ((t * ray.dy) + ray.sy) * sc.inv_vy, fz = ((t * ray.dz) + ray.sz) * sc.inv_vz;
                 int n;
                 const bool empty = locate<SLAB>(fx, fy, fz, sc, g, occ, rp, n);
@@ -858,7 +866,7 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
             bool shell = false;
             float t = 0.f, px = 0.f, py = 0.f, pz = 0.f;
             if (k != kDone) {
-                t = T[k];
+                t = T(k);
                 px = (t * ray.dx) + ray.sx; py = (t * ray.dy) + ray.sy; pz = (t * ray.dz) + ray.sz;
                 // lower tap index of the sample's dual cell, as process_sample derives it: off the lattice on some axis?
                 const int lx = (int)floorf(px * sc.inv_vx - 0.5f), ly = (int)floorf(py * sc.inv_vy - 0.5f), lz = (int)floorf(pz * sc.inv_vz - 0.5f);
@@ -887,7 +895,7 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
         dbg_trips = trip + 1;
         if (STATS) work.trips++;
         if (k != kDone) {
-            const float t = T[k];
+            const float t = T(k);
             int jump, ahead;
             const float tsdf = process_sample<SLAB, STATS, FASTDIV>(t, k, ray, sc, bc, dist, g, tc, rp, occ, touched, work, jump, ahead);
             if (jump > 0) {
@@ -932,7 +940,8 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
     }
     if (TAIL && !STATS && counters && lane == 0) {   // diagnostics: {range, passes of the main loop, start and end of the marching part} per wave
         const size_t w = ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave;
-        counters[3 * w + 0] = ((unsigned long long)range << 32) | dbg_trips;
+        // {range : 8, entry -> set-up done : 16, set-up done -> march : 16 (10 ns ticks), -, passes : 16}
+        counters[3 * w + 0] = ((unsigned long long)range << 56) | (min(dbg_setup - dbg_entry, 0xffffull) << 40) | (min(dbg_t0 - dbg_setup, 0xffffull) << 24) | (dbg_trips & 0xffffu);
         counters[3 * w + 1] = dbg_t0;
         counters[3 * w + 2] = wall_clock64();
     }
@@ -1283,6 +1292,13 @@ __global__ __launch_bounds__(256) void popcount_kernel(const unsigned int *__res
     if ((threadIdx.x & 63u) == 0 && c) atomicAdd(counter, c);
 }
 
+// LDS of a process_ray_kernel workgroup: T[0], T[1] and the table entries of one sample range (the whole table when the ranges
+// are cut per ray: slabs, seg_len == 0)
+static size_t ray_table_lds_bytes(const RayParams &rp, bool per_ray_ranges) {
+    const size_t entries = (rp.seg_len && !per_ray_ranges) ? std::min<size_t>(kMaxSamples, rp.seg_len) + 1 : (size_t)kMaxSamples + 1;
+    return (entries + 2) * sizeof(float);
+}
+
 static RayParams make_params(const tsdf_volume *v, uint32_t width, uint32_t height, const float pose[16],
                              const float kinv[9]) {
     RayParams rp;
@@ -1370,12 +1386,13 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
         (void)hipMalloc((void **)&wave_log, 3 * n_waves_log * sizeof(unsigned long long));
         (void)hipMemset(wave_log, 0, 3 * n_waves_log * sizeof(unsigned long long));
     }
+    const size_t table_lds = ray_table_lds_bytes(rp, SLAB && rp.slab_ranges > 0);
     if (v->fast_div)
-        TSDF_LAUNCH_TIMED(v, 1, (process_ray_kernel<SLAB, false, true, true, true, true>), grid, dim3(256), v->dist, v->g, rp,
-                          (float *)nullptr, wave_log, (unsigned int *)nullptr, v->occ, v->t_table, tail);
+        TSDF_LAUNCH_TIMED_LDS(v, 1, (process_ray_kernel<SLAB, false, true, true, true, true>), grid, dim3(256), table_lds, v->dist, v->g, rp,
+                              (float *)nullptr, wave_log, (unsigned int *)nullptr, v->occ, v->t_table, tail);
     else
-        TSDF_LAUNCH_TIMED(v, 1, (process_ray_kernel<SLAB, false, true, false, true, true>), grid, dim3(256), v->dist, v->g, rp,
-                          (float *)nullptr, (unsigned long long *)nullptr, (unsigned int *)nullptr, v->occ, v->t_table, tail);
+        TSDF_LAUNCH_TIMED_LDS(v, 1, (process_ray_kernel<SLAB, false, true, false, true, true>), grid, dim3(256), table_lds, v->dist, v->g, rp,
+                              (float *)nullptr, (unsigned long long *)nullptr, (unsigned int *)nullptr, v->occ, v->t_table, tail);
     TSDF_HIP(hipGetLastError(), "process_ray failed");
     if (debug_waves) {   // diagnostics (synchronises): the bulk kernel's waves by sample range
         (void)hipStreamSynchronize(v->stream);
@@ -1387,15 +1404,16 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
         fprintf(stderr, "tsdf: bulk ray kernel, marching part %.1f us (100 MHz clock); per range: waves, mean passes, waves with all %u passes, mean / max wave time us, last end us\n",
                 (t1 - t0) / 100.0, (unsigned)trip_budget());
         for (uint32_t r = 0; r < grid.z; r++) {
-            size_t n = 0, full = 0; double passes = 0, dur = 0, dmax = 0, last = 0;
+            size_t n = 0, full = 0; double passes = 0, dur = 0, dmax = 0, last = 0, t_setup = 0, t_lead = 0;
             for (size_t w = 0; w < n_waves_log; w++) {
-                if (!log[3 * w + 1] || (log[3 * w] >> 32) != r) continue;
-                const uint32_t p_ = (uint32_t)log[3 * w];
+                if (!log[3 * w + 1] || (log[3 * w] >> 56) != r) continue;
+                const uint32_t p_ = (uint32_t)(log[3 * w] & 0xffffu);
+                t_setup += (double)((log[3 * w] >> 40) & 0xffffu) / 100.0; t_lead += (double)((log[3 * w] >> 24) & 0xffffu) / 100.0;
                 const double d = (double)(log[3 * w + 2] - log[3 * w + 1]) / 100.0;
                 n++; passes += p_; full += p_ >= (uint32_t)trip_budget(); dur += d; dmax = std::max(dmax, d);
                 last = std::max(last, (double)(log[3 * w + 2] - t0) / 100.0);
             }
-            fprintf(stderr, "tsdf:   range %u: %zu waves, %.1f passes, %zu full, %.1f / %.1f us, last end %.1f\n", r, n, n ? passes / n : 0.0, full, n ? dur / n : 0.0, dmax, last);
+            fprintf(stderr, "tsdf:   range %u: %zu waves, %.1f passes, %zu full, %.1f / %.1f us, last end %.1f; before the march: table + set-up %.1f us, lead-in + shell %.1f us\n", r, n, n ? passes / n : 0.0, full, n ? dur / n : 0.0, dmax, last, n ? t_setup / n : 0.0, n ? t_lead / n : 0.0);
         }
     }
     unsigned long long *tail_log = nullptr;
@@ -1545,7 +1563,7 @@ int tsdf_raycast_stats(const tsdf_volume *v, uint32_t width, uint32_t height, co
     (void)hipMemsetAsync(bitmap, 0, words * sizeof(unsigned int), v->stream);
     (void)hipMemsetAsync(v->counter_dev, 0, 4 * sizeof(unsigned long long), v->stream);
     dim3 grid((width + 15) / 16, (height + 15) / 16);
-    hipLaunchKernelGGL((process_ray_kernel<false, true, false, false, false, false>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp, verts,
+    hipLaunchKernelGGL((process_ray_kernel<false, true, false, false, false, false>), grid, dim3(256), ray_table_lds_bytes(rp, false), v->stream, v->dist, v->g, rp, verts,
                        v->counter_dev, bitmap, v->occ, v->t_table, TailQueue{nullptr, nullptr, 0, 0, nullptr, 0});
     hipLaunchKernelGGL(popcount_kernel, dim3(1024), dim3(256), 0, v->stream, bitmap, words, v->counter_dev + 3);
     unsigned long long c[4] = {0, 0, 0, 0};
@@ -1580,7 +1598,7 @@ int tsdf_raycast_evaluated_samples(const tsdf_volume *v, uint32_t width, uint32_
     }
     (void)hipMemsetAsync(v->counter_dev, 0, 4 * sizeof(unsigned long long), v->stream);
     dim3 grid((width + 15) / 16, (height + 15) / 16);
-    hipLaunchKernelGGL((process_ray_kernel<false, true, true, true, false, false>), grid, dim3(256), 0, v->stream, v->dist, v->g, rp, verts,
+    hipLaunchKernelGGL((process_ray_kernel<false, true, true, true, false, false>), grid, dim3(256), ray_table_lds_bytes(rp, false), v->stream, v->dist, v->g, rp, verts,
                        v->counter_dev, bitmap, v->occ, v->t_table, TailQueue{nullptr, nullptr, 0, 0, nullptr, 0});
     unsigned long long c[4] = {0, 0, 0, 0};
     e = hipMemcpyAsync(c, v->counter_dev, sizeof(c), hipMemcpyDeviceToHost, v->stream);
