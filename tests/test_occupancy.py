@@ -89,3 +89,31 @@ def test_marks_left_by_integrate_cover_the_exact_flags_and_rebuild_tightens_them
     fine, cell, _ = v.occupancy_data(force_rebuild=True)
     assert np.array_equal(fine, ef) and np.array_equal(cell, ec)
     assert fine.sum() <= sticky_fine.sum()
+
+
+@pytest.mark.parametrize("slab", [None, (32, 80), (30, 71)])
+def test_second_rebuild_reads_only_what_integrate_touched_and_still_equals_the_definition(slab):
+    """After the first rebuild a rebuild scans only the integrate bricks marked since (volume.hip: touched); the flags must
+    equal the definition on the current distances all the same.  Slab (30, 71) does not start on a brick boundary: full scan."""
+    n = 96
+    v = tsdf_amd.TSDFVolume((n, n, n), (3000.0,) * 3, slab=slab)
+    tau = np.float32(0.01) * np.float32(v.truncation_distance())
+    lo, hi = v.resident_planes()
+
+    def definition():
+        D = np.full((n, n, n), v.truncation_distance(), np.float32)     # (planes outside the slab: never low)
+        D[lo:hi] = v.get_distance_data().reshape(hi - lo, n, n)
+        return _expected(D.reshape(-1), (n, n, n), tau)
+
+    def resident(a):
+        # bricks wholly inside the resident planes (the others depend on planes this volume does not hold)
+        return a[(lo + 3) // 4 + 1:hi // 4 - 1]
+
+    for rnd, first in enumerate((0, 60, 120)):
+        for i in range(3):
+            d, cam = synth.depth_frame(first + i * 7, 200, seed=0x5EED0003)
+            v.integrate(d, synth.WIDTH, synth.HEIGHT, cam)
+        fine, cell, _ = v.occupancy_data(force_rebuild=True)
+        ef, ec = definition()
+        assert np.array_equal(resident(fine), resident(ef)), "fine flags, rebuild %d" % rnd
+        assert np.array_equal(resident(cell), resident(ec)), "cell flags, rebuild %d" % rnd

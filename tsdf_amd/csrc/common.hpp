@@ -19,6 +19,12 @@ struct tsdf_volume;
 
 namespace tsdf {
 
+// integrate's brick: one wave along x, kIntBrickY waves per workgroup, kIntBrickZ planes walked by a workgroup (integrate.hip)
+#ifndef TSDF_CHUNK_Z
+#define TSDF_CHUNK_Z 32
+#endif
+constexpr int kIntBrickX = 64, kIntBrickY = 4, kIntBrickZ = TSDF_CHUNK_Z;
+
 // ---- error plumbing ----------------------------------------------------------------------
 void set_error(const char *fmt, ...);
 int hip_fail(hipError_t e, const char *what);
@@ -172,7 +178,13 @@ struct tsdf_volume {
     tsdf::OccGrid occ;
     int occ_dirty;   // 1 = rebuild from the distance array before the next ray cast
     int reach_dirty; // 1 = `fine` changed since `reach` was computed
-    uint16_t *occ_bits;              // scratch of the rebuild: 16 summary bits per brick (volume.hip)
+    uint16_t *occ_bits;              // 16 summary bits per brick, kept between rebuilds (volume.hip)
+    // A rebuild reads only the distances integrate may have written since the previous one: integrate_kernel marks its brick
+    // in `touched` (one byte per integrate brick, index order), the scan skips the others and their summary bits stand.
+    // occ_scan_all = 1: the next rebuild reads everything (first rebuild, clear, set_distance_data, mark_dirty, new truncation).
+    uint8_t *touched;
+    uint32_t touched_nx, touched_ny, touched_nz;
+    int occ_scan_all;
     // integrate only ever SETS flags (a voxel that stops being low is not noticed), so the flags are refreshed from
     // the distance array after 2, 4, 8, 16 integrations and then every kOccRebuildPeriod (integrate.hip)
     uint32_t integrations_since_rebuild;

@@ -34,12 +34,9 @@
 
 namespace tsdf {
 
-constexpr int kTileX = 64;  // one wave along x
-constexpr int kTileY = 4;   // waves per workgroup
-#ifndef TSDF_CHUNK_Z
-#define TSDF_CHUNK_Z 32
-#endif
-constexpr int kChunkZ = TSDF_CHUNK_Z; // planes walked by one workgroup
+constexpr int kTileX = kIntBrickX;  // one wave along x
+constexpr int kTileY = kIntBrickY;  // waves per workgroup
+constexpr int kChunkZ = kIntBrickZ; // planes walked by one workgroup
 #ifndef TSDF_BATCH_Z
 #define TSDF_BATCH_Z 4
 #endif
@@ -373,7 +370,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                                                         const OccGrid occ, const uint32_t *__restrict__ list,
                                                         const uint4 *__restrict__ boxes,
                                                         const uint32_t *__restrict__ count,
-                                                        const float4 *__restrict__ plane_const) {
+                                                        const float4 *__restrict__ plane_const,
+                                                        uint8_t *__restrict__ touched) {
     // Depth tile of the current brick: the pixel box the cull kernel derived for it, staged once per brick with
     // coalesced row loads; the per-voxel depth look-ups then read LDS instead of gathering from L2.
     __shared__ uint16_t tile[kTilePixels + 2];  // [kTilePixels] stays 0: where look-ups that miss the box are pointed
@@ -391,6 +389,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         const unsigned long long dbg_t0 = (!COUNT && counter) ? wall_clock64() : 0ull;   // (diagnostics, TSDF_DEBUG_BRICKS=3: per-brick clocks)
         const uint32_t b = DEFORM ? i : list[i];
         const uint32_t bx = b % bg.nx, by = (b / bg.nx) % bg.ny, bz = b / (bg.nx * bg.ny);
+        if (tid == 0) touched[b] = 1;   // for the next occupancy rebuild: this brick's distances may change (volume.hip)
         const uint32_t vx = bx * kTileX + threadIdx.x;
         const uint32_t vy = by * kTileY + threadIdx.y;
         const uint32_t z0 = g.z_store_begin + bz * kChunkZ;
@@ -648,6 +647,14 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
     const size_t n_bricks = (size_t)bg.nx * bg.ny * bg.nz;
     TSDF_REQUIRE(n_bricks < 0xFFFFFFFFull, "volume too large for the brick list");
 
+    if (!v->touched || v->touched_nx != bg.nx || v->touched_ny != bg.ny || v->touched_nz != bg.nz) {
+        if (v->touched) (void)hipFree(v->touched);
+        v->touched = nullptr;
+        TSDF_HIP(hipMalloc((void **)&v->touched, n_bricks), "touched bricks alloc");
+        TSDF_HIP(hipMemsetAsync(v->touched, 0, n_bricks, v->stream), "touched bricks alloc");
+        v->touched_nx = bg.nx; v->touched_ny = bg.ny; v->touched_nz = bg.nz;
+        v->occ_scan_all = 1;
+    }
     // scratch: brick list + counter, depth tile maxima
     const uint32_t tiles_x = (width + kDepthTile - 1) / kDepthTile, tiles_y = (height + kDepthTile - 1) / kDepthTile;
     if (v->brick_list_cap < n_bricks + 2) {
@@ -773,7 +780,7 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
     unsigned long long *counter_arg = brick_log ? brick_log : (v->counting ? v->counter_dev : nullptr);
 #define LAUNCH(DEF, CNT, STDC)                                                                                       \
     TSDF_LAUNCH_TIMED(v, 0, (integrate_kernel<DEF, CNT, STDC>), grid, block, v->dist, v->weight, v->nodes,          \
-                      g, bg, ip, mk, mkinv, width, height, d_depth, counter_arg, v->occ, v->brick_list, boxes, count, plane_const)
+                      g, bg, ip, mk, mkinv, width, height, d_depth, counter_arg, v->occ, v->brick_list, boxes, count, plane_const, v->touched)
     if (v->nodes) {
         if (v->counting) LAUNCH(true, true, false); else LAUNCH(true, false, false);
     } else if (std_camera) {

@@ -122,16 +122,29 @@ __global__ __launch_bounds__(256) void occupancy_init_kernel(OccGrid occ, uint32
 //    voxels (= one octant) is marked; `cell[b]` = some voxel in [4b, 4b+4]^3 is marked, i.e. the brick itself plus the
 //    x/y/z = 0 layers, edges and corner of the bricks on its + side.  Boundary / partial bricks keep their permanent marks.
 // Workgroup of scan: 64 bricks along x (lane) x the 4 voxel rows of one brick row (wave); loops over the brick's 4 planes.
+// touched != nullptr (z_store_begin a multiple of 4): only the bricks inside integrate bricks marked there are read -- the
+// distances of the others have not been written since their summary bits were formed, and those stand.
 __global__ __launch_bounds__(256) void occupancy_scan_kernel(const float *__restrict__ dist, Geom g, OccGrid occ,
-                                                             uint16_t *__restrict__ bits) {
+                                                             uint16_t *__restrict__ bits, const uint8_t *__restrict__ touched,
+                                                             const uint32_t tnx, const uint32_t tny, const uint32_t tnz) {
     __shared__ uint32_t acc[64];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t bx = blockIdx.x * 64 + lane, by = blockIdx.y, bz = blockIdx.z;
     const uint32_t y = by * kBrick + wave;
+    bool scan = true;
+    if (touched) {
+        // the integrate brick (64 x 4 x 32 voxels from plane z_store_begin; a slab's halo planes hang on the last layer) that holds
+        // this 4^3 brick
+        const uint32_t z0 = bz * kBrick;
+        const uint32_t ibx = min(bx * kBrick / kIntBrickX, tnx - 1u), iby = min(by * kBrick / kIntBrickY, tny - 1u);
+        const uint32_t ibz = z0 >= g.z_store_begin ? min((z0 - g.z_store_begin) / kIntBrickZ, tnz - 1u) : 0u;
+        scan = touched[((size_t)ibz * tny + iby) * tnx + ibx] != 0;
+        if (__syncthreads_or(scan) == 0) return;   // nothing in reach of this workgroup has been written
+    }
     if (threadIdx.x < 64) acc[threadIdx.x] = 0;
     __syncthreads();
     uint32_t oct = 0, low = 0;
-    if (bx < occ.nbx && y < g.Y) {
+    if (scan && bx < occ.nbx && y < g.Y) {
         const uint32_t x0 = bx * kBrick;
         const bool vec = (g.X & 3u) == 0;  // rows are 16-byte aligned and a brick never straddles the row end
         const uint32_t y0f = wave == 0 ? 1u : 0u, yo = wave >> 1;
@@ -159,12 +172,14 @@ __global__ __launch_bounds__(256) void occupancy_scan_kernel(const float *__rest
     const uint32_t both = oct | (low << 8);
     if (both) atomicOr(&acc[lane], both);
     __syncthreads();
-    if (threadIdx.x < 64 && bx < occ.nbx) bits[((size_t)bz * occ.nby + by) * occ.nbx + bx] = (uint16_t)acc[lane];
+    if (threadIdx.x < 64 && bx < occ.nbx && scan) bits[((size_t)bz * occ.nby + by) * occ.nbx + bx] = (uint16_t)acc[lane];
 }
 
 __global__ __launch_bounds__(256) void occupancy_flags_kernel(const uint16_t *__restrict__ bits, OccGrid occ, uint32_t size_x,
-                                                              uint32_t size_y, uint32_t size_z) {
+                                                              uint32_t size_y, uint32_t size_z, uint8_t *__restrict__ touched,
+                                                              const uint32_t n_touched) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (touched && i < n_touched) touched[i] = 0;   // (the scan before this launch has read the marks: they start again)
     if (i >= occ.fine_count()) return;
     const int bx = (int)(i % occ.nbx), by = (int)((i / occ.nbx) % occ.nby), bz = (int)(i / ((size_t)occ.nbx * occ.nby));
     // the permanent marks of occupancy_init_kernel
@@ -172,26 +187,38 @@ __global__ __launch_bounds__(256) void occupancy_flags_kernel(const uint16_t *__
     bool cell = bx * kBrick + kBrick > (int)size_x - 1 || by * kBrick + kBrick > (int)size_y - 1 || bz * kBrick + kBrick > (int)size_z - 1;
     // octants of a neighbour at offset d that lie within 2 voxels of this brick: all (d = 0), the high half (d = -1),
     // the low half (d = +1); per axis, as masks over the octant index xo + 2 yo + 4 zo
-    const uint32_t mx[3] = {0xAAu, 0xFFu, 0x55u}, my[3] = {0xCCu, 0xFFu, 0x33u}, mz[3] = {0xF0u, 0xFFu, 0x0Fu};
+    // (No branch around the 27 look-ups -- a neighbour outside the grid is read at a clamped index and masked to 0 -- so that
+    // they are all requested before the first is waited for: with `continue` for the outside ones the loads went out one by
+    // one, 38 us for 2 M bricks at 512^3.)
+    uint32_t fine_acc = 0, cell_acc = 0;
+#pragma unroll
     for (int dz = -1; dz <= 1; dz++) {
         const int z = bz + dz;
-        if (z < 0 || z >= (int)occ.nbz) continue;
+        const bool zin = z >= 0 && z < (int)occ.nbz;
+        const uint32_t mz = dz < 0 ? 0xF0u : dz == 0 ? 0xFFu : 0x0Fu;
+#pragma unroll
         for (int dy = -1; dy <= 1; dy++) {
             const int y = by + dy;
-            if (y < 0 || y >= (int)occ.nby) continue;
+            const bool yin = zin && y >= 0 && y < (int)occ.nby;
+            const uint32_t my = dy < 0 ? 0xCCu : dy == 0 ? 0xFFu : 0x33u;
+#pragma unroll
             for (int dx = -1; dx <= 1; dx++) {
                 const int x = bx + dx;
-                if (x < 0 || x >= (int)occ.nbx) continue;
-                const uint32_t w = bits[((size_t)z * occ.nby + y) * occ.nbx + x];
-                if (w & mx[dx + 1] & my[dy + 1] & mz[dz + 1]) fine = true;
+                const bool in = yin && x >= 0 && x < (int)occ.nbx;
+                const uint32_t mx = dx < 0 ? 0xAAu : dx == 0 ? 0xFFu : 0x55u;
+                const size_t at = in ? ((size_t)z * occ.nby + y) * occ.nbx + x : i;
+                const uint32_t w = (uint32_t)bits[at] & (in ? 0xffffu : 0u);
+                fine_acc |= w & mx & my & mz;
                 if (dx >= 0 && dy >= 0 && dz >= 0) {
                     // which summary of the + side neighbour touches [4b, 4b+4]^3: A, Fx, Fy, Exy, Fz, Exz, Eyz, C
-                    const uint32_t sel[8] = {1u << 8, 1u << 9, 1u << 10, 1u << 12, 1u << 11, 1u << 13, 1u << 14, 1u << 15};
-                    if (w & sel[dx + 2 * dy + 4 * dz]) cell = true;
+                    constexpr uint32_t sel[8] = {1u << 8, 1u << 9, 1u << 10, 1u << 12, 1u << 11, 1u << 13, 1u << 14, 1u << 15};
+                    cell_acc |= w & sel[dx + 2 * dy + 4 * dz];
                 }
             }
         }
     }
+    fine = fine || fine_acc != 0u;
+    cell = cell || cell_acc != 0u;
     occ.fine[i] = fine ? 1 : 0;
     occ.cell[i] = cell ? 1 : 0;
 }
@@ -292,8 +319,11 @@ __device__ inline uint32_t or_x2(uint32_t w) { const uint32_t a = (w | (w >> 8))
 __device__ inline uint32_t or_x4(uint32_t w) { const uint32_t a = (w | (w >> 16)) & 0x0000ffffu; return a | (a << 16); }   // (of a pair-uniform word)
 __device__ inline uint32_t or_lanes(uint32_t v, int mask) { return v | (uint32_t)__shfl_xor((int)v, mask); }
 __global__ __launch_bounds__(64) void reach_mip_wave_kernel(OccGrid occ) {
-    const uint32_t lane = threadIdx.x, y = blockIdx.y * kSuper + (lane & 15u), z0 = blockIdx.z * kSuper + (lane >> 4) * 4u;
-    const size_t row0 = ((size_t)z0 * occ.nby + y) * occ.nbx + (size_t)blockIdx.x * kSuper, zstride = (size_t)occ.nby * occ.nbx;
+    // blockIdx.x counts the super blocks along Z, blockIdx.z those along X: workgroups go to the 8 XCDs round robin in launch order
+    // (x fastest), and the super blocks that are neighbours along X read the same 128-byte lines -- with X as the fastest launch
+    // index every line was fetched by up to 8 XCDs (16.8 MB fetched for 2 MiB of flags at 512^3)
+    const uint32_t lane = threadIdx.x, y = blockIdx.y * kSuper + (lane & 15u), z0 = blockIdx.x * kSuper + (lane >> 4) * 4u;
+    const size_t row0 = ((size_t)z0 * occ.nby + y) * occ.nbx + (size_t)blockIdx.z * kSuper, zstride = (size_t)occ.nby * occ.nbx;
     uint32_t f[4][4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -334,11 +364,17 @@ int occupancy_rebuild(tsdf_volume *v) {
     const size_t n = v->occ.fine_count();
     if (!v->occ_bits) TSDF_HIP(hipMalloc((void **)&v->occ_bits, n * sizeof(uint16_t)), "occupancy scratch alloc");
     dim3 grid((v->occ.nbx + 63) / 64, v->occ.nby, v->occ.nbz);
-    hipLaunchKernelGGL(occupancy_scan_kernel, grid, dim3(256), 0, v->stream, v->dist, v->g, v->occ, v->occ_bits);
+    static const bool always_all = [] { const char *e = getenv("TSDF_OCC_SCAN_ALL"); return e && atoi(e) != 0; }();   // tuning aid
+    const bool incremental = !always_all && !v->occ_scan_all && v->touched && (v->g.z_store_begin % kBrick) == 0;
+    const uint32_t n_touched = v->touched ? v->touched_nx * v->touched_ny * v->touched_nz : 0u;
+    TSDF_REQUIRE(n_touched <= n || !v->touched, "occupancy rebuild: more integrate bricks than occupancy bricks");
+    hipLaunchKernelGGL(occupancy_scan_kernel, grid, dim3(256), 0, v->stream, v->dist, v->g, v->occ, v->occ_bits,
+                       incremental ? (const uint8_t *)v->touched : (const uint8_t *)nullptr, v->touched_nx, v->touched_ny, v->touched_nz);
     TSDF_HIP(hipGetLastError(), "occupancy scan");
     hipLaunchKernelGGL(occupancy_flags_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, v->stream, v->occ_bits, v->occ,
-                       v->g.X, v->g.Y, v->g.Z);
+                       v->g.X, v->g.Y, v->g.Z, v->touched, n_touched);
     TSDF_HIP(hipGetLastError(), "occupancy rebuild");
+    v->occ_scan_all = 0;
     v->occ_dirty = 0;
     v->reach_dirty = 1;
     v->integrations_since_rebuild = 0;
@@ -356,7 +392,7 @@ int occupancy_refresh(tsdf_volume *v) {
         const bool whole_blocks = v->occ.nbx % kSuper == 0 && v->occ.nby % kSuper == 0 && v->occ.nbz % kSuper == 0 &&
                                   (reinterpret_cast<uintptr_t>(v->occ.fine) & 15u) == 0 && (reinterpret_cast<uintptr_t>(v->occ.reach) & 15u) == 0;
         if (whole_blocks && !lds_variant)
-            hipLaunchKernelGGL(reach_mip_wave_kernel, grid, dim3(64), 0, v->stream, v->occ);
+            hipLaunchKernelGGL(reach_mip_wave_kernel, dim3(grid.z, grid.y, grid.x), dim3(64), 0, v->stream, v->occ);
         else
             hipLaunchKernelGGL(reach_mip_kernel, grid, dim3(256), 0, v->stream, v->occ);
         TSDF_HIP(hipGetLastError(), "occupancy summary");
@@ -594,6 +630,7 @@ int tsdf_volume_create_slab(uint32_t sx, uint32_t sy, uint32_t sz, float px, flo
         return TSDF_ERR_NOMEM;
     }
     std::memset(v, 0, sizeof(*v));
+    v->occ_scan_all = 1;
     Geom &g = v->g;
     g.X = sx; g.Y = sy; g.Z = sz;
     g.phys = {px, py, pz};
@@ -664,6 +701,7 @@ int tsdf_volume_destroy(tsdf_volume *v) {
     if (v->occ.cell) (void)hipFree(v->occ.cell);
     if (v->occ.reach) (void)hipFree(v->occ.reach);
     if (v->occ_bits) (void)hipFree(v->occ_bits);
+    if (v->touched) (void)hipFree(v->touched);
     if (v->plane_const) (void)hipFree(v->plane_const);
     if (v->tail_entries) (void)hipFree(v->tail_entries);
     if (v->tail_count) (void)hipFree(v->tail_count);
@@ -701,6 +739,7 @@ int tsdf_volume_clear(tsdf_volume *v) {
     // every distance is +trunc again: only the permanent boundary marks remain
     int rc0 = occupancy_reset(v);
     if (rc0 != TSDF_OK) return rc0;
+    v->occ_scan_all = 1;
     v->occ_dirty = 0;
     v->integrations_since_rebuild = v->integrations_total = 0;
     // initialise_deformation bakes the CURRENT offset into the node translations (Q1)
@@ -744,6 +783,7 @@ int tsdf_volume_set_header(tsdf_volume *v, const float offset[3], float trunc, f
     v->g.trunc = trunc;
     v->occ.tau = 0.01f * trunc;
     v->occ_dirty = 1;
+    v->occ_scan_all = 1;
     int rc = build_t_table(v);
     if (rc != TSDF_OK) return rc;
     v->max_weight = max_weight;
@@ -841,6 +881,7 @@ int tsdf_volume_deform_points(const tsdf_volume *v, int num_points, float *host_
 int tsdf_volume_mark_dirty(tsdf_volume *v) {
     TSDF_REQUIRE(v, "null volume");
     v->occ_dirty = 1;
+    v->occ_scan_all = 1;   // (written from outside: anywhere)
     return TSDF_OK;
 }
 
@@ -883,6 +924,7 @@ static int copy_in(tsdf_volume *v, void *dst, const void *src, size_t bytes, con
 int tsdf_volume_set_distance_data(tsdf_volume *v, const float *host) {
     TSDF_REQUIRE(v, "null volume");
     v->occ_dirty = 1;
+    v->occ_scan_all = 1;
     return copy_in(v, v->dist, host, v->resident_voxels() * sizeof(float), "Couldn't set distance data");
 }
 
