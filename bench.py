@@ -53,6 +53,10 @@ def parse():
                     help="N > 1: Z-slab boundaries re-cut from the ranks' measured times on the first frames (default), from a "
                          "work estimate of a small planner volume, or equal plane counts")
     ap.add_argument("--plan-rounds", type=int, default=3, help="--slab-plan measured: rebalancing rounds (each costs a few frames)")
+    ap.add_argument("--one-rank-slab-path", action="store_true",
+                    help="--gpus 1 only: run the N > 1 code path (slab volume, slab ray cast, all-gather of the hit records over the "
+                         "nccl = RCCL backend, merge) with a world of one rank -- the collective degenerates but RCCL initialises, "
+                         "builds a communicator and runs on the box's GPU; what a 1-GPU box can check of the multi-GPU path")
     ap.add_argument("--separate-tile-max", action="store_true",
                     help="integrate computes the depth tile maxima in a launch of its own (tsdf_integrate_device) instead of taking "
                          "them from the bilateral filter's launch (tsdf_bilateral_filter_u16_device_tiles + tsdf_integrate_device_tiles)")
@@ -69,6 +73,11 @@ def parse():
 
 def main():
     args = parse()
+    # stdout carries exactly one JSON line.  Libraries write there too (RCCL prints a version banner on stdout when it builds
+    # a communicator): file descriptor 1 is pointed at stderr for the life of the process and the line goes to the saved one.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (before the HIP runtime starts: RCCL's IPC needs it on this host driver)
     import torch
     import torch.distributed as dist
@@ -86,7 +95,13 @@ def main():
     if share:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    sharded = world > 1 or args.one_rank_slab_path
+    if world == 1 and sharded:   # (a world of one, without torchrun)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if sharded:
         if share:
             dist.init_process_group("gloo")
         else:
@@ -122,7 +137,7 @@ def main():
     norm_dev = torch.empty((H * W, 3), dtype=torch.float32, device="cuda")
 
     # ---- volume (whole, or this rank's Z-slab) -----------------------------------------------------
-    if world == 1:
+    if not sharded:
         vol = tsdf_amd.TSDFVolume((n, n, n), (args.physical,) * 3)
     else:
         from tsdf_amd.multi import balanced_slab_ranges, plane_costs, refine_slab_ranges, slab_range
@@ -207,7 +222,7 @@ def main():
     # volume (two filtered-frame buffers).  Every timed step still contains one filter, one integrate, one ray cast, one
     # exchange, one normal map.  (On one GPU there is no idle phase to fill: tried, no gain -- the single-GPU step stays
     # strictly sequential.)
-    overlap = world > 1 and not args.no_overlap
+    overlap = sharded and not args.no_overlap
     side = torch.cuda.Stream() if overlap else None
     filt2 = [filt_dev, torch.empty_like(filt_dev)] if overlap else [filt_dev, filt_dev]
     prefiltered = {}        # frame index -> (event on the side stream: filtered and integrated, timing pairs or None)
@@ -237,7 +252,7 @@ def main():
             ev["integrate"].append(pairs[1])
         e = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timed else None
         if timed: e[0].record(stream)
-        if world == 1:
+        if not sharded:
             rc.raycast_device(vol, cam, vert_dev.data_ptr(), None if os.environ.get('BENCH_SPLIT_NORMALS') else norm_dev.data_ptr())   # vertices and normals in one go
             if timed: e[1].record(stream)
         else:
@@ -268,7 +283,7 @@ def main():
             ev["normals"].append((e[2], e[3]))
 
     def barrier():
-        if world > 1:
+        if sharded:
             dist.barrier()
 
     # The replays below record ~13 events per step; the HIP runtime grows its pool of signals in steps of a few hundred events, and
@@ -294,7 +309,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if sharded:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -351,7 +366,8 @@ def main():
                                                                 " inside the volume" if inside else "", seed),
                    "grid": [n, n, n], "image": [W, H], "parallelism": "zslab%d" % world,
                    "overlap": "bilateral + integrate of frame i+1 on a second stream during the exchange of frame i" if overlap else "none",
-                   "depth_tile_maxima": "integrate's own launch" if args.separate_tile_max else "left by the bilateral filter's launch"},
+                   "depth_tile_maxima": "integrate's own launch" if args.separate_tile_max else "left by the bilateral filter's launch",
+                   "collective_backend": (dist.get_backend() if sharded else None), "ranks": (dist.get_world_size() if sharded else 1)},
         "integrate_mvoxels_per_s": round(N_vox / (stage_ms["integrate"] * 1e-3) / 1e6, 1),
         "raycast_mrays_per_s": round(W * H / ((stage_ms["raycast"] + stage_ms["exchange"] + stage_ms["normals"]) * 1e-3) / 1e6, 2),
         "stage_ms": {s: (round(v, 4) if v is not None else None) for s, v in stage_ms.items()},
@@ -371,7 +387,7 @@ def main():
                 "algorithmic_bytes": int_bytes, "avg_launch_ms": round(int_ms, 4), "launches_timed": kern["integrate"][0],
                 "U_voxels_updated": U, "U_min_max": [int(min(U_frames)), int(max(U_frames))], "dense_bytes": 16 * N_vox}
     roof_int.update(traffic_meta)
-    if world == 1:
+    if not sharded:
         st = rc.stats(vol, cams[last - 1])             # S samples, T distinct voxels touched at the end state
         ray_bytes = 4 * st["touched"] + 12 * W * H     # 4*T + vertex store (normals kernel: +12*W*H)
         # the march is two kernels (bulk + tail queue); its bytes are priced against their summed duration.  The
@@ -400,12 +416,12 @@ def main():
         # (read-modify-write of both arrays, brick by brick, no projection): the ceiling of the access shape
         check(lib.tsdf_measure_update_bandwidth(5, C.c_void_p(stream.cuda_stream), C.byref(gbs)))
         update_gbs = float(gbs.value)
-        for r_ in ([roof_int] if world > 1 else [roof_ray, roof_int]):
+        for r_ in ([roof_int] if sharded else [roof_ray, roof_int]):
             r_["measured_copy_gbs"] = round(copy_gbs, 1)
             r_["frac_of_measured_copy"] = round(r_["achieved"] / copy_gbs, 5)
         roof_int["measured_inplace_update_gbs"] = round(update_gbs, 1)
         roof_int["frac_of_inplace_update"] = round(roof_int["achieved"] / update_gbs, 5)
-    if rank == 0 and world == 1:
+    if rank == 0 and not sharded:
         out["roofline"] = roof_ray if dominant == "raycast" else roof_int
         out["roofline_other"] = roof_int if dominant == "raycast" else roof_ray
         if not args.path_only:
@@ -420,7 +436,7 @@ def main():
                                      "reference compiled natively")
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(vol, frames[last], cams[last], n, args.physical, args.cpu_budget_s)
-    if world > 1:
+    if sharded:
         # every rank's stage and kernel times (the step waits for the slowest), and a parity flag: rank 0 replays the whole
         # stream on ONE volume and compares the merged picture of the last timed frame with it, bit for bit
         mine = torch.tensor([stage_ms[s_] or 0.0 for s_ in stage_names] + [kern["integrate"][1], kern["raycast"][1], kern["raycast_tail"][1], float(U)],
@@ -463,8 +479,8 @@ def main():
             if isinstance(o, (list, tuple)):
                 return [finite(v) for v in o]
             return o
-        print(json.dumps(finite(out), allow_nan=False))
-    if world > 1:
+        os.write(json_fd, (json.dumps(finite(out), allow_nan=False) + "\n").encode())
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -69,3 +69,14 @@ def test_two_ranks_on_one_gpu_walk_the_sharded_path_and_agree_with_one_volume():
     assert len(d["slabs"]) == 2 and d["slabs"][0][0] == 0 and d["slabs"][0][1] == d["slabs"][1][0] and d["slabs"][1][1] == 512
     for name in ("integrate", "raycast", "exchange", "integrate_kernel", "process_ray_kernel"):
         assert len(d["per_rank_ms"][name]) == 2 and all(x > 0 for x in d["per_rank_ms"][name]), name
+
+
+def test_one_rank_walks_the_sharded_path_over_rccl():
+    """What a one-GPU box can check of the multi-GPU path on the real backend: a world of ONE rank initialises nccl (= RCCL),
+    builds a communicator on the box's GPU and pushes the hit records through all_gather_into_tensor on device memory, between the
+    slab ray cast and the merge kernel of every step; the merged picture must equal a single-volume replay."""
+    d = run_bench("--gpus", "1", "--one-rank-slab-path", "--steps", "6", "--warmup", "2", "--plan-rounds", "1", "--no-cpu-baseline")
+    assert d["config"]["collective_backend"] == "nccl" and d["config"]["ranks"] == 1 and d["config"]["parallelism"] == "zslab1"
+    assert d["parity"]["pass"] is True and d["parity"]["merged_picture_equals_single_volume_replay"] is True
+    assert d["slabs"] == [[0, 512]]
+    assert d["per_rank_ms"]["exchange"][0] > 0 and d["value"] > 0
