@@ -57,6 +57,9 @@ def parse():
                     help="--gpus 1 only: run the N > 1 code path (slab volume, slab ray cast, all-gather of the hit records over the "
                          "nccl = RCCL backend, merge) with a world of one rank -- the collective degenerates but RCCL initialises, "
                          "builds a communicator and runs on the box's GPU; what a 1-GPU box can check of the multi-GPU path")
+    ap.add_argument("--torch-collective", action="store_true",
+                    help="N > 1: the hit records go through torch.distributed.all_gather_into_tensor (the process group's own stream, "
+                         "events on either side) instead of ncclAllGather called on the step's own HIP stream (tsdf_amd.multi.StreamAllGather)")
     ap.add_argument("--separate-tile-max", action="store_true",
                     help="integrate computes the depth tile maxima in a launch of its own (tsdf_integrate_device) instead of taking "
                          "them from the bilateral filter's launch (tsdf_bilateral_filter_u16_device_tiles + tsdf_integrate_device_tiles)")
@@ -69,6 +72,15 @@ def parse():
     if a.stream_frames is None:
         a.stream_frames = 100 if a.workload == "config4" else 200
     return a
+
+
+_T0 = time.time()
+
+
+def trace(msg):
+    """BENCH_TRACE=1: wall-clock marks of the run's phases on stderr."""
+    if os.environ.get("BENCH_TRACE"):
+        print("[bench %8.2f s] %s" % (time.time() - _T0, msg), file=sys.stderr, flush=True)
 
 
 def main():
@@ -120,6 +132,7 @@ def main():
     inside = args.workload == "config4"
     seed = 0x5EED0004 if inside else SEED
 
+    trace("process group / device ready")
     # ---- inputs: synthetic stream, resident in HBM before timing ---------------------------------
     frames, cams = [], []
     for i in range(n_frames):
@@ -136,6 +149,7 @@ def main():
     vert_dev = torch.empty((H * W, 3), dtype=torch.float32, device="cuda")
     norm_dev = torch.empty((H * W, 3), dtype=torch.float32, device="cuda")
 
+    trace("frames synthesised")
     # ---- volume (whole, or this rank's Z-slab) -----------------------------------------------------
     if not sharded:
         vol = tsdf_amd.TSDFVolume((n, n, n), (args.physical,) * 3)
@@ -209,11 +223,21 @@ def main():
         vol = tsdf_amd.TSDFVolume((n, n, n), (args.physical,) * 3, slab=(zb, ze))
         hits_mine = torch.empty((H * W, 4), dtype=torch.float32, device="cuda")
         hits_all = torch.empty((world, H * W, 4), dtype=torch.float32, device="cuda")
+        # the frame's collective on the step's own stream (RCCL called directly); torch's collective if that cannot be set up
+        exch, exch_note = None, "torch.distributed.all_gather_into_tensor (gloo, staged through the host)" if share else "torch.distributed.all_gather_into_tensor"
+        if not share and not args.torch_collective:
+            try:
+                from tsdf_amd.multi import StreamAllGather
+                exch = StreamAllGather()
+                exch_note = "ncclAllGather on the step's stream (librccl, own communicator)"
+            except Exception as e_:      # (every rank takes the same branch: the failure modes are a missing library or symbol)
+                exch_note += " (direct RCCL unavailable: %s)" % e_
     stream = torch.cuda.current_stream()
     vol.set_stream(stream.cuda_stream)
     bil = tsdf_amd.BilateralFilter(30.0, 4.5)
     rc = tsdf_amd.GPURaycaster(W, H)
 
+    trace("volume and slab plan ready")
     stage_names = ["bilateral", "integrate", "raycast", "exchange", "normals"]
     ev = {s: [] for s in stage_names}
 
@@ -270,6 +294,8 @@ def main():
                 h_all = torch.empty(hits_all.shape, dtype=hits_all.dtype)
                 dist.all_gather_into_tensor(h_all.view(-1), hits_mine.cpu().view(-1))
                 hits_all.copy_(h_all)
+            elif exch is not None:
+                exch.all_gather(hits_mine, hits_all, stream.cuda_stream)
             else:
                 dist.all_gather_into_tensor(hits_all.view(-1), hits_mine.view(-1))
             tsdf_amd.merge_hits_normals_device(hits_all.data_ptr(), world, W, H, vert_dev.data_ptr(), norm_dev.data_ptr(), stream.cuda_stream)   # merged vertices and their normals in one go
@@ -295,6 +321,7 @@ def main():
     torch.cuda.synchronize()
     del pool
 
+    trace("event pool grown")
     # ---- warmup, then the timed region -------------------------------------------------------------
     for i in range(Wu):
         step(i, False)
@@ -316,6 +343,7 @@ def main():
     checksum = float(torch.nan_to_num(vert_dev.double(), nan=0.0).sum().item())   # the picture of the last timed frame
     last_vertices = vert_dev.clone()
 
+    trace("timed region done")
     # ---- untimed replays of the SAME K frames: (1) every stage and every launch of the dominant kernels bracketed with HIP
     # events on the launch stream (K launches timed, none of their cost inside `value`); (2) the voxels each frame updates,
     # counted by the kernel (which voxels a frame updates does not depend on the volume's state: depth > 0 and sdf >= -trunc,
@@ -367,7 +395,8 @@ def main():
                    "grid": [n, n, n], "image": [W, H], "parallelism": "zslab%d" % world,
                    "overlap": "bilateral + integrate of frame i+1 on a second stream during the exchange of frame i" if overlap else "none",
                    "depth_tile_maxima": "integrate's own launch" if args.separate_tile_max else "left by the bilateral filter's launch",
-                   "collective_backend": (dist.get_backend() if sharded else None), "ranks": (dist.get_world_size() if sharded else 1)},
+                   "collective_backend": (dist.get_backend() if sharded else None), "ranks": (dist.get_world_size() if sharded else 1),
+                   "collective": (exch_note if sharded else None)},
         "integrate_mvoxels_per_s": round(N_vox / (stage_ms["integrate"] * 1e-3) / 1e6, 1),
         "raycast_mrays_per_s": round(W * H / ((stage_ms["raycast"] + stage_ms["exchange"] + stage_ms["normals"]) * 1e-3) / 1e6, 2),
         "stage_ms": {s: (round(v, 4) if v is not None else None) for s, v in stage_ms.items()},
@@ -375,6 +404,7 @@ def main():
         "last_frame_vertex_checksum": checksum,
     }
 
+    trace("replays done")
     # ---- roofline of the dominant kernel (by time): HIP-event durations of the replay, bytes of the same launches ----------
     last = Wu + K                                  # one more frame (untimed legs below)
     U = int(round(float(np.mean(U_frames))))       # voxels updated per launch, mean over the K timed frames (this rank's slab)
@@ -436,6 +466,7 @@ def main():
                                      "reference compiled natively")
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(vol, frames[last], cams[last], n, args.physical, args.cpu_budget_s)
+    trace("single-GPU extras done")
     if sharded:
         # every rank's stage and kernel times (the step waits for the slowest), and a parity flag: rank 0 replays the whole
         # stream on ONE volume and compares the merged picture of the last timed frame with it, bit for bit
@@ -470,6 +501,7 @@ def main():
                                  "hits": int((~torch.isnan(ref_v[:, 0])).sum().item()), "pass": same}
                 whole.close()
 
+    trace("parity replay done")
     if rank == 0:
         def finite(o):      # strict JSON: a non-finite number (an unsampled average, an empty ratio) becomes null
             if isinstance(o, float):
@@ -482,6 +514,8 @@ def main():
         os.write(json_fd, (json.dumps(finite(out), allow_nan=False) + "\n").encode())
     if sharded:
         dist.barrier()
+        if exch is not None:
+            exch.close()
         dist.destroy_process_group()
 
 

@@ -80,3 +80,9 @@ def test_one_rank_walks_the_sharded_path_over_rccl():
     assert d["parity"]["pass"] is True and d["parity"]["merged_picture_equals_single_volume_replay"] is True
     assert d["slabs"] == [[0, 512]]
     assert d["per_rank_ms"]["exchange"][0] > 0 and d["value"] > 0
+    # the collective was RCCL's, called on the step's own stream (no fallback to torch's)
+    assert d["config"]["collective"].startswith("ncclAllGather on the step's stream"), d["config"]["collective"]
+    t = run_bench("--gpus", "1", "--one-rank-slab-path", "--torch-collective", "--steps", "6", "--warmup", "2", "--plan-rounds", "0",
+                  "--no-cpu-baseline")
+    assert t["config"]["collective"].startswith("torch.distributed") and t["parity"]["pass"] is True
+    assert t["last_frame_vertex_checksum"] == d["last_frame_vertex_checksum"]
