@@ -32,6 +32,8 @@ class FrameToModelTracker:
         self.depth_cutoff = float(depth_cutoff)
         n = self.width * self.height
         self._filtered = torch.empty((n,), dtype=torch.int16, device="cuda")
+        # the filter leaves the 16 x 16 tile maxima of its output for integrate's brick culling (one launch fewer per frame)
+        self._tile_max = torch.empty((((self.width + 15) // 16) * ((self.height + 15) // 16),), dtype=torch.int16, device="cuda")
         self._model = torch.empty((n,), dtype=torch.int16, device="cuda")
         self._vertices = torch.empty((n, 3), dtype=torch.float32, device="cuda")
         self.stream = torch.cuda.current_stream()
@@ -50,7 +52,8 @@ class FrameToModelTracker:
         if self.bilateral is None:
             self.torch.cuda.synchronize()
             raise ValueError("tracking needs the bilateral filter (raw one-pixel normals fail the ICP angle gate)")
-        self.bilateral.filter_device(depth_ptr, self._filtered.data_ptr(), self.width, self.height, bits=16, stream=s)
+        self.bilateral.filter_device(depth_ptr, self._filtered.data_ptr(), self.width, self.height, bits=16, stream=s,
+                                     tile_max_ptr=self._tile_max.data_ptr())
 
     def process_device(self, depth_ptr, initial_pose=None):
         """One frame (uint16 millimetres on the device).  The first frame is placed at `initial_pose` (4x4, camera ->
@@ -71,7 +74,7 @@ class FrameToModelTracker:
             T[:3, 3] *= 1000.0
             self.last_error, self.last_inliers = self.icp.last_error, self.icp.last_inliers
             self.camera.set_pose_rows(self.pose() @ T)
-        self.volume.integrate_device(self._filtered.data_ptr(), W, H, self.camera)
+        self.volume.integrate_device(self._filtered.data_ptr(), W, H, self.camera, tile_max_ptr=self._tile_max.data_ptr())
         self.frames += 1
         return self.pose()
 
