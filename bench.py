@@ -48,7 +48,8 @@ def parse():
                     help="per-stage HIP events inside the TIMED region on every n-th step (0 = none: each record costs a few "
                          "microseconds of stream time).  Stage and kernel times always come from an untimed replay of the same frames "
                          "with every launch bracketed")
-    ap.add_argument("--no-overlap", action="store_true", help="N > 1: filter + integrate frame i+1 after, not during, the exchange of frame i")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: filter + integrate frame i+1 after, not during, the exchange of frame i; N = 1: the next frame's filter "
+                                                                 "after, not during, this frame's ray cast")
     ap.add_argument("--slab-plan", choices=("measured", "model", "uniform"), default="measured",
                     help="N > 1: Z-slab boundaries re-cut from the ranks' measured times on the first frames (default), from a "
                          "work estimate of a small planner volume, or equal plane counts")
@@ -236,6 +237,15 @@ def main():
     vol.set_stream(stream.cuda_stream)
     bil = tsdf_amd.BilateralFilter(30.0, 4.5)
     rc = tsdf_amd.GPURaycaster(W, H)
+    # N = 1: the step runs through tsdf_amd.pipeline.FusionPipeline -- filter, integrate, ray cast + normals on one stream, and
+    # the NEXT frame's filter (it depends on nothing before it) on a second stream of lower priority, released when this
+    # frame's integrate is done: it fills the ramp-downs and the latency-bound small kernels of the ray cast (--no-overlap:
+    # strictly one after the other).  Every timed step still holds one filter, one integrate, one ray cast.
+    pipe = None
+    if not sharded:
+        from tsdf_amd.pipeline import FusionPipeline
+        pipe = FusionPipeline(vol, bil, rc, W, H, overlap=not args.no_overlap)
+        stream = pipe.main          # (the volume's stream now)
 
     trace("volume and slab plan ready")
     stage_names = ["bilateral", "integrate", "raycast", "exchange", "normals"]
@@ -244,8 +254,7 @@ def main():
     # N > 1: while the hit records are exchanged and merged the compute units idle, and the next frame's filter + integrate
     # depend on nothing the exchange produces: they are queued on a second stream as soon as this frame's slab cast has read the
     # volume (two filtered-frame buffers).  Every timed step still contains one filter, one integrate, one ray cast, one
-    # exchange, one normal map.  (On one GPU there is no idle phase to fill: tried, no gain -- the single-GPU step stays
-    # strictly sequential.)
+    # exchange, one normal map.  (N = 1: FusionPipeline above.)
     overlap = sharded and not args.no_overlap
     side = torch.cuda.Stream() if overlap else None
     filt2 = [filt_dev, torch.empty_like(filt_dev)] if overlap else [filt_dev, filt_dev]
@@ -266,6 +275,10 @@ def main():
 
     def step(i, timed, timed_next=False):
         cam = cams[i]
+        if pipe is not None and not timed:
+            pipe.step(depth_dev[i].data_ptr(), cam, vert_dev.data_ptr(), norm_dev.data_ptr(),
+                      depth_dev[i + 1].data_ptr() if i + 1 < n_frames else None)
+            return
         if i in prefiltered:
             done, pairs = prefiltered.pop(i)
             stream.wait_event(done)
@@ -381,7 +394,8 @@ def main():
         "steps": K,
         "warmup": Wu,
         "event_period": period,     # HIP events inside the timed region on every n-th step (0 = none)
-        "stage_and_kernel_times_from": "untimed replay of the %d timed frames, every launch bracketed with HIP events on the launch stream" % K,
+        "stage_and_kernel_times_from": "untimed replay of the %d timed frames, one stage after the other (no overlap), every launch bracketed with "
+                                       "HIP events on the launch stream" % K,
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True,
         "scaling": "strong",
@@ -393,7 +407,9 @@ def main():
                                "raycast + normals per frame" % (3 if inside else 2, n, args.physical, args.stream_frames,
                                                                 " inside the volume" if inside else "", seed),
                    "grid": [n, n, n], "image": [W, H], "parallelism": "zslab%d" % world,
-                   "overlap": "bilateral + integrate of frame i+1 on a second stream during the exchange of frame i" if overlap else "none",
+                   "overlap": ("bilateral + integrate of frame i+1 on a second stream during the exchange of frame i" if overlap else
+                               "bilateral of frame i+1 on a lower-priority stream during the ray cast of frame i (tsdf_amd.pipeline.FusionPipeline)"
+                               if (pipe is not None and pipe.overlap) else "none"),
                    "depth_tile_maxima": "integrate's own launch" if args.separate_tile_max else "left by the bilateral filter's launch",
                    "collective_backend": (dist.get_backend() if sharded else None), "ranks": (dist.get_world_size() if sharded else 1),
                    "collective": (exch_note if sharded else None)},

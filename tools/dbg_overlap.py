@@ -24,10 +24,13 @@ rc = tsdf_amd.GPURaycaster(W, H)
 
 def run(mode):
     vol = tsdf_amd.TSDFVolume((n, n, n), (3000.0,) * 3)
-    main = torch.cuda.current_stream()
+    main = torch.cuda.Stream(priority=-1) if mode in ("mainhigh", "seqhigh") else torch.cuda.current_stream()
     vol.set_stream(main.cuda_stream)
-    if mode == "seq":
+    rc_stream = main
+    if mode in ("seq", "seqhigh"):
         side = None
+    elif mode == "mainhigh":
+        side = torch.cuda.Stream(priority=0)      # (lower than the main stream: fills what the main stream leaves idle)
     elif mode == "low":
         side = torch.cuda.Stream(priority=0)     # (torch: lower number = higher priority; 0 is the default / lowest)
     elif mode == "high":
@@ -74,8 +77,9 @@ def run(mode):
 
 
 ref = None
+print("stream priority range:", torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else "n/a")
 for rep in range(2):
-    for mode in ("seq", "side", "high"):
+    for mode in ("seq", "seqhigh", "side", "mainhigh"):
         dt, pic = run(mode)
         if ref is None:
             ref = pic

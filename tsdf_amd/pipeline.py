@@ -1,0 +1,75 @@
+"""The per-frame pipeline of the reference's kinfu loop on frames that live in HBM (src/Tools/kinfu.cpp: filter the depth
+frame, integrate it, ray cast the model), with the one piece of a frame that depends on nothing before it -- the bilateral
+filter of the NEXT frame -- queued on a second, lower-priority HIP stream while this frame's ray cast runs.
+
+Why a second stream pays at all on one GPU: every kernel of the step fills the chip while it is in full swing, but each ends
+with a ramp-down (integrate ~10 us, the two ray kernels ~15 and ~20 us) and the small kernels between them (brick cull, reach
+summary, resolve + normals) are chains of memory round trips on a few thousand waves.  A kernel of EQUAL priority beside them
+only takes turns with them (measured: no gain); one of LOWER priority gets the slots the main stream cannot
+use at that moment.  The filter of frame i + 1 is released when integrate of frame i has finished, so it never runs beside
+integrate_kernel (which is bound by memory, not by slots), and it must be done before integrate of frame i + 1 starts: the
+main stream waits for its event.  0.356 -> 0.345 ms per step on the bench stream (tools/dbg_overlap.py).
+
+Results cannot change: the same kernels run on the same inputs, only earlier."""
+import torch
+
+from . import api
+
+
+class FusionPipeline:
+    """step(depth_ptr, camera, vertices_ptr, normals_ptr, next_depth_ptr=None): one frame through filter -> integrate ->
+    raycast (+ normals).  `next_depth_ptr`, when given, is the device pointer of the frame the next call will pass: its filter
+    is queued now.  All pointers are device pointers to width * height uint16 (depth) / 3 * width * height float32 (maps);
+    the depth buffers must stay valid until the frame after them has been processed."""
+
+    def __init__(self, volume, bilateral, raycaster, width, height, overlap=True, release_after_integrate=True):
+        self.volume, self.bilateral, self.raycaster = volume, bilateral, raycaster
+        self.width, self.height = int(width), int(height)
+        self.overlap = bool(overlap)
+        self.release_after_integrate = bool(release_after_integrate)
+        # (torch: a lower number is a higher priority; the range on this device is 0 .. -1)
+        self.main = torch.cuda.Stream(priority=-1) if self.overlap else torch.cuda.current_stream()
+        self.side = torch.cuda.Stream(priority=0) if self.overlap else None
+        volume.set_stream(self.main.cuda_stream)
+        n = self.width * self.height
+        tiles = ((self.width + 15) // 16) * ((self.height + 15) // 16)
+        self._filtered = [torch.empty((n,), dtype=torch.int16, device="cuda") for _ in range(2)]
+        self._tile_max = [torch.empty((tiles,), dtype=torch.int16, device="cuda") for _ in range(2)]
+        self._integrated = [None, None]     # per buffer: the event after the integrate that last read it
+        self._ahead = None                  # (depth_ptr, buffer, event on the side stream) of the frame filtered ahead
+        self._frames = 0
+
+    def _filter(self, depth_ptr, b, stream):
+        self.bilateral.filter_device(depth_ptr, self._filtered[b].data_ptr(), self.width, self.height, bits=16,
+                                     stream=stream.cuda_stream, tile_max_ptr=self._tile_max[b].data_ptr())
+
+    def step(self, depth_ptr, camera, vertices_ptr, normals_ptr=None, next_depth_ptr=None):
+        main, W, H = self.main, self.width, self.height
+        b = self._frames % 2
+        if self._ahead is not None and self._ahead[0] == int(depth_ptr) and self._ahead[1] == b:
+            main.wait_event(self._ahead[2])                 # filtered ahead, on the side stream
+        else:
+            self._filter(depth_ptr, b, main)
+        self._ahead = None
+        self.volume.integrate_device(self._filtered[b].data_ptr(), W, H, camera, tile_max_ptr=self._tile_max[b].data_ptr())
+        if self.overlap:
+            done = torch.cuda.Event()
+            done.record(main)
+            self._integrated[b] = done
+            if next_depth_ptr is not None:
+                # released by THIS frame's integrate (never beside integrate_kernel); the other buffer was last read by the
+                # previous frame's integrate, which lies before it on the main stream
+                gate = done if self.release_after_integrate else self._integrated[1 - b]
+                if gate is not None:
+                    self.side.wait_event(gate)
+                self._filter(next_depth_ptr, 1 - b, self.side)
+                ready = torch.cuda.Event()
+                ready.record(self.side)
+                self._ahead = (int(next_depth_ptr), 1 - b, ready)
+        self.raycaster.raycast_device(self.volume, camera, vertices_ptr, normals_ptr)
+        self._frames += 1
+
+    def synchronize(self):
+        self.main.synchronize()
+        if self.side is not None:
+            self.side.synchronize()
