@@ -276,8 +276,10 @@ def main():
     def step(i, timed, timed_next=False):
         cam = cams[i]
         if pipe is not None and not timed:
+            # (the stream's poses are given, as in BASELINE configs[2]: the next frame's brick culling goes ahead with its filter)
+            nxt = i + 1 if i + 1 < n_frames else None
             pipe.step(depth_dev[i].data_ptr(), cam, vert_dev.data_ptr(), norm_dev.data_ptr(),
-                      depth_dev[i + 1].data_ptr() if i + 1 < n_frames else None)
+                      depth_dev[nxt].data_ptr() if nxt is not None else None, cams[nxt] if nxt is not None else None)
             return
         if i in prefiltered:
             done, pairs = prefiltered.pop(i)
@@ -408,7 +410,7 @@ def main():
                                                                 " inside the volume" if inside else "", seed),
                    "grid": [n, n, n], "image": [W, H], "parallelism": "zslab%d" % world,
                    "overlap": ("bilateral + integrate of frame i+1 on a second stream during the exchange of frame i" if overlap else
-                               "bilateral of frame i+1 on a lower-priority stream during the ray cast of frame i (tsdf_amd.pipeline.FusionPipeline)"
+                               "bilateral + brick culling of frame i+1 on a lower-priority stream during the ray cast of frame i (tsdf_amd.pipeline.FusionPipeline)"
                                if (pipe is not None and pipe.overlap) else "none"),
                    "depth_tile_maxima": "integrate's own launch" if args.separate_tile_max else "left by the bilateral filter's launch",
                    "collective_backend": (dist.get_backend() if sharded else None), "ranks": (dist.get_world_size() if sharded else 1),

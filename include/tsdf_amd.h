@@ -159,6 +159,15 @@ int tsdf_integrate_device(tsdf_volume *volume, const uint16_t *device_depth, uin
 int tsdf_integrate_device_tiles(tsdf_volume *volume, const uint16_t *device_depth, uint32_t width,
                                 uint32_t height, const float pose[16], const float inv_pose[16],
                                 const float k[9], const float kinv[9], const uint16_t *device_tile_max);
+/* The first half of tsdf_integrate_device_tiles ahead of time: the brick culling of a frame (it reads the tile maxima and the
+ * pose, not the volume) on `hip_stream` -- e.g. a lower-priority stream, while the previous frame's ray cast runs on the
+ * volume's stream.  The next tsdf_integrate_device_tiles with the same image, matrices and tile maxima launches only the
+ * integrate kernel; any other integrate call ignores the preparation.  The caller orders the streams: the prepare call after
+ * the volume's previous integrate has finished, the integrate call after the prepare call's work (events).  Same result. */
+int tsdf_integrate_prepare_device_tiles(tsdf_volume *volume, const uint16_t *device_depth, uint32_t width,
+                                        uint32_t height, const float pose[16], const float inv_pose[16],
+                                        const float k[9], const float kinv[9], const uint16_t *device_tile_max,
+                                        void *hip_stream);
 /* Optional kernel timing for roofline reports: when enabled, every launch of integrate_kernel (which = 0) and of
  * process_ray_kernel (which = 1) and process_ray_tail_kernel (which = 2) is bracketed by HIP events on the volume's stream; tsdf_volume_kernel_time
  * synchronises the stream and returns the number of bracketed launches and their average duration since timing was

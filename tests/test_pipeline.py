@@ -10,7 +10,7 @@ from tsdf_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def _run(overlap, release_after_integrate, frames, n):
+def _run(overlap, release_after_integrate, frames, n, prepare=False):
     import torch
     from tsdf_amd.pipeline import FusionPipeline
     vol = tsdf_amd.TSDFVolume((n, n, n), (3000.0,) * 3)
@@ -23,7 +23,8 @@ def _run(overlap, release_after_integrate, frames, n):
     for i, (_, cam) in enumerate(frames):
         # (the third frame is NOT announced: the pipeline must filter it itself when it arrives)
         nxt = depth[i + 1].data_ptr() if i + 1 < len(frames) and i != 1 else None
-        pipe.step(depth[i].data_ptr(), cam, vert.data_ptr(), norm.data_ptr(), nxt)
+        pipe.step(depth[i].data_ptr(), cam, vert.data_ptr(), norm.data_ptr(), nxt,
+                  frames[i + 1][1] if (prepare and nxt is not None) else None)
         pipe.synchronize()
         pictures.append((vert.cpu().numpy().copy(), norm.cpu().numpy().copy()))
     out = (vol.get_distance_data(), vol.get_weight_data(), pictures)
@@ -35,8 +36,8 @@ def test_filter_ahead_gives_the_bits_of_the_sequential_step_and_of_the_oracle(or
     n = 96
     frames = [synth.depth_frame(i * 3, 200, seed=0x5EED0003) for i in range(7)]
     seq = _run(False, True, frames, n)
-    for overlap, gate in ((True, True), (True, False)):
-        got = _run(overlap, gate, frames, n)
+    for overlap, gate, prepare in ((True, True, False), (True, False, False), (True, True, True)):
+        got = _run(overlap, gate, frames, n, prepare)
         assert_same_floats(got[0], seq[0], "distances (overlap, release after integrate = %s)" % gate)
         assert_same_floats(got[1], seq[1], "weights")
         for i, ((v, nn), (vs, ns)) in enumerate(zip(got[2], seq[2])):
@@ -52,3 +53,54 @@ def test_filter_ahead_gives_the_bits_of_the_sequential_step_and_of_the_oracle(or
     Vo, No = ov.raycast(W, H, frames[-1][1].pose(), frames[-1][1].kinv(), nthreads=threads)
     assert_same_floats(seq[2][-1][0], Vo, "last picture vs oracle")
     assert_same_floats(seq[2][-1][1], No, "last normals vs oracle")
+
+
+def test_a_prepared_brick_list_is_used_only_by_the_matching_integrate(oracle):
+    """tsdf_integrate_prepare_device_tiles builds a frame's brick list ahead; an integrate call with other arguments must ignore
+    it (and cull for itself), the matching one must use it, and a second prepare replaces the first -- the volume equals the
+    oracle's after every call."""
+    import torch
+    n = 80
+    s = torch.cuda.current_stream()
+    side = torch.cuda.Stream()
+    bil = tsdf_amd.BilateralFilter(30.0, 4.5)
+    gv = tsdf_amd.TSDFVolume((n, n, n), (3000.0,) * 3)
+    gv.set_stream(s.cuda_stream)
+    ov = oracle.Volume((n, n, n), (3000.0,) * 3)
+    fr = [synth.depth_frame(i * 5, 200, seed=0x5EED0003) for i in range(4)]
+    filt = [torch.empty((H * W,), dtype=torch.int16, device="cuda") for _ in fr]
+    tmax = [torch.empty((1200,), dtype=torch.int16, device="cuda") for _ in fr]
+    for (d, _), f, t in zip(fr, filt, tmax):
+        src = torch.from_numpy(d.view(np.int16).copy()).cuda()
+        bil.filter_device(src.data_ptr(), f.data_ptr(), W, H, bits=16, stream=s.cuda_stream, tile_max_ptr=t.data_ptr())
+    torch.cuda.synchronize()
+
+    def check(i, what):
+        torch.cuda.synchronize()
+        ov.integrate(filt[i].cpu().numpy().view(np.uint16), W, H, fr[i][1].inverse_pose(), fr[i][1].k(), fr[i][1].kinv(),
+                     nthreads=oracle.max_threads())
+        assert_same_floats(gv.get_weight_data(), ov.weight, what + ": weights")
+        assert_same_floats(gv.get_distance_data(), ov.dist, what + ": distances")
+
+    gv.integrate_device(filt[0].data_ptr(), W, H, fr[0][1], tile_max_ptr=tmax[0].data_ptr())
+    check(0, "first frame, nothing prepared")
+    # prepared for frame 1 on another stream, used by frame 1
+    gv.integrate_prepare_device(filt[1].data_ptr(), W, H, fr[1][1], tmax[1].data_ptr(), side.cuda_stream)
+    side.synchronize()
+    gv.integrate_device(filt[1].data_ptr(), W, H, fr[1][1], tile_max_ptr=tmax[1].data_ptr())
+    check(1, "prepared and used")
+    # prepared for frame 3, but frame 2 arrives: the list must be ignored
+    gv.integrate_prepare_device(filt[3].data_ptr(), W, H, fr[3][1], tmax[3].data_ptr(), side.cuda_stream)
+    side.synchronize()
+    gv.integrate_device(filt[2].data_ptr(), W, H, fr[2][1], tile_max_ptr=tmax[2].data_ptr())
+    check(2, "prepared for another frame")
+    # two prepare calls, the second one counts; and the plain entry point (no tile maxima) ignores any preparation
+    gv.integrate_prepare_device(filt[0].data_ptr(), W, H, fr[0][1], tmax[0].data_ptr(), side.cuda_stream)
+    gv.integrate_prepare_device(filt[3].data_ptr(), W, H, fr[3][1], tmax[3].data_ptr(), side.cuda_stream)
+    side.synchronize()
+    gv.integrate_device(filt[3].data_ptr(), W, H, fr[3][1], tile_max_ptr=tmax[3].data_ptr())
+    check(3, "second of two preparations")
+    gv.integrate_prepare_device(filt[1].data_ptr(), W, H, fr[1][1], tmax[1].data_ptr(), side.cuda_stream)
+    side.synchronize()
+    gv.integrate_device(filt[1].data_ptr(), W, H, fr[1][1])
+    check(1, "plain integrate after a preparation")

@@ -13,11 +13,12 @@ for i in range(K + Wu + 1):
 depth = torch.from_numpy(np.stack(frames).view(np.int16)).cuda()
 vert = torch.empty((H * W, 3), dtype=torch.float32, device="cuda"); norm = torch.empty_like(vert)
 bil = tsdf_amd.BilateralFilter(30.0, 4.5); rc = tsdf_amd.GPURaycaster(W, H)
-def run(overlap, gate):
+def run(overlap, gate, prepare=False):
     vol = tsdf_amd.TSDFVolume((n, n, n), (3000.0,) * 3)
     p = FusionPipeline(vol, bil, rc, W, H, overlap=overlap, release_after_integrate=gate)
     def step(i, last):
-        p.step(depth[i].data_ptr(), cams[i], vert.data_ptr(), norm.data_ptr(), None if last else depth[i + 1].data_ptr())
+        p.step(depth[i].data_ptr(), cams[i], vert.data_ptr(), norm.data_ptr(), None if last else depth[i + 1].data_ptr(),
+               cams[i + 1] if (prepare and not last) else None)
     for i in range(Wu): step(i, False)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -28,8 +29,9 @@ def run(overlap, gate):
     return dt, pic
 ref = None
 for rep in range(3):
-    for name, ov, gate in (("sequential", False, True), ("filter ahead, released after integrate", True, True), ("filter ahead, free to start", True, False)):
-        dt, pic = run(ov, gate)
+    for name, ov, gate, prep in (("sequential", False, True, False), ("filter ahead, released after integrate", True, True, False),
+                                 ("filter + brick culling ahead", True, True, True)):
+        dt, pic = run(ov, gate, prep)
         if ref is None: ref = pic
         same = bool(((pic.view(torch.int32) == ref.view(torch.int32)) | (torch.isnan(pic) & torch.isnan(ref))).all().item())
         print("%-42s %.4f ms per step, picture identical: %s" % (name, dt, same), flush=True)

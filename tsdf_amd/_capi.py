@@ -74,6 +74,7 @@ _SIGS = {
     "tsdf_integrate": (_i, [_vp, _vp, _u32, _u32, _fp, _fp, _fp, _fp]),
     "tsdf_integrate_device": (_i, [_vp, _vp, _u32, _u32, _fp, _fp, _fp, _fp]),
     "tsdf_integrate_device_tiles": (_i, [_vp, _vp, _u32, _u32, _fp, _fp, _fp, _fp, _vp]),
+    "tsdf_integrate_prepare_device_tiles": (_i, [_vp, _vp, _u32, _u32, _fp, _fp, _fp, _fp, _vp, _vp]),
     "tsdf_volume_set_timing": (_i, [_vp, _i]),
     "tsdf_volume_kernel_time": (_i, [_vp, _i, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]),
     "tsdf_volume_set_counting": (_i, [_vp, _i]),

@@ -194,6 +194,13 @@ class TSDFVolume:
             check(lib.tsdf_integrate_device(self._h, C.c_void_p(int(depth_ptr)), width, height, _fp(pose), _fp(ipose),
                                             _fp(k), _fp(kinv)))
 
+    def integrate_prepare_device(self, depth_ptr, width, height, camera, tile_max_ptr, stream):
+        """The brick culling of integrate_device(depth_ptr, ..., tile_max_ptr=...) ahead of time, on `stream` (see
+        tsdf_integrate_prepare_device_tiles); the matching integrate_device call then launches the integrate kernel alone."""
+        pose, ipose, k, kinv = _camera_matrices(camera)
+        check(lib.tsdf_integrate_prepare_device_tiles(self._h, C.c_void_p(int(depth_ptr)), width, height, _fp(pose), _fp(ipose),
+                                                      _fp(k), _fp(kinv), C.c_void_p(int(tile_max_ptr)), C.c_void_p(int(stream))))
+
     def occupancy(self):
         """(occupied, total) bricks of the ray caster's empty-space summary."""
         o, t = C.c_uint64(), C.c_uint64()

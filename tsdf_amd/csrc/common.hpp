@@ -19,6 +19,13 @@ struct tsdf_volume;
 
 namespace tsdf {
 
+// What a prepared brick list (tsdf_integrate_prepare_device_tiles) was built for
+struct PreparedCull {
+    const uint16_t *depth, *tile_max;
+    uint32_t width, height;
+    float inv_pose[16], k[9], kinv[9];
+};
+
 // integrate's brick: one wave along x, kIntBrickY waves per workgroup, kIntBrickZ planes walked by a workgroup (integrate.hip)
 #ifndef TSDF_CHUNK_Z
 #define TSDF_CHUNK_Z 32
@@ -192,6 +199,8 @@ struct tsdf_volume {
     // integrate scratch: compact list of bricks a frame can touch (+ its counter), depth tile maxima
     uint32_t *brick_list;
     size_t brick_list_cap;
+    tsdf::PreparedCull prepared;  // the brick list on the device was built for these arguments ...
+    int prepared_valid;           // ... by a prepare call that no integrate has used yet
     uint32_t brick_count_side;    // which of the list's two length words the next integration appends behind (integrate.hip)
     uint32_t *brick_boxes;   // uint4 per active brick: pixel box of the brick's projection
     size_t brick_box_cap;

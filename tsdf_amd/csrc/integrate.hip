@@ -626,8 +626,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     }
 }
 
+// phase: kIntBoth = culling + integrate_kernel on the volume's stream; kIntPrepare = the culling only, on `prepare_stream`
+// (tsdf_integrate_prepare_device_tiles: the brick list of a frame built ahead, e.g. on a lower-priority stream while the
+// previous frame's ray cast runs -- the culling needs the depth image's tile maxima and the pose, not the volume); kIntBoth
+// then finds the list prepared (same image, pose, intrinsics, tile maxima) and launches integrate_kernel alone.
+enum IntegratePhase { kIntBoth = 0, kIntPrepare = 1 };
 static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t width, uint32_t height,
-                            const float inv_pose[16], const float k[9], const float kinv[9], const uint16_t *caller_tile_max = nullptr) {
+                            const float inv_pose[16], const float k[9], const float kinv[9], const uint16_t *caller_tile_max = nullptr,
+                            IntegratePhase phase = kIntBoth, hipStream_t prepare_stream = nullptr) {
     Mat44 ip;
     Mat33 mk, mkinv;
     memcpy(&ip, inv_pose, sizeof(ip));
@@ -647,7 +653,9 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
     const size_t n_bricks = (size_t)bg.nx * bg.ny * bg.nz;
     TSDF_REQUIRE(n_bricks < 0xFFFFFFFFull, "volume too large for the brick list");
 
+    bool fresh_scratch = false;   // scratch allocated (and zeroed, on the volume's stream) by this very call
     if (!v->touched || v->touched_nx != bg.nx || v->touched_ny != bg.ny || v->touched_nz != bg.nz) {
+        fresh_scratch = true;
         if (v->touched) (void)hipFree(v->touched);
         v->touched = nullptr;
         TSDF_HIP(hipMalloc((void **)&v->touched, n_bricks), "touched bricks alloc");
@@ -658,6 +666,7 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
     // scratch: brick list + counter, depth tile maxima
     const uint32_t tiles_x = (width + kDepthTile - 1) / kDepthTile, tiles_y = (height + kDepthTile - 1) / kDepthTile;
     if (v->brick_list_cap < n_bricks + 2) {
+        fresh_scratch = true;
         if (v->brick_list) (void)hipFree(v->brick_list);
         v->brick_list = nullptr;
         v->brick_list_cap = 0;
@@ -674,6 +683,14 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
         v->tile_max_cap = (size_t)tiles_x * tiles_y;
     }
     // the list's length: the last two slots, used alternately (see brick_cull_kernel)
+    // (a prepared list: its length is behind the word the culling of the prepare call used)
+    PreparedCull sig;
+    memset(&sig, 0, sizeof(sig));
+    sig.depth = d_depth; sig.tile_max = caller_tile_max; sig.width = width; sig.height = height;
+    memcpy(sig.inv_pose, inv_pose, sizeof(sig.inv_pose)); memcpy(sig.k, k, sizeof(sig.k)); memcpy(sig.kinv, kinv, sizeof(sig.kinv));
+    const bool prepared = phase == kIntBoth && v->prepared_valid && !v->nodes && memcmp(&sig, &v->prepared, sizeof(sig)) == 0;
+    if (phase == kIntBoth) v->prepared_valid = 0;     // (used up, or stale)
+    if (prepared) v->brick_count_side = 1u - v->brick_count_side;   // back to the side the prepare call appended behind (toggled again below)
     uint32_t *count = v->brick_list + n_bricks + v->brick_count_side, *count_next = v->brick_list + n_bricks + (1u - v->brick_count_side);
     if (v->brick_box_cap < n_bricks) {
         if (v->brick_boxes) (void)hipFree(v->brick_boxes);
@@ -687,19 +704,30 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
     if (!v->plane_const) TSDF_HIP(hipMalloc((void **)&v->plane_const, n_plane_const * 4 * sizeof(float)), "plane constants alloc");
     float4 *plane_const = reinterpret_cast<float4 *>(v->plane_const);
 
-    if (v->counting) TSDF_HIP(hipMemsetAsync(v->counter_dev, 0, sizeof(unsigned long long), v->stream), "reset counter");
-    if (!v->nodes) {
+    if (v->counting && phase == kIntBoth) TSDF_HIP(hipMemsetAsync(v->counter_dev, 0, sizeof(unsigned long long), v->stream), "reset counter");
+    if (prepared) {
+        v->brick_count_side = 1u - v->brick_count_side;
+    } else if (!v->nodes) {
+        const hipStream_t cull_stream = phase == kIntPrepare ? prepare_stream : v->stream;
+        if (phase == kIntPrepare && fresh_scratch) TSDF_HIP(hipStreamSynchronize(v->stream), "integrate scratch");   // (zeroed on the volume's stream)
         // the depth tests need surface z == depth and w == 1 exactly (rigid pose, standard intrinsics)
         const int depth_test = (ip.m41 == 0.0f && ip.m42 == 0.0f && ip.m43 == 0.0f && ip.m44 == 1.0f &&
                                 mkinv.m31 == 0.0f && mkinv.m32 == 0.0f && mkinv.m33 == 1.0f) ? 1 : 0;
         if (!caller_tile_max)
-            hipLaunchKernelGGL(depth_tile_max_kernel, dim3(tiles_x, tiles_y), dim3(64), 0, v->stream, d_depth, width, height,
+            hipLaunchKernelGGL(depth_tile_max_kernel, dim3(tiles_x, tiles_y), dim3(64), 0, cull_stream, d_depth, width, height,
                                tiles_x, v->tile_max);
-        hipLaunchKernelGGL(brick_cull_kernel, dim3((unsigned)((8 * n_bricks + 255) / 256)), dim3(256), 0, v->stream, g, bg, ip, mk,
+        hipLaunchKernelGGL(brick_cull_kernel, dim3((unsigned)((8 * n_bricks + 255) / 256)), dim3(256), 0, cull_stream, g, bg, ip, mk,
                            width, height, caller_tile_max ? caller_tile_max : v->tile_max, tiles_x, depth_test, v->brick_list, boxes, count,
                            count_next, plane_const, n_plane_const);
         v->brick_count_side = 1u - v->brick_count_side;
+        if (phase == kIntPrepare) {
+            TSDF_HIP(hipGetLastError(), "Integrate culling failed");
+            v->prepared = sig;
+            v->prepared_valid = 1;
+            return TSDF_OK;
+        }
     }
+    if (phase == kIntPrepare) return TSDF_OK;   // (custom nodes: every brick is walked, nothing to prepare)
     if (!v->nodes) {   // diagnostics, TSDF_DEBUG_SORT = 1..8: the list reordered on the host (synchronises), to time integrate_kernel on other orders --
                        // 1 index order, 2 scattered, 3 position in the layer then layer, 4 x / z / y (what the cull kernel produces), 5 x / y / z, 6 x then
                        // scattered rows, 7 z / x / y, 8 even rows first
@@ -882,6 +910,15 @@ int tsdf_integrate_device_tiles(tsdf_volume *v, const uint16_t *device_depth, ui
     TSDF_REQUIRE(width > 0 && height > 0, "tsdf_integrate: empty depth map");
     (void)pose;
     return launch_integrate(v, device_depth, width, height, inv_pose, k, kinv, device_tile_max);
+}
+
+int tsdf_integrate_prepare_device_tiles(tsdf_volume *v, const uint16_t *device_depth, uint32_t width, uint32_t height,
+                                        const float pose[16], const float inv_pose[16], const float k[9], const float kinv[9],
+                                        const uint16_t *device_tile_max, void *hip_stream) {
+    TSDF_REQUIRE(v && device_depth && inv_pose && k && kinv && device_tile_max, "tsdf_integrate: null argument");
+    TSDF_REQUIRE(width > 0 && height > 0, "tsdf_integrate: empty depth map");
+    (void)pose;
+    return launch_integrate(v, device_depth, width, height, inv_pose, k, kinv, device_tile_max, kIntPrepare, (hipStream_t)hip_stream);
 }
 
 int tsdf_integrate(tsdf_volume *v, const uint16_t *host_depth, uint32_t width, uint32_t height,

@@ -43,7 +43,9 @@ class FusionPipeline:
         self.bilateral.filter_device(depth_ptr, self._filtered[b].data_ptr(), self.width, self.height, bits=16,
                                      stream=stream.cuda_stream, tile_max_ptr=self._tile_max[b].data_ptr())
 
-    def step(self, depth_ptr, camera, vertices_ptr, normals_ptr=None, next_depth_ptr=None):
+    def step(self, depth_ptr, camera, vertices_ptr, normals_ptr=None, next_depth_ptr=None, next_camera=None):
+        """next_camera (with next_depth_ptr): the next frame's pose is known already (ground-truth trajectories; not when the
+        pose comes from tracking against this frame's ray cast) -- its brick culling is queued behind its filter as well."""
         main, W, H = self.main, self.width, self.height
         b = self._frames % 2
         if self._ahead is not None and self._ahead[0] == int(depth_ptr) and self._ahead[1] == b:
@@ -63,6 +65,10 @@ class FusionPipeline:
                 if gate is not None:
                     self.side.wait_event(gate)
                 self._filter(next_depth_ptr, 1 - b, self.side)
+                if next_camera is not None and self.release_after_integrate:
+                    # (the list, the boxes and the plane constants are free once this frame's integrate_kernel is done)
+                    self.volume.integrate_prepare_device(self._filtered[1 - b].data_ptr(), W, H, next_camera,
+                                                         self._tile_max[1 - b].data_ptr(), self.side.cuda_stream)
                 ready = torch.cuda.Event()
                 ready.record(self.side)
                 self._ahead = (int(next_depth_ptr), 1 - b, ready)
