@@ -370,7 +370,17 @@ def main():
     for i in range(Wu, Wu + K):
         step(i, True, True)
     torch.cuda.synchronize()
-    stage_ms = {s_: (float(np.mean([a.elapsed_time(b) for a, b in ev[s_]])) if ev[s_] else None) for s_ in stage_names}
+    # (mean over the K replayed steps; a step in which the runtime stalls for tens of milliseconds -- it grows its pools of signals
+    # now and then, see above -- is not the stage's time: values beyond 20 x the median are left out and counted)
+    stage_outliers = 0
+
+    def stage_mean(pairs):
+        nonlocal stage_outliers
+        v = np.array([a.elapsed_time(b) for a, b in pairs], np.float64)
+        keep = v <= 20.0 * max(float(np.median(v)), 1e-4)
+        stage_outliers += int((~keep).sum())
+        return float(v[keep].mean())
+    stage_ms = {s_: (stage_mean(ev[s_]) if ev[s_] else None) for s_ in stage_names}
     if os.environ.get("BENCH_DEBUG_STAGES"):
         print("raycast stage per step:", [round(a.elapsed_time(b), 3) for a, b in ev["raycast"]], file=sys.stderr)
     kern = {w: vol.kernel_time(w) for w in ("integrate", "raycast", "raycast_tail")}     # (launches, avg ms), kernel only
@@ -418,6 +428,7 @@ def main():
         "integrate_mvoxels_per_s": round(N_vox / (stage_ms["integrate"] * 1e-3) / 1e6, 1),
         "raycast_mrays_per_s": round(W * H / ((stage_ms["raycast"] + stage_ms["exchange"] + stage_ms["normals"]) * 1e-3) / 1e6, 2),
         "stage_ms": {s: (round(v, 4) if v is not None else None) for s, v in stage_ms.items()},
+        "stage_outliers_dropped": stage_outliers,
         # sum of the finite vertex coordinates of the last frame's picture: equal between runs that differ only in schedule
         "last_frame_vertex_checksum": checksum,
     }
