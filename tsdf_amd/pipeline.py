@@ -36,6 +36,10 @@ class FusionPipeline:
         self._filtered = [torch.empty((n,), dtype=torch.int16, device="cuda") for _ in range(2)]
         self._tile_max = [torch.empty((tiles,), dtype=torch.int16, device="cuda") for _ in range(2)]
         self._integrated = [None, None]     # per buffer: the event after the integrate that last read it
+        # (the events are made once and recorded again every other frame: creating one per frame makes the runtime grow its
+        # pool of signals now and then, a stall of tens of milliseconds in the middle of a stream)
+        self._done_events = [torch.cuda.Event(), torch.cuda.Event()] if self.overlap else None
+        self._ready_events = [torch.cuda.Event(), torch.cuda.Event()] if self.overlap else None
         self._ahead = None                  # (depth_ptr, buffer, event on the side stream) of the frame filtered ahead
         self._frames = 0
 
@@ -55,7 +59,7 @@ class FusionPipeline:
         self._ahead = None
         self.volume.integrate_device(self._filtered[b].data_ptr(), W, H, camera, tile_max_ptr=self._tile_max[b].data_ptr())
         if self.overlap:
-            done = torch.cuda.Event()
+            done = self._done_events[b]
             done.record(main)
             self._integrated[b] = done
             if next_depth_ptr is not None:
@@ -69,7 +73,7 @@ class FusionPipeline:
                     # (the list, the boxes and the plane constants are free once this frame's integrate_kernel is done)
                     self.volume.integrate_prepare_device(self._filtered[1 - b].data_ptr(), W, H, next_camera,
                                                          self._tile_max[1 - b].data_ptr(), self.side.cuda_stream)
-                ready = torch.cuda.Event()
+                ready = self._ready_events[1 - b]
                 ready.record(self.side)
                 self._ahead = (int(next_depth_ptr), 1 - b, ready)
         self.raycaster.raycast_device(self.volume, camera, vertices_ptr, normals_ptr)
