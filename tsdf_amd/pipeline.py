@@ -1,6 +1,7 @@
-"""The per-frame pipeline of the reference's kinfu loop on frames that live in HBM (src/Tools/kinfu.cpp: filter the depth
-frame, integrate it, ray cast the model), with the one piece of a frame that depends on nothing before it -- the bilateral
-filter of the NEXT frame -- queued on a second, lower-priority HIP stream while this frame's ray cast runs.
+"""The per-frame step of BASELINE configs[2] -- bilateral filter, integrate, ray cast + normals, frame after frame as the
+reference's kinfu loop integrates them (src/Tools/kinfu.cpp:32-56: one blocking call per frame on host buffers) -- on frames
+that live in HBM, with the one piece of a frame that depends on nothing before it -- the bilateral filter of the NEXT frame
+-- queued on a second, lower-priority HIP stream while this frame's ray cast runs.
 
 Why a second stream pays at all on one GPU: every kernel of the step fills the chip while it is in full swing, but each ends
 with a ramp-down (integrate ~10 us, the two ray kernels ~15 and ~20 us) and the small kernels between them (brick cull, reach
@@ -8,7 +9,8 @@ summary, resolve + normals) are chains of memory round trips on a few thousand w
 only takes turns with them (measured: no gain); one of LOWER priority gets the slots the main stream cannot
 use at that moment.  The filter of frame i + 1 is released when integrate of frame i has finished, so it never runs beside
 integrate_kernel (which is bound by memory, not by slots), and it must be done before integrate of frame i + 1 starts: the
-main stream waits for its event.  0.356 -> 0.345 ms per step on the bench stream (tools/dbg_overlap.py).
+main stream waits for its event.  0.342-0.351 -> 0.328-0.333 ms per step on the bench stream (tools/dbg_pipeline.py), 0.324-0.326
+with the next frame's brick culling queued behind its filter (next_camera).
 
 Results cannot change: the same kernels run on the same inputs, only earlier."""
 import torch
