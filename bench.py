@@ -237,91 +237,66 @@ def main():
     vol.set_stream(stream.cuda_stream)
     bil = tsdf_amd.BilateralFilter(30.0, 4.5)
     rc = tsdf_amd.GPURaycaster(W, H)
-    # N = 1: the step runs through tsdf_amd.pipeline.FusionPipeline -- filter, integrate, ray cast + normals on one stream, and
-    # the NEXT frame's filter (it depends on nothing before it) on a second stream of lower priority, released when this
-    # frame's integrate is done: it fills the ramp-downs and the latency-bound small kernels of the ray cast (--no-overlap:
-    # strictly one after the other).  Every timed step still holds one filter, one integrate, one ray cast.
-    pipe = None
-    if not sharded:
-        from tsdf_amd.pipeline import FusionPipeline
-        pipe = FusionPipeline(vol, bil, rc, W, H, overlap=not args.no_overlap)
-        stream = pipe.main          # (the volume's stream now)
+    # The step runs through tsdf_amd.pipeline.FusionPipeline -- filter, integrate, ray cast + normals on one stream, and the NEXT
+    # frame's filter and brick culling (they depend on nothing before them; the stream's poses are given, as in BASELINE
+    # configs[2]) on a second stream of lower priority, released when this frame's integrate is done: they fill the ramp-downs
+    # and the latency-bound small kernels of the ray cast (--no-overlap: strictly one after the other).  N > 1: the ray cast is
+    # the rank's slab cast, the frame's all-gather and the merge of the ranks' records, all on the step's stream.  Every timed
+    # step holds one filter, one integrate, one ray cast (one exchange).
+    from tsdf_amd.pipeline import FusionPipeline
+
+    def exchange_hits(on):
+        if share:   # gloo: stage through the host
+            h_all = torch.empty(hits_all.shape, dtype=hits_all.dtype)
+            on.synchronize()
+            dist.all_gather_into_tensor(h_all.view(-1), hits_mine.cpu().view(-1))
+            with torch.cuda.stream(on):
+                hits_all.copy_(h_all)
+        elif exch is not None:
+            exch.all_gather(hits_mine, hits_all, on.cuda_stream)
+        else:
+            with torch.cuda.stream(on):     # (torch orders the process group's stream against the current stream)
+                dist.all_gather_into_tensor(hits_all.view(-1), hits_mine.view(-1))
+
+    overlap = not args.no_overlap
+    pipe = FusionPipeline(vol, bil, rc, W, H, overlap=overlap, slab_exchange=(hits_mine, hits_all, exchange_hits) if sharded else None)
+    stream = pipe.main          # (the volume's stream now)
 
     trace("volume and slab plan ready")
     stage_names = ["bilateral", "integrate", "raycast", "exchange", "normals"]
     ev = {s: [] for s in stage_names}
 
-    # N > 1: while the hit records are exchanged and merged the compute units idle, and the next frame's filter + integrate
-    # depend on nothing the exchange produces: they are queued on a second stream as soon as this frame's slab cast has read the
-    # volume (two filtered-frame buffers).  Every timed step still contains one filter, one integrate, one ray cast, one
-    # exchange, one normal map.  (N = 1: FusionPipeline above.)
-    overlap = sharded and not args.no_overlap
-    side = torch.cuda.Stream() if overlap else None
-    filt2 = [filt_dev, torch.empty_like(filt_dev)] if overlap else [filt_dev, filt_dev]
-    prefiltered = {}        # frame index -> (event on the side stream: filtered and integrated, timing pairs or None)
-
-    def filter_and_integrate(i, on, timed):
-        """bilateral + integrate of frame i on stream `on`; returns the event pairs (bilateral, integrate) when timed."""
-        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if timed else None
-        fbuf = filt2[i % 2]
-        if timed: e[0].record(on)
-        bil.filter_device(depth_dev[i].data_ptr(), fbuf.data_ptr(), W, H, bits=16, stream=on.cuda_stream, tile_max_ptr=tiles_of(i))
-        if timed: e[1].record(on)
-        vol.set_stream(on.cuda_stream)
-        vol.integrate_device(fbuf.data_ptr(), W, H, cams[i], tile_max_ptr=tiles_of(i))
-        vol.set_stream(stream.cuda_stream)
-        if timed: e[2].record(on)
-        return ((e[0], e[1]), (e[1], e[2])) if timed else None
-
     def step(i, timed, timed_next=False):
+        """timed: the replay -- one stage after the other on the step's stream, every stage between two events."""
         cam = cams[i]
-        if pipe is not None and not timed:
-            # (the stream's poses are given, as in BASELINE configs[2]: the next frame's brick culling goes ahead with its filter)
+        if not timed:
             nxt = i + 1 if i + 1 < n_frames else None
             pipe.step(depth_dev[i].data_ptr(), cam, vert_dev.data_ptr(), norm_dev.data_ptr(),
                       depth_dev[nxt].data_ptr() if nxt is not None else None, cams[nxt] if nxt is not None else None)
             return
-        if i in prefiltered:
-            done, pairs = prefiltered.pop(i)
-            stream.wait_event(done)
-        else:
-            pairs = filter_and_integrate(i, stream, timed)
-        if timed and pairs is not None:
-            ev["bilateral"].append(pairs[0])
-            ev["integrate"].append(pairs[1])
-        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timed else None
-        if timed: e[0].record(stream)
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        e[0].record(stream)
+        bil.filter_device(depth_dev[i].data_ptr(), filt_dev.data_ptr(), W, H, bits=16, stream=stream.cuda_stream, tile_max_ptr=tiles_of(0))
+        e[1].record(stream)
+        vol.integrate_device(filt_dev.data_ptr(), W, H, cam, tile_max_ptr=tiles_of(0))
+        e[2].record(stream)
         if not sharded:
             rc.raycast_device(vol, cam, vert_dev.data_ptr(), None if os.environ.get('BENCH_SPLIT_NORMALS') else norm_dev.data_ptr())   # vertices and normals in one go
-            if timed: e[1].record(stream)
+            e[3].record(stream)
         else:
             rc.raycast_slab_device(vol, cam, hits_mine.data_ptr())
-            if timed: e[1].record(stream)
-            if overlap and i + 1 < n_frames:
-                cast = torch.cuda.Event()
-                cast.record(stream)            # the slab cast has read the volume: frame i+1 may go in, on the idle compute units
-                side.wait_event(cast)
-                nxt = filter_and_integrate(i + 1, side, timed_next)
-                done = torch.cuda.Event()
-                done.record(side)
-                prefiltered[i + 1] = (done, nxt)
-            if share:   # gloo: stage through the host
-                h_all = torch.empty(hits_all.shape, dtype=hits_all.dtype)
-                dist.all_gather_into_tensor(h_all.view(-1), hits_mine.cpu().view(-1))
-                hits_all.copy_(h_all)
-            elif exch is not None:
-                exch.all_gather(hits_mine, hits_all, stream.cuda_stream)
-            else:
-                dist.all_gather_into_tensor(hits_all.view(-1), hits_mine.view(-1))
+            e[3].record(stream)
+            exchange_hits(stream)
             tsdf_amd.merge_hits_normals_device(hits_all.data_ptr(), world, W, H, vert_dev.data_ptr(), norm_dev.data_ptr(), stream.cuda_stream)   # merged vertices and their normals in one go
-        if timed: e[2].record(stream)
+        e[4].record(stream)
         if os.environ.get('BENCH_SPLIT_NORMALS'):    # (the ray cast, or the merge of the slabs' records, has formed the normals with the vertices)
             tsdf_amd.compute_normals_device(W, H, vert_dev.data_ptr(), norm_dev.data_ptr(), stream.cuda_stream)
-        if timed:
-            e[3].record(stream)
-            ev["raycast"].append((e[0], e[1]))
-            ev["exchange"].append((e[1], e[2]))
-            ev["normals"].append((e[2], e[3]))
+        e[5].record(stream)
+        ev["bilateral"].append((e[0], e[1]))
+        ev["integrate"].append((e[1], e[2]))
+        ev["raycast"].append((e[2], e[3]))
+        ev["exchange"].append((e[3], e[4]))
+        ev["normals"].append((e[4], e[5]))
 
     def barrier():
         if sharded:
@@ -365,7 +340,6 @@ def main():
     # src/TSDF/TSDFVolume.cu:355,366 -- so the byte model prices exactly the launches that were timed)
     for s_ in stage_names:
         ev[s_].clear()
-    prefiltered.clear()
     vol.set_timing(1)
     for i in range(Wu, Wu + K):
         step(i, True, True)
@@ -385,7 +359,6 @@ def main():
         print("raycast stage per step:", [round(a.elapsed_time(b), 3) for a, b in ev["raycast"]], file=sys.stderr)
     kern = {w: vol.kernel_time(w) for w in ("integrate", "raycast", "raycast_tail")}     # (launches, avg ms), kernel only
     vol.set_timing(False)
-    prefiltered.clear()
     vol.set_counting(True)
     U_frames = []
     for i in range(Wu, Wu + K):
@@ -419,9 +392,8 @@ def main():
                                "raycast + normals per frame" % (3 if inside else 2, n, args.physical, args.stream_frames,
                                                                 " inside the volume" if inside else "", seed),
                    "grid": [n, n, n], "image": [W, H], "parallelism": "zslab%d" % world,
-                   "overlap": ("bilateral + integrate of frame i+1 on a second stream during the exchange of frame i" if overlap else
-                               "bilateral + brick culling of frame i+1 on a lower-priority stream during the ray cast of frame i (tsdf_amd.pipeline.FusionPipeline)"
-                               if (pipe is not None and pipe.overlap) else "none"),
+                   "overlap": ("bilateral + brick culling of frame i+1 on a lower-priority stream during the ray cast of frame i (tsdf_amd.pipeline.FusionPipeline)"
+                               if pipe.overlap else "none"),
                    "depth_tile_maxima": "integrate's own launch" if args.separate_tile_max else "left by the bilateral filter's launch",
                    "collective_backend": (dist.get_backend() if sharded else None), "ranks": (dist.get_world_size() if sharded else 1),
                    "collective": (exch_note if sharded else None)},

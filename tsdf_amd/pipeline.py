@@ -24,13 +24,22 @@ class FusionPipeline:
     is queued now.  All pointers are device pointers to width * height uint16 (depth) / 3 * width * height float32 (maps);
     the depth buffers must stay valid until the frame after them has been processed."""
 
-    def __init__(self, volume, bilateral, raycaster, width, height, overlap=True, release_after_integrate=True):
+    def __init__(self, volume, bilateral, raycaster, width, height, overlap=True, release_after_integrate=True, slab_exchange=None):
+        """slab_exchange = (hits_mine, hits_all, exchange): the volume is one rank's Z-slab; a step ray casts the slab into
+        `hits_mine` ((W*H, 4) float32), calls exchange(stream) -- the frame's all-gather into `hits_all` ((world, W*H, 4)),
+        enqueued on or ordered behind `stream` -- and merges the ranks' records into the vertex and normal maps."""
         self.volume, self.bilateral, self.raycaster = volume, bilateral, raycaster
         self.width, self.height = int(width), int(height)
         self.overlap = bool(overlap)
         self.release_after_integrate = bool(release_after_integrate)
+        self.slab_exchange = slab_exchange
         # (torch: a lower number is a higher priority; the range on this device is 0 .. -1)
-        self.main = torch.cuda.Stream(priority=-1) if self.overlap else torch.cuda.current_stream()
+        import os
+        # With a slab exchange the two streams get EQUAL priority: ncclAllGather enqueued on a stream of raised priority made the
+        # one-rank step 0.58 ms instead of 0.37 (RCCL 2.26.6; torch's collective is not affected), and equal priorities still
+        # give 0.366 against 0.381 without the second stream.  TSDF_PIPE_EQUAL_PRIORITY=1 forces that everywhere (diagnostics).
+        equal = os.environ.get("TSDF_PIPE_EQUAL_PRIORITY") == "1" or slab_exchange is not None
+        self.main = torch.cuda.Stream(priority=0 if equal else -1) if self.overlap else torch.cuda.current_stream()
         self.side = torch.cuda.Stream(priority=0) if self.overlap else None
         volume.set_stream(self.main.cuda_stream)
         n = self.width * self.height
@@ -78,7 +87,16 @@ class FusionPipeline:
                 ready = self._ready_events[1 - b]
                 ready.record(self.side)
                 self._ahead = (int(next_depth_ptr), 1 - b, ready)
-        self.raycaster.raycast_device(self.volume, camera, vertices_ptr, normals_ptr)
+        if self.slab_exchange is None:
+            self.raycaster.raycast_device(self.volume, camera, vertices_ptr, normals_ptr)
+        else:
+            hits_mine, hits_all, exchange = self.slab_exchange
+            self.raycaster.raycast_slab_device(self.volume, camera, hits_mine.data_ptr())
+            exchange(main)
+            if normals_ptr is not None:
+                api.merge_hits_normals_device(hits_all.data_ptr(), hits_all.shape[0], W, H, vertices_ptr, normals_ptr, main.cuda_stream)
+            else:
+                api.merge_hits_device(hits_all.data_ptr(), hits_all.shape[0], W, H, vertices_ptr, main.cuda_stream)
         self._frames += 1
 
     def synchronize(self):
