@@ -76,8 +76,10 @@ __global__ __launch_bounds__(256) void bilateral_kernel(const PIX *__restrict__ 
     const int radius = R > 0 ? R : radius_arg;
     const int n = 2 * radius + 1;
     const int span = kBTile + 2 * radius;
+    // (the double-precision copy of the tile serves the run-time-radius path only: the staged path widens the intensity from the
+    // word it has read for the similarity look-up, and neither allocates nor fills the copy -- 7 KB of LDS per workgroup less)
     double *tile_d = reinterpret_cast<double *>(smem_raw);
-    float *kern_lds = reinterpret_cast<float *>(tile_d + span * span);
+    float *kern_lds = reinterpret_cast<float *>(tile_d + (STAGED ? 0 : span * span));
     float *sim_lds = kern_lds + n * n;
     uint32_t *tile4 = reinterpret_cast<uint32_t *>(sim_lds + (STAGED ? kSimLds : 0));
     const int tx0 = blockIdx.x * kBTile - radius;
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256) void bilateral_kernel(const PIX *__restrict__ 
         unsigned v = 0;
         if (gx >= 0 && gx < width && gy >= 0 && gy < height) v = in[(size_t)gy * width + gx];
         tile4[i] = v * 4u;
-        tile_d[i] = (double)(int)v;
+        if (!STAGED) tile_d[i] = (double)(int)v;
     }
     for (int i = threadIdx.x; i < n * n; i += 256) kern_lds[i] = kernel[i];
     if (STAGED) {
@@ -235,7 +237,7 @@ static int launch_bilateral(const tsdf_bilateral *f, const PIX *in, PIX *out, in
     static const int variant = [] { const char *e = getenv("TSDF_BIL_VARIANT"); return e ? atoi(e) : 1; }();   // tuning aid: 0 = plain loops
     static const int debug_skip = [] { const char *e = getenv("TSDF_BIL_DEBUG_SKIP"); return e ? atoi(e) : 0; }();
     const bool staged = f->radius == 7 && variant >= 1;      // the depth filter of the pipeline: sigma_space 4.5 -> 15 x 15 taps
-    size_t smem = (size_t)span * span * (sizeof(double) + sizeof(uint32_t)) + (size_t)n * n * sizeof(float) +
+    size_t smem = (size_t)span * span * ((staged ? 0 : sizeof(double)) + sizeof(uint32_t)) + (size_t)n * n * sizeof(float) +
                   (staged ? kSimLds * sizeof(float) : 0);
     if (staged)
         hipLaunchKernelGGL((bilateral_kernel<PIX, 7>), grid, dim3(256), smem, s, in, out, width, height, f->radius, f->kernel_dev,
