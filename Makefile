@@ -7,7 +7,7 @@ ARCH     ?= gfx950
 # -ffp-contract=off: every fp32 op rounds on its own, in the reference's order (parity contract)
 HIPFLAGS  = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Iinclude -Itsdf_amd/csrc -Wall -Wno-unused-function
 CSRC      = tsdf_amd/csrc
-HIP_SRCS  = $(CSRC)/volume.hip $(CSRC)/integrate.hip $(CSRC)/raycast.hip $(CSRC)/bilateral.hip $(CSRC)/icp.hip $(CSRC)/mcubes.hip
+HIP_SRCS  = $(CSRC)/volume.hip $(CSRC)/integrate.hip $(CSRC)/raycast.hip $(CSRC)/bilateral.hip $(CSRC)/icp.hip $(CSRC)/mcubes.hip $(CSRC)/pipeline.hip
 HIP_OBJS  = $(HIP_SRCS:.hip=.o)
 LIBDIR    = tsdf_amd/lib
 
@@ -45,13 +45,18 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.hpp include/tsdf_amd.h
 
 $(LIBDIR)/libtsdf_hip.so: $(HIP_OBJS)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(HIP_OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(HIP_OBJS) -ldl
 
 oracle:
 	$(MAKE) -C oracle -s all
 
 # C++ test program of the class surface (run by tests/test_cpp_surface.py on the GPU box)
-cpptest: build/test_surface
+cpptest: build/test_surface build/kinfu_stream
+
+# C++ driver of BASELINE configs[2] (TUM directory -> tsdf_pipeline_step, no Python): tools/kinfu_stream.cpp
+build/kinfu_stream: tools/kinfu_stream.cpp $(LIBDIR)/libtsdf_host.so include/tsdf_amd.h
+	@mkdir -p build
+	$(CXX) $(HOSTFLAGS) -o $@ tools/kinfu_stream.cpp -L$(LIBDIR) -ltsdf_host -ltsdf_hip -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)'
 
 build/test_surface: tests/cpp/test_surface.cpp $(LIBDIR)/libtsdf_host.so
 	@mkdir -p build

@@ -7,7 +7,7 @@ A "step" is one 640x480 depth frame of the synthetic TUM surrogate (tsdf_amd/syn
 whole path on a 512^3 / 3000 mm volume (BASELINE.json configs[2]); inputs are resident in HBM before the
 timed region starts.  N > 1: the volume is split into N Z-slabs, one process per GPU (torch.distributed over
 RCCL); every rank integrates its slab (+1 halo plane), ray casts the samples it owns, and one all-gather of
-16-byte hit records per pixel is merged by a min-k select.  Total work is fixed => "strong".
+8-byte hit records {k, t} per pixel is merged by a min-k select.  Total work is fixed => "strong".
 
 Rank 0 prints ONE JSON line.  `value` = voxels of the grid pushed through the whole step per second (whole
 job); per-stage figures (integrate Mvoxels/s, raycast Mrays/s), the roofline of the dominant kernel and the
@@ -156,7 +156,7 @@ def main():
         vol = tsdf_amd.TSDFVolume((n, n, n), (args.physical,) * 3)
     else:
         from tsdf_amd.multi import balanced_slab_ranges, plane_costs, refine_slab_ranges, slab_range
-        hits_probe = torch.empty((H * W, 4), dtype=torch.float32, device="cuda")
+        hits_probe = torch.empty((H * W, 2), dtype=torch.float32, device="cuda")    # {k, t} records
         bil0 = tsdf_amd.BilateralFilter(30.0, 4.5)
         rc0 = tsdf_amd.GPURaycaster(W, H)
         s0 = torch.cuda.current_stream()
@@ -222,22 +222,37 @@ def main():
             best[2].close()          # (a fresh volume below: the probe frames must not stay integrated)
         zb, ze = slab_plan[rank]
         vol = tsdf_amd.TSDFVolume((n, n, n), (args.physical,) * 3, slab=(zb, ze))
-        hits_mine = torch.empty((H * W, 4), dtype=torch.float32, device="cuda")
-        hits_all = torch.empty((world, H * W, 4), dtype=torch.float32, device="cuda")
-        # the frame's collective on the step's own stream (RCCL called directly); torch's collective if that cannot be set up
+        # the frame's collective on the step's own stream (RCCL called directly by the C++ library: tsdf_slab_exchange); torch's
+        # collective, through the same object's callback form, if that cannot be set up
+        from tsdf_amd.multi import SlabExchange
+
+        def torch_all_gather(mine, allr, stream_ptr):
+            on = torch.cuda.ExternalStream(stream_ptr) if stream_ptr else torch.cuda.default_stream()
+            if share:   # gloo: staged through the host
+                h_all = torch.empty(allr.shape, dtype=allr.dtype)
+                on.synchronize()
+                dist.all_gather_into_tensor(h_all, mine.cpu())
+                with torch.cuda.stream(on):
+                    allr.copy_(h_all)
+            else:
+                with torch.cuda.stream(on):     # (torch orders the process group's stream against the current stream)
+                    dist.all_gather_into_tensor(allr, mine)
+
         exch, exch_note = None, "torch.distributed.all_gather_into_tensor (gloo, staged through the host)" if share else "torch.distributed.all_gather_into_tensor"
         if not share and not args.torch_collective:
             try:
-                from tsdf_amd.multi import StreamAllGather
-                exch = StreamAllGather()
-                exch_note = "ncclAllGather on the step's stream (librccl, own communicator)"
+                exch = SlabExchange()
+                exch_note = "ncclAllGather on the step's stream (tsdf_slab_exchange: librccl, own communicator)"
             except Exception as e_:      # (every rank takes the same branch: the failure modes are a missing library or symbol)
                 exch_note += " (direct RCCL unavailable: %s)" % e_
+        if exch is None:
+            exch = SlabExchange(callback=torch_all_gather)
     stream = torch.cuda.current_stream()
     vol.set_stream(stream.cuda_stream)
     bil = tsdf_amd.BilateralFilter(30.0, 4.5)
     rc = tsdf_amd.GPURaycaster(W, H)
-    # The step runs through tsdf_amd.pipeline.FusionPipeline -- filter, integrate, ray cast + normals on one stream, and the NEXT
+    # The step runs through tsdf_pipeline_step (C++ behind the C ABI, tsdf_amd/csrc/pipeline.hip; tsdf_amd.pipeline.FusionPipeline is
+    # its ctypes mirror) -- filter, integrate, ray cast + normals on one stream, and the NEXT
     # frame's filter and brick culling (they depend on nothing before them; the stream's poses are given, as in BASELINE
     # configs[2]) on a second stream of lower priority, released when this frame's integrate is done: they fill the ramp-downs
     # and the latency-bound small kernels of the ray cast (--no-overlap: strictly one after the other).  N > 1: the ray cast is
@@ -245,22 +260,17 @@ def main():
     # step holds one filter, one integrate, one ray cast (one exchange).
     from tsdf_amd.pipeline import FusionPipeline
 
-    def exchange_hits(on):
-        if share:   # gloo: stage through the host
-            h_all = torch.empty(hits_all.shape, dtype=hits_all.dtype)
-            on.synchronize()
-            dist.all_gather_into_tensor(h_all.view(-1), hits_mine.cpu().view(-1))
-            with torch.cuda.stream(on):
-                hits_all.copy_(h_all)
-        elif exch is not None:
-            exch.all_gather(hits_mine, hits_all, on.cuda_stream)
-        else:
-            with torch.cuda.stream(on):     # (torch orders the process group's stream against the current stream)
-                dist.all_gather_into_tensor(hits_all.view(-1), hits_mine.view(-1))
-
     overlap = not args.no_overlap
-    pipe = FusionPipeline(vol, bil, rc, W, H, overlap=overlap, slab_exchange=(hits_mine, hits_all, exchange_hits) if sharded else None)
+    pipe = FusionPipeline(vol, bil, rc, W, H, overlap=overlap, exchange=exch if sharded else None,
+                          exchange_stream=os.environ.get("TSDF_PIPE_EXCHANGE_STREAM") == "1")
     stream = pipe.main          # (the volume's stream now)
+    if sharded:                 # the pipeline's record buffers, for the stage-by-stage replay
+        from tsdf_amd.multi import device_words
+        mine_ptr, all_ptr = pipe.hit_buffers()
+        hits_mine, hits_all = device_words(mine_ptr, 2 * H * W), device_words(all_ptr, 2 * H * W * world)
+
+    def exchange_hits(on):
+        exch.all_gather(hits_mine, hits_all, on.cuda_stream)
 
     trace("volume and slab plan ready")
     stage_names = ["bilateral", "integrate", "raycast", "exchange", "normals"]
@@ -287,7 +297,7 @@ def main():
             rc.raycast_slab_device(vol, cam, hits_mine.data_ptr())
             e[3].record(stream)
             exchange_hits(stream)
-            tsdf_amd.merge_hits_normals_device(hits_all.data_ptr(), world, W, H, vert_dev.data_ptr(), norm_dev.data_ptr(), stream.cuda_stream)   # merged vertices and their normals in one go
+            tsdf_amd.merge_hits_normals_device(vol, hits_all.data_ptr(), world, W, H, cam, vert_dev.data_ptr(), norm_dev.data_ptr(), stream.cuda_stream)   # merged vertices and their normals in one go
         e[4].record(stream)
         if os.environ.get('BENCH_SPLIT_NORMALS'):    # (the ray cast, or the merge of the slabs' records, has formed the normals with the vertices)
             tsdf_amd.compute_normals_device(W, H, vert_dev.data_ptr(), norm_dev.data_ptr(), stream.cuda_stream)
@@ -392,7 +402,7 @@ def main():
                                "raycast + normals per frame" % (3 if inside else 2, n, args.physical, args.stream_frames,
                                                                 " inside the volume" if inside else "", seed),
                    "grid": [n, n, n], "image": [W, H], "parallelism": "zslab%d" % world,
-                   "overlap": ("bilateral + brick culling of frame i+1 on a lower-priority stream during the ray cast of frame i (tsdf_amd.pipeline.FusionPipeline)"
+                   "overlap": ("bilateral + brick culling of frame i+1 on a lower-priority stream during the ray cast of frame i (tsdf_pipeline_step, C++)"
                                if pipe.overlap else "none"),
                    "depth_tile_maxima": "integrate's own launch" if args.separate_tile_max else "left by the bilateral filter's launch",
                    "collective_backend": (dist.get_backend() if sharded else None), "ranks": (dist.get_world_size() if sharded else 1),
@@ -515,6 +525,7 @@ def main():
         os.write(json_fd, (json.dumps(finite(out), allow_nan=False) + "\n").encode())
     if sharded:
         dist.barrier()
+        pipe.close()
         if exch is not None:
             exch.close()
         dist.destroy_process_group()

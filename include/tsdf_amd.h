@@ -74,6 +74,13 @@ int tsdf_get_device(int *device);
 /* Name of the GPU architecture the library was compiled for ("gfx950"). */
 const char *tsdf_build_arch(void);
 
+/* Device memory for callers that keep frames and maps resident in HBM (the _device entry points, tsdf_pipeline_*) without
+ * including the HIP headers: hipMalloc / hipFree / blocking hipMemcpy. */
+int tsdf_device_alloc(size_t bytes, void **device_ptr);
+int tsdf_device_free(void *device_ptr);
+int tsdf_device_upload(void *device_dst, const void *host_src, size_t bytes);
+int tsdf_device_download(void *host_dst, const void *device_src, size_t bytes);
+
 /* ---- volume lifecycle ------------------------------------------------------------------ */
 /* Replaces TSDFVolume::TSDFVolume / set_size (src/TSDF/TSDFVolume.cu:430-457, 679-722):
  * validates sizes (TSDF_ERR_INVALID if any is zero/negative), computes voxel size and
@@ -163,11 +170,15 @@ int tsdf_integrate_device_tiles(tsdf_volume *volume, const uint16_t *device_dept
  * pose, not the volume) on `hip_stream` -- e.g. a lower-priority stream, while the previous frame's ray cast runs on the
  * volume's stream.  The next tsdf_integrate_device_tiles with the same image, matrices and tile maxima launches only the
  * integrate kernel; any other integrate call ignores the preparation.  The caller orders the streams: the prepare call after
- * the volume's previous integrate has finished, the integrate call after the prepare call's work (events).  Same result. */
+ * the volume's previous integrate has finished, the integrate call after the prepare call's work (events).  Same result.
+ * The preparation is recognised by the ARGUMENTS (pointers, sizes, matrices), not by the buffers' content: between the prepare
+ * call and the integrate call the image and its tile maxima must not be rewritten -- a caller that does rewrite them calls
+ * tsdf_integrate_discard_prepared first (clear, a new offset or header, set_deformation discard it themselves). */
 int tsdf_integrate_prepare_device_tiles(tsdf_volume *volume, const uint16_t *device_depth, uint32_t width,
                                         uint32_t height, const float pose[16], const float inv_pose[16],
                                         const float k[9], const float kinv[9], const uint16_t *device_tile_max,
                                         void *hip_stream);
+int tsdf_integrate_discard_prepared(tsdf_volume *volume);
 /* Optional kernel timing for roofline reports: when enabled, every launch of integrate_kernel (which = 0) and of
  * process_ray_kernel (which = 1) and process_ray_tail_kernel (which = 2) is bracketed by HIP events on the volume's stream; tsdf_volume_kernel_time
  * synchronises the stream and returns the number of bracketed launches and their average duration since timing was
@@ -227,17 +238,82 @@ int tsdf_volume_get_occupancy_data(const tsdf_volume *volume, int force_rebuild,
 int tsdf_volume_marching_cubes(const tsdf_volume *volume, const int8_t *table, uint64_t *n_vertices, float *host_vertices,
                                uint64_t capacity);
 
-/* Multi-GPU raycast: a slab evaluates only the samples whose lower trilinear
- * tap plane it owns and writes one 16-byte record per pixel {k, x, y, z}: k = index of the
- * first owned sample with tsdf <= 0 (+inf if none).  After an all-gather of the records,
- * tsdf_merge_hits_device keeps, per pixel, the record with the smallest k. */
+/* Multi-GPU raycast: a slab evaluates only the samples whose lower trilinear tap plane it owns and writes
+ * one 8-byte record per pixel: k = index of the first owned sample with tsdf <= 0 (TSDF_NO_HIT if none), t = that sample's
+ * refined ray parameter (src/RayCaster/GPURaycaster.cu:338-341).  After an all-gather of the records (layout
+ * [slab][pixel]), tsdf_merge_hits_device keeps, per pixel, the record with the smallest k and forms the vertex
+ * space_min + (start + t * dir) with the reference's expressions (:306, :344-347): start and dir are functions of the pixel
+ * and the pose, which every rank computes bit-identically -- so the record needs neither of them.  (Up to round 2 the record
+ * was {k, x, y, z}, 16 bytes.)  `volume` supplies the grid's offset and physical size (any slab of the grid, or the whole). */
+#define TSDF_NO_HIT 0xffffffffu
+typedef struct tsdf_hit_record {
+    uint32_t k;
+    float t;
+} tsdf_hit_record;
 int tsdf_raycast_slab_device(const tsdf_volume *volume, uint32_t width, uint32_t height,
-                             const float pose[16], const float kinv[9], float *device_hits);
-int tsdf_merge_hits_device(const float *device_hits_all, uint32_t n_slabs, uint32_t width,
-                           uint32_t height, float *device_vertices, void *hip_stream);
+                             const float pose[16], const float kinv[9], tsdf_hit_record *device_hits);
+int tsdf_merge_hits_device(const tsdf_volume *volume, const tsdf_hit_record *device_hits_all, uint32_t n_slabs,
+                           uint32_t width, uint32_t height, const float pose[16], const float kinv[9],
+                           float *device_vertices, void *hip_stream);
 /* The same select and compute_normals (src/RayCaster/GPURaycaster.cu:393-427) on the merged map in one launch. */
-int tsdf_merge_hits_normals_device(const float *device_hits_all, uint32_t n_slabs, uint32_t width, uint32_t height,
+int tsdf_merge_hits_normals_device(const tsdf_volume *volume, const tsdf_hit_record *device_hits_all, uint32_t n_slabs,
+                                   uint32_t width, uint32_t height, const float pose[16], const float kinv[9],
                                    float *device_vertices, float *device_normals, void *hip_stream);
+
+/* ---- slab exchange: the one collective of a sharded frame (no reference counterpart) ------------------------- */
+/* ncclAllGather of the ranks' hit records by RCCL ON THE CALLER'S HIP STREAM: one more launch between the slab ray cast and the
+ * merge kernel, no event, no second stream.  librccl is opened at run time: rccl_library = path of the library to use (a process
+ * that already holds one, e.g. torch's, passes that path), NULL = the one already loaded if any, else the ROCm installation's.
+ * Rank 0 makes the 128-byte id (tsdf_slab_exchange_unique_id) and hands it to the other ranks by whatever means the caller has
+ * (torch.distributed, MPI, a file); then EVERY rank calls tsdf_slab_exchange_create (it is collective: ncclCommInitRank). */
+typedef struct tsdf_slab_exchange tsdf_slab_exchange;
+#define TSDF_EXCHANGE_ID_BYTES 128
+int tsdf_slab_exchange_unique_id(uint8_t id[TSDF_EXCHANGE_ID_BYTES], const char *rccl_library);
+int tsdf_slab_exchange_create(int rank, int world, const uint8_t id[TSDF_EXCHANGE_ID_BYTES], const char *rccl_library,
+                              tsdf_slab_exchange **out);
+/* The same object over the caller's own collective (MPI, torch.distributed, a test double): all_gather must leave rank r's
+ * n_pixels records at device_all + r * n_pixels on every rank, enqueued on or ordered behind hip_stream; returns TSDF_OK. */
+typedef int (*tsdf_exchange_fn)(void *user, const tsdf_hit_record *device_mine, tsdf_hit_record *device_all, uint32_t n_pixels,
+                                void *hip_stream);
+int tsdf_slab_exchange_create_callback(int rank, int world, tsdf_exchange_fn all_gather, void *user, tsdf_slab_exchange **out);
+int tsdf_slab_exchange_world(const tsdf_slab_exchange *exchange, int *rank, int *world);
+/* device_all: world x n_pixels records, rank r's at [r * n_pixels, (r + 1) * n_pixels).  Asynchronous on hip_stream. */
+int tsdf_slab_exchange_all_gather(tsdf_slab_exchange *exchange, const tsdf_hit_record *device_mine, tsdf_hit_record *device_all,
+                                  uint32_t n_pixels, void *hip_stream);
+int tsdf_slab_exchange_destroy(tsdf_slab_exchange *exchange);
+
+/* ---- the per-frame loop ------------------------------------------------------------------------------------------------- */
+/* Replaces the body of the reference's frame loop (src/Tools/kinfu.cpp:32-56: load, integrate, one blocking call each; BASELINE
+ * configs[2] adds the bilateral filter and a ray cast per frame) on frames that live in HBM: filter -> integrate -> ray cast +
+ * normals per step on a HIP stream of the pipeline's own, and -- with TSDF_PIPELINE_OVERLAP -- the NEXT frame's filter (and its
+ * brick culling, when next_camera is given: ground-truth trajectories; not when the pose comes from tracking against this
+ * frame's ray cast) on a second stream of lower priority, released by this frame's integrate and awaited by the next step.
+ * Same results as the three calls one after the other (tests/test_pipeline.py, tests/cpp/test_stream.cpp); 0.345 -> 0.325 ms per
+ * step at 512^3.  With a slab exchange the volume is one rank's Z-slab: a step ray casts the slab, all-gathers the ranks' records
+ * on the step's stream and merges them (vertices + normals on every rank); TSDF_PIPELINE_EXCHANGE_STREAM moves the all-gather
+ * and the merge to a third stream so that the next frame's integrate need not wait for the collective (results are then
+ * ordered behind tsdf_pipeline_synchronize only).  The pipeline owns its streams, events, the two filtered frames + tile
+ * maxima and the record buffers; while it lives the volume's stream is the pipeline's (tsdf_pipeline_streams), restored
+ * by tsdf_pipeline_destroy.  All pointers are device pointers: width * height uint16 depth (it must stay valid until the step
+ * after the one it was announced to has run), 3 * width * height floats per map (device_normals may be NULL). */
+typedef struct tsdf_pipeline tsdf_pipeline;
+typedef struct tsdf_camera_matrices {   /* camera.pose(), inverse_pose(), k(), kinv(): column-major, as everywhere in this header */
+    float pose[16], inv_pose[16], k[9], kinv[9];
+} tsdf_camera_matrices;
+#define TSDF_PIPELINE_OVERLAP 1          /* the next frame's filter / culling on a second, lower-priority stream                */
+#define TSDF_PIPELINE_EQUAL_PRIORITY 2   /* diagnostics: both streams at the same priority (always so with a slab exchange)      */
+#define TSDF_PIPELINE_EXCHANGE_STREAM 4  /* slab exchange + merge on a third stream                                            */
+int tsdf_pipeline_create(tsdf_volume *volume, const tsdf_bilateral *filter, uint32_t width, uint32_t height, int flags,
+                         tsdf_slab_exchange *exchange /* NULL: a whole volume */, tsdf_pipeline **out);
+int tsdf_pipeline_step(tsdf_pipeline *pipeline, const uint16_t *device_depth, const tsdf_camera_matrices *camera,
+                       float *device_vertices, float *device_normals, const uint16_t *next_device_depth /* or NULL */,
+                       const tsdf_camera_matrices *next_camera /* or NULL */);
+int tsdf_pipeline_synchronize(tsdf_pipeline *pipeline);
+/* The pipeline's hipStream_t handles (side_stream is NULL without TSDF_PIPELINE_OVERLAP), e.g. to order the caller's own work. */
+int tsdf_pipeline_streams(const tsdf_pipeline *pipeline, void **main_stream, void **side_stream);
+/* The record buffers of a sharded pipeline (NULL for a whole volume): this rank's n_pixels records, all ranks' world x n_pixels. */
+int tsdf_pipeline_hit_buffers(const tsdf_pipeline *pipeline, tsdf_hit_record **device_mine, tsdf_hit_record **device_all);
+int tsdf_pipeline_destroy(tsdf_pipeline *pipeline);
 
 /* ---- ICP tracking: replaces third_party/ICP_CUDA ------------------------------------------ */
 /* ICPOdometry::ICPOdometry (third_party/ICP_CUDA/ICPOdometry.cpp:10-57): three pyramid levels of vertex / normal maps for

@@ -54,7 +54,8 @@ def lib():
         L.orc_raycast_rows.argtypes = [fp, C.POINTER(Geom), fp, fp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                        C.c_uint32, fp, C.c_int]
         L.orc_raycast_slab.argtypes = [fp, C.POINTER(Geom), fp, fp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
-                                       C.c_uint32, fp, C.c_int]
+                                       C.c_uint32, C.POINTER(C.c_uint32), C.c_int]
+        L.orc_merge_hits.argtypes = [C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(Geom), fp, fp, C.c_uint32, C.c_uint32, fp]
         L.orc_normals.argtypes = [C.c_uint32, C.c_uint32, fp, fp]
         L.orc_ray_box.restype = C.c_int
         L.orc_ray_box.argtypes = [fp, fp, fp, fp, fp, fp]
@@ -262,10 +263,19 @@ class Volume:
         return V.reshape(-1, 3), int(s)
 
     def raycast_slab(self, width, height, pose, kinv, own, nthreads=1):
-        hits = np.empty(width * height * 4, np.float32)
+        """(W*H, 2) uint32 records {k, bits of t}: the first owned sample <= 0 (0xffffffff: none), its refined parameter."""
+        hits = np.empty(width * height * 2, np.uint32)
         lib().orc_raycast_slab(_fp(self.dist), C.byref(self.g), _fp(_f32(pose, 16)), _fp(_f32(kinv, 9)), width,
-                               height, self.z0, own[0], own[1], _fp(hits), nthreads)
-        return hits.reshape(-1, 4)
+                               height, self.z0, own[0], own[1], hits.ctypes.data_as(C.POINTER(C.c_uint32)), nthreads)
+        return hits.reshape(-1, 2)
+
+    def merge_hits(self, hits_all, width, height, pose, kinv):
+        """Min-k select over (n_slabs, W*H, 2) records and the vertices the reference forms from the refined parameter."""
+        h = np.ascontiguousarray(hits_all).view(np.uint32).reshape(-1, width * height, 2)
+        V = np.empty(width * height * 3, np.float32)
+        lib().orc_merge_hits(h.ctypes.data_as(C.POINTER(C.c_uint32)), h.shape[0], C.byref(self.g), _fp(_f32(pose, 16)),
+                             _fp(_f32(kinv, 9)), width, height, _fp(V))
+        return V.reshape(-1, 3)
 
 
 def normals(width, height, V):

@@ -307,8 +307,9 @@ float orc_trilinear(const float point[3], const uint32_t dims[3], const float vs
 /*
  * One ray.  ref: src/RayCaster/GPURaycaster.cu:265-377.
  * slab == 0: full semantics, writes vertex (NaN triple on miss), returns #samples.
- * slab == 1: evaluates only owned samples; hit[0] = k of first owned sample with tsdf<=0
- *            (+inf if none), hit[1..3] = vertex.
+ * slab == 1: evaluates only owned samples; out[0] = k of first owned sample with tsdf<=0
+ *            (+inf if none), out[1] = the refined ray parameter t of :338-341 (NaN if none); the
+ *            vertex is formed from t by orc_merge_hits (:344-347), as every rank can.
  */
 static int march_ray(int imx, int imy, const float *dist, const uint32_t dims[3], const float vs[3],
                      const float space_min[3], const float space_max[3], float trunc,
@@ -320,7 +321,7 @@ static int march_ray(int imx, int imy, const float *dist, const uint32_t dims[3]
     float near_t, far_t;
     int intersects = orc_ray_box(origin, dir, space_min, space_max, &near_t, &far_t);
     float ix = NAN, iy = NAN, iz = NAN;
-    float hit_k = INFINITY;
+    float hit_k = INFINITY, hit_t = NAN;
     int samples = 0;
     if (intersects) {
         /* :306 start = (origin + near*dir) - space_min */
@@ -353,6 +354,7 @@ static int march_ray(int imx, int imy, const float *dist, const uint32_t dims[3]
                 iy = p[1] + space_min[1];
                 iz = p[2] + space_min[2];
                 hit_k = (float)count;
+                hit_t = t;
                 done = 1;
             } else if (previous_tsdf < 0) {
                 done = 1; /* never taken (Q7) */
@@ -365,7 +367,7 @@ static int march_ray(int imx, int imy, const float *dist, const uint32_t dims[3]
         }
     }
     if (slab) {
-        out[0] = hit_k; out[1] = ix; out[2] = iy; out[3] = iz;
+        out[0] = hit_k; out[1] = hit_t; out[2] = 0; out[3] = 0;
     } else {
         out[0] = ix; out[1] = iy; out[2] = iz;
     }
@@ -453,9 +455,11 @@ int64_t orc_raycast_rows(const float *dist, const orc_geom *g, const float pose[
     return total_samples;
 }
 
+/* One slab's hit records: 8 bytes per pixel {uint32 k, float t} -- k = index of the first owned sample with tsdf <= 0
+ * (0xffffffff: none), t = its refined ray parameter (src/RayCaster/GPURaycaster.cu:338-341).  hits = 2 * width * height words. */
 void orc_raycast_slab(const float *dist, const orc_geom *g, const float pose[16], const float kinv[9], uint32_t width,
                       uint32_t height, uint32_t z_store_begin, uint32_t z_own_begin,
-                      uint32_t z_own_end, float *hits, int nthreads) {
+                      uint32_t z_own_end, uint32_t *hits, int nthreads) {
     float origin[3], rot[9], smin[3], smax[3];
     ray_setup(pose, g, origin, rot, smin, smax);
     const uint32_t *dims = g->dims;
@@ -466,8 +470,50 @@ void orc_raycast_slab(const float *dist, const orc_geom *g, const float pose[16]
     for (int64_t imy = 0; imy < (int64_t)height; imy++) {
         for (uint32_t imx = 0; imx < width; imx++) {
             size_t idx = (size_t)imy * width + imx;
+            float out[4];
             march_ray((int)imx, (int)imy, dist, dims, vs, smin, smax, trunc, origin, rot, kinv,
-                      z_store_begin, NULL, 1, z_own_begin, z_own_end, hits + idx * 4);
+                      z_store_begin, NULL, 1, z_own_begin, z_own_end, out);
+            hits[idx * 2 + 0] = isinf(out[0]) ? 0xffffffffu : (uint32_t)out[0];
+            memcpy(&hits[idx * 2 + 1], &out[1], sizeof(float));
+        }
+    }
+}
+
+/* The merge of n_slabs gathered record arrays (layout [slab][pixel]{k, t}): per pixel the record with the smallest k, its
+ * vertex formed as process_ray does from the refined t: start = (origin + near * dir) - space_min (:306), vertex =
+ * space_min + (start + t * dir) (:344-347).  Direction, near and start depend on the pixel and the pose only. */
+void orc_merge_hits(const uint32_t *hits_all, uint32_t n_slabs, const orc_geom *g, const float pose[16], const float kinv[9],
+                    uint32_t width, uint32_t height, float *vertices) {
+    float origin[3], rot[9], smin[3], smax[3];
+    ray_setup(pose, g, origin, rot, smin, smax);
+    const size_t n_pixels = (size_t)width * height;
+    for (uint32_t imy = 0; imy < height; imy++) {
+        for (uint32_t imx = 0; imx < width; imx++) {
+            const size_t idx = (size_t)imy * width + imx;
+            uint32_t best_k = 0xffffffffu;
+            float t = NAN;
+            for (uint32_t s = 0; s < n_slabs; s++) {
+                const uint32_t *h = hits_all + ((size_t)s * n_pixels + idx) * 2;
+                if (h[0] < best_k) {
+                    best_k = h[0];
+                    memcpy(&t, &h[1], sizeof(float));
+                }
+            }
+            float ix = NAN, iy = NAN, iz = NAN;
+            if (best_k != 0xffffffffu) {
+                float dir[3], near_t, far_t;
+                orc_ray_direction((uint16_t)imx, (uint16_t)imy, rot, kinv, dir);
+                (void)orc_ray_box(origin, dir, smin, smax, &near_t, &far_t);
+                float sx = ((near_t * dir[0]) + origin[0]) - smin[0];
+                float sy = ((near_t * dir[1]) + origin[1]) - smin[1];
+                float sz = ((near_t * dir[2]) + origin[2]) - smin[2];
+                ix = ((t * dir[0]) + sx) + smin[0];
+                iy = ((t * dir[1]) + sy) + smin[1];
+                iz = ((t * dir[2]) + sz) + smin[2];
+            }
+            vertices[idx * 3 + 0] = ix;
+            vertices[idx * 3 + 1] = iy;
+            vertices[idx * 3 + 2] = iz;
         }
     }
 }

@@ -95,12 +95,17 @@ int64_t orc_raycast_rows(const float *dist, const orc_geom *g, const float pose[
 /*
  * Slab variant used to check the multi-GPU protocol: dist holds planes
  * [z_store_begin, ...) and only samples whose lower tap plane lies in [z_own_begin, z_own_end)
- * are evaluated.  hits: W*H records of 4 floats (k, x, y, z); k = index of the first owned
- * sample with tsdf <= 0, +inf when none.
+ * are evaluated.  hits: W*H records of 8 bytes {uint32 k, float t}; k = index of the first owned
+ * sample with tsdf <= 0 (0xffffffff when none), t = that sample's refined ray parameter
+ * (src/RayCaster/GPURaycaster.cu:338-341).
  */
 void orc_raycast_slab(const float *dist, const orc_geom *g, const float pose[16], const float kinv[9], uint32_t width,
                       uint32_t height, uint32_t z_store_begin, uint32_t z_own_begin,
-                      uint32_t z_own_end, float *hits, int nthreads);
+                      uint32_t z_own_end, uint32_t *hits, int nthreads);
+/* Per pixel the record with the smallest k among n_slabs record arrays ([slab][pixel]{k, t}); its vertex
+ * = space_min + (start + t * dir) with the pixel's own start and direction (:306, :344-347). */
+void orc_merge_hits(const uint32_t *hits_all, uint32_t n_slabs, const orc_geom *g, const float pose[16], const float kinv[9],
+                    uint32_t width, uint32_t height, float *vertices);
 
 /* compute_normals kernel (src/RayCaster/GPURaycaster.cu:393-427) */
 void orc_normals(uint32_t width, uint32_t height, const float *vertices, float *normals);

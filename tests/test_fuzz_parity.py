@@ -175,14 +175,14 @@ def test_random_slab_splits_equal_the_whole_volume(seed):
     rc = tsdf_amd.GPURaycaster(width, height)
     for cam in cams:
         V, N = whole.raycast(width, height, cam)
-        hits = torch.empty((P, width * height, 4), dtype=torch.float32, device="cuda")
+        hits = torch.empty((P, width * height, 2), dtype=torch.float32, device="cuda")
         for r, s in enumerate(slabs):
             lo, hi = s.resident_planes()
             assert_same_floats(s.get_distance_data().reshape(hi - lo, -1), Dw[lo:hi], "seed %d slab %d distances" % (seed, r))
             rc.raycast_slab_device(s, cam, hits[r].data_ptr())
             s.synchronize()
         Vm = torch.empty((width * height, 3), dtype=torch.float32, device="cuda")
-        tsdf_amd.merge_hits_device(hits.data_ptr(), P, width, height, Vm.data_ptr())
+        tsdf_amd.merge_hits_device(slabs[0], hits.data_ptr(), P, width, height, cam, Vm.data_ptr())
         torch.cuda.synchronize()
         assert_same_floats(Vm.cpu().numpy(), V, "seed %d: %d slabs of %s, image %dx%d" % (seed, P, dims, width, height))
 

@@ -96,18 +96,17 @@ def _worker(rank, world, port, n, W, H, tmp):
         for depth, pose in frames:          # each rank integrates its planes + halo, no communication
             slab.integrate(depth, W, H, O.mat4_inverse(pose), k, kinv)
         pose = frames[0][1]
-        mine = torch.from_numpy(slab.raycast_slab(W, H, pose, kinv, (zb, ze)))
-        allh = gather_hits(mine).numpy()                          # (world, W*H, 4) on every rank
-        best = np.argmin(allh[:, :, 0], axis=0)                   # per-pixel min-k select
-        V = allh[best, np.arange(W * H), 1:4]
+        mine = torch.from_numpy(slab.raycast_slab(W, H, pose, kinv, (zb, ze)).view(np.float32))   # {k, t} records as words
+        allh = gather_hits(mine).numpy().view(np.uint32)           # (world, W*H, 2) on every rank
+        V = slab.merge_hits(allh, W, H, pose, kinv)               # per-pixel min-k select, vertex from t and the pixel's ray
         if rank == 0:
             whole = O.Volume((n, n, n), (3000, 3000, 3000))
             for depth, p in frames:
                 whole.integrate(depth, W, H, O.mat4_inverse(p), k, kinv)
             Vw, Nw = whole.raycast(W, H, pose, kinv)
             same = (V.view(np.uint32) == Vw.view(np.uint32)) | (np.isnan(V) & np.isnan(Vw))
-            ks = allh[:, :, 0]
-            finite = np.isfinite(ks)
+            ks = allh[:, :, 0].astype(np.int64)
+            finite = ks != 0xffffffff
             np.save(os.path.join(tmp, "result.npy"),
                     np.array([int(same.all()), int((~np.isnan(Vw[:, 0])).sum()),
                               # a sample has exactly one owner: no two ranks may report the same finite k
@@ -131,7 +130,7 @@ def test_slab_records_gathered_over_gloo_reproduce_the_single_volume_raycast(tmp
 def test_merge_hits_refuses_cpu_tensors():
     from tsdf_amd.multi import merge_hits
     with pytest.raises(TypeError):
-        merge_hits(torch.zeros((2, 4, 4)), 2, 2)
+        merge_hits(None, torch.zeros((2, 4, 2)), 2, 2, None)
 
 
 def _mesh_worker(rank, world, port, tmp):

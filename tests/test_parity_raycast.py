@@ -180,7 +180,7 @@ def test_slab_hit_records_merge_to_the_single_volume_result(oracle):
     cam = frames[0][1]
     Vw, Nw = whole.raycast(W, H, cam)
     import torch
-    hits = torch.empty((len(slabs), W * H, 4), dtype=torch.float32, device="cuda")
+    hits = torch.empty((len(slabs), W * H, 2), dtype=torch.float32, device="cuda")     # {k, t} records
     rc = tsdf_amd.GPURaycaster(W, H)
     for i, s in enumerate(slabs):
         rc.raycast_slab_device(s, cam, hits[i].data_ptr())
@@ -190,19 +190,22 @@ def test_slab_hit_records_merge_to_the_single_volume_result(oracle):
         os_ = oracle.Volume((n, n, n), (3000, 3000, 3000), z_store=(slo, shi))
         os_.set_distance_data(ov.dist.reshape(n, -1)[slo:shi])
         ho = os_.raycast_slab(W, H, cam.pose(), cam.kinv(), (lo, hi), nthreads=oracle.max_threads())
-        assert_same_floats(hits[i].cpu().numpy(), ho, "slab %d records" % i)
+        assert np.array_equal(hits[i].cpu().numpy().view(np.uint32), ho), "slab %d records {k, t} differ from the oracle's" % i
     V = torch.empty((W * H, 3), dtype=torch.float32, device="cuda")
     Nn = torch.empty_like(V)
-    tsdf_amd.merge_hits_device(hits.data_ptr(), len(slabs), W, H, V.data_ptr())
+    tsdf_amd.merge_hits_device(slabs[0], hits.data_ptr(), len(slabs), W, H, cam, V.data_ptr())
     tsdf_amd.compute_normals_device(W, H, V.data_ptr(), Nn.data_ptr())
     torch.cuda.synchronize()
     assert_same_floats(V.cpu().numpy(), Vw, "merged vertices")
     assert_same_floats(Nn.cpu().numpy(), Nw, "merged normals")
     V2, N2 = torch.zeros_like(V), torch.zeros_like(V)          # the same in one launch
-    tsdf_amd.merge_hits_normals_device(hits.data_ptr(), len(slabs), W, H, V2.data_ptr(), N2.data_ptr())
+    tsdf_amd.merge_hits_normals_device(slabs[1], hits.data_ptr(), len(slabs), W, H, cam, V2.data_ptr(), N2.data_ptr())
     torch.cuda.synchronize()
     assert_same_floats(V2.cpu().numpy(), Vw, "merged vertices (one launch)")
     assert_same_floats(N2.cpu().numpy(), Nw, "merged normals (one launch)")
+    # the oracle's own merge of the records: the protocol, restated on the CPU
+    Vo = ov.merge_hits(hits.cpu().numpy(), W, H, cam.pose(), cam.kinv())
+    assert_same_floats(Vo, Vw, "oracle merge of the records")
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -1,5 +1,6 @@
-"""tsdf_amd.pipeline.FusionPipeline: the next frame's bilateral filter on a second, lower-priority stream during this frame's
-ray cast.  Scheduling only -- volume and pictures must be the bits of the strictly sequential step and of the oracle."""
+"""tsdf_pipeline_* (C++ behind the C ABI; tsdf_amd.pipeline.FusionPipeline is the ctypes mirror): the next frame's bilateral
+filter and brick culling on a second, lower-priority stream during this frame's ray cast.  Scheduling only -- volume and
+pictures must be the bits of the strictly sequential step and of the oracle."""
 import numpy as np
 import pytest
 
@@ -10,24 +11,29 @@ from tsdf_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def _run(overlap, release_after_integrate, frames, n, prepare=False):
+def _run(overlap, equal_priority, frames, n, prepare=False, unannounced=(1,), wrong_announcement=()):
     import torch
     from tsdf_amd.pipeline import FusionPipeline
     vol = tsdf_amd.TSDFVolume((n, n, n), (3000.0,) * 3)
     pipe = FusionPipeline(vol, tsdf_amd.BilateralFilter(30.0, 4.5), tsdf_amd.GPURaycaster(W, H), W, H, overlap=overlap,
-                          release_after_integrate=release_after_integrate)
+                          equal_priority=equal_priority)
     depth = torch.from_numpy(np.stack([d for d, _ in frames]).view(np.int16)).cuda()
     vert = torch.empty((H * W, 3), dtype=torch.float32, device="cuda")
     norm = torch.empty_like(vert)
     pictures = []
     for i, (_, cam) in enumerate(frames):
-        # (the third frame is NOT announced: the pipeline must filter it itself when it arrives)
-        nxt = depth[i + 1].data_ptr() if i + 1 < len(frames) and i != 1 else None
+        # (the third frame is NOT announced: the pipeline must filter it itself when it arrives; a WRONG announcement -- another
+        # frame arrives than the one filtered and culled ahead -- must be waited for and dropped, round-2 advisor finding)
+        j = i + 1
+        if i in wrong_announcement and i + 2 < len(frames):
+            j = i + 2
+        nxt = depth[j].data_ptr() if j < len(frames) and i not in unannounced else None
         pipe.step(depth[i].data_ptr(), cam, vert.data_ptr(), norm.data_ptr(), nxt,
-                  frames[i + 1][1] if (prepare and nxt is not None) else None)
+                  frames[j][1] if (prepare and nxt is not None) else None)
         pipe.synchronize()
         pictures.append((vert.cpu().numpy().copy(), norm.cpu().numpy().copy()))
     out = (vol.get_distance_data(), vol.get_weight_data(), pictures)
+    pipe.close()
     vol.close()
     return out
 
@@ -35,10 +41,10 @@ def _run(overlap, release_after_integrate, frames, n, prepare=False):
 def test_filter_ahead_gives_the_bits_of_the_sequential_step_and_of_the_oracle(oracle):
     n = 96
     frames = [synth.depth_frame(i * 3, 200, seed=0x5EED0003) for i in range(7)]
-    seq = _run(False, True, frames, n)
-    for overlap, gate, prepare in ((True, True, False), (True, False, False), (True, True, True)):
-        got = _run(overlap, gate, frames, n, prepare)
-        assert_same_floats(got[0], seq[0], "distances (overlap, release after integrate = %s)" % gate)
+    seq = _run(False, False, frames, n)
+    for overlap, equal, prepare, wrong in ((True, False, False, ()), (True, True, False, ()), (True, False, True, ()), (True, False, True, (3, 4))):
+        got = _run(overlap, equal, frames, n, prepare, wrong_announcement=wrong)
+        assert_same_floats(got[0], seq[0], "distances (overlap, equal priority = %s, wrong announcements = %s)" % (equal, wrong))
         assert_same_floats(got[1], seq[1], "weights")
         for i, ((v, nn), (vs, ns)) in enumerate(zip(got[2], seq[2])):
             assert_same_floats(v, vs, "vertices of frame %d" % i)
@@ -104,3 +110,63 @@ def test_a_prepared_brick_list_is_used_only_by_the_matching_integrate(oracle):
     side.synchronize()
     gv.integrate_device(filt[1].data_ptr(), W, H, fr[1][1])
     check(1, "plain integrate after a preparation")
+
+
+def test_a_prepared_brick_list_does_not_outlive_the_state_it_was_culled_for(oracle):
+    """The prepared list and the per-plane constants bake in the volume's offset (now and at the last clear) and the truncation
+    distance: clear(), a new offset and a rewritten image (tsdf_integrate_discard_prepared) must make the matching integrate call
+    cull again.  After each, the volume equals the oracle's (round-2 advisor finding)."""
+    import ctypes as C
+    import torch
+    from tsdf_amd._capi import check as ck, lib
+    n = 72
+    s = torch.cuda.current_stream()
+    side = torch.cuda.Stream()
+    bil = tsdf_amd.BilateralFilter(30.0, 4.5)
+    gv = tsdf_amd.TSDFVolume((n, n, n), (3000.0,) * 3)
+    gv.set_stream(s.cuda_stream)
+    ov = oracle.Volume((n, n, n), (3000.0,) * 3)
+    fr = [synth.depth_frame(i * 7, 200, seed=0x5EED0003) for i in range(2)]
+    src = [torch.from_numpy(d.view(np.int16).copy()).cuda() for d, _ in fr]
+    filt = torch.empty((H * W,), dtype=torch.int16, device="cuda")
+    tmax = torch.empty((1200,), dtype=torch.int16, device="cuda")
+
+    def refilter(i):
+        bil.filter_device(src[i].data_ptr(), filt.data_ptr(), W, H, bits=16, stream=s.cuda_stream, tile_max_ptr=tmax.data_ptr())
+        torch.cuda.synchronize()
+
+    def check(i, what):
+        torch.cuda.synchronize()
+        ov.integrate(filt.cpu().numpy().view(np.uint16), W, H, fr[i][1].inverse_pose(), fr[i][1].k(), fr[i][1].kinv(),
+                     nthreads=oracle.max_threads())
+        assert_same_floats(gv.get_weight_data(), ov.weight, what + ": weights")
+        assert_same_floats(gv.get_distance_data(), ov.dist, what + ": distances")
+
+    def prepare(i):
+        gv.integrate_prepare_device(filt.data_ptr(), W, H, fr[i][1], tmax.data_ptr(), side.cuda_stream)
+        side.synchronize()
+
+    refilter(0)
+    # (1) a new offset between prepare and integrate: the list was culled for the old position of the grid
+    prepare(0)
+    gv.offset(400.0, -250.0, 300.0)
+    ov.offset(400.0, -250.0, 300.0)
+    gv.integrate_device(filt.data_ptr(), W, H, fr[0][1], tile_max_ptr=tmax.data_ptr())
+    check(0, "offset changed after the preparation")
+    # (2) clear() between prepare and integrate: offset_at_clear changes (Q1), the plane constants with it
+    prepare(0)
+    gv.clear()
+    ov.clear()
+    gv.integrate_device(filt.data_ptr(), W, H, fr[0][1], tile_max_ptr=tmax.data_ptr())
+    check(0, "cleared after the preparation")
+    # (3) same pointers and pose, other content: the caller says so
+    prepare(0)
+    refilter(1)
+    ck(lib.tsdf_integrate_discard_prepared(gv._h))
+    cam0_image1 = fr[0][1]
+    gv.integrate_device(filt.data_ptr(), W, H, cam0_image1, tile_max_ptr=tmax.data_ptr())
+    torch.cuda.synchronize()
+    ov.integrate(filt.cpu().numpy().view(np.uint16), W, H, cam0_image1.inverse_pose(), cam0_image1.k(), cam0_image1.kinv(),
+                 nthreads=oracle.max_threads())
+    assert_same_floats(gv.get_weight_data(), ov.weight, "image rewritten after the preparation: weights")
+    assert_same_floats(gv.get_distance_data(), ov.dist, "image rewritten after the preparation: distances")

@@ -15,7 +15,7 @@ vert = torch.empty((H * W, 3), dtype=torch.float32, device="cuda"); norm = torch
 bil = tsdf_amd.BilateralFilter(30.0, 4.5); rc = tsdf_amd.GPURaycaster(W, H)
 def run(overlap, gate, prepare=False):
     vol = tsdf_amd.TSDFVolume((n, n, n), (3000.0,) * 3)
-    p = FusionPipeline(vol, bil, rc, W, H, overlap=overlap, release_after_integrate=gate)
+    p = FusionPipeline(vol, bil, rc, W, H, overlap=overlap, equal_priority=not gate)
     def step(i, last):
         p.step(depth[i].data_ptr(), cams[i], vert.data_ptr(), norm.data_ptr(), None if last else depth[i + 1].data_ptr(),
                cams[i + 1] if (prepare and not last) else None)
@@ -25,11 +25,11 @@ def run(overlap, gate, prepare=False):
     for i in range(Wu, Wu + K): step(i, False)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / K * 1e3
-    pic = vert.clone(); vol.close()
+    pic = vert.clone(); p.close(); vol.close()
     return dt, pic
 ref = None
 for rep in range(3):
-    for name, ov, gate, prep in (("sequential", False, True, False), ("filter ahead, released after integrate", True, True, False),
+    for name, ov, gate, prep in (("sequential", False, True, False), ("filter ahead", True, True, False), ("filter ahead, equal priorities", True, False, False),
                                  ("filter + brick culling ahead", True, True, True)):
         dt, pic = run(ov, gate, prep)
         if ref is None: ref = pic

@@ -12,7 +12,7 @@ for i in range(12):
     f = d.copy(); bil.filter(f, W, H)
     frames.append((torch.from_numpy(f.view(np.int16)).cuda(), cam))
 rc = tsdf_amd.GPURaycaster(W, H)
-hits = torch.empty((W * H, 4), dtype=torch.float32, device="cuda")
+hits = torch.empty((W * H, 2), dtype=torch.float32, device="cuda")
 stream = torch.cuda.current_stream()
 def timed(fn, reps):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

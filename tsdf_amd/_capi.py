@@ -28,6 +28,15 @@ class VolumeInfo(C.Structure):
                 ("fast_division_verified", C.c_int32)]
 
 
+class CameraMatrices(C.Structure):
+    """struct tsdf_camera_matrices (include/tsdf_amd.h)."""
+    _fields_ = [("pose", C.c_float * 16), ("inv_pose", C.c_float * 16), ("k", C.c_float * 9), ("kinv", C.c_float * 9)]
+
+
+#: tsdf_exchange_fn (include/tsdf_amd.h): int (*)(void *user, const record *mine, record *all, uint32_t n_pixels, void *stream)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p)
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -49,6 +58,10 @@ _SIGS = {
     "tsdf_device_count": (_i, [C.POINTER(_i)]),
     "tsdf_set_device": (_i, [_i]),
     "tsdf_get_device": (_i, [C.POINTER(_i)]),
+    "tsdf_device_alloc": (_i, [C.c_size_t, C.POINTER(_vp)]),
+    "tsdf_device_free": (_i, [_vp]),
+    "tsdf_device_upload": (_i, [_vp, _vp, C.c_size_t]),
+    "tsdf_device_download": (_i, [_vp, _vp, C.c_size_t]),
     "tsdf_volume_create": (_i, [_u32, _u32, _u32, _f, _f, _f, C.POINTER(_vp)]),
     "tsdf_volume_create_slab": (_i, [_u32, _u32, _u32, _f, _f, _f, _u32, _u32, C.POINTER(_vp)]),
     "tsdf_volume_destroy": (_i, [_vp]),
@@ -75,6 +88,7 @@ _SIGS = {
     "tsdf_integrate_device": (_i, [_vp, _vp, _u32, _u32, _fp, _fp, _fp, _fp]),
     "tsdf_integrate_device_tiles": (_i, [_vp, _vp, _u32, _u32, _fp, _fp, _fp, _fp, _vp]),
     "tsdf_integrate_prepare_device_tiles": (_i, [_vp, _vp, _u32, _u32, _fp, _fp, _fp, _fp, _vp, _vp]),
+    "tsdf_integrate_discard_prepared": (_i, [_vp]),
     "tsdf_volume_set_timing": (_i, [_vp, _i]),
     "tsdf_volume_kernel_time": (_i, [_vp, _i, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]),
     "tsdf_volume_set_counting": (_i, [_vp, _i]),
@@ -92,8 +106,20 @@ _SIGS = {
     "tsdf_raycast_slab_device": (_i, [_vp, _u32, _u32, _fp, _fp, _vp]),
     "tsdf_vertices_to_depth_device": (_i, [_u32, _u32, _vp, _vp, _vp, _vp]),
     "tsdf_volume_marching_cubes": (_i, [_vp, _vp, _vp, _vp, C.c_uint64]),
-    "tsdf_merge_hits_device": (_i, [_vp, _u32, _u32, _u32, _vp, _vp]),
-    "tsdf_merge_hits_normals_device": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp]),
+    "tsdf_merge_hits_device": (_i, [_vp, _vp, _u32, _u32, _u32, _fp, _fp, _vp, _vp]),
+    "tsdf_merge_hits_normals_device": (_i, [_vp, _vp, _u32, _u32, _u32, _fp, _fp, _vp, _vp, _vp]),
+    "tsdf_slab_exchange_unique_id": (_i, [_vp, C.c_char_p]),
+    "tsdf_slab_exchange_create": (_i, [_i, _i, _vp, C.c_char_p, C.POINTER(_vp)]),
+    "tsdf_slab_exchange_create_callback": (_i, [_i, _i, EXCHANGE_FN, _vp, C.POINTER(_vp)]),
+    "tsdf_slab_exchange_world": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    "tsdf_slab_exchange_all_gather": (_i, [_vp, _vp, _vp, _u32, _vp]),
+    "tsdf_slab_exchange_destroy": (_i, [_vp]),
+    "tsdf_pipeline_create": (_i, [_vp, _vp, _u32, _u32, _i, _vp, C.POINTER(_vp)]),
+    "tsdf_pipeline_step": (_i, [_vp, _vp, C.POINTER(CameraMatrices), _vp, _vp, _vp, C.POINTER(CameraMatrices)]),
+    "tsdf_pipeline_synchronize": (_i, [_vp]),
+    "tsdf_pipeline_streams": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
+    "tsdf_pipeline_hit_buffers": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
+    "tsdf_pipeline_destroy": (_i, [_vp]),
     "tsdf_icp_create": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, C.POINTER(_vp)]),
     "tsdf_icp_destroy": (None, [_vp]),
     "tsdf_icp_set_stream": (_i, [_vp, _vp]),
@@ -158,6 +184,9 @@ _HOST_SIGS = {
     "tsdf_camera_image_plane_to_pixel": (None, [_vp, _fp, _ip]),
     "tsdf_host_marching_cubes_c": (C.c_size_t, [_vp, C.c_uint, C.c_uint, C.c_uint, _vp, _vp, _vp, C.c_size_t]),
     "tsdf_host_mc_table": (None, [_vp]),
+    "tsdf_host_tum_open": (_vp, [C.c_char_p]),
+    "tsdf_host_tum_next": (_i, [_vp, _vp, C.c_size_t, C.POINTER(C.c_uint), _fp]),
+    "tsdf_host_tum_close": (None, [_vp]),
     "tsdf_host_block_loader_parse": (_i, [C.c_char_p, _vp, _vp, _vp, _vp, C.c_size_t]),
 }
 for _name, (_res, _args) in _HOST_SIGS.items():

@@ -46,6 +46,10 @@ class TSDFVolume:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
+            for ref in getattr(self, "_dependents", ()):      # pipelines built on this volume hold its stream: they go first
+                dep = ref()
+                if dep is not None:
+                    dep.close()
             lib.tsdf_volume_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -301,14 +305,22 @@ def vertices_to_depth_device(width, height, vertices_ptr, camera, depth_ptr, str
                                             C.c_void_p(int(depth_ptr)), C.c_void_p(int(stream) if stream else 0)))
 
 
-def merge_hits_device(hits_all_ptr, n_slabs, width, height, vertices_ptr, stream=0):
-    check(lib.tsdf_merge_hits_device(C.c_void_p(int(hits_all_ptr)), n_slabs, width, height,
+#: bytes of one slab hit record {uint32 k, float t} (struct tsdf_hit_record)
+HIT_RECORD_BYTES = 8
+
+
+def merge_hits_device(volume, hits_all_ptr, n_slabs, width, height, camera, vertices_ptr, stream=0):
+    """Min-k select over the gathered slab records ((n_slabs, W*H) x {k, t}); the vertex of a pixel is formed from the winning
+    record's refined ray parameter and the pixel's own ray (`camera`; `volume`: any slab of the grid, for its offset / size)."""
+    pose, _, _, kinv = _camera_matrices(camera)
+    check(lib.tsdf_merge_hits_device(volume._h, C.c_void_p(int(hits_all_ptr)), n_slabs, width, height, _fp(pose), _fp(kinv),
                                      C.c_void_p(int(vertices_ptr)), C.c_void_p(int(stream) if stream else 0)))
 
 
-def merge_hits_normals_device(hits_all_ptr, n_slabs, width, height, vertices_ptr, normals_ptr, stream=0):
-    """Min-k select over the gathered slab records and the normals of the merged map, one launch."""
-    check(lib.tsdf_merge_hits_normals_device(C.c_void_p(int(hits_all_ptr)), n_slabs, width, height,
+def merge_hits_normals_device(volume, hits_all_ptr, n_slabs, width, height, camera, vertices_ptr, normals_ptr, stream=0):
+    """The same select and the normals of the merged map, one launch."""
+    pose, _, _, kinv = _camera_matrices(camera)
+    check(lib.tsdf_merge_hits_normals_device(volume._h, C.c_void_p(int(hits_all_ptr)), n_slabs, width, height, _fp(pose), _fp(kinv),
                                              C.c_void_p(int(vertices_ptr)), C.c_void_p(int(normals_ptr)),
                                              C.c_void_p(int(stream) if stream else 0)))
 

@@ -921,6 +921,12 @@ int tsdf_integrate_prepare_device_tiles(tsdf_volume *v, const uint16_t *device_d
     return launch_integrate(v, device_depth, width, height, inv_pose, k, kinv, device_tile_max, kIntPrepare, (hipStream_t)hip_stream);
 }
 
+int tsdf_integrate_discard_prepared(tsdf_volume *v) {
+    TSDF_REQUIRE(v, "null volume");
+    v->prepared_valid = 0;
+    return TSDF_OK;
+}
+
 int tsdf_integrate(tsdf_volume *v, const uint16_t *host_depth, uint32_t width, uint32_t height,
                    const float pose[16], const float inv_pose[16], const float k[9], const float kinv[9]) {
     TSDF_REQUIRE(v && host_depth && inv_pose && k && kinv, "tsdf_integrate: null argument");

@@ -1,0 +1,395 @@
+// The per-frame schedule and the slab exchange behind the C ABI (include/tsdf_amd.h: tsdf_pipeline_*, tsdf_slab_exchange_*).
+//
+// tsdf_pipeline: the step of BASELINE configs[2] -- bilateral filter, integrate, ray cast + normals, frame after frame as the
+// reference's kinfu loop integrates them (src/Tools/kinfu.cpp:32-56: one blocking call per frame on host buffers; its ray cast
+// comes once at the end, :181) -- on frames that live in HBM, on two HIP streams: the step's own, and a second one of lower
+// priority for the pieces of the NEXT frame that depend on nothing before them (its filter, and its brick culling when its pose
+// is known already).  Every kernel of the step fills the chip while it is in full swing, but each ends with a ramp-down (integrate
+// ~10 us, the two ray kernels ~15 and ~20 us) and the small kernels between them (reach summary, resolve + normals) are chains of
+// memory round trips on a few thousand waves: a kernel of EQUAL priority beside them only takes turns with them (measured: no
+// gain), one of LOWER priority gets the slots the step cannot use at that moment (0.345 -> 0.325 ms per step).
+// The next frame's work is released by THIS frame's integrate (an event), so it never runs beside the memory-bound
+// integrate_kernel, and the next step waits for it (another event).  Results cannot change: the same kernels run on the same
+// inputs, only earlier.  (Up to round 2 this schedule lived in Python, tsdf_amd/pipeline.py on torch streams; that file is now a
+// ctypes wrapper of these entry points, and tools/kinfu_stream.cpp drives them from C++.)
+//
+// tsdf_slab_exchange: the one collective of a sharded frame -- ncclAllGather of the ranks' 8-byte hit records -- enqueued by
+// RCCL on the caller's HIP stream: one more launch between the slab ray cast and the merge kernel, no event, no second stream
+// (torch.distributed's all_gather_into_tensor runs on the process group's own stream and hands over with events on either side:
+// 0.2-1.2 ms between kernels of a compute stream on an MI355X box against 0.02 ms this way).  librccl is opened at
+// run time (dlopen), so that a process that already holds one -- torch ships its own -- uses that one; the 128-byte unique id is
+// made by rank 0 and travels to the other ranks by whatever means the caller has (torch.distributed, MPI, a file).
+#include <dlfcn.h>
+
+#include <new>
+
+#include <cstdlib>
+#include <cstring>
+
+#include "common.hpp"
+
+// ---- RCCL, by hand: only the five entry points used, resolved with dlsym (rccl.h: NCCL_UNIQUE_ID_BYTES = 128, ncclUint8 = 1)
+namespace {
+struct NcclUniqueId {
+    char internal[128];
+};
+typedef int (*nccl_get_unique_id_fn)(NcclUniqueId *);
+typedef int (*nccl_comm_init_rank_fn)(void **comm, int nranks, NcclUniqueId id, int rank);
+typedef int (*nccl_all_gather_fn)(const void *send, void *recv, size_t count, int dtype, void *comm, hipStream_t stream);
+typedef int (*nccl_comm_destroy_fn)(void *comm);
+typedef const char *(*nccl_get_error_string_fn)(int);
+constexpr int kNcclUint8 = 1;
+
+struct Rccl {
+    void *dl = nullptr;
+    nccl_get_unique_id_fn get_unique_id = nullptr;
+    nccl_comm_init_rank_fn comm_init_rank = nullptr;
+    nccl_all_gather_fn all_gather = nullptr;
+    nccl_comm_destroy_fn comm_destroy = nullptr;
+    nccl_get_error_string_fn error_string = nullptr;
+};
+
+// library == nullptr: the librccl this process holds already if any, else the one of the ROCm installation
+int open_rccl(const char *library, Rccl &r) {
+    const char *fallbacks[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    if (library && *library) {
+        r.dl = dlopen(library, RTLD_NOW | RTLD_LOCAL);
+    } else {
+        for (const char *f : fallbacks)
+            if (!r.dl) r.dl = dlopen(f, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+        for (const char *f : fallbacks)
+            if (!r.dl) r.dl = dlopen(f, RTLD_NOW | RTLD_LOCAL);
+    }
+    if (!r.dl) {
+        tsdf::set_error("slab exchange: cannot open librccl (%s)", dlerror());
+        return TSDF_ERR_DEVICE;
+    }
+    r.get_unique_id = (nccl_get_unique_id_fn)dlsym(r.dl, "ncclGetUniqueId");
+    r.comm_init_rank = (nccl_comm_init_rank_fn)dlsym(r.dl, "ncclCommInitRank");
+    r.all_gather = (nccl_all_gather_fn)dlsym(r.dl, "ncclAllGather");
+    r.comm_destroy = (nccl_comm_destroy_fn)dlsym(r.dl, "ncclCommDestroy");
+    r.error_string = (nccl_get_error_string_fn)dlsym(r.dl, "ncclGetErrorString");
+    if (!r.get_unique_id || !r.comm_init_rank || !r.all_gather || !r.comm_destroy || !r.error_string) {
+        tsdf::set_error("slab exchange: librccl lacks a symbol (ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy / ncclGetErrorString)");
+        dlclose(r.dl);
+        r.dl = nullptr;
+        return TSDF_ERR_DEVICE;
+    }
+    return TSDF_OK;
+}
+
+int rccl_fail(const Rccl &r, int rc, const char *what) {
+    tsdf::set_error("%s failed: %s", what, r.error_string ? r.error_string(rc) : "?");
+    return TSDF_ERR_DEVICE;
+}
+}  // namespace
+
+struct tsdf_slab_exchange {
+    Rccl rccl;
+    void *comm;
+    int rank, world;
+    tsdf_exchange_fn callback;   // != nullptr: the caller's own collective instead of RCCL
+    void *user;
+};
+
+struct tsdf_pipeline {
+    tsdf_volume *volume;
+    const tsdf_bilateral *filter;
+    tsdf_slab_exchange *exchange;   // nullptr: a whole volume
+    uint32_t width, height;
+    int flags;
+    hipStream_t main, side, xstream;
+    hipStream_t volume_stream_before;
+    uint16_t *filtered[2], *tile_max[2];
+    // events are made once and recorded again every other frame (creating one per frame makes the runtime grow its pool of
+    // signals now and then: a stall of tens of milliseconds in the middle of a stream)
+    hipEvent_t done[2], ready[2];   // [b]: the integrate that read buffer b has finished; buffer b has been filtered (and culled) ahead
+    hipEvent_t cast, merged;        // third-stream exchange: the slab cast has left its records; the merge has consumed them
+    bool merged_pending;
+    const uint16_t *ahead_depth;    // the frame filtered ahead into buffer ahead_buf (nullptr: none)
+    int ahead_buf;
+    bool ahead_culled;
+    uint64_t frames;
+    tsdf_hit_record *hits_mine, *hits_all;
+};
+
+using namespace tsdf;
+
+static int run_filter(tsdf_pipeline *p, const uint16_t *depth, int b, hipStream_t s) {
+    return tsdf_bilateral_filter_u16_device_tiles(p->filter, depth, p->filtered[b], (int)p->width, (int)p->height, p->tile_max[b], s);
+}
+
+extern "C" {
+
+int tsdf_slab_exchange_unique_id(uint8_t id[TSDF_EXCHANGE_ID_BYTES], const char *rccl_library) {
+    TSDF_REQUIRE(id, "tsdf_slab_exchange_unique_id: null argument");
+    Rccl r;
+    int rc = open_rccl(rccl_library, r);
+    if (rc != TSDF_OK) return rc;
+    NcclUniqueId u;
+    memset(&u, 0, sizeof(u));
+    const int e = r.get_unique_id(&u);
+    if (e != 0) return rccl_fail(r, e, "ncclGetUniqueId");
+    static_assert(sizeof(u) == TSDF_EXCHANGE_ID_BYTES, "unique id size");
+    memcpy(id, &u, sizeof(u));
+    return TSDF_OK;   // (the library stays open: the communicator that follows uses it)
+}
+
+int tsdf_slab_exchange_create(int rank, int world, const uint8_t id[TSDF_EXCHANGE_ID_BYTES], const char *rccl_library,
+                              tsdf_slab_exchange **out) {
+    TSDF_REQUIRE(out && id, "tsdf_slab_exchange_create: null argument");
+    *out = nullptr;
+    TSDF_REQUIRE(world >= 1 && rank >= 0 && rank < world, "tsdf_slab_exchange_create: rank %d outside a world of %d", rank, world);
+    tsdf_slab_exchange *x = new (std::nothrow) tsdf_slab_exchange();
+    if (!x) {
+        set_error("out of host memory");
+        return TSDF_ERR_NOMEM;
+    }
+    x->comm = nullptr;
+    x->rank = rank;
+    x->world = world;
+    x->callback = nullptr;
+    x->user = nullptr;
+    int rc = open_rccl(rccl_library, x->rccl);
+    if (rc != TSDF_OK) {
+        delete x;
+        return rc;
+    }
+    NcclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    const int e = x->rccl.comm_init_rank(&x->comm, world, u, rank);   // (collective: every rank of the world calls it)
+    if (e != 0) {
+        rc = rccl_fail(x->rccl, e, "ncclCommInitRank");
+        delete x;
+        return rc;
+    }
+    *out = x;
+    return TSDF_OK;
+}
+
+int tsdf_slab_exchange_create_callback(int rank, int world, tsdf_exchange_fn all_gather, void *user, tsdf_slab_exchange **out) {
+    TSDF_REQUIRE(out && all_gather, "tsdf_slab_exchange_create_callback: null argument");
+    *out = nullptr;
+    TSDF_REQUIRE(world >= 1 && rank >= 0 && rank < world, "tsdf_slab_exchange_create_callback: rank %d outside a world of %d", rank, world);
+    tsdf_slab_exchange *x = new (std::nothrow) tsdf_slab_exchange();
+    if (!x) {
+        set_error("out of host memory");
+        return TSDF_ERR_NOMEM;
+    }
+    x->comm = nullptr;
+    x->rank = rank;
+    x->world = world;
+    x->callback = all_gather;
+    x->user = user;
+    *out = x;
+    return TSDF_OK;
+}
+
+int tsdf_slab_exchange_world(const tsdf_slab_exchange *x, int *rank, int *world) {
+    TSDF_REQUIRE(x, "null exchange");
+    if (rank) *rank = x->rank;
+    if (world) *world = x->world;
+    return TSDF_OK;
+}
+
+int tsdf_slab_exchange_all_gather(tsdf_slab_exchange *x, const tsdf_hit_record *device_mine, tsdf_hit_record *device_all,
+                                  uint32_t n_pixels, void *hip_stream) {
+    TSDF_REQUIRE(x && device_mine && device_all && n_pixels > 0, "tsdf_slab_exchange_all_gather: bad argument");
+    if (x->callback) {
+        const int rc = x->callback(x->user, device_mine, device_all, n_pixels, hip_stream);
+        if (rc != TSDF_OK) {
+            set_error("slab exchange: the caller's all-gather returned %d", rc);
+            return TSDF_ERR_DEVICE;
+        }
+        return TSDF_OK;
+    }
+    const int e = x->rccl.all_gather(device_mine, device_all, (size_t)n_pixels * sizeof(tsdf_hit_record), kNcclUint8, x->comm,
+                                     (hipStream_t)hip_stream);
+    if (e != 0) return rccl_fail(x->rccl, e, "ncclAllGather");
+    return TSDF_OK;
+}
+
+int tsdf_slab_exchange_destroy(tsdf_slab_exchange *x) {
+    if (!x) return TSDF_OK;
+    if (x->comm && x->rccl.comm_destroy) (void)x->rccl.comm_destroy(x->comm);
+    // (the library handle is left open: RCCL keeps threads and device state of its own until the process ends)
+    delete x;
+    return TSDF_OK;
+}
+
+int tsdf_pipeline_destroy(tsdf_pipeline *p) {
+    if (!p) return TSDF_OK;
+    if (p->main) (void)hipStreamSynchronize(p->main);
+    if (p->side) (void)hipStreamSynchronize(p->side);
+    if (p->xstream) (void)hipStreamSynchronize(p->xstream);
+    if (p->volume) (void)tsdf_volume_set_stream(p->volume, p->volume_stream_before);
+    for (int b = 0; b < 2; b++) {
+        if (p->filtered[b]) (void)hipFree(p->filtered[b]);
+        if (p->tile_max[b]) (void)hipFree(p->tile_max[b]);
+        if (p->done[b]) (void)hipEventDestroy(p->done[b]);
+        if (p->ready[b]) (void)hipEventDestroy(p->ready[b]);
+    }
+    if (p->cast) (void)hipEventDestroy(p->cast);
+    if (p->merged) (void)hipEventDestroy(p->merged);
+    if (p->hits_mine) (void)hipFree(p->hits_mine);
+    if (p->hits_all) (void)hipFree(p->hits_all);
+    if (p->side) (void)hipStreamDestroy(p->side);
+    if (p->xstream) (void)hipStreamDestroy(p->xstream);
+    if (p->main) (void)hipStreamDestroy(p->main);
+    delete p;
+    return TSDF_OK;
+}
+
+int tsdf_pipeline_create(tsdf_volume *volume, const tsdf_bilateral *filter, uint32_t width, uint32_t height, int flags,
+                         tsdf_slab_exchange *exchange, tsdf_pipeline **out) {
+    TSDF_REQUIRE(out, "tsdf_pipeline_create: null out pointer");
+    *out = nullptr;
+    TSDF_REQUIRE(volume && filter && width > 0 && height > 0 && width <= 65535 && height <= 65535, "tsdf_pipeline_create: bad argument");
+    const bool slab = volume->z_begin != 0 || volume->z_end != volume->g.Z;
+    TSDF_REQUIRE(exchange || !slab, "tsdf_pipeline_create: a Z-slab needs a slab exchange");
+    tsdf_pipeline *p = new (std::nothrow) tsdf_pipeline();
+    if (!p) {
+        set_error("out of host memory");
+        return TSDF_ERR_NOMEM;
+    }
+    memset(p, 0, sizeof(*p));
+    p->volume = volume;
+    p->filter = filter;
+    p->exchange = exchange;
+    p->width = width;
+    p->height = height;
+    p->flags = flags;
+    p->volume_stream_before = volume->stream;
+    // Priorities: the step's stream above the side stream.  With a slab exchange the two are EQUAL: ncclAllGather enqueued on a
+    // stream of raised priority made the one-rank step 0.58 ms instead of 0.37 (RCCL 2.26.6), and equal priorities still give
+    // 0.366 against 0.381 without the second stream.
+    int least = 0, greatest = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);   // (numerically: greatest <= least)
+    const bool overlap = (flags & TSDF_PIPELINE_OVERLAP) != 0;
+    const bool equal = (flags & TSDF_PIPELINE_EQUAL_PRIORITY) != 0 || exchange != nullptr || !overlap;
+    const int normal = (greatest <= 0 && 0 <= least) ? 0 : least;
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&p->main, hipStreamNonBlocking, equal ? normal : greatest);
+    if (e == hipSuccess && overlap) e = hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, normal);
+    if (e == hipSuccess && exchange && (flags & TSDF_PIPELINE_EXCHANGE_STREAM)) e = hipStreamCreateWithPriority(&p->xstream, hipStreamNonBlocking, normal);
+    const size_t n = (size_t)width * height;
+    const size_t tiles = (size_t)((width + TSDF_DEPTH_TILE - 1) / TSDF_DEPTH_TILE) * ((height + TSDF_DEPTH_TILE - 1) / TSDF_DEPTH_TILE);
+    for (int b = 0; b < 2 && e == hipSuccess; b++) {
+        e = hipMalloc((void **)&p->filtered[b], n * sizeof(uint16_t));
+        if (e == hipSuccess) e = hipMalloc((void **)&p->tile_max[b], tiles * sizeof(uint16_t));
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->done[b], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ready[b], hipEventDisableTiming);
+    }
+    if (e == hipSuccess && p->xstream) e = hipEventCreateWithFlags(&p->cast, hipEventDisableTiming);
+    if (e == hipSuccess && p->xstream) e = hipEventCreateWithFlags(&p->merged, hipEventDisableTiming);
+    if (e == hipSuccess && exchange) {
+        e = hipMalloc((void **)&p->hits_mine, n * sizeof(tsdf_hit_record));
+        if (e == hipSuccess) e = hipMalloc((void **)&p->hits_all, n * sizeof(tsdf_hit_record) * (size_t)exchange->world);
+    }
+    if (e != hipSuccess) {
+        const int rc = hip_fail(e, "tsdf_pipeline_create");
+        p->volume = nullptr;   // (its stream was not changed yet)
+        tsdf_pipeline_destroy(p);
+        return rc;
+    }
+    // whatever the volume has in flight on its previous stream comes before the pipeline's first launch
+    (void)hipStreamSynchronize(volume->stream);
+    (void)tsdf_volume_set_stream(volume, p->main);
+    *out = p;
+    return TSDF_OK;
+}
+
+int tsdf_pipeline_streams(const tsdf_pipeline *p, void **main_stream, void **side_stream) {
+    TSDF_REQUIRE(p, "null pipeline");
+    if (main_stream) *main_stream = p->main;
+    if (side_stream) *side_stream = p->side;
+    return TSDF_OK;
+}
+
+int tsdf_pipeline_hit_buffers(const tsdf_pipeline *p, tsdf_hit_record **device_mine, tsdf_hit_record **device_all) {
+    TSDF_REQUIRE(p, "null pipeline");
+    if (device_mine) *device_mine = p->hits_mine;
+    if (device_all) *device_all = p->hits_all;
+    return TSDF_OK;
+}
+
+int tsdf_pipeline_step(tsdf_pipeline *p, const uint16_t *device_depth, const tsdf_camera_matrices *cam, float *device_vertices,
+                       float *device_normals, const uint16_t *next_device_depth, const tsdf_camera_matrices *next_cam) {
+    TSDF_REQUIRE(p && device_depth && cam && device_vertices, "tsdf_pipeline_step: null argument");
+    const uint32_t W = p->width, H = p->height;
+    const int b = (int)(p->frames & 1u);
+    int rc;
+    if (p->ahead_depth && p->ahead_depth == device_depth && p->ahead_buf == b) {
+        TSDF_HIP(hipStreamWaitEvent(p->main, p->ready[b], 0), "pipeline: wait for the frame filtered ahead");
+    } else {
+        if (p->ahead_depth) {
+            // Another frame than the one announced: the side stream may still be writing a filtered buffer, its tile maxima and
+            // the volume's brick list (prepare) -- wait for it before this step filters and culls for itself, and drop the list.
+            TSDF_HIP(hipStreamWaitEvent(p->main, p->ready[p->ahead_buf], 0), "pipeline: wait for the side stream");
+            (void)tsdf_integrate_discard_prepared(p->volume);
+        }
+        rc = run_filter(p, device_depth, b, p->main);
+        if (rc != TSDF_OK) return rc;
+    }
+    p->ahead_depth = nullptr;
+    rc = tsdf_integrate_device_tiles(p->volume, p->filtered[b], W, H, cam->pose, cam->inv_pose, cam->k, cam->kinv, p->tile_max[b]);
+    if (rc != TSDF_OK) return rc;
+    if (p->side) {
+        TSDF_HIP(hipEventRecord(p->done[b], p->main), "pipeline: integrate done");
+        if (next_device_depth) {
+            // released by THIS frame's integrate (never beside integrate_kernel); the other buffer was last read by the previous
+            // frame's integrate, which lies before it on the step's stream; the brick list, the boxes and the plane constants
+            // are free once this frame's integrate_kernel is done
+            TSDF_HIP(hipStreamWaitEvent(p->side, p->done[b], 0), "pipeline: release the next frame's filter");
+            rc = run_filter(p, next_device_depth, 1 - b, p->side);
+            if (rc != TSDF_OK) return rc;
+            if (next_cam) {
+                rc = tsdf_integrate_prepare_device_tiles(p->volume, p->filtered[1 - b], W, H, next_cam->pose, next_cam->inv_pose, next_cam->k,
+                                                         next_cam->kinv, p->tile_max[1 - b], p->side);
+                if (rc != TSDF_OK) return rc;
+            }
+            TSDF_HIP(hipEventRecord(p->ready[1 - b], p->side), "pipeline: next frame ready");
+            p->ahead_depth = next_device_depth;
+            p->ahead_buf = 1 - b;
+        }
+    }
+    if (!p->exchange) {
+        rc = tsdf_raycast_device(p->volume, W, H, cam->pose, cam->kinv, device_vertices, device_normals);
+        if (rc != TSDF_OK) return rc;
+    } else {
+        if (p->xstream && p->merged_pending)   // the previous frame's merge still reads hits_all / the collective hits_mine
+            TSDF_HIP(hipStreamWaitEvent(p->main, p->merged, 0), "pipeline: wait for the previous exchange");
+        rc = tsdf_raycast_slab_device(p->volume, W, H, cam->pose, cam->kinv, p->hits_mine);
+        if (rc != TSDF_OK) return rc;
+        hipStream_t xs = p->main;
+        if (p->xstream) {
+            // exchange + merge on a third stream: the next frame's integrate need not wait for the collective
+            TSDF_HIP(hipEventRecord(p->cast, p->main), "pipeline: slab cast done");
+            TSDF_HIP(hipStreamWaitEvent(p->xstream, p->cast, 0), "pipeline: exchange after the slab cast");
+            xs = p->xstream;
+        }
+        rc = tsdf_slab_exchange_all_gather(p->exchange, p->hits_mine, p->hits_all, W * H, xs);
+        if (rc != TSDF_OK) return rc;
+        if (device_normals)
+            rc = tsdf_merge_hits_normals_device(p->volume, p->hits_all, (uint32_t)p->exchange->world, W, H, cam->pose, cam->kinv, device_vertices,
+                                                device_normals, xs);
+        else
+            rc = tsdf_merge_hits_device(p->volume, p->hits_all, (uint32_t)p->exchange->world, W, H, cam->pose, cam->kinv, device_vertices, xs);
+        if (rc != TSDF_OK) return rc;
+        if (p->xstream) {
+            TSDF_HIP(hipEventRecord(p->merged, p->xstream), "pipeline: merge done");
+            p->merged_pending = true;
+        }
+    }
+    p->frames++;
+    return TSDF_OK;
+}
+
+int tsdf_pipeline_synchronize(tsdf_pipeline *p) {
+    TSDF_REQUIRE(p, "null pipeline");
+    TSDF_HIP(hipStreamSynchronize(p->main), "pipeline synchronize");
+    if (p->side) TSDF_HIP(hipStreamSynchronize(p->side), "pipeline synchronize");
+    if (p->xstream) TSDF_HIP(hipStreamSynchronize(p->xstream), "pipeline synchronize");
+    return TSDF_OK;
+}
+
+}  // extern "C"

@@ -435,17 +435,25 @@ __device__ inline void set_ray(SkipCtx &sc, const RayState &r, float step_size, 
                  fabsf(r.dz) * step_size < 0.25f * g.vs.z;
 }
 
-// The hit point for a sample with tsdf <= 0 at parameter t (:336-350), previous_tsdf == trunc (Q7).
-__device__ inline void refine_hit(float t, float tsdf, float previous_tsdf, float step_size, const RayState &r,
-                                  const RayParams &rp, float &ix, float &iy, float &iz) {
+// The hit point for a sample with tsdf <= 0 at parameter t (:336-350), previous_tsdf == trunc (Q7): the refined parameter
+// (refine_t, :338-341), then the point on the ray (hit_point, :344-347).  A slab ships the refined parameter; the merge forms the
+// point with the same expressions on the same values (tsdf_merge_hits_device).
+__device__ inline float refine_t(float t, float tsdf, float previous_tsdf, float step_size) {
     float th = t;
     if (tsdf < 0) {
         th = th - step_size;
         th = th + (previous_tsdf / (previous_tsdf - tsdf)) * step_size;
     }
+    return th;
+}
+__device__ inline void hit_point(float th, const RayState &r, const RayParams &rp, float &ix, float &iy, float &iz) {
     ix = ((th * r.dx) + r.sx) + rp.space_min.x;
     iy = ((th * r.dy) + r.sy) + rp.space_min.y;
     iz = ((th * r.dz) + r.sz) + rp.space_min.z;
+}
+__device__ inline void refine_hit(float t, float tsdf, float previous_tsdf, float step_size, const RayState &r,
+                                  const RayParams &rp, float &ix, float &iy, float &iz) {
+    hit_point(refine_t(t, tsdf, previous_tsdf, step_size), r, rp, ix, iy, iz);
 }
 
 // Sample k of ray r, at parameter t = T[k].  Either proves that samples k .. k+jump-1 cannot be <= 0 (jump > 0),
@@ -1066,9 +1074,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 template <bool SLAB, bool FASTDIV>
 __device__ inline uint32_t resolve_pixel(uint32_t i, const float *__restrict__ dist, const Geom &g, const RayParams &rp,
                                          const float *__restrict__ t_table, const uint32_t *__restrict__ best, float &ix, float &iy,
-                                         float &iz) {
+                                         float &iz, float &th) {
     const uint32_t kb = best[i];
-    ix = iy = iz = NAN;
+    ix = iy = iz = th = NAN;
     if (kb != kNoHit) {
         RayState ray;
         float max_t;
@@ -1077,7 +1085,8 @@ __device__ inline uint32_t resolve_pixel(uint32_t i, const float *__restrict__ d
         const float px = (t * ray.dx) + ray.sx, py = (t * ray.dy) + ray.sy, pz = (t * ray.dz) + ray.sz;
         bool owned;
         const float tsdf = trilinear<SLAB, false, FASTDIV>(px, py, pz, dist, g, rp.tc, rp, owned, nullptr);
-        refine_hit(t, tsdf, g.trunc, step_size, ray, rp, ix, iy, iz);   // previous_tsdf == trunc (Q7)
+        th = refine_t(t, tsdf, g.trunc, step_size);   // previous_tsdf == trunc (Q7)
+        hit_point(th, ray, rp, ix, iy, iz);
     }
     return kb;
 }
@@ -1085,7 +1094,7 @@ __device__ inline uint32_t resolve_pixel(uint32_t i, const float *__restrict__ d
 // The vertices of all pixels.  best[] is double buffered: a march lowers one copy, this kernel reads it and resets the OTHER
 // one (consumed by the previous march's resolve) for the next march, together with the tail queue's counter -- so a
 // pixel's word may be read by several workgroups (resolve_normals_kernel) without racing against its reset.
-//   SLAB: out = float4 records {k, x, y, z} for the min-k merge across slabs; otherwise packed float3 vertices.
+//   SLAB: out = 8-byte records {k, t} (tsdf_hit_record) for the min-k merge across slabs; otherwise packed float3 vertices.
 template <bool SLAB, bool FASTDIV>
 __global__ __launch_bounds__(256) void resolve_hits_kernel(const float *__restrict__ dist, const Geom g, const RayParams rp,
                                                            const float *__restrict__ t_table, const uint32_t *__restrict__ best,
@@ -1095,10 +1104,10 @@ __global__ __launch_bounds__(256) void resolve_hits_kernel(const float *__restri
     if (i == 0) *reset = 0;
     if (i >= rp.width * rp.height) return;
     best_next[i] = kNoHit;
-    float ix, iy, iz;
-    const uint32_t kb = resolve_pixel<SLAB, FASTDIV>(i, dist, g, rp, t_table, best, ix, iy, iz);
+    float ix, iy, iz, th;
+    const uint32_t kb = resolve_pixel<SLAB, FASTDIV>(i, dist, g, rp, t_table, best, ix, iy, iz, th);
     if (SLAB) {
-        reinterpret_cast<float4 *>(out)[i] = make_float4(kb != kNoHit ? (float)kb : INFINITY, ix, iy, iz);
+        reinterpret_cast<uint2 *>(out)[i] = make_uint2(kb, __float_as_uint(th));
     } else {
         out[(size_t)i * 3 + 0] = ix;
         out[(size_t)i * 3 + 1] = iy;
@@ -1135,7 +1144,8 @@ __global__ __launch_bounds__(kResolveThreads) void resolve_normals_kernel(const 
         float ix = NAN, iy = NAN, iz = NAN;
         if (x < rp.width && y < rp.height) {
             const uint32_t i = y * rp.width + x;
-            (void)resolve_pixel<false, FASTDIV>(i, dist, g, rp, t_table, best, ix, iy, iz);
+            float th;
+            (void)resolve_pixel<false, FASTDIV>(i, dist, g, rp, t_table, best, ix, iy, iz, th);
             if (lx < (uint32_t)kT && ly < (uint32_t)kT) {   // this workgroup's own pixel
                 best_next[i] = kNoHit;
                 V[(size_t)i * 3 + 0] = ix;
@@ -1207,30 +1217,50 @@ __global__ __launch_bounds__(256) void vertices_to_depth_kernel(uint32_t n_pixel
     depth[i] = (r == r && r > 0.0f && r < 65536.0f) ? (uint16_t)r : (uint16_t)0;
 }
 
-// Per pixel, keep the record with the smallest k among n_slabs gathered buffers
-// (layout [slab][pixel][4]).  Ties cannot occur: a sample has exactly one owner.
-__global__ __launch_bounds__(256) void merge_hits_kernel(const float4 *__restrict__ hits, uint32_t n_slabs,
-                                                         uint32_t n_pixels, float *__restrict__ V) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_pixels) return;
-    float4 best = hits[i];
+// Per pixel, the record {k, t} with the smallest k among n_slabs gathered buffers (layout [slab][pixel]); ties cannot occur: a
+// sample has exactly one owner.  The vertex is formed here, from the winner's refined parameter t, with the expressions of
+// process_ray (:306, :344-347) on the pixel's own start point and direction -- which depend on the pixel and the pose only, so
+// every rank computes the bits the owning rank would have (ray_geometry / hit_point are the functions the march itself uses).
+// Why not t alone (4 bytes, min-t): with previous_tsdf == trunc (Q7) a hit at sample k refines to t in (T[k] - step, T[k]] in exact
+// arithmetic, so smaller k <=> smaller t as long as |tsdf| is moderate; but set_distance_data can hold anything, a hugely negative
+// sample refines to fl(T[k] - step), which may equal the T[k-1] of another slab's exact-zero hit: the order by t is not strict,
+// and "no hit" would need a sentinel value of t.  The index k is the reference's own stopping criterion; it stays in the record.
+__device__ inline void merged_vertex(const uint2 *__restrict__ hits, uint32_t n_slabs, uint32_t n_pixels, uint32_t i,
+                                     const RayParams &rp, float &ix, float &iy, float &iz) {
+    uint2 best = hits[i];
     for (uint32_t s = 1; s < n_slabs; s++) {
-        float4 h = hits[(size_t)s * n_pixels + i];
+        const uint2 h = hits[(size_t)s * n_pixels + i];
         if (h.x < best.x) best = h;
     }
-    V[(size_t)i * 3 + 0] = best.y;
-    V[(size_t)i * 3 + 1] = best.z;
-    V[(size_t)i * 3 + 2] = best.w;
+    ix = iy = iz = NAN;
+    if (best.x != kNoHit) {
+        RayState ray;
+        float max_t;
+        (void)ray_geometry((int)(i % rp.width), (int)(i / rp.width), true, rp, ray, max_t);
+        hit_point(__uint_as_float(best.y), ray, rp, ix, iy, iz);
+    }
+}
+
+__global__ __launch_bounds__(256) void merge_hits_kernel(const uint2 *__restrict__ hits, uint32_t n_slabs, const RayParams rp,
+                                                         float *__restrict__ V) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, n_pixels = rp.width * rp.height;
+    if (i >= n_pixels) return;
+    float ix, iy, iz;
+    merged_vertex(hits, n_slabs, n_pixels, i, rp, ix, iy, iz);
+    V[(size_t)i * 3 + 0] = ix;
+    V[(size_t)i * 3 + 1] = iy;
+    V[(size_t)i * 3 + 2] = iz;
 }
 
 // The same select together with the normals (compute_normals, Q11) in one launch: a workgroup merges a 16x16 pixel tile
 // plus the column to its right and the row below -- one pixel per thread of its five waves -- into LDS, like
 // resolve_normals_kernel.
-__global__ __launch_bounds__(kResolveThreads) void merge_hits_normals_kernel(const float4 *__restrict__ hits, uint32_t n_slabs,
-                                                                             uint32_t width, uint32_t height, float *__restrict__ V,
+__global__ __launch_bounds__(kResolveThreads) void merge_hits_normals_kernel(const uint2 *__restrict__ hits, uint32_t n_slabs,
+                                                                             const RayParams rp, float *__restrict__ V,
                                                                              float *__restrict__ N) {
     constexpr int kT = 16, kS = kT + 1;
     __shared__ float vx[kS * kS], vy[kS * kS], vz[kS * kS];
+    const uint32_t width = rp.width, height = rp.height;
     const uint32_t x0 = blockIdx.x * kT, y0 = blockIdx.y * kT, n_pixels = width * height;
     const uint32_t s_ = threadIdx.x;
     if (s_ < (uint32_t)(kS * kS)) {
@@ -1243,22 +1273,18 @@ __global__ __launch_bounds__(kResolveThreads) void merge_hits_normals_kernel(con
             lx = s_ - (kT * kT + kT); ly = kT;
         }
         const uint32_t x = x0 + lx, y = y0 + ly;
-        float4 best = make_float4(INFINITY, NAN, NAN, NAN);
+        float ix = NAN, iy = NAN, iz = NAN;
         if (x < width && y < height) {
             const uint32_t i = y * width + x;
-            best = hits[i];
-            for (uint32_t s2 = 1; s2 < n_slabs; s2++) {
-                const float4 h = hits[(size_t)s2 * n_pixels + i];
-                if (h.x < best.x) best = h;
-            }
+            merged_vertex(hits, n_slabs, n_pixels, i, rp, ix, iy, iz);
             if (lx < (uint32_t)kT && ly < (uint32_t)kT) {
-                V[(size_t)i * 3 + 0] = best.y;
-                V[(size_t)i * 3 + 1] = best.z;
-                V[(size_t)i * 3 + 2] = best.w;
+                V[(size_t)i * 3 + 0] = ix;
+                V[(size_t)i * 3 + 1] = iy;
+                V[(size_t)i * 3 + 2] = iz;
             }
         }
         const uint32_t slot = ly * kS + lx;
-        vx[slot] = best.y; vy[slot] = best.z; vz[slot] = best.w;
+        vx[slot] = ix; vy[slot] = iy; vz[slot] = iz;
     }
     __syncthreads();
     if (threadIdx.x >= (uint32_t)(kT * kT)) return;
@@ -1335,7 +1361,7 @@ static int check_ray_args(const tsdf_volume *v, uint32_t width, uint32_t height,
 }
 
 // The production march: process_ray_kernel over the sample ranges of every ray with a pass budget, process_ray_tail_kernel
-// for the stretches it handed over, resolve_hits_kernel for the vertices (packed float3, or {k,x,y,z} records for a slab).
+// for the stretches it handed over, resolve_hits_kernel for the vertices (packed float3, or {k, t} records for a slab).
 template <bool SLAB>
 static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *normals = nullptr) {
     const size_t n_pix = (size_t)rp.width * rp.height;
@@ -1613,34 +1639,39 @@ int tsdf_raycast_evaluated_samples(const tsdf_volume *v, uint32_t width, uint32_
 }
 
 int tsdf_raycast_slab_device(const tsdf_volume *v, uint32_t width, uint32_t height, const float pose[16],
-                             const float kinv[9], float *device_hits) {
+                             const float kinv[9], tsdf_hit_record *device_hits) {
     int rc = check_ray_args(v, width, height, pose, kinv);
     if (rc != TSDF_OK) return rc;
     TSDF_REQUIRE(device_hits, "tsdf_raycast_slab: null hit buffer");
     rc = occupancy_refresh(const_cast<tsdf_volume *>(v));
     if (rc != TSDF_OK) return rc;
     RayParams rp = make_params(v, width, height, pose, kinv);
-    // as on a single GPU the march is split into sample ranges; one {k,x,y,z} record per pixel leaves this rank
-    return march_and_resolve<true>(const_cast<tsdf_volume *>(v), rp, device_hits);
+    // as on a single GPU the march is split into sample ranges; one {k, t} record per pixel leaves this rank
+    return march_and_resolve<true>(const_cast<tsdf_volume *>(v), rp, reinterpret_cast<float *>(device_hits));
 }
 
-int tsdf_merge_hits_device(const float *device_hits_all, uint32_t n_slabs, uint32_t width, uint32_t height,
-                           float *device_vertices, void *hip_stream) {
-    TSDF_REQUIRE(device_hits_all && device_vertices && n_slabs > 0 && width > 0 && height > 0,
-                 "tsdf_merge_hits: bad argument");
-    uint32_t n = width * height;
+int tsdf_merge_hits_device(const tsdf_volume *v, const tsdf_hit_record *device_hits_all, uint32_t n_slabs, uint32_t width,
+                           uint32_t height, const float pose[16], const float kinv[9], float *device_vertices, void *hip_stream) {
+    int rc = check_ray_args(v, width, height, pose, kinv);
+    if (rc != TSDF_OK) return rc;
+    TSDF_REQUIRE(device_hits_all && device_vertices && n_slabs > 0, "tsdf_merge_hits: bad argument");
+    const RayParams rp = make_params(v, width, height, pose, kinv);
+    const uint32_t n = width * height;
     hipLaunchKernelGGL(merge_hits_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream,
-                       reinterpret_cast<const float4 *>(device_hits_all), n_slabs, n, device_vertices);
+                       reinterpret_cast<const uint2 *>(device_hits_all), n_slabs, rp, device_vertices);
     TSDF_HIP(hipGetLastError(), "merge hits failed");
     return TSDF_OK;
 }
 
-int tsdf_merge_hits_normals_device(const float *device_hits_all, uint32_t n_slabs, uint32_t width, uint32_t height,
-                                   float *device_vertices, float *device_normals, void *hip_stream) {
-    TSDF_REQUIRE(device_hits_all && device_vertices && device_normals && n_slabs > 0 && width > 0 && height > 0,
-                 "tsdf_merge_hits_normals: bad argument");
+int tsdf_merge_hits_normals_device(const tsdf_volume *v, const tsdf_hit_record *device_hits_all, uint32_t n_slabs, uint32_t width,
+                                   uint32_t height, const float pose[16], const float kinv[9], float *device_vertices,
+                                   float *device_normals, void *hip_stream) {
+    int rc = check_ray_args(v, width, height, pose, kinv);
+    if (rc != TSDF_OK) return rc;
+    TSDF_REQUIRE(device_hits_all && device_vertices && device_normals && n_slabs > 0, "tsdf_merge_hits_normals: bad argument");
+    const RayParams rp = make_params(v, width, height, pose, kinv);
     hipLaunchKernelGGL(merge_hits_normals_kernel, dim3((width + 15) / 16, (height + 15) / 16), dim3(kResolveThreads), 0,
-                       (hipStream_t)hip_stream, reinterpret_cast<const float4 *>(device_hits_all), n_slabs, width, height, device_vertices,
+                       (hipStream_t)hip_stream, reinterpret_cast<const uint2 *>(device_hits_all), n_slabs, rp, device_vertices,
                        device_normals);
     TSDF_HIP(hipGetLastError(), "merge hits + normals failed");
     return TSDF_OK;

@@ -613,6 +613,31 @@ int tsdf_get_device(int *device) {
     return TSDF_OK;
 }
 
+// Device memory for callers that keep their frames and maps in HBM without touching the HIP headers (tools/kinfu_stream.cpp).
+int tsdf_device_alloc(size_t bytes, void **device_ptr) {
+    TSDF_REQUIRE(device_ptr && bytes > 0, "tsdf_device_alloc: bad argument");
+    *device_ptr = nullptr;
+    TSDF_HIP(hipMalloc(device_ptr, bytes), "device allocation");
+    return TSDF_OK;
+}
+
+int tsdf_device_free(void *device_ptr) {
+    if (device_ptr) TSDF_HIP(hipFree(device_ptr), "device free");
+    return TSDF_OK;
+}
+
+int tsdf_device_upload(void *device_dst, const void *host_src, size_t bytes) {
+    TSDF_REQUIRE(device_dst && host_src, "tsdf_device_upload: null argument");
+    TSDF_HIP(hipMemcpy(device_dst, host_src, bytes, hipMemcpyHostToDevice), "upload");
+    return TSDF_OK;
+}
+
+int tsdf_device_download(void *host_dst, const void *device_src, size_t bytes) {
+    TSDF_REQUIRE(host_dst && device_src, "tsdf_device_download: null argument");
+    TSDF_HIP(hipMemcpy(host_dst, device_src, bytes, hipMemcpyDeviceToHost), "download");
+    return TSDF_OK;
+}
+
 int tsdf_volume_create_slab(uint32_t sx, uint32_t sy, uint32_t sz, float px, float py, float pz,
                             uint32_t z_begin, uint32_t z_end, tsdf_volume **out) {
     TSDF_REQUIRE(out, "tsdf_volume_create: null out pointer");
@@ -741,6 +766,7 @@ int tsdf_volume_clear(tsdf_volume *v) {
     if (rc0 != TSDF_OK) return rc0;
     v->occ_scan_all = 1;
     v->occ_dirty = 0;
+    v->prepared_valid = 0;   // (a brick list prepared ahead bakes in the offset at clear time)
     v->integrations_since_rebuild = v->integrations_total = 0;
     // initialise_deformation bakes the CURRENT offset into the node translations (Q1)
     v->g.offset_clear = v->g.offset;
@@ -773,6 +799,7 @@ int tsdf_volume_get_info(const tsdf_volume *v, tsdf_volume_info *info) {
 int tsdf_volume_set_offset(tsdf_volume *v, float ox, float oy, float oz) {
     TSDF_REQUIRE(v, "null volume");
     v->g.offset = {ox, oy, oz};
+    v->prepared_valid = 0;   // (a brick list prepared ahead was culled with the old offset)
     return TSDF_OK;
 }
 
@@ -781,6 +808,7 @@ int tsdf_volume_set_header(tsdf_volume *v, const float offset[3], float trunc, f
     TSDF_REQUIRE(v && offset && gt && gr, "null argument");
     v->g.offset = {offset[0], offset[1], offset[2]};
     v->g.trunc = trunc;
+    v->prepared_valid = 0;
     v->occ.tau = 0.01f * trunc;
     v->occ_dirty = 1;
     v->occ_scan_all = 1;
@@ -900,6 +928,7 @@ int tsdf_volume_weights(const tsdf_volume *v, float **p) {
 int tsdf_volume_deformation(tsdf_volume *v, tsdf_deformation_node **p) {
     TSDF_REQUIRE(v && p, "null argument");
     if (!v->nodes) {
+        v->prepared_valid = 0;   // (custom nodes: every brick is walked)
         TSDF_HIP(hipMalloc((void **)&v->nodes, v->resident_voxels() * sizeof(tsdf_deformation_node)),
                  "Couldn't allocate space for deformation nodes for TSDF");
         // materialise what clear() would have written: centres + the offset at the time of clear()
@@ -988,6 +1017,7 @@ int tsdf_volume_set_offset_at_clear(tsdf_volume *v, const float oc[3]) {
     TSDF_REQUIRE(v && oc, "null argument");
     TSDF_REQUIRE(!v->nodes, "the deformation nodes are materialised: their translations are what they are");
     v->g.offset_clear = {oc[0], oc[1], oc[2]};
+    v->prepared_valid = 0;
     return TSDF_OK;
 }
 

@@ -9,6 +9,7 @@
 #include "Camera.hpp"
 #include "BlockTSDFLoader.hpp"
 #include "MarkAndSweepMC.hpp"
+#include "TUMDataLoader.hpp"
 
 const int8_t *tsdf_host_mc_triangle_table();
 
@@ -90,4 +91,34 @@ int tsdf_host_block_loader_parse(const char *file_name, unsigned size[3], float 
     }
     return ok ? 1 : 0;
 }
+
+// TUMDataLoader for bindings (bench.py --tum-dir: the frames and poses tools/kinfu_stream.cpp sees, through the same loader).
+// open: nullptr when the directory does not have the layout.  next: 1 = a frame was returned (depth in millimetres, copied when
+// capacity >= width * height; pose 4x4 column-major), 0 = exhausted.
+typedef struct tsdf_tum_loader tsdf_tum_loader;
+tsdf_tum_loader *tsdf_host_tum_open(const char *directory) {
+    try {
+        return reinterpret_cast<tsdf_tum_loader *>(new TUMDataLoader(directory));
+    } catch (const std::exception &) {
+        return nullptr;
+    }
+}
+int tsdf_host_tum_next(tsdf_tum_loader *l, uint16_t *depth, size_t capacity, unsigned size[2], float pose[16]) {
+    Eigen::Matrix4f p;
+    DepthImage *image = nullptr;
+    try {
+        image = reinterpret_cast<TUMDataLoader *>(l)->next(p);
+    } catch (const std::exception &) {
+        return 0;
+    }
+    if (!image) return 0;
+    size[0] = image->width();
+    size[1] = image->height();
+    const size_t n = (size_t)image->width() * image->height();
+    if (depth && capacity >= n) memcpy(depth, image->data(), n * sizeof(uint16_t));
+    memcpy(pose, p.data(), 16 * sizeof(float));
+    delete image;
+    return 1;
+}
+void tsdf_host_tum_close(tsdf_tum_loader *l) { delete reinterpret_cast<TUMDataLoader *>(l); }
 }  // extern "C"

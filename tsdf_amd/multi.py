@@ -3,9 +3,10 @@
 Integrate shards with no communication: voxels are independent, so rank r integrates planes
 [z_begin, z_end) plus one halo plane above (recomputed locally, deterministic).  Raycast has one exchange
 step: every rank marches the GLOBAL sample lattice of every ray but evaluates only the samples whose lower
-trilinear tap plane it owns, records the first owned sample with tsdf <= 0 as {k, x, y, z}, and a single
-all-gather of those 16-byte records (RCCL over xGMI: W*H*16 B = 4.9 MB per rank) followed by a per-pixel
-min-k select reproduces the single-GPU vertex map bit for bit.
+trilinear tap plane it owns, records the first owned sample with tsdf <= 0 as {k, t} (its index and its refined ray
+parameter), and a single all-gather of those 8-byte records (RCCL over xGMI: W*H*8 B = 2.5 MB per rank) followed by a
+per-pixel min-k select -- which forms the vertex from t and the pixel's own ray, identical on every rank -- reproduces the
+single-GPU vertex map bit for bit.  (Up to round 2 the record carried the vertex: 16 bytes.)
 """
 import torch
 import torch.distributed as dist
@@ -123,8 +124,13 @@ def owner_of_plane(size_z, world, z):
     raise ValueError("plane %d outside 0..%d" % (z, size_z))
 
 
+def new_hit_records(n_slabs, width, height, device="cuda"):
+    """(n_slabs, W*H, 2) words: the records {uint32 k, float t} of n_slabs slabs (struct tsdf_hit_record), as float32 storage."""
+    return torch.empty((n_slabs, width * height, 2), dtype=torch.float32, device=device)
+
+
 def gather_hits(hits_mine, hits_all=None, group=None):
-    """All-gather of the per-pixel hit records: (W*H, 4) float32 per rank -> (world, W*H, 4)."""
+    """All-gather of the per-pixel hit records: (W*H, 2) words per rank -> (world, W*H, 2)."""
     world = dist.get_world_size(group)
     if hits_all is None:
         hits_all = torch.empty((world,) + tuple(hits_mine.shape), dtype=hits_mine.dtype, device=hits_mine.device)
@@ -132,7 +138,7 @@ def gather_hits(hits_mine, hits_all=None, group=None):
     return hits_all
 
 
-def merge_hits(hits_all, width, height, vertices=None, stream=None):
+def merge_hits(volume, hits_all, width, height, camera, vertices=None, stream=None):
     """Per-pixel min-k select on the GPU (tsdf_merge_hits_device).  CUDA tensors only: there is no CPU path."""
     from .api import merge_hits_device
     if not hits_all.is_cuda:
@@ -140,7 +146,7 @@ def merge_hits(hits_all, width, height, vertices=None, stream=None):
     if vertices is None:
         vertices = torch.empty((width * height, 3), dtype=torch.float32, device=hits_all.device)
     s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
-    merge_hits_device(hits_all.data_ptr(), hits_all.shape[0], width, height, vertices.data_ptr(), s)
+    merge_hits_device(volume, hits_all.data_ptr(), hits_all.shape[0], width, height, camera, vertices.data_ptr(), s)
     return vertices
 
 
@@ -162,65 +168,79 @@ def gather_vertices(vertices_mine, group=None):
     return torch.cat([parts[r, :int(counts[r].item())] for r in range(world)], dim=0)
 
 
-class StreamAllGather:
-    """The frame's one collective, enqueued by RCCL **on the caller's HIP stream**: ncclAllGather of librccl.so (the library
-    torch's nccl backend is built on) called directly, with a communicator of its own whose unique id rank 0 hands to the others
-    through torch.distributed.  torch's own all_gather_into_tensor runs on the process group's internal stream and hands over
-    to the caller's stream with events on either side; between kernels of that stream one call cost 0.2-1.2 ms on a MI355X box
-    (12.8 us back to back, tools/dbg_allgather.py) -- as much as the whole ray cast.  On the stream it is one more launch
-    between the slab ray cast and the merge kernel and needs no synchronisation at all.
+class _DeviceWords:
+    """A device buffer of 32-bit words as an object torch.as_tensor understands (__cuda_array_interface__)."""
 
-    all_gather(send, recv, stream): send = this rank's contiguous CUDA tensor, recv = (world, ...) of the same dtype."""
+    def __init__(self, ptr, words):
+        self.__cuda_array_interface__ = {"shape": (int(words),), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
 
-    _DTYPES = {torch.float32: 7, torch.int32: 2, torch.uint8: 1, torch.int64: 4, torch.float64: 8, torch.float16: 6}   # ncclDataType_t
 
-    def __init__(self, group=None):
+def device_words(ptr, words):
+    """float32 tensor view of `words` 32-bit words of device memory at `ptr` (no copy; the caller keeps the memory alive)."""
+    return torch.as_tensor(_DeviceWords(ptr, words), device="cuda")
+
+
+class SlabExchange:
+    """The frame's one collective (tsdf_slab_exchange, tsdf_amd/csrc/pipeline.hip), enqueued by RCCL **on the caller's HIP
+    stream**: ncclAllGather of librccl.so called directly by the C++ library, with a communicator of its own whose unique id rank 0
+    hands to the others through torch.distributed.  torch's own all_gather_into_tensor runs on the process group's internal
+    stream and hands over to the caller's stream with events on either side; between kernels of that stream one call cost
+    0.2-1.2 ms on a MI355X box (12.8 us back to back, tools/dbg_allgather.py) -- as much as the whole ray cast.  On the stream
+    it is one more launch between the slab ray cast and the merge kernel and needs no synchronisation at all.
+
+    SlabExchange(group)                -- RCCL (the librccl torch's nccl backend loaded), id broadcast through `group`
+    SlabExchange(group, callback=fn)   -- fn(mine, all, stream_ptr): the caller's own collective on float32 views of the
+                                          record buffers ((n_pixels * 2,), (world * n_pixels * 2,)); used for gloo / torch
+                                          collectives in tests and on a box without direct RCCL
+    all_gather(send, recv, stream): send = this rank's contiguous CUDA tensor of records, recv = (world, ...) of the same dtype."""
+
+    def __init__(self, group=None, callback=None):
         import ctypes as C
         import os
-        self._C = C
-        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-        self._lib = C.CDLL(path)
-
-        class UniqueId(C.Structure):
-            _fields_ = [("internal", C.c_char * 128)]      # NCCL_UNIQUE_ID_BYTES
-
-        lib = self._lib
-        lib.ncclGetUniqueId.restype = C.c_int
-        lib.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
-        lib.ncclCommInitRank.restype = C.c_int
-        lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
-        lib.ncclAllGather.restype = C.c_int
-        lib.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
-        lib.ncclCommDestroy.restype = C.c_int
-        lib.ncclCommDestroy.argtypes = [C.c_void_p]
-        lib.ncclGetErrorString.restype = C.c_char_p
-        lib.ncclGetErrorString.argtypes = [C.c_int]
+        from ._capi import EXCHANGE_FN, check, lib
+        self._C, self._lib, self._check = C, lib, check
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
-        uid = UniqueId()
+        self._h = C.c_void_p()
+        self._cb = None
+        if callback is not None:
+            def thunk(user, mine, allr, n_pixels, stream):
+                try:
+                    callback(device_words(mine, 2 * n_pixels), device_words(allr, 2 * n_pixels * self.world), stream or 0)
+                    return 0
+                except Exception:      # (an exception cannot cross the C frames)
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            self._cb = EXCHANGE_FN(thunk)
+            check(lib.tsdf_slab_exchange_create_callback(self.rank, self.world, self._cb, None, C.byref(self._h)))
+            return
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so").encode()
+        uid = (C.c_uint8 * 128)()
         if self.rank == 0:
-            self._check(lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+            check(lib.tsdf_slab_exchange_unique_id(uid, path))
         # the id travels as 128 bytes through the process group that exists already (nccl: on the device; gloo: on the host)
         dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
         t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).clone().to(dev)
         dist.broadcast(t, src=0, group=group)
-        C.memmove(C.byref(uid), bytes(t.cpu().numpy().tobytes()), 128)
-        self._comm = C.c_void_p()
-        self._check(lib.ncclCommInitRank(C.byref(self._comm), self.world, uid, self.rank), "ncclCommInitRank")
-
-    def _check(self, rc, what):
-        if rc != 0:
-            raise RuntimeError("%s failed: %s" % (what, self._lib.ncclGetErrorString(rc).decode()))
+        C.memmove(uid, bytes(t.cpu().numpy().tobytes()), 128)
+        check(lib.tsdf_slab_exchange_create(self.rank, self.world, uid, path, C.byref(self._h)))
 
     def all_gather(self, send, recv, stream):
         if not (send.is_cuda and recv.is_cuda and send.is_contiguous() and recv.is_contiguous()):
-            raise TypeError("StreamAllGather works on contiguous CUDA tensors")
+            raise TypeError("SlabExchange works on contiguous CUDA tensors")
         if recv.numel() != send.numel() * self.world or recv.dtype != send.dtype:
             raise ValueError("recv must hold world x send elements of the same dtype")
+        nbytes = send.numel() * send.element_size()
+        if nbytes % 8:
+            raise ValueError("SlabExchange moves 8-byte records")
         C = self._C
-        self._check(self._lib.ncclAllGather(C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()), send.numel(),
-                                            self._DTYPES[send.dtype], self._comm, C.c_void_p(int(stream))), "ncclAllGather")
+        self._check(self._lib.tsdf_slab_exchange_all_gather(self._h, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()), nbytes // 8,
+                                                            C.c_void_p(int(stream))))
 
     def close(self):
-        if getattr(self, "_comm", None):
-            self._lib.ncclCommDestroy(self._comm)
-            self._comm = None
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.tsdf_slab_exchange_destroy(self._h)
+            self._h = self._C.c_void_p()
+
+
+StreamAllGather = SlabExchange      # (round-2 name)
