@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--separate-tile-max", action="store_true",
                     help="integrate computes the depth tile maxima in a launch of its own (tsdf_integrate_device) instead of taking "
                          "them from the bilateral filter's launch (tsdf_bilateral_filter_u16_device_tiles + tsdf_integrate_device_tiles)")
+    ap.add_argument("--tum-dir", default=None,
+                    help="take the stream from a TUM-layout directory (depth/*.png + ground_truth.txt) through the host library's "
+                         "TUMDataLoader instead of synthesising it: the frames tools/kinfu_stream.cpp sees (tools/compare_drivers.sh)")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--path-only", action="store_true",
                     help="only the timed hot path and its roofline (no ICP / tracking / host-buffer legs): what the profiling passes run")
@@ -136,7 +139,14 @@ def main():
     trace("process group / device ready")
     # ---- inputs: synthetic stream, resident in HBM before timing ---------------------------------
     frames, cams = [], []
-    for i in range(n_frames):
+    if args.tum_dir:
+        loaded, size = tsdf_amd.load_tum_directory(args.tum_dir)
+        if not loaded or size != (W, H):
+            raise SystemExit("bench.py --tum-dir: %d frames of %s in %s (need %dx%d)" % (len(loaded), size, args.tum_dir, W, H))
+        for i in range(n_frames):
+            frames.append(loaded[i % len(loaded)][0])
+            cams.append(loaded[i % len(loaded)][1])
+    for i in range(0 if args.tum_dir else n_frames):
         d, cam = synth.depth_frame(i % args.stream_frames, args.stream_frames, seed=seed, inside=inside)
         frames.append(d)
         cams.append(cam)
@@ -342,6 +352,9 @@ def main():
         elapsed = float(t.item())
     checksum = float(torch.nan_to_num(vert_dev.double(), nan=0.0).sum().item())   # the picture of the last timed frame
     last_vertices = vert_dev.clone()
+    # order-independent, exact: the sum of the 32-bit patterns of every word of the maps, as signed integers (what tools/kinfu_stream.cpp prints)
+    bits_v = int(vert_dev.view(torch.int32).to(torch.int64).sum().item())
+    bits_n = int(norm_dev.view(torch.int32).to(torch.int64).sum().item())
 
     trace("timed region done")
     # ---- untimed replays of the SAME K frames: (1) every stage and every launch of the dominant kernels bracketed with HIP
@@ -413,6 +426,8 @@ def main():
         "stage_outliers_dropped": stage_outliers,
         # sum of the finite vertex coordinates of the last frame's picture: equal between runs that differ only in schedule
         "last_frame_vertex_checksum": checksum,
+        "last_frame_vertex_bits": bits_v, "last_frame_normal_bits": bits_n,
+        "stream": ("TUM directory %s through TUMDataLoader" % args.tum_dir) if args.tum_dir else "synthesised in memory (tsdf_amd/synth.py)",
     }
 
     trace("replays done")

@@ -1,0 +1,96 @@
+"""tools/kinfu_stream.cpp: BASELINE configs[2] driven from C++ through tsdf_pipeline_step (no Python in the loop) on a synthetic
+TUM-layout directory.  Its final volume and last picture must be the oracle's, bit for bit, and its checksum the one the Python
+mirror of the same entry points gets on the same directory."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import tsdf_amd
+from tests.helpers import H, W, assert_same_floats
+from tsdf_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "build", "kinfu_stream")
+
+
+def test_kinfu_stream_is_built_and_checks_its_arguments(tmp_path):
+    """No GPU needed: the binary exists (make cpptest) and refuses a call without a directory / with a missing one."""
+    assert os.path.exists(BIN), "build/kinfu_stream missing: run `make cpptest` (build() does)"
+    r = subprocess.run([BIN], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "-d <tum dir>" in r.stderr
+    r = subprocess.run([BIN, "-d", str(tmp_path / "nothing_here")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and r.stdout == ""
+
+
+def test_tum_directory_read_back_through_the_host_loader(tmp_path):
+    """The loader both drivers use (TUMDataLoader + DepthImage + PNG codec of the host library): depth x 5 in the PNGs comes back
+    as the millimetres that were written, poses to fp32 rounding of the quaternion round trip."""
+    written = synth.write_tum_directory(str(tmp_path), 3, seed=0x5EED0002)
+    frames, size = tsdf_amd.load_tum_directory(str(tmp_path))
+    assert size == (W, H) and len(frames) == 3
+    for (d, pose), (got, cam) in zip(written, frames):
+        assert np.array_equal(d, got)
+        assert np.abs(pose - cam.pose()).max() < 1e-3
+    with pytest.raises(ValueError):
+        tsdf_amd.load_tum_directory(str(tmp_path / "missing"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("overlap", [True, False])
+def test_kinfu_stream_matches_the_oracle_and_the_python_mirror(tmp_path, oracle, overlap):
+    import torch
+    from tsdf_amd.pipeline import FusionPipeline
+    n, F, Wu, K = 96, 5, 2, 5                       # 7 steps over 5 frames: the stream wraps round
+    d = tmp_path / "tum"
+    synth.write_tum_directory(str(d), F, seed=0x5EED0003, stream_frames=40)
+    out = tmp_path / "out"
+    out.mkdir()
+    cmd = [BIN, "-d", str(d), "-n", str(n), "-k", str(K), "-w", str(Wu), "--dump", str(out)] + ([] if overlap else ["--no-overlap"])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["steps"] == K and line["frames_in_directory"] == F and line["overlap"] is overlap and line["ms_per_step"] > 0
+
+    frames, _ = tsdf_amd.load_tum_directory(str(d))
+    poses = np.fromfile(str(out / "poses.f32"), np.float32).reshape(F, 16)
+    for (_, cam), p in zip(frames, poses):
+        assert np.array_equal(cam.pose().view(np.uint32), p.view(np.uint32))      # the same loader, the same Camera
+
+    # the oracle on the same steps
+    ov = oracle.Volume((n, n, n), (3000.0,) * 3)
+    threads = oracle.max_threads()
+    for i in range(Wu + K):
+        depth, cam = frames[i % F]
+        f = oracle.bilateral_u16(depth, W, H, 30.0, 4.5, nthreads=threads).reshape(-1)
+        ov.integrate(f, W, H, cam.inverse_pose(), cam.k(), cam.kinv(), nthreads=threads)
+    last = frames[(Wu + K - 1) % F][1]
+    Vo, No = ov.raycast(W, H, last.pose(), last.kinv(), nthreads=threads)
+    assert_same_floats(np.fromfile(str(out / "distances.f32"), np.float32), ov.dist, "C++ driver: distances vs oracle")
+    assert_same_floats(np.fromfile(str(out / "weights.f32"), np.float32), ov.weight, "C++ driver: weights vs oracle")
+    V = np.fromfile(str(out / "vertices.f32"), np.float32).reshape(-1, 3)
+    N = np.fromfile(str(out / "normals.f32"), np.float32).reshape(-1, 3)
+    assert_same_floats(V, Vo, "C++ driver: last picture vs oracle")
+    assert_same_floats(N, No, "C++ driver: last normals vs oracle")
+    assert line["last_frame_hits"] == int((~np.isnan(Vo[:, 0])).sum()) > 1000
+    assert line["last_frame_vertex_bits"] == int(Vo.view(np.int32).astype(np.int64).sum())
+    # (the normals' NaNs come out of arithmetic: the host's have another bit pattern than the device's -- their checksum is
+    # compared with the Python mirror's below, device against device)
+
+    # the Python mirror of the same entry points on the same directory: the same bits
+    vol = tsdf_amd.TSDFVolume((n, n, n), (3000.0,) * 3)
+    pipe = FusionPipeline(vol, tsdf_amd.BilateralFilter(30.0, 4.5), tsdf_amd.GPURaycaster(W, H), W, H, overlap=overlap)
+    depth = torch.from_numpy(np.stack([f for f, _ in frames]).view(np.int16)).cuda()
+    vert = torch.empty((H * W, 3), dtype=torch.float32, device="cuda")
+    norm = torch.empty_like(vert)
+    for i in range(Wu + K):
+        a, b = i % F, (i + 1) % F
+        pipe.step(depth[a].data_ptr(), frames[a][1], vert.data_ptr(), norm.data_ptr(), depth[b].data_ptr(), frames[b][1])
+    pipe.synchronize()
+    assert int(vert.cpu().numpy().view(np.int32).astype(np.int64).sum()) == line["last_frame_vertex_bits"]
+    assert int(norm.cpu().numpy().view(np.int32).astype(np.int64).sum()) == line["last_frame_normal_bits"]
+    assert_same_floats(vol.get_distance_data(), ov.dist, "Python mirror: distances vs oracle")
+    pipe.close()
+    vol.close()

@@ -555,3 +555,33 @@ class Camera:
         out = (C.c_int * 2)()
         _capi.host.tsdf_camera_image_plane_to_pixel(self._h, _fp(_mat(p, 2)), out)
         return int(out[0]), int(out[1])
+
+
+def load_tum_directory(directory):
+    """Every frame of a TUM-layout directory through the host library's TUMDataLoader (the loader tools/kinfu_stream.cpp and
+    the reference's kinfu.cpp use): [(depth uint16 (H*W,) in millimetres, Camera at the frame's ground-truth pose)], (W, H)."""
+    def opened():
+        h = _capi.host.tsdf_host_tum_open(str(directory).encode())
+        if not h:
+            raise ValueError("%s does not have the TUM layout (depth/*.png + ground_truth.txt)" % directory)
+        return h
+
+    size, pose = (C.c_uint * 2)(), np.zeros(16, np.float32)
+    h = opened()       # the first frame's size (nothing is copied without a buffer)
+    got = _capi.host.tsdf_host_tum_next(h, None, 0, size, _fp(pose))
+    _capi.host.tsdf_host_tum_close(h)
+    if not got:
+        return [], (0, 0)
+    w, hh = int(size[0]), int(size[1])
+    buf, frames = np.zeros(w * hh, np.uint16), []
+    h = opened()
+    try:
+        while _capi.host.tsdf_host_tum_next(h, buf.ctypes.data, buf.size, size, _fp(pose)):
+            if (int(size[0]), int(size[1])) != (w, hh):
+                raise ValueError("depth images of different sizes in %s" % directory)
+            cam = Camera.default_depth_camera()
+            cam.set_pose(pose)
+            frames.append((buf.copy(), cam))
+    finally:
+        _capi.host.tsdf_host_tum_close(h)
+    return frames, (w, hh)
