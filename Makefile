@@ -7,7 +7,11 @@ ARCH     ?= gfx950
 # -ffp-contract=off: every fp32 op rounds on its own, in the reference's order (parity contract)
 HIPFLAGS  = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Iinclude -Itsdf_amd/csrc -Wall -Wno-unused-function
 CSRC      = tsdf_amd/csrc
-HIP_SRCS  = $(CSRC)/volume.hip $(CSRC)/integrate.hip $(CSRC)/raycast.hip $(CSRC)/bilateral.hip $(CSRC)/icp.hip $(CSRC)/mcubes.hip $(CSRC)/pipeline.hip
+# `make DIAG=1`: a library with the host-side diagnostics of diagnostics.hip (TSDF_DEBUG_SORT / TSDF_DEBUG_BRICKS); not the product build
+ifeq ($(DIAG),1)
+HIPFLAGS += -DTSDF_DIAGNOSTICS
+endif
+HIP_SRCS  = $(CSRC)/diagnostics.hip $(CSRC)/volume.hip $(CSRC)/integrate.hip $(CSRC)/raycast.hip $(CSRC)/bilateral.hip $(CSRC)/icp.hip $(CSRC)/mcubes.hip $(CSRC)/pipeline.hip
 HIP_OBJS  = $(HIP_SRCS:.hip=.o)
 LIBDIR    = tsdf_amd/lib
 
@@ -40,7 +44,7 @@ $(LIBDIR)/libtsdf_host.so: $(HOST_OBJS) $(LIBDIR)/libtsdf_hip.so
 
 hip: $(LIBDIR)/libtsdf_hip.so
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.hpp include/tsdf_amd.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.hpp $(CSRC)/integrate_grid.hpp include/tsdf_amd.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIBDIR)/libtsdf_hip.so: $(HIP_OBJS)

@@ -66,69 +66,6 @@ int main(int argc, char **argv) {
     assert r.returncode == 0 and "file utilities ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
 
 
-def test_reference_tsdf_view_writes_its_slice_images(tmp_path):
-    """src/Tools/tsdf_view.cpp of the reference, compiled unchanged against this repo's PNG utilities (no GPU needed): it
-    reads dims + 3 floats + a cubic distance array and writes three tiled colour PNGs into the working directory."""
-    tool = os.path.join(ROOT, "build", "linkcheck", "bin", "tsdf_view")
-    if not os.path.exists(tool):
-        pytest.skip("build/linkcheck/bin/tsdf_view not built (needs the reference tree at build time)")
-    n = 8
-    rng = np.random.default_rng(1)
-    with open(tmp_path / "v.bin", "wb") as f:
-        f.write(np.array([n, n, n], np.uint32).tobytes())
-        f.write(np.array([80.0, 80.0, 80.0], np.float32).tobytes())
-        f.write(rng.uniform(-10, 10, n ** 3).astype(np.float32).tobytes())
-    r = subprocess.run([tool, str(tmp_path / "v.bin")], capture_output=True, text=True, timeout=60, cwd=str(tmp_path))
-    assert r.returncode == 0, r.stdout + r.stderr
-    import struct
-    import zlib
-    for name in ("top.png", "right.png", "front.png"):
-        data = (tmp_path / name).read_bytes()
-        assert data[:8] == b"\x89PNG\r\n\x1a\n"
-        w, h, depth, colour = struct.unpack(">IIBB", data[16:26])
-        assert depth == 8 and colour == 2 and w > n and h > n            # 8-bit RGB, several tiles
-        # the pixel stream inflates to h rows of 1 filter byte + 3 * w bytes
-        idat = b""
-        pos = 8
-        while pos < len(data):
-            ln, tag = struct.unpack(">I4s", data[pos:pos + 8])
-            if tag == b"IDAT":
-                idat += data[pos + 8:pos + 8 + ln]
-            pos += 12 + ln
-        assert len(zlib.decompress(idat)) == h * (1 + 3 * w)
-
-
-def test_reference_pgm2png_converts_a_depth_map(tmp_path):
-    """src/Tools/pgm2png.cpp of the reference, compiled unchanged: read_nyu_depth_map (16-bit PGM, bytes of every sample
-    swapped after the read, src/Utilities/DepthMapUtilities.cpp:29-31) + save_png_to_file (16-bit greyscale PNG)."""
-    tool = os.path.join(ROOT, "build", "linkcheck", "bin", "pgm2png")
-    if not os.path.exists(tool):
-        pytest.skip("build/linkcheck/bin/pgm2png not built (needs the reference tree at build time)")
-    w, h = 7, 5
-    img = (np.arange(w * h, dtype=np.uint32) * 1234 % 65536).astype(np.uint16).reshape(h, w)
-    with open(tmp_path / "d.pgm", "wb") as f:
-        f.write(b"P5 %d %d 65535\n" % (w, h))
-        f.write(img.astype(">u2").tobytes())
-    r = subprocess.run([tool, str(tmp_path / "d.pgm")], capture_output=True, text=True, timeout=60)
-    assert r.returncode == 0, r.stdout + r.stderr
-    import struct
-    import zlib
-    data = (tmp_path / "d.png").read_bytes()
-    pw, ph, depth, colour = struct.unpack(">IIBB", data[16:26])
-    assert (pw, ph, depth, colour) == (w, h, 16, 0)
-    idat, pos = b"", 8
-    while pos < len(data):
-        ln, tag = struct.unpack(">I4s", data[pos:pos + 8])
-        if tag == b"IDAT":
-            idat += data[pos + 8:pos + 8 + ln]
-        pos += 12 + ln
-    raw = zlib.decompress(idat)
-    rows = [raw[y * (1 + 2 * w):(y + 1) * (1 + 2 * w)] for y in range(h)]
-    assert all(row[0] == 0 for row in rows)                       # filter type none
-    got = np.frombuffer(b"".join(row[1:] for row in rows), ">u2").reshape(h, w)
-    assert np.array_equal(got, img.byteswap())                    # the reference's byte swap of every sample
-
-
 @pytest.mark.gpu
 def test_cpp_surface_matches_the_oracle(tmp_path, oracle):
     if not os.path.exists(BIN):

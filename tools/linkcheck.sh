@@ -14,7 +14,6 @@ W="$ROOT/build/linkcheck"
 OUT="$ROOT/build/linkcheck/bin"   # product binaries from the reference's unchanged tool sources (git-ignored, travel to the GPU box);
                                   # oracle/_ref holds only the reference compiled on its own (libref_bilateral.so)
 rm -rf "$W"; mkdir -p "$W/src/Tools"
-rm -f "$ROOT"/oracle/_ref/kinfu "$ROOT"/oracle/_ref/tsdf_icp "$ROOT"/oracle/_ref/tsdf_view "$ROOT"/oracle/_ref/pgm2png; rm -f "$ROOT"/oracle/_ref/{kinfu,tsdf_icp,tsdf_view,pgm2png}
 ln -s "$SRC" "$W/src/Tools/kinfu.cpp"
 ln -s "$ROOT/tsdf_amd/host/include" "$W/src/include"
 EIGEN=""
@@ -35,21 +34,6 @@ if [ -f "$ICPSRC" ]; then
   g++ -std=c++11 -O1 -w $EIGEN $SOPHUS -I"$ROOT/include" -I"$ROOT/tsdf_amd/host/third_party" -c "$W/src/Tools/tsdf_icp.cpp" -o "$W/tsdf_icp.o"
   g++ -o "$OUT/tsdf_icp" "$W/tsdf_icp.o" -L"$ROOT/tsdf_amd/lib" -ltsdf_host -ltsdf_hip -Wl,-rpath,'$ORIGIN/../../../tsdf_amd/lib'
   echo "linkcheck: reference tsdf_icp.cpp compiled unchanged and linked -> $OUT/tsdf_icp"
-fi
-# src/Tools/tsdf_view.cpp: slices of a distance array as colour PNGs -- only the PNG utilities of the class surface
-VIEWSRC="$REF/src/Tools/tsdf_view.cpp"
-if [ -f "$VIEWSRC" ]; then
-  ln -s "$VIEWSRC" "$W/src/Tools/tsdf_view.cpp"
-  g++ -std=c++11 -O1 -w $EIGEN -I"$ROOT/include" -c "$W/src/Tools/tsdf_view.cpp" -o "$W/tsdf_view.o"
-  g++ -o "$OUT/tsdf_view" "$W/tsdf_view.o" -L"$ROOT/tsdf_amd/lib" -ltsdf_host -ltsdf_hip -Wl,-rpath,'$ORIGIN/../../../tsdf_amd/lib'
-  echo "linkcheck: reference tsdf_view.cpp compiled unchanged and linked -> $OUT/tsdf_view"
-fi
-# src/Tools/pgm2png.cpp (NYU 16-bit PGM depth map -> PNG); it includes the headers by bare name
-PGMSRC="$REF/src/Tools/pgm2png.cpp"
-if [ -f "$PGMSRC" ]; then
-  g++ -std=c++11 -O1 -w $EIGEN -I"$ROOT/include" -I"$ROOT/tsdf_amd/host/include" -c "$PGMSRC" -o "$W/pgm2png.o"
-  g++ -o "$OUT/pgm2png" "$W/pgm2png.o" -L"$ROOT/tsdf_amd/lib" -ltsdf_host -ltsdf_hip -Wl,-rpath,'$ORIGIN/../../../tsdf_amd/lib'
-  echo "linkcheck: reference pgm2png.cpp compiled unchanged and linked -> $OUT/pgm2png"
 fi
 # usage line only (no GPU needed): the binary must start and reject a bad command line like the reference
 "$OUT/kinfu" 2>&1 | head -2 || true

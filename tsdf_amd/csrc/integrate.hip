@@ -28,20 +28,12 @@
 #include <cmath>
 
 #include <cstdlib>
-#include <unordered_map>
 
 #include "common.hpp"
+#include "integrate_grid.hpp"
 
 namespace tsdf {
 
-constexpr int kTileX = kIntBrickX;  // one wave along x
-constexpr int kTileY = kIntBrickY;  // waves per workgroup
-constexpr int kChunkZ = kIntBrickZ; // planes walked by one workgroup
-#ifndef TSDF_BATCH_Z
-#define TSDF_BATCH_Z 4
-#endif
-constexpr int kBatchZ = TSDF_BATCH_Z;  // planes whose loads are issued together
-constexpr int kTilePixels = 8192;  // LDS depth tile of a brick: 16 KiB
 
 struct Projected {
     float ix, iy, iz;  // K * cam
@@ -147,8 +139,6 @@ __device__ inline void mark_low_voxels(const OccGrid &occ, const uint32_t bits_l
 constexpr int kDepthTile = TSDF_DEPTH_TILE;  // pixels per side of a depth tile (16)
 constexpr int kCullTilesLds = 4096;  // tile maxima brick_cull_kernel keeps in LDS (1200 at 640x480)
 
-static std::unordered_map<uint32_t, float> g_prev_brick_us;   // diagnostics (TSDF_DEBUG_SORT=9/10): brick -> microseconds in the previous launch
-
 static uint32_t occupancy_rebuild_period() {
     static const uint32_t n = [] {
         const char *e = getenv("TSDF_OCC_REBUILD_PERIOD");  // tuning aid; 0 = never
@@ -171,13 +161,6 @@ __global__ __launch_bounds__(64) void depth_tile_max_kernel(const uint16_t *__re
     for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_down(m, o));
     if (threadIdx.x == 0) tile_max[ty * tiles_x + tx] = (uint16_t)m;
 }
-
-struct BrickGrid {
-    uint32_t nx, ny, nz;  // bricks per axis over the resident planes
-    uint32_t z_extra;     // planes (<= kBatchZ) appended to the bricks of the last z layer: a slab's halo plane, which would
-                          // otherwise cost a whole layer of bricks that project 32 planes to update one
-    uint32_t pair_loads;  // 1 = the image has an even width and a 4-byte aligned base: pixel boxes are made even and staged two pixels per lane
-};
 
 // Eight lanes per 64x4x32 brick: decide whether any voxel of it can be updated by this frame (see the header).
 __global__ __launch_bounds__(256) void brick_cull_kernel(const Geom g, const BrickGrid bg, const Mat44 ip, const Mat33 k,
@@ -560,23 +543,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                 }
                 const float sdf = surf_z - voxel_cam_z;
                 // depth > 0 (:355; also false for planes past the brick and pixels off the image) and sdf >= -trunc (:366)
-#ifdef TSDF_DEBUG_ALLUPDATE
-                const bool update = act[j];     // (experiment, DESIGN.md 3.1: every voxel of a surviving brick takes the memory path)
-#else
                 const bool update = d_[j] != 0 && sdf >= neg_trunc;
-#endif
                 // (sdf > 0) ? min(sdf, trunc) : sdf  ==  sdf < trunc ? sdf : trunc   (trunc > 0)
                 tsdf_[j] = update ? (sdf < g.trunc ? sdf : g.trunc) : NAN;
                 pw_[j] = pd_[j] = 0.f;
-#ifndef TSDF_DEBUG_NOMEM
-#ifndef TSDF_DEBUG_NOMEM     // (experiment, DESIGN.md 3.1: the kernel without its HBM loads and stores)
                 if (update) {
                     const size_t pb = brick_base + plane * (size_t)(zb - z0 + j);
                     pw_[j] = (weight + pb)[lane_off];
                     pd_[j] = (dist + pb)[lane_off];
                 }
-#endif
-#endif
             }
         };
         auto blend_and_store = [&](const uint32_t zb, const float (&tsdf_)[kBatchZ], const float (&pw_)[kBatchZ], const float (&pd_)[kBatchZ]) {
@@ -586,12 +561,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                     const float new_weight = pw_[j] + 1.0f;
                     const float new_distance = ((pd_[j] * pw_[j]) + (tsdf_[j] * 1.0f)) / new_weight;
                     const size_t pb = brick_base + plane * (size_t)(zb - z0 + j);
-#ifndef TSDF_DEBUG_NOMEM
                     (weight + pb)[lane_off] = new_weight;
                     (dist + pb)[lane_off] = new_distance;
-#else
-                    if (new_weight == -123.0f && new_distance == 77.0f) (dist + pb)[lane_off] = new_distance;   // (keeps the arithmetic alive)
-#endif
                     if (!(new_distance > occ.tau)) {   // not safely positive: remember the plane, the bricks are marked when this one is done
                         const uint32_t o_ = zb + j - z0;
                         if (o_ < 32u) low_lo |= 1u << o_; else low_hi |= 1u << (o_ - 32u);
@@ -728,64 +699,9 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
         }
     }
     if (phase == kIntPrepare) return TSDF_OK;   // (custom nodes: every brick is walked, nothing to prepare)
-    if (!v->nodes) {   // diagnostics, TSDF_DEBUG_SORT = 1..8: the list reordered on the host (synchronises), to time integrate_kernel on other orders --
-                       // 1 index order, 2 scattered, 3 position in the layer then layer, 4 x / z / y (what the cull kernel produces), 5 x / y / z, 6 x then
-                       // scattered rows, 7 z / x / y, 8 even rows first
-        static const int sort_mode = [] { const char *e = getenv("TSDF_DEBUG_SORT"); return e ? atoi(e) : 0; }();
-        // 9 / 10 (with TSDF_DEBUG_BRICKS=3): bricks that took long in the previous launch first, in 2 / 3 classes, each class column by column
-        if (sort_mode >= 9 && !g_prev_brick_us.empty()) {
-            (void)hipStreamSynchronize(v->stream);
-            uint32_t n = 0;
-            (void)hipMemcpy(&n, count, sizeof(n), hipMemcpyDeviceToHost);
-            std::vector<uint32_t> l(n), idx(n), l2(n);
-            std::vector<uint4> bx(n), bx2(n);
-            (void)hipMemcpy(l.data(), v->brick_list, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
-            (void)hipMemcpy(bx.data(), boxes, n * sizeof(uint4), hipMemcpyDeviceToHost);
-            std::vector<float> known;
-            for (uint32_t i = 0; i < n; i++) { idx[i] = i; auto it = g_prev_brick_us.find(l[i]); if (it != g_prev_brick_us.end()) known.push_back(it->second); }
-            std::sort(known.begin(), known.end());
-            const int classes = sort_mode == 9 ? 2 : 3;
-            auto cls = [&](uint32_t i) -> uint64_t {
-                auto it = g_prev_brick_us.find(l[i]);
-                if (it == g_prev_brick_us.end() || known.empty()) return 0;   // unknown: with the expensive ones
-                const size_t rank = std::lower_bound(known.begin(), known.end(), it->second) - known.begin();
-                return (uint64_t)(classes - 1 - std::min<size_t>(classes - 1, rank * classes / known.size()));
-            };
-            std::vector<uint64_t> key(n);
-            for (uint32_t i = 0; i < n; i++) key[i] = (cls(i) << 56) | ((uint64_t)(l[i] % bg.nx) << 32) | (l[i] / bg.nx);
-            std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t c) { return key[a] < key[c]; });
-            for (uint32_t i = 0; i < n; i++) { l2[i] = l[idx[i]]; bx2[i] = bx[idx[i]]; }
-            (void)hipMemcpy(v->brick_list, l2.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice);
-            (void)hipMemcpy(boxes, bx2.data(), n * sizeof(uint4), hipMemcpyHostToDevice);
-        } else if (sort_mode && sort_mode < 9) {
-            (void)hipStreamSynchronize(v->stream);
-            uint32_t n = 0;
-            (void)hipMemcpy(&n, count, sizeof(n), hipMemcpyDeviceToHost);
-            std::vector<uint32_t> l(n), idx(n);
-            std::vector<uint4> bx(n), bx2(n);
-            (void)hipMemcpy(l.data(), v->brick_list, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
-            (void)hipMemcpy(bx.data(), boxes, n * sizeof(uint4), hipMemcpyDeviceToHost);
-            for (uint32_t i = 0; i < n; i++) idx[i] = i;
-            const uint32_t layer = bg.nx * bg.ny;
-            auto key = [&](uint32_t i) -> uint64_t {
-                const uint32_t b = l[i];
-                if (sort_mode == 1) return b;
-                if (sort_mode == 2) return ((uint64_t)b * 2654435761u) & 0xffffffffu;
-                if (sort_mode == 3) return ((uint64_t)(b % layer) << 8) | (b / layer);           // position in the layer, then the layer
-                if (sort_mode == 4) return ((uint64_t)(b % bg.nx) << 32) | (b / bg.nx);             // x, then the row
-                const uint32_t bxx = b % bg.nx, byy = (b / bg.nx) % bg.ny, bzz = b / layer;
-                if (sort_mode == 5) return ((uint64_t)bxx << 32) | ((uint64_t)byy << 16) | bzz;      // x, y, then the layer
-                if (sort_mode == 6) return ((uint64_t)bxx << 32) | (((uint64_t)(b / bg.nx) * 2654435761u) & 0xffffffffu);   // x, rows scattered
-                if (sort_mode == 7) return ((uint64_t)bzz << 32) | ((uint64_t)bxx << 16) | byy;      // layer, x, y
-                return ((uint64_t)(byy & 1u) << 48) | ((uint64_t)bxx << 32) | (b / bg.nx);          // even rows first, x, row
-            };
-            std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t c) { return key(a) < key(c); });
-            std::vector<uint32_t> l2(n);
-            for (uint32_t i = 0; i < n; i++) { l2[i] = l[idx[i]]; bx2[i] = bx[idx[i]]; }
-            (void)hipMemcpy(v->brick_list, l2.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice);
-            (void)hipMemcpy(boxes, bx2.data(), n * sizeof(uint4), hipMemcpyHostToDevice);
-        }
-    }
+#ifdef TSDF_DIAGNOSTICS
+    diag_sort_brick_list(v, bg, count, boxes);   // TSDF_DEBUG_SORT: the list re-ordered on the host (synchronises), diagnostics.hip
+#endif
     dim3 block(kTileX, kTileY, 1);
     // One workgroup per brick of the grid; those beyond the list's length leave at once.  The dispatcher hands the next brick to
     // whichever compute unit frees a slot, which balances the uneven bricks better than a resident grid walking the list
@@ -799,12 +715,10 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
     const bool std_camera = finite && ip.m41 == 0.0f && ip.m42 == 0.0f && ip.m43 == 0.0f && ip.m44 == 1.0f &&
                             mk.m21 == 0.0f && mk.m31 == 0.0f && mk.m12 == 0.0f && mk.m32 == 0.0f && mk.m33 == 1.0f &&
                             mkinv.m31 == 0.0f && mkinv.m32 == 0.0f && mkinv.m33 == 1.0f;
-    static const int debug_clocks = [] { const char *e = getenv("TSDF_DEBUG_BRICKS"); return e && atoi(e) >= 3; }();
     unsigned long long *brick_log = nullptr;
-    if (debug_clocks && !v->counting && !v->nodes) {
-        (void)hipMalloc((void **)&brick_log, 2 * n_bricks * sizeof(unsigned long long));
-        (void)hipMemset(brick_log, 0, 2 * n_bricks * sizeof(unsigned long long));
-    }
+#ifdef TSDF_DIAGNOSTICS
+    brick_log = diag_brick_log_alloc(v, n_bricks);   // TSDF_DEBUG_BRICKS=3: per-brick clocks of the launch (diagnostics.hip)
+#endif
     unsigned long long *counter_arg = brick_log ? brick_log : (v->counting ? v->counter_dev : nullptr);
 #define LAUNCH(DEF, CNT, STDC)                                                                                       \
     TSDF_LAUNCH_TIMED(v, 0, (integrate_kernel<DEF, CNT, STDC>), grid, block, v->dist, v->weight, v->nodes,          \
@@ -818,62 +732,9 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
     }
 #undef LAUNCH
     TSDF_HIP(hipGetLastError(), "Integrate kernel failed");
-    if (brick_log) {   // diagnostics (synchronises): the launch's bricks over time
-        (void)hipStreamSynchronize(v->stream);
-        uint32_t n = 0;
-        (void)hipMemcpy(&n, count, sizeof(n), hipMemcpyDeviceToHost);
-        std::vector<unsigned long long> log(2 * (size_t)n);
-        (void)hipMemcpy(log.data(), brick_log, log.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-        (void)hipFree(brick_log);
-        unsigned long long t0 = ~0ull, t1 = 0;
-        for (uint32_t e = 0; e < n; e++) if (log[2 * e]) { t0 = std::min(t0, log[2 * e]); t1 = std::max(t1, log[2 * e + 1]); }
-        {
-            std::vector<uint32_t> lst(n);
-            (void)hipMemcpy(lst.data(), v->brick_list, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
-            g_prev_brick_us.clear();
-            for (uint32_t e = 0; e < n; e++) g_prev_brick_us[lst[e]] = (float)((double)(log[2 * e + 1] - log[2 * e]) / 100.0);
-        }
-        size_t alive[16] = {};
-        double dur = 0, dmax = 0, dmin = 1e18, last_start = 0;
-        for (uint32_t e = 0; e < n; e++) {
-            const double b0 = (double)(log[2 * e] - t0) / 100.0, e0 = (double)(log[2 * e + 1] - t0) / 100.0;
-            dur += e0 - b0; dmax = std::max(dmax, e0 - b0); dmin = std::min(dmin, e0 - b0); last_start = std::max(last_start, b0);
-            for (int q = 0; q < 16; q++) { const double tq = (q + 0.5) / 16.0 * (double)(t1 - t0) / 100.0; if (b0 <= tq && tq < e0) alive[q]++; }
-        }
-        fprintf(stderr, "tsdf: integrate_kernel %.1f us (100 MHz clock): %u bricks, %.1f us each (%.1f .. %.1f), last start %.1f; alive per sixteenth:", (t1 - t0) / 100.0, n,
-                n ? dur / n : 0.0, dmin, dmax, last_start);
-        for (int q = 0; q < 16; q++) fprintf(stderr, " %zu", alive[q]);
-        fprintf(stderr, "\n");
-        {   // the bricks that end last, and the longest ones: start, duration, pixel box
-            std::vector<uint4> bx(n);
-            (void)hipMemcpy(bx.data(), boxes, n * sizeof(uint4), hipMemcpyDeviceToHost);
-            std::vector<uint32_t> idx(n);
-            for (uint32_t e = 0; e < n; e++) idx[e] = e;
-            std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t c) { return log[2 * a + 1] > log[2 * c + 1]; });
-            fprintf(stderr, "tsdf:   last to end (entry: start + duration us, box):");
-            for (uint32_t r = 0; r < std::min(n, 6u); r++) { const uint32_t e = idx[r]; fprintf(stderr, " %u: %.0f + %.0f, %ux%u;", e, (log[2 * e] - t0) / 100.0, (log[2 * e + 1] - log[2 * e]) / 100.0, bx[e].z, bx[e].w); }
-            std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t c) { return log[2 * a + 1] - log[2 * a] > log[2 * c + 1] - log[2 * c]; });
-            fprintf(stderr, "\ntsdf:   longest:");
-            for (uint32_t r = 0; r < std::min(n, 6u); r++) { const uint32_t e = idx[r]; fprintf(stderr, " %u: %.0f + %.0f, %ux%u;", e, (log[2 * e] - t0) / 100.0, (log[2 * e + 1] - log[2 * e]) / 100.0, bx[e].z, bx[e].w); }
-            size_t n_unstaged = 0; double d_unstaged = 0, d_staged = 0;
-            for (uint32_t e = 0; e < n; e++) { const bool st = bx[e].z != 0 && ((bx[e].z + 1u) & ~1u) * bx[e].w <= (uint32_t)kTilePixels; const double d = (log[2 * e + 1] - log[2 * e]) / 100.0; if (st) d_staged += d; else { d_unstaged += d; n_unstaged++; } }
-            fprintf(stderr, "\ntsdf:   %zu bricks without a tile: %.1f us each; the others %.1f us\n", n_unstaged, n_unstaged ? d_unstaged / n_unstaged : 0.0, n > n_unstaged ? d_staged / (n - n_unstaged) : 0.0);
-        }
-    }
-    if (getenv("TSDF_DEBUG_BRICKS") && !v->nodes) {   // diagnostics: how many bricks survived the cull
-        uint32_t n_active = 0;
-        (void)hipMemcpy(&n_active, count, sizeof(n_active), hipMemcpyDeviceToHost);
-        fprintf(stderr, "tsdf: %u of %zu bricks active (%.1f M voxels processed)\n", n_active, n_bricks, n_active * 4096.0 / 1e6);
-        if (atoi(getenv("TSDF_DEBUG_BRICKS")) > 1) {   // the order of the list: its first entries, and how long its runs of consecutive bricks are
-            std::vector<uint32_t> l(n_active);
-            (void)hipMemcpy(l.data(), v->brick_list, n_active * sizeof(uint32_t), hipMemcpyDeviceToHost);
-            fprintf(stderr, "tsdf: list starts");
-            for (uint32_t i = 0; i < std::min(n_active, 40u); i++) fprintf(stderr, " %u", l[i]);
-            size_t runs = 1, same_row = 0;
-            for (uint32_t i = 1; i < n_active; i++) { runs += l[i] != l[i - 1] + 1; same_row += (l[i] / bg.nx == l[i - 1] / bg.nx); }
-            fprintf(stderr, "\ntsdf: %zu runs of consecutive bricks (mean length %.1f), %zu neighbours in the same row\n", runs, (double)n_active / runs, same_row);
-        }
-    }
+#ifdef TSDF_DIAGNOSTICS
+    diag_brick_report(v, bg, n_bricks, count, boxes, brick_log);   // TSDF_DEBUG_BRICKS: survivors, list order, per-brick clocks
+#endif
     v->reach_dirty = 1;  // bricks may have been flagged
     // The kernel only sets occupancy flags.  A voxel that was low when first seen (sensor dropouts smeared by the
     // bilateral filter put phantom surfaces into free space) and has since been averaged back up keeps its bricks

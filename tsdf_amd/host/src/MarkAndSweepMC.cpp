@@ -8,7 +8,7 @@
 // fixed order, until it coincides with one of 30 base configurations, and that base's triangulation is turned back.
 // The base triangulations and the try-order below reproduce the reference's TRIANGLE_TABLE entry for entry -- same
 // triangles, same order, same first vertex (tools/mc_table_sha.py compares a SHA-256 of the 256 x 16 table with the
-// reference's file where that is mounted; tests/golden/mc_triangle_table.sha256 carries the digest to the GPU box) -- so
+// reference's file where that is mounted; tests/golden/mc_tables.sha256.json carries the digest to the GPU box) -- so
 // extract_surface emits the vertex array the reference's loop (MarkAndSweepMC.cu:285) emits.
 #include "MarkAndSweepMC.hpp"
 

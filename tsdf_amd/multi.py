@@ -30,6 +30,8 @@ def balanced_slab_ranges(cost_per_plane, world, min_planes=1):
     right keeping at least `min_planes` planes for every slab still to come."""
     cost = [max(0.0, float(c)) for c in cost_per_plane]
     Z = len(cost)
+    if min_planes < 1:
+        raise ValueError("min_planes must be at least 1 (a slab volume holds at least one plane)")
     if world < 1 or world * min_planes > Z:
         raise ValueError("cannot split %d planes over %d ranks" % (Z, world))
     if world == 1:
@@ -60,10 +62,7 @@ def balanced_slab_ranges(cost_per_plane, world, min_planes=1):
             lo = mid
         else:
             hi = mid
-    ranges = layout(hi)
-    # the last slabs may have been left with exactly min_planes each although they could take more: even them out by
-    # re-running the greedy from the right with the same bound when that lowers the largest cost (cheap: world <= 8)
-    return ranges
+    return layout(hi)
 
 
 def refine_slab_ranges(ranges, seconds, size_z, min_planes=1, floor=None):
@@ -82,7 +81,8 @@ def refine_slab_ranges(ranges, seconds, size_z, min_planes=1, floor=None):
     return balanced_slab_ranges(density, world, min_planes)
 
 
-def plane_costs(volume_factory, frames, cameras, size, planner_z=128, integrate_weight=0.4, raycast_weight=0.6, constant=0.02):
+def plane_costs(volume_factory, frames, cameras, size, planner_z=128, integrate_weight=0.4, raycast_weight=0.6, constant=0.02,
+                width=640, height=480):
     """Work estimate per Z plane of a `size` grid, for balanced_slab_ranges: a small planner volume of the same physical box
     (planner_z planes) integrates the given frames; per planner plane, the share of updated voxels (what integrate_kernel
     does per frame) and of occupied ray-caster bricks (where the march evaluates samples instead of jumping) are blended with
@@ -94,7 +94,7 @@ def plane_costs(volume_factory, frames, cameras, size, planner_z=128, integrate_
     grid = (max(8, X * pz // Z), max(8, Y * pz // Z), pz)
     vol = volume_factory(grid)
     for depth, cam in zip(frames, cameras):
-        vol.integrate(depth, 640, 480, cam)
+        vol.integrate(depth, int(width), int(height), cam)
     w = vol.get_weight_data().reshape(pz, -1)
     updated = (w > 0).sum(axis=1).astype(np.float64)
     fine = vol.occupancy_data(force_rebuild=True)[0]                     # (nbz, nby, nbx), 4-voxel bricks
