@@ -19,16 +19,14 @@ public:
     DepthImage *next(Eigen::Matrix4f &pose);
 
 private:
-    struct DATA_RECORD {
-        std::string file_name;
-        float data[7];
+    struct Frame {
+        std::string png;   // <dir>/depth/<stem>.png
+        float tq[7];       // tx ty tz (metres), qx qy qz qw
     };
-    Eigen::Matrix4f to_pose(float vars[7]) const;
-    void process_line(const std::string &line);
-    void load_data_from(const std::string &gt_file_name);
+    static Eigen::Matrix4f pose_of(const Frame &f);
 
-    size_t m_current_idx;
-    std::vector<struct DATA_RECORD> m_data_records;
-    std::string m_directory_name;
+    size_t m_next;
+    std::vector<Frame> m_frames;
+    std::string m_root;
 };
 #endif

@@ -1,77 +1,76 @@
-// reference: src/DataLoader/TUMDataLoader.cpp
+// Replays a TUM RGB-D directory for the kinfu loop: "<stem> tx ty tz qx qy qz qw" per line of <dir>/ground_truth.txt, the frame
+// in <dir>/depth/<stem>.png.  Behaviour (what is accepted, what is thrown, the poses bit for bit) follows the reference's
+// src/DataLoader/TUMDataLoader.cpp; the class surface is the one src/Tools/kinfu.cpp is written against.
 #include "TUMDataLoader.hpp"
 
-#include <functional>
+#include <fstream>
 #include <iostream>
 #include <sstream>
 #include <stdexcept>
 
 #include "FileUtilities.hpp"
 
-TUMDataLoader::TUMDataLoader(const std::string &directory) : m_current_idx{0} {
-    bool is_directory = false;
-    if (!(file_exists(directory, is_directory) && is_directory)) throw std::invalid_argument("Directory not found " + directory);
-    m_directory_name = directory;
-    const std::string gt = directory + "/ground_truth.txt";
-    if (!(file_exists(gt, is_directory) && !is_directory)) throw std::invalid_argument("Ground truth file not found " + gt);
-    load_data_from(gt);
+namespace {
+bool is_plain_file(const std::string &path) {
+    bool dir = false;
+    return file_exists(path, dir) && !dir;
+}
+}  // namespace
+
+TUMDataLoader::TUMDataLoader(const std::string &directory) : m_next{0}, m_root{directory} {
+    bool dir = false;
+    if (!file_exists(directory, dir) || !dir) throw std::invalid_argument("Directory not found " + directory);
+    const std::string index = m_root + "/ground_truth.txt";
+    if (!is_plain_file(index)) throw std::invalid_argument("Ground truth file not found " + index);
+    std::ifstream in(index);
+    if (!in.is_open()) throw std::runtime_error("Failed to parse the ground truth file");
+    // one record per line that is neither empty nor a '#' comment (reference :111-128); fields that fail to parse read as the
+    // stream leaves them, like there
+    for (std::string line; std::getline(in, line);) {
+        if (line.empty() || line[0] == '#') continue;
+        std::istringstream fields(line);
+        std::string stem;
+        Frame f = Frame();
+        fields >> stem;
+        for (float &value : f.tq) fields >> value;
+        f.png = m_root + "/depth/" + stem + ".png";
+        m_frames.push_back(f);
+    }
 }
 
 TUMDataLoader::~TUMDataLoader() {}
 
-// reference: :47-76 -- quaternion (qx qy qz qw) to rotation, translation metres -> millimetres
-Eigen::Matrix4f TUMDataLoader::to_pose(float vars[7]) const {
-    const float w = vars[6], x = vars[3], y = vars[4], z = vars[5];
+// Unit quaternion (qx, qy, qz, qw) + translation in metres -> camera pose in millimetres (reference :47-76).  Every entry is the
+// reference's float expression -- products first, their sum or difference, the doubling, then 1 - (...) on the diagonal -- so the
+// poses kinfu integrates with are the same bits.
+Eigen::Matrix4f TUMDataLoader::pose_of(const Frame &f) {
+    const float qx = f.tq[3], qy = f.tq[4], qz = f.tq[5], qw = f.tq[6];
+    const float xx = qx * qx, yy = qy * qy, zz = qz * qz;
+    const float xy = qx * qy, xz = qx * qz, yz = qy * qz;
+    const float wx = qw * qx, wy = qw * qy, wz = qw * qz;
+    const float rot[3][3] = {{1 - 2 * (yy + zz), 2 * (xy - wz), 2 * (xz + wy)},
+                             {2 * (xy + wz), 1 - 2 * (xx + zz), 2 * (yz - wx)},
+                             {2 * (xz - wy), 2 * (yz + wx), 1 - 2 * (xx + yy)}};
     Eigen::Matrix4f pose = Eigen::Matrix4f::Zero();
-    pose(0, 0) = 1 - 2 * (y * y + z * z);
-    pose(0, 1) = 2 * (x * y - w * z);
-    pose(0, 2) = 2 * (x * z + w * y);
-    pose(1, 0) = 2 * (x * y + w * z);
-    pose(1, 1) = 1 - 2 * (x * x + z * z);
-    pose(1, 2) = 2 * (y * z - w * x);
-    pose(2, 0) = 2 * (x * z - w * y);
-    pose(2, 1) = 2 * (y * z + w * x);
-    pose(2, 2) = 1 - 2 * (x * x + y * y);
-    pose(0, 3) = vars[0] * 1000.0f;
-    pose(1, 3) = vars[1] * 1000.0f;
-    pose(2, 3) = vars[2] * 1000.0f;
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) pose(r, c) = rot[r][c];
+        pose(r, 3) = f.tq[r] * 1000.0f;
+    }
     pose(3, 3) = 1.0f;
     return pose;
 }
 
-// reference: :84-108
+// The next frame in millimetres (TUM stores 5000 units per metre: x 0.2) and its pose; a record whose PNG is missing is reported,
+// consumed and answered with nullptr, as the reference does (:84-108).
 DepthImage *TUMDataLoader::next(Eigen::Matrix4f &pose) {
-    DepthImage *image = nullptr;
-    if (m_current_idx < m_data_records.size()) {
-        struct DATA_RECORD dr = m_data_records[m_current_idx];
-        bool is_directory;
-        if (file_exists(dr.file_name, is_directory) && !is_directory) {
-            image = new DepthImage(dr.file_name);
-            image->scale_depth(0.2f);  // TUM: 5000 units per metre -> mm
-            pose = to_pose(dr.data);
-        } else {
-            std::cerr << "Couldn't find file " << dr.file_name << std::endl;
-        }
-        m_current_idx++;
+    if (m_next >= m_frames.size()) return nullptr;
+    const Frame &f = m_frames[m_next++];
+    if (!is_plain_file(f.png)) {
+        std::cerr << "Couldn't find file " << f.png << std::endl;
+        return nullptr;
     }
+    DepthImage *image = new DepthImage(f.png);
+    image->scale_depth(0.2f);
+    pose = pose_of(f);
     return image;
-}
-
-// reference: :111-128
-void TUMDataLoader::process_line(const std::string &line) {
-    if (line.size() > 0 && line[0] != '#') {
-        std::stringstream iss(line);
-        struct DATA_RECORD dr;
-        std::string stem;
-        iss >> stem;
-        dr.file_name = m_directory_name + "/depth/" + stem + ".png";
-        for (int i = 0; i < 7; i++) iss >> dr.data[i];
-        m_data_records.push_back(dr);
-    }
-}
-
-void TUMDataLoader::load_data_from(const std::string &gt_file_name) {
-    std::function<void(const std::string &)> f = std::bind(&TUMDataLoader::process_line, this, std::placeholders::_1);
-    if (!process_file_by_lines(gt_file_name, f)) throw std::runtime_error("Failed to parse the ground truth file");
-    m_current_idx = 0;
 }
