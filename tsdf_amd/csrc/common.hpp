@@ -164,9 +164,9 @@ struct tsdf_volume {
     float *vert_buf;
     float *norm_buf;
     size_t ray_cap;
-    // per pixel: the smallest sample index found <= 0 so far by the ray march (0xffffffff = none); every kernel of the
-    // march lowers it with atomicMin, resolve_hits_kernel turns it into the vertex and resets it (raycast.hip)
-    uint32_t *ray_best;      // two copies of ray_best_cap words, used alternately (ray_best_side)
+    // per pixel: {the smallest sample index found <= 0 so far by the ray march, that sample's value} in one 64-bit word (all ones
+    // = none); every kernel of the march lowers it with atomicMin, resolve_hits_kernel turns it into the vertex and resets it (raycast.hip)
+    uint64_t *ray_best;      // two copies of ray_best_cap words, used alternately (ray_best_side)
     size_t ray_best_cap;
     int ray_best_side;
     size_t ray_best_pixels;  // image size of the last march (a different one refills both copies)

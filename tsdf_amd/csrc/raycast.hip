@@ -50,6 +50,7 @@ struct RayParams {
     uint32_t own_lo, own_hi;  // slab ownership (planes of the lower trilinear tap)
     uint32_t seg_len;         // > 0: blockIdx.z handles samples [z*seg_len, (z+1)*seg_len) and writes records
     uint32_t slab_ranges;     // > 0 (slabs): blockIdx.z handles that part of each ray's own stretch through the slab
+    uint32_t tile_map;        // which image tiles an XCD gets (see process_ray_kernel): 0 every eighth tile, 1 one contiguous eighth of the image, 2 one 5x5-tile block per block row
     uint32_t range_order;     // order in which the sample ranges are dispatched (see process_ray_kernel): 0 ascending, 1 descending (default), 2 last, first, then descending
     TriConst tc;              // loop-invariant pieces of the interpolation, formed once on the host (same IEEE operations)
 };
@@ -743,15 +744,24 @@ struct TailQueue {
     uint32_t *count;       // [0] entries appended
     uint32_t trip_budget;  // passes of the marching loop before a wave hands its unfinished rays over
     uint32_t lanes;        // lanes per ray in the tail kernel (power of two, 4..64)
-    uint32_t *best;        // per pixel: smallest sample index found <= 0 so far (kNoHit = none)
+    uint64_t *best;        // per pixel: {smallest sample index found <= 0 so far, that sample's value}: hit_word (kNoHitWord = none)
     int piece_min;         // shortest piece a handed-over stretch is cut into
     unsigned long long *wave_log;   // diagnostics (TSDF_DEBUG_WAVES): per wave of the tail kernel {batches << 32 | rounds, start, end}
 };
 constexpr uint32_t kNoHit = 0xffffffffu;
+constexpr uint64_t kNoHitWord = ~0ull;
+// The per-pixel word of the march: the index of the sample in the high half, the bits of its value (<= 0) in the low half.  An
+// unsigned 64-bit minimum orders by the index; two writers of the same index computed the same sample with the same expressions, so
+// their low halves are equal.  resolve_*_kernel refine the hit from the stored value instead of gathering the sample's 8 voxels again
+// (up to round 2 the word held the index only: resolve_normals_kernel fetched 20.9 MB to write 7.4 MB, 9.4 us).
+__device__ inline uint64_t hit_word(int k, float tsdf) { return ((uint64_t)(uint32_t)k << 32) | (uint64_t)__float_as_uint(tsdf); }
 
 // best[] is only ever lowered (atomicMin at device scope) during a march; a reader that sees an old, larger value merely
 // misses a shortcut.  Read past this XCD's L2 so that hits found on the other XCDs show up.
-__device__ inline uint32_t load_best(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline uint32_t load_best(const uint64_t *p) {   // (the index half: little endian, the high word is the second one)
+    return __hip_atomic_load(reinterpret_cast<const uint32_t *>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline void lower_best(uint64_t *p, int k, float tsdf) { atomicMin(reinterpret_cast<unsigned long long *>(p), (unsigned long long)hit_word(k, tsdf)); }
 
 // One lane per pixel, a wave is an 8x8 pixel tile of coherent rays, a workgroup a 16x16 tile.  Every pass of the loop
 // does the same straight-line work for all lanes (process_sample), so lanes do not serialise on divergent code paths.
@@ -804,14 +814,25 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
     auto T = [&](int k_) { return Ts[k_ + t_off]; };
 
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    // Workgroups are dealt to the 8 XCDs round robin in launch order; remap the linear tile index so that each XCD (own
-    // L2) gets one contiguous eighth of the image's tiles instead of every eighth tile.
+    // Workgroups are dealt to the 8 XCDs round robin in launch order.  Which tiles an XCD gets decides two things: how much of what
+    // its rays read stays in ITS L2 (neighbouring tiles read neighbouring voxels) and how even the XCDs' shares of the work are (the
+    // long waves sit where the surfaces and silhouettes are).  Every eighth tile (tile_map 0): even, no locality, bulk kernel 93.5 us on
+    // the bench scene; one contiguous eighth of the image per XCD (1, up to round 2): local, uneven, 91 us; the image cut into 8 x 6
+    // blocks of 5 x 5 tiles and each XCD given one block of every block row, in a different column each time (2, when the tile
+    // counts divide that way -- 640 x 480 does): 87.5 us.
     uint32_t tile_x = blockIdx.x, tile_y = blockIdx.y;
-    {
+    if (rp.tile_map != 0u) {
         const uint32_t n_tiles = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
         const uint32_t per_xcd = n_tiles / 8;
         if (lin < per_xcd * 8) {   // (the last n_tiles % 8 tiles keep their place)
-            const uint32_t remapped = (lin & 7u) * per_xcd + (lin >> 3);
+            const uint32_t xcd = lin & 7u, j = lin >> 3;
+            uint32_t remapped = xcd * per_xcd + j;
+            if (rp.tile_map == 2u && gridDim.x % 8u == 0u && gridDim.y % 5u == 0u) {
+                // blocks of (gridDim.x / 8) x 5 tiles, 8 across: XCD x takes one block of every block row, a different column each
+                const uint32_t bw = gridDim.x / 8u, per_block = bw * 5u, jb = j / per_block, w = j - jb * per_block;
+                const uint32_t col = (xcd + 3u * jb) & 7u, wy = w / bw, wx = w - wy * bw;
+                remapped = (jb * 5u + wy) * gridDim.x + col * bw + wx;
+            }
             tile_y = remapped / gridDim.x;
             tile_x = remapped - tile_y * gridDim.x;
         }
@@ -885,7 +906,7 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
                 bool owned;
                 const float tsdf = trilinear<SLAB, false, FASTDIV>(px, py, pz, dist, g, tc, rp, owned, nullptr);
                 if (tsdf <= 0) {
-                    if (SEG) atomicMin(&tail.best[idx], (uint32_t)k);
+                    if (SEG) lower_best(&tail.best[idx], k, tsdf);
                     else refine_hit(t, tsdf, previous_tsdf, step_size, ray, rp, ix, iy, iz);
                     k = kDone;
                 } else {
@@ -909,7 +930,7 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
             if (jump > 0) {
                 k += jump;
             } else if (tsdf <= 0) {
-                if (SEG) atomicMin(&tail.best[idx], (uint32_t)k);
+                if (SEG) lower_best(&tail.best[idx], k, tsdf);
                 else refine_hit(t, tsdf, previous_tsdf, step_size, ray, rp, ix, iy, iz);
                 k = kDone;
             } else {
@@ -1012,7 +1033,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         dbg_batches++;
         RayState ray = {0, 0, 0, 0, 0, 0};
         int k = kDone, k_end = 0;   // the group's stretch (all its lanes hold the same values); kDone: none
-        uint32_t *best = tail.best;
+        uint64_t *best = tail.best;
         const uint32_t e = batch + (lane / lanes_per_ray);
         if (e < n_entries) {
             const uint2 q = tail.entries[e];
@@ -1029,6 +1050,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             const int kk = k + j;
             int adv = 0;
             bool hit = false;
+            float hit_value = 0.0f;
             uint32_t known = kNoHit;
             if (k != kDone && j == 0) known = load_best(best);   // in flight together with the sample's loads
             if (k != kDone && kk < k_end) {
@@ -1039,6 +1061,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                     adv = j + jump;
                 } else if (tsdf <= 0) {
                     hit = true;
+                    hit_value = tsdf;
                 } else {
                     adv = j + 1 + (tsdf > 0 ? ahead : 0);
                 }
@@ -1053,7 +1076,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             }
             if (k != kDone) {
                 if (first < (int)lanes_per_ray) {
-                    if (j == first) atomicMin(best, (uint32_t)kk);
+                    if (j == first) lower_best(best, kk, hit_value);
                     k = kDone;
                 } else {
                     k += adv;
@@ -1069,23 +1092,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     }
 }
 
-// The vertex of a pixel from best[]: the ray's first sample <= 0 is recomputed -- the same expressions on the same values
-// as when the march found it -- and refined into the hit point as the reference does (process_ray :336-350); no hit -> NaN.
-template <bool SLAB, bool FASTDIV>
-__device__ inline uint32_t resolve_pixel(uint32_t i, const float *__restrict__ dist, const Geom &g, const RayParams &rp,
-                                         const float *__restrict__ t_table, const uint32_t *__restrict__ best, float &ix, float &iy,
-                                         float &iz, float &th) {
-    const uint32_t kb = best[i];
+// The vertex of a pixel from best[]: the ray's first sample <= 0 -- its index and the value the march computed for it -- is refined
+// into the hit point as the reference does (process_ray :336-350); no hit -> NaN.
+__device__ inline uint32_t resolve_pixel(uint32_t i, const Geom &g, const RayParams &rp, const float *__restrict__ t_table,
+                                         const uint64_t *__restrict__ best, float &ix, float &iy, float &iz, float &th) {
+    const uint64_t word = best[i];
+    const uint32_t kb = (uint32_t)(word >> 32);
     ix = iy = iz = th = NAN;
     if (kb != kNoHit) {
         RayState ray;
         float max_t;
         (void)ray_geometry((int)(i % rp.width), (int)(i / rp.width), true, rp, ray, max_t);
         const float t = t_table[kb], step_size = t_table[1];
-        const float px = (t * ray.dx) + ray.sx, py = (t * ray.dy) + ray.sy, pz = (t * ray.dz) + ray.sz;
-        bool owned;
-        const float tsdf = trilinear<SLAB, false, FASTDIV>(px, py, pz, dist, g, rp.tc, rp, owned, nullptr);
-        th = refine_t(t, tsdf, g.trunc, step_size);   // previous_tsdf == trunc (Q7)
+        th = refine_t(t, __uint_as_float((uint32_t)word), g.trunc, step_size);   // previous_tsdf == trunc (Q7)
         hit_point(th, ray, rp, ix, iy, iz);
     }
     return kb;
@@ -1095,17 +1114,17 @@ __device__ inline uint32_t resolve_pixel(uint32_t i, const float *__restrict__ d
 // one (consumed by the previous march's resolve) for the next march, together with the tail queue's counter -- so a
 // pixel's word may be read by several workgroups (resolve_normals_kernel) without racing against its reset.
 //   SLAB: out = 8-byte records {k, t} (tsdf_hit_record) for the min-k merge across slabs; otherwise packed float3 vertices.
-template <bool SLAB, bool FASTDIV>
-__global__ __launch_bounds__(256) void resolve_hits_kernel(const float *__restrict__ dist, const Geom g, const RayParams rp,
-                                                           const float *__restrict__ t_table, const uint32_t *__restrict__ best,
-                                                           uint32_t *__restrict__ best_next, float *__restrict__ out,
+template <bool SLAB>
+__global__ __launch_bounds__(256) void resolve_hits_kernel(const Geom g, const RayParams rp,
+                                                           const float *__restrict__ t_table, const uint64_t *__restrict__ best,
+                                                           uint64_t *__restrict__ best_next, float *__restrict__ out,
                                                            uint32_t *__restrict__ reset) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) *reset = 0;
     if (i >= rp.width * rp.height) return;
-    best_next[i] = kNoHit;
+    best_next[i] = kNoHitWord;
     float ix, iy, iz, th;
-    const uint32_t kb = resolve_pixel<SLAB, FASTDIV>(i, dist, g, rp, t_table, best, ix, iy, iz, th);
+    const uint32_t kb = resolve_pixel(i, g, rp, t_table, best, ix, iy, iz, th);
     if (SLAB) {
         reinterpret_cast<uint2 *>(out)[i] = make_uint2(kb, __float_as_uint(th));
     } else {
@@ -1119,10 +1138,9 @@ __global__ __launch_bounds__(256) void resolve_hits_kernel(const float *__restri
 // and the row below -- 289 pixels, one per thread of its five waves -- into LDS, then forms the normals as normals_kernel
 // does (compute_normals, Q11) from those.
 constexpr int kResolveThreads = 320;
-template <bool FASTDIV>
-__global__ __launch_bounds__(kResolveThreads) void resolve_normals_kernel(const float *__restrict__ dist, const Geom g, const RayParams rp,
-                                                                          const float *__restrict__ t_table, const uint32_t *__restrict__ best,
-                                                                          uint32_t *__restrict__ best_next, float *__restrict__ V,
+__global__ __launch_bounds__(kResolveThreads) void resolve_normals_kernel(const Geom g, const RayParams rp,
+                                                                          const float *__restrict__ t_table, const uint64_t *__restrict__ best,
+                                                                          uint64_t *__restrict__ best_next, float *__restrict__ V,
                                                                           float *__restrict__ N, uint32_t *__restrict__ reset) {
     constexpr int kT = 16, kS = kT + 1;
     static_assert(kS * kS <= kResolveThreads, "one thread per pixel of the tile and its halo");
@@ -1145,9 +1163,9 @@ __global__ __launch_bounds__(kResolveThreads) void resolve_normals_kernel(const 
         if (x < rp.width && y < rp.height) {
             const uint32_t i = y * rp.width + x;
             float th;
-            (void)resolve_pixel<false, FASTDIV>(i, dist, g, rp, t_table, best, ix, iy, iz, th);
+            (void)resolve_pixel(i, g, rp, t_table, best, ix, iy, iz, th);
             if (lx < (uint32_t)kT && ly < (uint32_t)kT) {   // this workgroup's own pixel
-                best_next[i] = kNoHit;
+                best_next[i] = kNoHitWord;
                 V[(size_t)i * 3 + 0] = ix;
                 V[(size_t)i * 3 + 1] = iy;
                 V[(size_t)i * 3 + 2] = iz;
@@ -1342,6 +1360,7 @@ static RayParams make_params(const tsdf_volume *v, uint32_t width, uint32_t heig
     rp.seg_len = 0;
     rp.slab_ranges = 0;
     rp.range_order = 0;
+    rp.tile_map = 1;
     rp.tc = make_tri_const(g);
     return rp;
 }
@@ -1375,7 +1394,7 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
         if (v->ray_best) (void)hipFree(v->ray_best);
         v->ray_best = nullptr;
         v->ray_best_cap = 0;
-        TSDF_HIP(hipMalloc((void **)&v->ray_best, 2 * n_pix * sizeof(uint32_t)), "ray result alloc");   // (double buffered)
+        TSDF_HIP(hipMalloc((void **)&v->ray_best, 2 * n_pix * sizeof(uint64_t)), "ray result alloc");   // (double buffered)
         v->ray_best_cap = n_pix;
         v->ray_best_dirty = 1;
     }
@@ -1395,14 +1414,15 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
         v->ray_best_dirty = 1;
     }
     if (v->ray_best_dirty) {   // otherwise the previous march's resolve kernel left both reset
-        TSDF_HIP(hipMemsetAsync(v->ray_best, 0xff, 2 * v->ray_best_cap * sizeof(uint32_t), v->stream), "ray result reset");
+        TSDF_HIP(hipMemsetAsync(v->ray_best, 0xff, 2 * v->ray_best_cap * sizeof(uint64_t), v->stream), "ray result reset");
         TSDF_HIP(hipMemsetAsync(v->tail_count, 0, 2 * sizeof(uint32_t), v->stream), "ray tail counter reset");
     }
     v->ray_best_dirty = 1;
     TailQueue tail = {reinterpret_cast<uint2 *>(v->tail_entries), v->tail_count, (uint32_t)trip_budget(), (uint32_t)tail_lanes(), v->ray_best + (size_t)v->ray_best_side * v->ray_best_cap, tail_piece_min(), nullptr};
-    uint32_t *best_next = v->ray_best + (size_t)(1 - v->ray_best_side) * v->ray_best_cap;
+    uint64_t *best_next = v->ray_best + (size_t)(1 - v->ray_best_side) * v->ray_best_cap;
     rp.seg_len = (kMaxSamples + n_segments - 1) / n_segments;
     rp.slab_ranges = SLAB ? (uint32_t)n_segments : 0u;
+    { static const int map = [] { const char *e = getenv("TSDF_RAY_TILE_MAP"); return e ? atoi(e) : 2; }(); rp.tile_map = (uint32_t)std::min(std::max(map, 0), 2); }   // tuning aid
     { static const int order = [] { const char *e = getenv("TSDF_RAY_RANGE_ORDER"); return e ? atoi(e) : 1; }(); rp.range_order = (uint32_t)std::min(std::max(order, 0), 2); }
     dim3 grid((rp.width + 15) / 16, (rp.height + 15) / 16, n_segments);
     static const bool debug_waves = getenv("TSDF_DEBUG_WAVES") != nullptr;
@@ -1440,6 +1460,22 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
                 last = std::max(last, (double)(log[3 * w + 2] - t0) / 100.0);
             }
             fprintf(stderr, "tsdf:   range %u: %zu waves, %.1f passes, %zu full, %.1f / %.1f us, last end %.1f; before the march: table + set-up %.1f us, lead-in + shell %.1f us\n", r, n, n ? passes / n : 0.0, full, n ? dur / n : 0.0, dmax, last, n ? t_setup / n : 0.0, n ? t_lead / n : 0.0);
+        }
+        {   // waves alive (entry .. end) per sixteenth of the launch, all ranges and per range
+            unsigned long long e0 = ~0ull;
+            for (size_t w = 0; w < n_waves_log; w++) if (log[3 * w + 1]) e0 = std::min(e0, log[3 * w + 1] - ((log[3 * w] >> 40) & 0xffffu) - ((log[3 * w] >> 24) & 0xffffu));
+            const double span = (double)(t1 - e0);
+            for (int r = -1; r < (int)grid.z; r++) {
+                size_t alive[16] = {};
+                for (size_t w = 0; w < n_waves_log; w++) {
+                    if (!log[3 * w + 1] || (r >= 0 && (int)(log[3 * w] >> 56) != r)) continue;
+                    const double b0 = (double)(log[3 * w + 1] - ((log[3 * w] >> 40) & 0xffffu) - ((log[3 * w] >> 24) & 0xffffu) - e0), e1 = (double)(log[3 * w + 2] - e0);
+                    for (int q = 0; q < 16; q++) { const double tq = (q + 0.5) / 16.0 * span; if (b0 <= tq && tq < e1) alive[q]++; }
+                }
+                if (r < 0) fprintf(stderr, "tsdf:   whole launch %.1f us from the first wave's entry; waves alive per sixteenth:", span / 100.0); else fprintf(stderr, "tsdf:     range %d:", r);
+                for (int q = 0; q < 16; q++) fprintf(stderr, " %zu", alive[q]);
+                fprintf(stderr, "\n");
+            }
         }
     }
     unsigned long long *tail_log = nullptr;
@@ -1490,18 +1526,10 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
     }
     const dim3 rgrid((unsigned)((n_pix + 255) / 256)), tgrid((rp.width + 15) / 16, (rp.height + 15) / 16);
     if (!SLAB && normals) {
-        if (v->fast_div)
-            hipLaunchKernelGGL((resolve_normals_kernel<true>), tgrid, dim3(kResolveThreads), 0, v->stream, v->dist, v->g, rp, v->t_table, tail.best, best_next,
-                               out, normals, v->tail_count);
-        else
-            hipLaunchKernelGGL((resolve_normals_kernel<false>), tgrid, dim3(kResolveThreads), 0, v->stream, v->dist, v->g, rp, v->t_table, tail.best, best_next,
-                               out, normals, v->tail_count);
-    } else if (v->fast_div) {
-        hipLaunchKernelGGL((resolve_hits_kernel<SLAB, true>), rgrid, dim3(256), 0, v->stream, v->dist, v->g, rp, v->t_table, tail.best, best_next, out,
+        hipLaunchKernelGGL(resolve_normals_kernel, tgrid, dim3(kResolveThreads), 0, v->stream, v->g, rp, v->t_table, tail.best, best_next, out, normals,
                            v->tail_count);
     } else {
-        hipLaunchKernelGGL((resolve_hits_kernel<SLAB, false>), rgrid, dim3(256), 0, v->stream, v->dist, v->g, rp, v->t_table, tail.best, best_next, out,
-                           v->tail_count);
+        hipLaunchKernelGGL((resolve_hits_kernel<SLAB>), rgrid, dim3(256), 0, v->stream, v->g, rp, v->t_table, tail.best, best_next, out, v->tail_count);
     }
     TSDF_HIP(hipGetLastError(), "resolve ray hits failed");
     v->ray_best_side = 1 - v->ray_best_side;
