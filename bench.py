@@ -272,7 +272,8 @@ def main():
 
     overlap = not args.no_overlap
     pipe = FusionPipeline(vol, bil, rc, W, H, overlap=overlap, exchange=exch if sharded else None,
-                          exchange_stream=os.environ.get("TSDF_PIPE_EXCHANGE_STREAM") == "1")
+                          exchange_stream=os.environ.get("TSDF_PIPE_EXCHANGE_STREAM") == "1",
+                          tighten_ahead=os.environ.get("TSDF_PIPE_NO_TIGHTEN_AHEAD") != "1")
     stream = pipe.main          # (the volume's stream now)
     if sharded:                 # the pipeline's record buffers, for the stage-by-stage replay
         from tsdf_amd.multi import device_words

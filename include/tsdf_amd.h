@@ -303,6 +303,7 @@ typedef struct tsdf_camera_matrices {   /* camera.pose(), inverse_pose(), k(), k
 #define TSDF_PIPELINE_OVERLAP 1          /* the next frame's filter / culling on a second, lower-priority stream                */
 #define TSDF_PIPELINE_EQUAL_PRIORITY 2   /* diagnostics: both streams at the same priority (always so with a slab exchange)      */
 #define TSDF_PIPELINE_EXCHANGE_STREAM 4  /* slab exchange + merge on a third stream                                            */
+#define TSDF_PIPELINE_NO_TIGHTEN_AHEAD 8 /* diagnostics: the periodic tightening of the ray caster's flags stays in front of the ray cast */
 int tsdf_pipeline_create(tsdf_volume *volume, const tsdf_bilateral *filter, uint32_t width, uint32_t height, int flags,
                          tsdf_slab_exchange *exchange /* NULL: a whole volume */, tsdf_pipeline **out);
 int tsdf_pipeline_step(tsdf_pipeline *pipeline, const uint16_t *device_depth, const tsdf_camera_matrices *camera,

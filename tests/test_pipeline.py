@@ -11,12 +11,13 @@ from tsdf_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def _run(overlap, equal_priority, frames, n, prepare=False, unannounced=(1,), wrong_announcement=()):
+def _run(overlap, equal_priority, frames, n, prepare=False, unannounced=(1,), wrong_announcement=(), tighten_ahead=True, sync=True,
+         flags_after=None):
     import torch
     from tsdf_amd.pipeline import FusionPipeline
     vol = tsdf_amd.TSDFVolume((n, n, n), (3000.0,) * 3)
     pipe = FusionPipeline(vol, tsdf_amd.BilateralFilter(30.0, 4.5), tsdf_amd.GPURaycaster(W, H), W, H, overlap=overlap,
-                          equal_priority=equal_priority)
+                          equal_priority=equal_priority, tighten_ahead=tighten_ahead)
     depth = torch.from_numpy(np.stack([d for d, _ in frames]).view(np.int16)).cuda()
     vert = torch.empty((H * W, 3), dtype=torch.float32, device="cuda")
     norm = torch.empty_like(vert)
@@ -30,8 +31,17 @@ def _run(overlap, equal_priority, frames, n, prepare=False, unannounced=(1,), wr
         nxt = depth[j].data_ptr() if j < len(frames) and i not in unannounced else None
         pipe.step(depth[i].data_ptr(), cam, vert.data_ptr(), norm.data_ptr(), nxt,
                   frames[j][1] if (prepare and nxt is not None) else None)
-        pipe.synchronize()
-        pictures.append((vert.cpu().numpy().copy(), norm.cpu().numpy().copy()))
+        if sync:
+            pipe.synchronize()
+            pictures.append((vert.cpu().numpy().copy(), norm.cpu().numpy().copy()))
+        else:   # (no host round trip between the steps: the streams really run ahead of each other)
+            with torch.cuda.stream(pipe.main):   # (the copies are ordered behind the step on ITS stream)
+                pictures.append((vert.clone(), norm.clone()))
+        if flags_after is not None and i in flags_after:
+            pipe.synchronize()
+            flags_after[i] = vol.occupancy_data(force_rebuild=False)
+    pipe.synchronize()
+    pictures = [(v if isinstance(v, np.ndarray) else v.cpu().numpy(), m if isinstance(m, np.ndarray) else m.cpu().numpy()) for v, m in pictures]
     out = (vol.get_distance_data(), vol.get_weight_data(), pictures)
     pipe.close()
     vol.close()
@@ -59,6 +69,44 @@ def test_filter_ahead_gives_the_bits_of_the_sequential_step_and_of_the_oracle(or
     Vo, No = ov.raycast(W, H, frames[-1][1].pose(), frames[-1][1].kinv(), nthreads=threads)
     assert_same_floats(seq[2][-1][0], Vo, "last picture vs oracle")
     assert_same_floats(seq[2][-1][1], No, "last normals vs oracle")
+
+
+def test_flags_tightened_beside_the_ray_cast_change_nothing(oracle):
+    """The periodic rebuild of the ray caster's flags (after 2, 4, 8, 16 integrations) runs on the second stream beside the ray
+    cast of the frame that made it due (occupancy_tighten_on); the next integrate waits for it.  Volume and every picture must be
+    the bits of the run that rebuilds in front of the ray cast, with and without a host round trip between the steps, and the
+    flags the next frames see must still cover the distances (a flag the rebuild cleared after integrate had set it would not)."""
+    n = 96
+    frames = [synth.depth_frame(i * 2, 200, seed=0x5EED0003) for i in range(19)]
+    ref = _run(True, False, frames, n, prepare=True, unannounced=(), tighten_ahead=False)
+    flags = {8: None, 16: None, 18: None}
+    for sync in (True, False):
+        got = _run(True, False, frames, n, prepare=True, unannounced=(), tighten_ahead=True, sync=sync, flags_after=flags if sync else None)
+        assert_same_floats(got[0], ref[0], "distances")
+        assert_same_floats(got[1], ref[1], "weights")
+        for i, ((v, nn), (vs, ns)) in enumerate(zip(got[2], ref[2])):
+            assert_same_floats(v, vs, "vertices of frame %d (host round trips: %s)" % (i, sync))
+            assert_same_floats(nn, ns, "normals of frame %d" % i)
+    # the flags after frames 8, 16 (tightened beside their ray cast) and 18 must cover the final distances' low voxels of that time;
+    # checked on the last state: every brick the definition flags for the final volume is flagged after frame 18
+    tau = np.float32(0.01) * np.float32(tsdf_amd.TSDFVolume((n, n, n), (3000.0,) * 3).truncation_distance())
+    low = ~(got[0].reshape(n, n, n) > tau)
+    zz, yy, xx = np.nonzero(low)
+    fine18 = flags[18][0].reshape(n // 4, n // 4, n // 4)
+    for dz in (-2, 2):
+        for dy in (-2, 2):
+            for dx in (-2, 2):
+                bz, by, bx = np.clip((zz + dz) // 4, 0, n // 4 - 1), np.clip((yy + dy) // 4, 0, n // 4 - 1), np.clip((xx + dx) // 4, 0, n // 4 - 1)
+                assert fine18[bz, by, bx].all(), "a low voxel's grown brick is not flagged after the deferred tightening"
+    ov = oracle.Volume((n, n, n), (3000.0,) * 3)
+    threads = oracle.max_threads()
+    for d, cam in frames:
+        f = oracle.bilateral_u16(d, W, H, 30.0, 4.5, nthreads=threads).reshape(-1)
+        ov.integrate(f, W, H, cam.inverse_pose(), cam.k(), cam.kinv(), nthreads=threads)
+    assert_same_floats(ref[0], ov.dist, "distances vs oracle")
+    Vo, No = ov.raycast(W, H, frames[-1][1].pose(), frames[-1][1].kinv(), nthreads=threads)
+    assert_same_floats(got[2][-1][0], Vo, "last picture vs oracle")
+    assert_same_floats(got[2][-1][1], No, "last normals vs oracle")
 
 
 def test_a_prepared_brick_list_is_used_only_by_the_matching_integrate(oracle):

@@ -36,6 +36,8 @@ constexpr int kIntBrickX = 64, kIntBrickY = 4, kIntBrickZ = TSDF_CHUNK_Z;
 void set_error(const char *fmt, ...);
 int hip_fail(hipError_t e, const char *what);
 int occupancy_rebuild(struct ::tsdf_volume *v);  // volume.hip
+int occupancy_join(struct ::tsdf_volume *v);     // volume.hip: the volume's stream waits for a tightening enqueued elsewhere
+int occupancy_tighten_on(struct ::tsdf_volume *v, hipStream_t stream);  // volume.hip: the periodic rebuild on another stream
 int occupancy_refresh(struct ::tsdf_volume *v);  // volume.hip: bring fine + reach up to date
 int build_t_table(struct ::tsdf_volume *v);      // volume.hip
 // timing helpers (volume.hip).  When timing is on, a launch of kernel `which` carries a start and a stop event that take the
@@ -183,7 +185,14 @@ struct tsdf_volume {
     unsigned long long fast_div_mismatches;
     // brick occupancy (see OccGrid)
     tsdf::OccGrid occ;
-    int occ_dirty;   // 1 = rebuild from the distance array before the next ray cast
+    int occ_dirty;   // 1 = the flags do not cover the distances (upload, new truncation): rebuild before the next ray cast
+    // 1 = the periodic tightening is due (integrate.hip).  The flags still cover the distances -- integrate only ever sets them --
+    // they are just looser than they could be, so this rebuild may also run BESIDE the ray cast that follows (occupancy_tighten_on:
+    // the per-frame pipeline puts it on its second stream; every byte it writes is a true statement about the distances integrate
+    // left, and so is the byte it replaces) as long as the next writer of flags or distances waits for it (occupancy_join).
+    int occ_tighten_due;
+    hipEvent_t occ_tightened;   // recorded behind a tightening enqueued on another stream ...
+    int occ_tighten_pending;    // ... that the volume's own stream has not waited for yet
     int reach_dirty; // 1 = `fine` changed since `reach` was computed
     uint16_t *occ_bits;              // 16 summary bits per brick, kept between rebuilds (volume.hip)
     // A rebuild reads only the distances integrate may have written since the previous one: integrate_kernel marks its brick

@@ -699,6 +699,10 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
         }
     }
     if (phase == kIntPrepare) return TSDF_OK;   // (custom nodes: every brick is walked, nothing to prepare)
+    {   // integrate_kernel sets occupancy flags: a tightening still running on another stream comes first
+        const int rcj = occupancy_join(v);
+        if (rcj != TSDF_OK) return rcj;
+    }
 #ifdef TSDF_DIAGNOSTICS
     diag_sort_brick_list(v, bg, count, boxes);   // TSDF_DEBUG_SORT: the list re-ordered on the host (synchronises), diagnostics.hip
 #endif
@@ -746,7 +750,7 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
     if (period && (v->integrations_since_rebuild >= period ||
                    (v->integrations_total <= period && (v->integrations_total & (v->integrations_total - 1)) == 0 &&
                     v->integrations_total >= 2)))
-        v->occ_dirty = 1;
+        v->occ_tighten_due = 1;
     return TSDF_OK;
 }
 

@@ -335,6 +335,14 @@ int tsdf_pipeline_step(tsdf_pipeline *p, const uint16_t *device_depth, const tsd
     if (rc != TSDF_OK) return rc;
     if (p->side) {
         TSDF_HIP(hipEventRecord(p->done[b], p->main), "pipeline: integrate done");
+        if (p->volume->occ_tighten_due && !p->volume->occ_dirty && !(p->flags & TSDF_PIPELINE_NO_TIGHTEN_AHEAD)) {
+            // the periodic tightening of the ray caster's flags (every 16th frame: a scan of what integrate has written since the last
+            // one, 60-125 us) goes beside this frame's ray cast instead of in front of it: the flags as they are still cover the
+            // distances, and the next integrate waits (occupancy_join)
+            TSDF_HIP(hipStreamWaitEvent(p->side, p->done[b], 0), "pipeline: release the occupancy rebuild");
+            rc = occupancy_tighten_on(p->volume, p->side);
+            if (rc != TSDF_OK) return rc;
+        }
         if (next_device_depth) {
             // released by THIS frame's integrate (never beside integrate_kernel); the other buffer was last read by the previous
             // frame's integrate, which lies before it on the step's stream; the brick list, the boxes and the plane constants

@@ -360,7 +360,18 @@ static int occupancy_reset(tsdf_volume *v) {
     return TSDF_OK;
 }
 
-int occupancy_rebuild(tsdf_volume *v) {
+// The volume's stream waits for a tightening that was enqueued on another stream (before anything writes flags or distances,
+// or frees them).
+int occupancy_join(tsdf_volume *v) {
+    if (v->occ_tighten_pending) {
+        TSDF_HIP(hipStreamWaitEvent(v->stream, v->occ_tightened, 0), "occupancy: wait for the rebuild on the other stream");
+        v->occ_tighten_pending = 0;
+        v->reach_dirty = 1;   // `fine` has changed under the last summary
+    }
+    return TSDF_OK;
+}
+
+static int occupancy_rebuild_on(tsdf_volume *v, hipStream_t stream) {
     const size_t n = v->occ.fine_count();
     if (!v->occ_bits) TSDF_HIP(hipMalloc((void **)&v->occ_bits, n * sizeof(uint16_t)), "occupancy scratch alloc");
     dim3 grid((v->occ.nbx + 63) / 64, v->occ.nby, v->occ.nbz);
@@ -368,21 +379,42 @@ int occupancy_rebuild(tsdf_volume *v) {
     const bool incremental = !always_all && !v->occ_scan_all && v->touched && (v->g.z_store_begin % kBrick) == 0;
     const uint32_t n_touched = v->touched ? v->touched_nx * v->touched_ny * v->touched_nz : 0u;
     TSDF_REQUIRE(n_touched <= n || !v->touched, "occupancy rebuild: more integrate bricks than occupancy bricks");
-    hipLaunchKernelGGL(occupancy_scan_kernel, grid, dim3(256), 0, v->stream, v->dist, v->g, v->occ, v->occ_bits,
+    hipLaunchKernelGGL(occupancy_scan_kernel, grid, dim3(256), 0, stream, v->dist, v->g, v->occ, v->occ_bits,
                        incremental ? (const uint8_t *)v->touched : (const uint8_t *)nullptr, v->touched_nx, v->touched_ny, v->touched_nz);
     TSDF_HIP(hipGetLastError(), "occupancy scan");
-    hipLaunchKernelGGL(occupancy_flags_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, v->stream, v->occ_bits, v->occ,
+    hipLaunchKernelGGL(occupancy_flags_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, v->occ_bits, v->occ,
                        v->g.X, v->g.Y, v->g.Z, v->touched, n_touched);
     TSDF_HIP(hipGetLastError(), "occupancy rebuild");
     v->occ_scan_all = 0;
     v->occ_dirty = 0;
+    v->occ_tighten_due = 0;
     v->reach_dirty = 1;
     v->integrations_since_rebuild = 0;
     return TSDF_OK;
 }
 
+int occupancy_rebuild(tsdf_volume *v) {
+    int rc = occupancy_join(v);
+    if (rc != TSDF_OK) return rc;
+    return occupancy_rebuild_on(v, v->stream);
+}
+
+// The periodic tightening on `stream`, which the caller has ordered behind the integrate that made it due.  What runs on the
+// volume's stream meanwhile may READ the flags (a ray cast: whichever byte it sees, old or new, is true of the distances, which
+// do not change); the next writer joins first.  Not taken (0 returned through *enqueued) when the flags are invalid rather than
+// loose -- then the ray cast itself must rebuild first -- or when nothing is due.
+int occupancy_tighten_on(tsdf_volume *v, hipStream_t stream) {
+    if (!v->occ_tighten_due || v->occ_dirty || v->occ_tighten_pending) return TSDF_OK;
+    if (!v->occ_tightened) TSDF_HIP(hipEventCreateWithFlags(&v->occ_tightened, hipEventDisableTiming), "occupancy event");
+    int rc = occupancy_rebuild_on(v, stream);
+    if (rc != TSDF_OK) return rc;
+    TSDF_HIP(hipEventRecord(v->occ_tightened, stream), "occupancy event");
+    v->occ_tighten_pending = 1;
+    return TSDF_OK;
+}
+
 int occupancy_refresh(tsdf_volume *v) {
-    if (v->occ_dirty) {
+    if (v->occ_dirty || v->occ_tighten_due) {
         int rc = occupancy_rebuild(v);
         if (rc != TSDF_OK) return rc;
     }
@@ -715,6 +747,8 @@ int tsdf_volume_create(uint32_t sx, uint32_t sy, uint32_t sz, float px, float py
 
 int tsdf_volume_destroy(tsdf_volume *v) {
     if (!v) return TSDF_OK;
+    if (v->occ_tighten_pending) (void)hipEventSynchronize(v->occ_tightened);
+    if (v->occ_tightened) (void)hipEventDestroy(v->occ_tightened);
     if (v->dist) (void)hipFree(v->dist);
     if (v->weight) (void)hipFree(v->weight);
     if (v->nodes) (void)hipFree(v->nodes);
@@ -758,6 +792,10 @@ int tsdf_volume_synchronize(const tsdf_volume *v) {
 
 int tsdf_volume_clear(tsdf_volume *v) {
     TSDF_REQUIRE(v, "null volume");
+    {
+        int rcj = occupancy_join(v);
+        if (rcj != TSDF_OK) return rcj;
+    }
     size_t n = v->resident_voxels();
     hipLaunchKernelGGL(fill2_kernel, dim3(2048), dim3(256), 0, v->stream, v->dist, v->weight, n, v->g.trunc, 0.0f);
     TSDF_HIP(hipGetLastError(), "Couldn't clear TSDF data");
@@ -766,6 +804,7 @@ int tsdf_volume_clear(tsdf_volume *v) {
     if (rc0 != TSDF_OK) return rc0;
     v->occ_scan_all = 1;
     v->occ_dirty = 0;
+    v->occ_tighten_due = 0;
     v->prepared_valid = 0;   // (a brick list prepared ahead bakes in the offset at clear time)
     v->integrations_since_rebuild = v->integrations_total = 0;
     // initialise_deformation bakes the CURRENT offset into the node translations (Q1)
@@ -825,7 +864,8 @@ int tsdf_volume_set_header(tsdf_volume *v, const float offset[3], float trunc, f
 int tsdf_volume_occupancy(const tsdf_volume *v, uint64_t *occupied_bricks, uint64_t *total_bricks) {
     TSDF_REQUIRE(v && occupied_bricks && total_bricks, "null argument");
     {
-        int rc = occupancy_refresh(const_cast<tsdf_volume *>(v));
+        int rc = occupancy_join(const_cast<tsdf_volume *>(v));
+        if (rc == TSDF_OK) rc = occupancy_refresh(const_cast<tsdf_volume *>(v));
         if (rc != TSDF_OK) return rc;
     }
     size_t n = v->occ.fine_count();
@@ -850,7 +890,8 @@ int tsdf_volume_get_occupancy_data(const tsdf_volume *cv, int force_rebuild, uin
     TSDF_REQUIRE(cv, "null volume");
     tsdf_volume *v = const_cast<tsdf_volume *>(cv);
     if (force_rebuild) v->occ_dirty = 1;
-    int rc = occupancy_refresh(v);
+    int rc = occupancy_join(v);
+    if (rc == TSDF_OK) rc = occupancy_refresh(v);
     if (rc != TSDF_OK) return rc;
     const size_t n = v->occ.fine_count();
     hipError_t e = hipSuccess;
@@ -952,6 +993,10 @@ static int copy_in(tsdf_volume *v, void *dst, const void *src, size_t bytes, con
 
 int tsdf_volume_set_distance_data(tsdf_volume *v, const float *host) {
     TSDF_REQUIRE(v, "null volume");
+    {
+        int rcj = occupancy_join(v);
+        if (rcj != TSDF_OK) return rcj;
+    }
     v->occ_dirty = 1;
     v->occ_scan_all = 1;
     return copy_in(v, v->dist, host, v->resident_voxels() * sizeof(float), "Couldn't set distance data");

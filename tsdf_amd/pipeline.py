@@ -14,7 +14,7 @@ from . import _capi
 from ._capi import check, lib
 from .api import _camera_matrices
 
-OVERLAP, EQUAL_PRIORITY, EXCHANGE_STREAM = 1, 2, 4     # TSDF_PIPELINE_* (include/tsdf_amd.h)
+OVERLAP, EQUAL_PRIORITY, EXCHANGE_STREAM, NO_TIGHTEN_AHEAD = 1, 2, 4, 8     # TSDF_PIPELINE_* (include/tsdf_amd.h)
 
 
 def _matrices(camera):
@@ -34,12 +34,14 @@ class FusionPipeline:
     width * height uint16 (depth) / 3 * width * height float32 (maps); the depth buffers must stay valid until the frame after
     them has been processed.  `exchange`: a tsdf_amd.multi.SlabExchange when the volume is one rank's Z-slab."""
 
-    def __init__(self, volume, bilateral, raycaster, width, height, overlap=True, exchange=None, equal_priority=False, exchange_stream=False):
+    def __init__(self, volume, bilateral, raycaster, width, height, overlap=True, exchange=None, equal_priority=False, exchange_stream=False,
+                 tighten_ahead=True):
         self.volume, self.bilateral, self.raycaster = volume, bilateral, raycaster
         self.width, self.height = int(width), int(height)
         self.overlap = bool(overlap)
         self.exchange = exchange
-        flags = (OVERLAP if overlap else 0) | (EQUAL_PRIORITY if equal_priority else 0) | (EXCHANGE_STREAM if exchange_stream else 0)
+        flags = (OVERLAP if overlap else 0) | (EQUAL_PRIORITY if equal_priority else 0) | (EXCHANGE_STREAM if exchange_stream else 0) | \
+            (0 if tighten_ahead else NO_TIGHTEN_AHEAD)
         self._h = C.c_void_p()
         check(lib.tsdf_pipeline_create(volume._h, bilateral._h, self.width, self.height, flags, exchange._h if exchange is not None else None,
                                        C.byref(self._h)))
