@@ -613,7 +613,7 @@ def tracking_loop(tsdf_amd, synth, n, physical, stream_frames, n_frames=24):
     import torch
     from tsdf_amd.tracking import FrameToModelTracker
     vol = tsdf_amd.TSDFVolume((n, n, n), (physical,) * 3)
-    tracker = FrameToModelTracker(vol, W, H)
+    tracker = FrameToModelTracker(vol, W, H, overlap=os.environ.get("TSDF_TRACK_NO_OVERLAP") != "1")
     frames = [synth.depth_frame(i, stream_frames, seed=SEED) for i in range(n_frames)]
     dev = [torch.from_numpy(d.view(np.int16)).cuda() for d, _ in frames]
     worst_t = worst_r = 0.0
@@ -641,7 +641,8 @@ def tracking_loop(tsdf_amd, synth, n, physical, stream_frames, n_frames=24):
     return {"ms_per_frame": round(ms, 4),
             "mesh": {"extract_surface_device_s": round(t1b - t1, 4), "same_as_host": bool(mesh_dev.shape == mesh.shape and np.array_equal(mesh_dev.view(np.uint32), mesh.view(np.uint32))), "host_download_s": round(t2 - t1b, 3), "host_marching_cubes_s": round(t3 - t2, 3), "triangles": int(mesh.shape[0] // 3)}, "frames": n_frames, "max_translation_error_mm": round(worst_t, 3),
             "max_rotation_error_rad": round(worst_r, 6),
-            "what": "bilateral + raycast(prev pose) + render depth + ICP (3 levels, 19 iterations) + integrate per frame"}
+            "what": "bilateral + raycast(prev pose) + render depth + ICP (3 levels, 19 iterations) + integrate per frame (tsdf_tracker_*: the new "
+                    "frame's filter and ICP maps on a second stream beside the model ray cast)"}
 
 
 def kernel_source_sha():

@@ -316,6 +316,30 @@ int tsdf_pipeline_streams(const tsdf_pipeline *pipeline, void **main_stream, voi
 int tsdf_pipeline_hit_buffers(const tsdf_pipeline *pipeline, tsdf_hit_record **device_mine, tsdf_hit_record **device_all);
 int tsdf_pipeline_destroy(tsdf_pipeline *pipeline);
 
+/* ---- the tracked loop (BASELINE configs[4]) ------------------------------------------------------------------------------- */
+/* Frame-to-model tracking: what src/Tools/tsdf_icp.cpp:115-198 does for one frame (render the volume to a depth image from a pose,
+ * ICPOdometry against the new frame) composed with kinfu.cpp's integrate, frame after frame on device buffers:
+ *     tsdf_tracker_filter(depth)                      bilateral filter (+ tile maxima) and, from the second frame on, initICP of
+ *                                                     the filtered frame -- on a second, lower-priority stream (TSDF_PIPELINE_OVERLAP)
+ *     tsdf_tracker_align(previous camera, T, ...)     ray cast from the previous pose, render_to_depth_image, initICPModel,
+ *                                                     getIncrementalTransformation; blocks for T (current camera -> previous
+ *                                                     camera, metres, column-major double as tsdf_icp_get_incremental_transformation)
+ *     tsdf_tracker_integrate(camera)                  the filtered frame at the pose the caller composed (asynchronous)
+ * The first frame is only filtered and integrated.  The tracker owns its streams, events and frame buffers; while it lives the
+ * volume's and the ICP object's stream are its own. */
+typedef struct tsdf_tracker tsdf_tracker;
+int tsdf_tracker_create(tsdf_volume *volume, const tsdf_bilateral *filter, tsdf_icp *icp, uint32_t width, uint32_t height,
+                        float depth_cutoff, int flags /* TSDF_PIPELINE_OVERLAP or 0 */, tsdf_tracker **out);
+int tsdf_tracker_filter(tsdf_tracker *tracker, const uint16_t *device_depth);
+int tsdf_tracker_align(tsdf_tracker *tracker, const tsdf_camera_matrices *previous, double T_prev_curr[16] /* in: start, out */,
+                       float *last_error, float *last_inliers);
+int tsdf_tracker_integrate(tsdf_tracker *tracker, const tsdf_camera_matrices *camera);
+int tsdf_tracker_synchronize(tsdf_tracker *tracker);
+int tsdf_tracker_streams(const tsdf_tracker *tracker, void **main_stream, void **side_stream);
+/* The ICP inputs of the last aligned frame: the rendered model depth and the filtered frame (width * height uint16, device). */
+int tsdf_tracker_buffers(const tsdf_tracker *tracker, const uint16_t **device_model, const uint16_t **device_filtered);
+int tsdf_tracker_destroy(tsdf_tracker *tracker);
+
 /* ---- ICP tracking: replaces third_party/ICP_CUDA ------------------------------------------ */
 /* ICPOdometry::ICPOdometry (third_party/ICP_CUDA/ICPOdometry.cpp:10-57): three pyramid levels of vertex / normal maps for
  * the model ("prev") and the current frame; angle_thresh is the sine of the angle gate. */

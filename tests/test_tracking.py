@@ -65,3 +65,29 @@ def test_tracking_follows_the_synthetic_trajectory():
     assert moved > 50.0                      # the camera really moved (mm)
     assert worst_t < 15.0, worst_t           # tracked to within 1.5 cm (voxels are 11.7 mm, depth noise +-3 mm)
     assert worst_r < 0.01, worst_r
+
+
+def test_the_two_stream_loop_gives_the_poses_of_the_sequential_one_bit_for_bit():
+    """tsdf_tracker_* with TSDF_PIPELINE_OVERLAP (the new frame's filter and ICP maps on a second stream beside the model ray cast,
+    frames queued on the device without a host round trip but the one for T) against the same calls on one stream: the same poses,
+    the same volume, bit for bit -- scheduling only."""
+    import torch
+    n, frames, stream_len = 128, 7, 200
+    data = [synth.depth_frame(i, stream_len, seed=0x5EED0005) for i in range(frames)]
+    dev = [torch.from_numpy(d.view(np.int16).copy()).cuda() for d, _ in data]
+    torch.cuda.synchronize()
+    runs = []
+    for overlap in (False, True):
+        vol = tsdf_amd.TSDFVolume((n, n, n), (3000.0,) * 3)
+        tracker = FrameToModelTracker(vol, W, H, overlap=overlap)
+        poses = []
+        for i, (_, cam) in enumerate(data):
+            truth = cam.pose().astype(np.float64).reshape(4, 4).T
+            poses.append(tracker.process_device(dev[i].data_ptr(), initial_pose=truth if i == 0 else None))
+        tracker.synchronize()
+        runs.append((np.stack(poses), vol.get_distance_data(), vol.get_weight_data()))
+        tracker.close()
+        vol.close()
+    assert np.array_equal(runs[0][0], runs[1][0]), np.max(np.abs(runs[0][0] - runs[1][0]))
+    assert np.array_equal(runs[0][1].view(np.uint32), runs[1][1].view(np.uint32))
+    assert np.array_equal(runs[0][2].view(np.uint32), runs[1][2].view(np.uint32))

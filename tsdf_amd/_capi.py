@@ -120,6 +120,14 @@ _SIGS = {
     "tsdf_pipeline_streams": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "tsdf_pipeline_hit_buffers": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "tsdf_pipeline_destroy": (_i, [_vp]),
+    "tsdf_tracker_create": (_i, [_vp, _vp, _vp, _u32, _u32, _f, _i, C.POINTER(_vp)]),
+    "tsdf_tracker_filter": (_i, [_vp, _vp]),
+    "tsdf_tracker_align": (_i, [_vp, C.POINTER(CameraMatrices), _vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "tsdf_tracker_integrate": (_i, [_vp, C.POINTER(CameraMatrices)]),
+    "tsdf_tracker_synchronize": (_i, [_vp]),
+    "tsdf_tracker_streams": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
+    "tsdf_tracker_buffers": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
+    "tsdf_tracker_destroy": (_i, [_vp]),
     "tsdf_icp_create": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, C.POINTER(_vp)]),
     "tsdf_icp_destroy": (None, [_vp]),
     "tsdf_icp_set_stream": (_i, [_vp, _vp]),

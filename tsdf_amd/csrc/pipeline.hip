@@ -113,6 +113,31 @@ struct tsdf_pipeline {
     tsdf_hit_record *hits_mine, *hits_all;
 };
 
+// tsdf_tracker: the closed loop of BASELINE configs[4], frame-to-model.  The reference has the two halves -- src/Tools/kinfu.cpp
+// integrates a sequence with given poses, src/Tools/tsdf_icp.cpp (:115-198) renders a volume to a depth image and aligns one frame to it
+// with ICPOdometry (third_party/ICP_CUDA/ICPOdometry.cpp:97-136) -- this composes them per frame on two streams: the new frame's
+// bilateral filter and its ICP pyramid / vertex / normal maps depend on nothing in the volume and run on the lower-priority stream
+// beside the ray cast that renders the model from the previous pose; the model's maps, the 19 ICP iterations and the integrate follow
+// on the step's stream.  The pose is composed by the caller (the Camera class lives in the host library): align() blocks for the
+// 4 x 4 result, integrate() is asynchronous.
+struct tsdf_tracker {
+    tsdf_volume *volume;
+    const tsdf_bilateral *filter;
+    tsdf_icp *icp;
+    uint32_t width, height;
+    float depth_cutoff;
+    hipStream_t main, side;
+    hipStream_t volume_stream_before;
+    uint16_t *filtered[2], *tile_max[2], *model;
+    float *vertices;
+    hipEvent_t integrated[2];   // [b]: the integrate that read buffer b is done
+    hipEvent_t ready;           // the frame in buffer `cur` has been filtered (and its ICP maps built)
+    bool ready_pending;         // ... and the step's stream has not waited for that yet
+    int cur;
+    bool have_frame;
+    uint64_t frames;            // frames integrated
+};
+
 using namespace tsdf;
 
 static int run_filter(tsdf_pipeline *p, const uint16_t *depth, int b, hipStream_t s) {
@@ -397,6 +422,157 @@ int tsdf_pipeline_synchronize(tsdf_pipeline *p) {
     TSDF_HIP(hipStreamSynchronize(p->main), "pipeline synchronize");
     if (p->side) TSDF_HIP(hipStreamSynchronize(p->side), "pipeline synchronize");
     if (p->xstream) TSDF_HIP(hipStreamSynchronize(p->xstream), "pipeline synchronize");
+    return TSDF_OK;
+}
+
+int tsdf_tracker_destroy(tsdf_tracker *t) {
+    if (!t) return TSDF_OK;
+    if (t->main) (void)hipStreamSynchronize(t->main);
+    if (t->side) (void)hipStreamSynchronize(t->side);
+    if (t->volume) (void)tsdf_volume_set_stream(t->volume, t->volume_stream_before);
+    if (t->icp) (void)tsdf_icp_set_stream(t->icp, t->volume_stream_before);
+    for (int b = 0; b < 2; b++) {
+        if (t->filtered[b]) (void)hipFree(t->filtered[b]);
+        if (t->tile_max[b]) (void)hipFree(t->tile_max[b]);
+        if (t->integrated[b]) (void)hipEventDestroy(t->integrated[b]);
+    }
+    if (t->ready) (void)hipEventDestroy(t->ready);
+    if (t->model) (void)hipFree(t->model);
+    if (t->vertices) (void)hipFree(t->vertices);
+    if (t->side) (void)hipStreamDestroy(t->side);
+    if (t->main) (void)hipStreamDestroy(t->main);
+    delete t;
+    return TSDF_OK;
+}
+
+int tsdf_tracker_create(tsdf_volume *volume, const tsdf_bilateral *filter, tsdf_icp *icp, uint32_t width, uint32_t height,
+                        float depth_cutoff, int flags, tsdf_tracker **out) {
+    TSDF_REQUIRE(out, "tsdf_tracker_create: null out pointer");
+    *out = nullptr;
+    TSDF_REQUIRE(volume && filter && icp && width > 0 && height > 0 && width <= 65535 && height <= 65535, "tsdf_tracker_create: bad argument");
+    TSDF_REQUIRE(volume->z_begin == 0 && volume->z_end == volume->g.Z, "tsdf_tracker_create: tracking needs a whole volume");
+    tsdf_tracker *t = new (std::nothrow) tsdf_tracker();
+    if (!t) {
+        set_error("out of host memory");
+        return TSDF_ERR_NOMEM;
+    }
+    memset(t, 0, sizeof(*t));
+    t->filter = filter;
+    t->width = width;
+    t->height = height;
+    t->depth_cutoff = depth_cutoff;
+    t->volume_stream_before = volume->stream;
+    int least = 0, greatest = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    const bool overlap = (flags & TSDF_PIPELINE_OVERLAP) != 0;
+    const int normal = (greatest <= 0 && 0 <= least) ? 0 : least;
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&t->main, hipStreamNonBlocking, overlap ? greatest : normal);
+    if (e == hipSuccess && overlap) e = hipStreamCreateWithPriority(&t->side, hipStreamNonBlocking, normal);
+    const size_t n = (size_t)width * height;
+    const size_t tiles = (size_t)((width + TSDF_DEPTH_TILE - 1) / TSDF_DEPTH_TILE) * ((height + TSDF_DEPTH_TILE - 1) / TSDF_DEPTH_TILE);
+    for (int b = 0; b < 2 && e == hipSuccess; b++) {
+        e = hipMalloc((void **)&t->filtered[b], n * sizeof(uint16_t));
+        if (e == hipSuccess) e = hipMalloc((void **)&t->tile_max[b], tiles * sizeof(uint16_t));
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&t->integrated[b], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&t->ready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc((void **)&t->model, n * sizeof(uint16_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&t->vertices, n * 3 * sizeof(float));
+    if (e != hipSuccess) {
+        const int rc = hip_fail(e, "tsdf_tracker_create");
+        tsdf_tracker_destroy(t);
+        return rc;
+    }
+    (void)hipStreamSynchronize(volume->stream);   // whatever the volume has in flight comes before the tracker's first launch
+    t->volume = volume;
+    t->icp = icp;
+    (void)tsdf_volume_set_stream(volume, t->main);
+    (void)tsdf_icp_set_stream(icp, t->main);
+    *out = t;
+    return TSDF_OK;
+}
+
+int tsdf_tracker_streams(const tsdf_tracker *t, void **main_stream, void **side_stream) {
+    TSDF_REQUIRE(t, "null tracker");
+    if (main_stream) *main_stream = t->main;
+    if (side_stream) *side_stream = t->side;
+    return TSDF_OK;
+}
+
+int tsdf_tracker_buffers(const tsdf_tracker *t, const uint16_t **device_model, const uint16_t **device_filtered) {
+    TSDF_REQUIRE(t, "null tracker");
+    if (device_model) *device_model = t->model;
+    if (device_filtered) *device_filtered = t->filtered[t->cur];
+    return TSDF_OK;
+}
+
+int tsdf_tracker_filter(tsdf_tracker *t, const uint16_t *device_depth) {
+    TSDF_REQUIRE(t && device_depth, "tsdf_tracker_filter: null argument");
+    const int b = (int)(t->frames & 1u);
+    const hipStream_t s = t->side ? t->side : t->main;
+    // buffer b was last read by the integrate two frames back
+    if (t->side) TSDF_HIP(hipStreamWaitEvent(t->side, t->integrated[b], 0), "tracker: the frame buffer is free");
+    int rc = tsdf_bilateral_filter_u16_device_tiles(t->filter, device_depth, t->filtered[b], (int)t->width, (int)t->height, t->tile_max[b], s);
+    if (rc != TSDF_OK) return rc;
+    if (t->frames > 0) {
+        // ICPOdometry::initICP of the new frame (pyramid, vertex and normal maps): they wait for nothing but the filter
+        (void)tsdf_icp_set_stream(t->icp, s);
+        rc = tsdf_icp_init_device(t->icp, 0, t->filtered[b], t->depth_cutoff);
+        (void)tsdf_icp_set_stream(t->icp, t->main);
+        if (rc != TSDF_OK) return rc;
+    }
+    if (t->side) {
+        TSDF_HIP(hipEventRecord(t->ready, t->side), "tracker: frame ready");
+        t->ready_pending = true;
+    }
+    t->cur = b;
+    t->have_frame = true;
+    return TSDF_OK;
+}
+
+static int tracker_join(tsdf_tracker *t) {
+    if (t->ready_pending) {
+        TSDF_HIP(hipStreamWaitEvent(t->main, t->ready, 0), "tracker: wait for the filtered frame");
+        t->ready_pending = false;
+    }
+    return TSDF_OK;
+}
+
+int tsdf_tracker_align(tsdf_tracker *t, const tsdf_camera_matrices *previous, double T_prev_curr[16], float *last_error,
+                       float *last_inliers) {
+    TSDF_REQUIRE(t && previous && T_prev_curr, "tsdf_tracker_align: null argument");
+    TSDF_REQUIRE(t->have_frame && t->frames > 0, "tsdf_tracker_align: no frame filtered, or nothing integrated to align it to");
+    // the model image: the volume rendered from the previous pose (GPURaycaster::render_to_depth_image, src/RayCaster/GPURaycaster.cu:575-579)
+    int rc = tsdf_raycast_device(t->volume, t->width, t->height, previous->pose, previous->kinv, t->vertices, nullptr);
+    if (rc != TSDF_OK) return rc;
+    rc = tsdf_vertices_to_depth_device(t->width, t->height, t->vertices, previous->inv_pose, t->model, t->main);
+    if (rc != TSDF_OK) return rc;
+    rc = tracker_join(t);   // (the model's maps reuse the pyramid scratch of the new frame's)
+    if (rc != TSDF_OK) return rc;
+    rc = tsdf_icp_init_device(t->icp, 1, t->model, t->depth_cutoff);
+    if (rc != TSDF_OK) return rc;
+    return tsdf_icp_get_incremental_transformation(t->icp, T_prev_curr, last_error, last_inliers);
+}
+
+int tsdf_tracker_integrate(tsdf_tracker *t, const tsdf_camera_matrices *camera) {
+    TSDF_REQUIRE(t && camera, "tsdf_tracker_integrate: null argument");
+    TSDF_REQUIRE(t->have_frame, "tsdf_tracker_integrate: no frame filtered");
+    int rc = tracker_join(t);
+    if (rc != TSDF_OK) return rc;
+    const int b = t->cur;
+    rc = tsdf_integrate_device_tiles(t->volume, t->filtered[b], t->width, t->height, camera->pose, camera->inv_pose, camera->k, camera->kinv,
+                                     t->tile_max[b]);
+    if (rc != TSDF_OK) return rc;
+    if (t->side) TSDF_HIP(hipEventRecord(t->integrated[b], t->main), "tracker: integrate done");
+    t->have_frame = false;
+    t->frames++;
+    return TSDF_OK;
+}
+
+int tsdf_tracker_synchronize(tsdf_tracker *t) {
+    TSDF_REQUIRE(t, "null tracker");
+    TSDF_HIP(hipStreamSynchronize(t->main), "tracker synchronize");
+    if (t->side) TSDF_HIP(hipStreamSynchronize(t->side), "tracker synchronize");
     return TSDF_OK;
 }
 
