@@ -11,22 +11,32 @@ from tsdf_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def _expected(D, dims, tau, planes=None):
+def _flat_band(trunc):
+    """[flat_lo, flat_hi] of tsdf_amd/csrc/common.hpp (OccGrid): the band every voxel in reach of a brick at the grid boundary
+    must lie in for the brick to be clear (there the reference extrapolates, Q10: positive taps alone prove nothing)."""
+    t = np.float32(trunc)
+    return np.float32(0.9375) * t, (np.float32(1.0) + np.float32(1.0) / np.float32(1024.0)) * t
+
+
+def _expected(D, dims, tau, planes=None, trunc=None):
     X, Y, Z = dims
     low = ~(D.reshape(Z, Y, X) > tau)                       # also NaN
+    flat_lo, flat_hi = _flat_band(trunc if trunc is not None else np.float32(tau) / np.float32(0.01))
+    not_flat = ~((D.reshape(Z, Y, X) >= flat_lo) & (D.reshape(Z, Y, X) <= flat_hi))   # also NaN
     if planes is not None:                                   # slab: only resident planes are scanned
         keep = np.zeros(Z, bool)
         keep[planes[0]:planes[1]] = True
         low &= keep[:, None, None]
+        not_flat &= keep[:, None, None]
     nbx, nby, nbz = (X + 3) // 4, (Y + 3) // 4, (Z + 3) // 4
     fine = np.zeros((nbz, nby, nbx), np.uint8)
     cell = np.zeros((nbz, nby, nbx), np.uint8)
     for bz in range(nbz):
         for by in range(nby):
             for bx in range(nbx):
-                g = low[max(4 * bz - 2, 0):4 * bz + 6, max(4 * by - 2, 0):4 * by + 6, max(4 * bx - 2, 0):4 * bx + 6]
                 boundary = bx == 0 or by == 0 or bz == 0 or bx == nbx - 1 or by == nby - 1 or bz == nbz - 1
-                fine[bz, by, bx] = 1 if (boundary or g.any()) else 0
+                g = (not_flat if boundary else low)[max(4 * bz - 2, 0):4 * bz + 6, max(4 * by - 2, 0):4 * by + 6, max(4 * bx - 2, 0):4 * bx + 6]
+                fine[bz, by, bx] = 1 if g.any() else 0
                 c = low[4 * bz:4 * bz + 5, 4 * by:4 * by + 5, 4 * bx:4 * bx + 5]
                 partial = 4 * bx + 4 > X - 1 or 4 * by + 4 > Y - 1 or 4 * bz + 4 > Z - 1
                 cell[bz, by, bx] = 1 if (partial or c.any()) else 0
@@ -66,10 +76,18 @@ def test_rebuilt_flags_equal_their_definition(dims):
     D[idx] = rng.choice(np.array([-trunc, 0.0, tau, np.nextafter(tau, np.float32(1e9)), 0.5 * tau], np.float32), idx.size)
     D[idx[0]] = np.nan
     Dv = D.reshape(Z, Y, X)
+    # values round the flat band, in reach of bricks at the grid boundary and elsewhere
+    flat_lo, flat_hi = _flat_band(trunc)
+    band = np.array([flat_lo, np.nextafter(flat_lo, np.float32(0)), flat_hi, np.nextafter(flat_hi, np.float32(1e9)), 0.5 * trunc, 2.0 * trunc], np.float32)
+    for i, val in enumerate(band):
+        Dv[(5 * i + 1) % Z, (3 * i) % 6, (7 * i + 2) % X] = val          # near the y = 0 face
+        Dv[Z - 1 - (i % 6), (4 * i + 9) % Y, (5 * i + 3) % X] = val      # near the far z face
+        Dv[(Z // 3 + i) % Z, (Y // 3 + 2 * i) % Y, X - 1 - (i % 6)] = val  # near the far x face
+        Dv[Z // 2 + 5, Y // 2 + 7 + i, X // 2 + 6] = val                 # interior: only values <= tau matter
     Dv[Z // 2:Z // 2 + 3, Y // 2:Y // 2 + 5, X // 2:X // 2 + 4] = -1.0
     v.set_distance_data(D)
     fine, cell, reach = v.occupancy_data(force_rebuild=True)
-    ef, ec = _expected(D, dims, tau)
+    ef, ec = _expected(D, dims, tau, trunc=trunc)
     assert np.array_equal(fine, ef)
     assert np.array_equal(cell, ec)
     assert np.array_equal(reach, _expected_reach(ef))
@@ -84,7 +102,7 @@ def test_marks_left_by_integrate_cover_the_exact_flags_and_rebuild_tightens_them
         v.integrate(d, synth.WIDTH, synth.HEIGHT, cam)
     sticky_fine, sticky_cell, _ = v.occupancy_data()
     D = v.get_distance_data()
-    ef, ec = _expected(D, (n, n, n), tau)
+    ef, ec = _expected(D, (n, n, n), tau, trunc=v.truncation_distance())
     assert np.all(sticky_fine >= ef) and np.all(sticky_cell >= ec)
     fine, cell, _ = v.occupancy_data(force_rebuild=True)
     assert np.array_equal(fine, ef) and np.array_equal(cell, ec)
@@ -103,7 +121,7 @@ def test_second_rebuild_reads_only_what_integrate_touched_and_still_equals_the_d
     def definition():
         D = np.full((n, n, n), v.truncation_distance(), np.float32)     # (planes outside the slab: never low)
         D[lo:hi] = v.get_distance_data().reshape(hi - lo, n, n)
-        return _expected(D.reshape(-1), (n, n, n), tau)
+        return _expected(D.reshape(-1), (n, n, n), tau, trunc=v.truncation_distance())
 
     def resident(a):
         # bricks wholly inside the resident planes (the others depend on planes this volume does not hold)

@@ -382,3 +382,48 @@ def test_schedule_knobs_do_not_change_a_bit(oracle, tmp_path, env):
     assert np.array_equal(np.isnan(got["V"]), np.isnan(Vo))
     assert_same_floats(got["V"], Vo, "vertices with %s" % env)
     assert_same_floats(got["N"], No, "normals with %s" % env)
+
+
+@pytest.mark.parametrize("case", ["positive_taps_that_extrapolate_below_zero", "flat_rim_with_a_surface_inside", "almost_flat", "rim_written_by_integrate"])
+def test_bricks_at_the_grid_boundary_are_skipped_only_when_their_voxels_are_flat(oracle, case):
+    """In the outer half-voxel shell the reference extrapolates (Q10): with taps 0.1 and 0.9 x trunc a sample half a voxel outside the
+    first voxel centre is 1.5 * 0.1 - 0.5 * 0.9 < 0 -- a hit among positive voxels.  Bricks at the boundary are therefore clear for the
+    ray caster only when every voxel in reach is FLAT (common.hpp: OccGrid); whatever the flags say, every ray must end where the
+    oracle's does."""
+    n, phys = 64, 640.0
+    rng = np.random.default_rng(11)
+    probe = tsdf_amd.TSDFVolume((n, n, n), (phys,) * 3)
+    trunc = np.float32(probe.truncation_distance())
+    probe.close()
+    D = np.full((n, n, n), trunc, np.float32)              # [z, y, x]
+    if case == "positive_taps_that_extrapolate_below_zero":
+        D[:, :, 0] = 0.1 * trunc; D[:, :, 1] = 0.9 * trunc         # x = 0 face
+        D[0, :, :] = 0.05 * trunc; D[1, :, :] = 0.6 * trunc        # z = 0 face
+        D[:, n - 1, :] = 0.2 * trunc; D[:, n - 2, :] = 0.99 * trunc  # far y face (upper tap clamped: no extrapolation there)
+    elif case == "flat_rim_with_a_surface_inside":
+        D[20:44, 20:44, 30] = -0.3 * trunc; D[20:44, 20:44, 29] = 0.4 * trunc
+    elif case == "almost_flat":
+        # inside the band everywhere but for a few voxels just outside it, some in the rim, some not
+        D[:] = (np.float32(0.94) + np.float32(0.06) * rng.random(D.shape, dtype=np.float32)) * trunc
+        for (z, y, x), f in zip(rng.integers(0, n, size=(40, 3)), rng.choice([0.93, 0.5, 1.01, 0.0], size=40)):
+            D[z, y, x] = np.float32(f) * trunc
+        D[3, 3, 0] = 0.93 * trunc; D[3, 4, 1] = 1.002 * trunc; D[n - 1, n - 2, n - 1] = 0.2 * trunc
+    gv, ov = volumes_with(oracle, (n, n, n), (phys,) * 3, D.reshape(-1))
+    if case == "rim_written_by_integrate":
+        # a surface that leaves the volume through its faces, fused from depth images: the flags are the marks integrate left, then
+        # (second picture) the rebuilt ones
+        gv.close()
+        gv = tsdf_amd.TSDFVolume((n, n, n), (3000.0,) * 3)
+        ov = oracle.Volume((n, n, n), (3000.0,) * 3)
+        for i in range(3):
+            d, cam = synth.depth_frame(i * 4, 200, seed=0x5EED0003)
+            gv.integrate(d, W, H, cam)
+            ov.integrate(d, W, H, cam.inverse_pose(), cam.k(), cam.kinv(), nthreads=oracle.max_threads())
+            compare(oracle, gv, ov, cam, what="%s, frame %d" % (case, i))
+        gv.occupancy_data(force_rebuild=True)
+        compare(oracle, gv, ov, cam, what="%s, rebuilt flags" % case)
+        return
+    c = phys / 2
+    for pos, look in (((-300.0, c + 7, c - 5), (c, c, c)), ((c + 3, c - 8, -250.0), (c, c, c)), ((c, phys + 280.0, c + 11), (c, c, c)),
+                      ((-200.0, -180.0, -150.0), (c, c, c)), ((c, c, c), (0.0, c + 40, c - 30))):
+        compare(oracle, gv, ov, camera_at(pos, look_at=look), what="%s from %s" % (case, pos))

@@ -109,9 +109,15 @@ struct Geom {
 // bricks of kBrick^3 voxels:
 //   fine[b] == 0 : every resident voxel within the brick grown by kBrickGrow voxels on every side is > tau,
 //                  i.e. no trilinear sample whose taps lie in the brick grown by one voxel can be <= 0.
-//                  Bricks touching the grid boundary are set once and for all (there the reference extrapolates,
-//                  Q10, and the argument does not hold).  Sticky: integrate only ever sets flags, a rebuild
-//                  (clear / whole-array upload) resets them.
+//                  Bricks touching the grid boundary need more: in the outer half-voxel shell the reference extrapolates (Q10:
+//                  weights 1 - u in (1, 1.5], u in [-0.5, 0) per axis), so positive taps alone prove nothing.  There the flag
+//                  is clear only when every resident voxel of the grown brick is FLAT: in [flat_lo, flat_hi] = [15/16, 1 + 2^-10]
+//                  x trunc -- what clear() leaves and what free space in front of a surface is averaged to.  With taps in
+//                  [c_min, c_max] and weights summing to 1 of which the negative ones sum to -N (N <= (2^3 - 1) / 2 = 3.5 at a
+//                  corner of the grid), a sample is >= c_min - N (c_max - c_min) >= 0.71 trunc, far above the rounding of the
+//                  reference's fp32 sum.  (Up to round 2 boundary bricks were flagged for good: every ray spent ~11 passes
+//                  on the entry rim -- 5 samples in the shell, then blocks of 1, 1, 2, 4, 8 bricks -- a quarter of the bulk
+//                  kernel's wave time.)  Sticky: integrate only ever sets flags, a rebuild (clear / whole-array upload) resets them.
 //   cell[b] == 0 : every resident voxel in [4b, 4b+4] on every axis is > tau, i.e. all 8 taps of every dual cell
 //                  (lower corner) in [4b, 4b+4) are safely positive: a sample whose cell is KNOWN to lie in that
 //                  "cell brick" cannot be <= 0.  Tighter than `fine` (no slack for approximate location: the ray
@@ -134,6 +140,11 @@ struct OccGrid {
     uint8_t *reach;
     uint32_t nbx, nby, nbz;  // bricks per axis = ceil(size / kBrick)
     float tau;               // "safely positive" threshold (a fraction of the truncation distance)
+    float flat_lo, flat_hi;  // bricks touching the grid boundary: the band every voxel in reach must lie in (see above)
+    // first / last voxel index per axis whose value a boundary brick's flag depends on: v < rim_lo or v >= rim_hi* (brick 0 grown
+    // by kBrickGrow reaches voxel kBrick + kBrickGrow - 1; the last brick starts at kBrick * (nb - 1))
+    __host__ __device__ bool in_rim_zone(uint32_t v, uint32_t nb) const { return v < (uint32_t)(kBrick + kBrickGrow) || v + kBrickGrow >= (uint32_t)kBrick * (nb - 1u); }
+    __host__ __device__ bool not_flat(float d) const { return !(d >= flat_lo && d <= flat_hi); }   // (true for NaN)
     __host__ __device__ size_t fine_count() const { return (size_t)nbx * nby * nbz; }
 };
 
@@ -195,6 +206,7 @@ struct tsdf_volume {
     int occ_tighten_pending;    // ... that the volume's own stream has not waited for yet
     int reach_dirty; // 1 = `fine` changed since `reach` was computed
     uint16_t *occ_bits;              // 16 summary bits per brick, kept between rebuilds (volume.hip)
+    uint8_t *occ_rim_bits;           // 8 more: which 2^3-voxel octants hold a voxel that is not flat (read for boundary bricks only)
     // A rebuild reads only the distances integrate may have written since the previous one: integrate_kernel marks its brick
     // in `touched` (one byte per integrate brick, index order), the scan skips the others and their summary bits stand.
     // occ_scan_all = 1: the next rebuild reads everything (first rebuild, clear, set_distance_data, mark_dirty, new truncation).

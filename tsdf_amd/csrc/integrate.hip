@@ -66,7 +66,8 @@ __device__ inline Projected project_with_bounds(float px, float py, float pz, co
 // A voxel whose new distance is not safely positive flags every brick whose grown region
 // (brick +- kBrickGrow voxels) contains it: the bricks holding voxel v-2 .. v+2 on each axis.
 // (The definition, voxel by voxel: what integrate_kernel did up to round 2.  It now makes the same marks once per brick,
-// mark_low_voxels below; this function is kept as the statement of which bricks a low voxel marks.)
+// mark_low_voxels below; this function is kept as the statement of which bricks a low voxel marks.  "Low" is "not safely positive";
+// for the voxels that bricks at the grid boundary depend on it is "not flat", the stricter test of those bricks -- OccGrid.)
 __device__ inline void mark_occupied(const OccGrid &occ, uint32_t vx, uint32_t vy, uint32_t vz) {
     const uint32_t bx0 = (max(vx, (uint32_t)kBrickGrow) - kBrickGrow) >> kBrickShift;
     const uint32_t by0 = (max(vy, (uint32_t)kBrickGrow) - kBrickGrow) >> kBrickShift;
@@ -448,6 +449,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         float r1 = 0.f, r2 = 0.f, r3 = 0.f, r4 = 0.f;
         float r4_[kBatchZ] = {};
         uint32_t low_lo = 0, low_hi = 0;   // bit o: my voxel of plane z0 + o got a distance that is not safely positive
+        // voxels a brick at the grid boundary depends on are held to the stricter test of those bricks (flat, not just positive: OccGrid)
+        const bool rim_xy = occ.in_rim_zone(vx, occ.nbx) || occ.in_rim_zone(vy, occ.nby);
         if (!DEFORM) {
             cx = ((((int)vx + 0.5f) * g.vs.x) + g.offset_clear.x) + g.offset.x;
             cy = ((((int)vy + 0.5f) * g.vs.y) + g.offset_clear.y) + g.offset.y;
@@ -563,7 +566,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                     const size_t pb = brick_base + plane * (size_t)(zb - z0 + j);
                     (weight + pb)[lane_off] = new_weight;
                     (dist + pb)[lane_off] = new_distance;
-                    if (!(new_distance > occ.tau)) {   // not safely positive: remember the plane, the bricks are marked when this one is done
+                    const bool rim = rim_xy || occ.in_rim_zone(zb + j, occ.nbz);
+                    if (rim ? occ.not_flat(new_distance) : !(new_distance > occ.tau)) {   // not safely positive (not flat): remember the plane, the bricks are marked when this one is done
                         const uint32_t o_ = zb + j - z0;
                         if (o_ < 32u) low_lo |= 1u << o_; else low_hi |= 1u << (o_ - 32u);
                     }

@@ -869,29 +869,27 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
     // Lead-in: most (tile, range) pairs start in empty space and many never leave it.  Jumping from block to block needs
     // only the brick look-up, so it gets a loop of its own -- a fraction of the instructions of the full pass below --
     // that runs until every lane has either finished or arrived in a flagged brick (its classification is kept in bc).
+    // Entry: a ray that starts on a face of the grid spends its first samples in the outer half-voxel shell, where the
+    // reference extrapolates (Q10); a sample there whose brick is flagged (its voxels are not flat, OccGrid) takes the reference's
+    // full interpolation.  The rays of a tile do that together, so these samples get a loop of their own too -- a third of the
+    // instructions of a full pass -- and after each of them the hops go on: behind a shell sample the next brick may be clear.
     if (SKIP && !STATS) {
         while (true) {
-            const bool hopping = k != kDone && sc.skip_ok && k >= bc.k_brick_end;
-            if (__ballot(hopping) == 0ull) break;
-            if (hopping) {
-                const float t = T(k);
-                const float fx = ((t * ray.dx) + ray.sx) * sc.inv_vx, fy = ((t * ray.dy) + ray.sy) * sc.inv_vy, fz = ((t * ray.dz) + ray.sz) * sc.inv_vz;
-                int n;
-                const bool empty = locate<SLAB>(fx, fy, fz, sc, g, occ, rp, n);
-                bc.k_brick_end = k + n;
-                if (empty) {
-                    k += n;
-                    if (k >= k_end) k = kDone;
+            while (true) {
+                const bool hopping = k != kDone && sc.skip_ok && k >= bc.k_brick_end;
+                if (__ballot(hopping) == 0ull) break;
+                if (hopping) {
+                    const float t = T(k);
+                    const float fx = ((t * ray.dx) + ray.sx) * sc.inv_vx, fy = ((t * ray.dy) + ray.sy) * sc.inv_vy, fz = ((t * ray.dz) + ray.sz) * sc.inv_vz;
+                    int n;
+                    const bool empty = locate<SLAB>(fx, fy, fz, sc, g, occ, rp, n);
+                    bc.k_brick_end = k + n;
+                    if (empty) {
+                        k += n;
+                        if (k >= k_end) k = kDone;
+                    }
                 }
             }
-        }
-    }
-
-    // Entry: a ray that starts on a face of the grid spends its first samples in the outer half-voxel shell, where the
-    // reference extrapolates (Q10) and nothing can be skipped.  The rays of a tile do that together, so these samples get
-    // a loop of their own that only interpolates -- a third of the instructions of a full pass.
-    if (SKIP && !STATS) {
-        while (true) {
             bool shell = false;
             float t = 0.f, px = 0.f, py = 0.f, pz = 0.f;
             if (k != kDone) {

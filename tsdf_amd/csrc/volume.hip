@@ -98,14 +98,13 @@ __global__ __launch_bounds__(256) void init_nodes_kernel(tsdf_deformation_node *
     nodes[idx] = nd;
 }
 
-// Occupancy with nothing but the permanent boundary marks: fine bricks touching the grid boundary (first / last
-// brick of an axis, the last one possibly partial).
+// Occupancy of a cleared volume: every distance is +trunc, so nothing is flagged (bricks at the grid boundary included: +trunc is
+// flat) but the cell bricks that hold dual cells beyond the grid, which are set for good.
 __global__ __launch_bounds__(256) void occupancy_init_kernel(OccGrid occ, uint32_t size_x, uint32_t size_y, uint32_t size_z) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < occ.fine_count()) {
         uint32_t bx = i % occ.nbx, by = (i / occ.nbx) % occ.nby, bz = i / ((size_t)occ.nbx * occ.nby);
-        bool boundary = bx == 0 || by == 0 || bz == 0 || bx + 1 == occ.nbx || by + 1 == occ.nby || bz + 1 == occ.nbz;
-        occ.fine[i] = boundary ? 1 : 0;
+        occ.fine[i] = 0;
         // cell brick b holds dual cells 4b .. 4b+3; cells exist for lower corners 0 .. size-2
         bool partial = bx * kBrick + kBrick > size_x - 1 || by * kBrick + kBrick > size_y - 1 || bz * kBrick + kBrick > size_z - 1;
         occ.cell[i] = partial ? 1 : 0;
@@ -118,14 +117,17 @@ __global__ __launch_bounds__(256) void occupancy_init_kernel(OccGrid occ, uint32
 //    4^3 brick: bits 0-7 = which of the brick's eight 2^3-voxel octants hold a value that is not safely positive
 //    (octant index xo + 2 yo + 4 zo); bits 8-15 = the same question for the whole brick (A), its x = 0, y = 0, z = 0
 //    voxel layers (Fx, Fy, Fz), the three edges shared by two of those layers (Exy, Exz, Eyz) and the corner voxel (C).
+//    A second byte per brick (rim_bits) holds the octants with a voxel that is not FLAT (OccGrid): read for boundary bricks only.
 // 2. occupancy_flags_kernel combines the 27 neighbours: `fine[b]` = some octant inside the brick grown by kBrickGrow = 2
 //    voxels (= one octant) is marked; `cell[b]` = some voxel in [4b, 4b+4]^3 is marked, i.e. the brick itself plus the
-//    x/y/z = 0 layers, edges and corner of the bricks on its + side.  Boundary / partial bricks keep their permanent marks.
+//    x/y/z = 0 layers, edges and corner of the bricks on its + side.  A brick touching the grid boundary is flagged when some
+//    octant inside its grown box is not flat (common.hpp); partial cell bricks keep their permanent marks.
 // Workgroup of scan: 64 bricks along x (lane) x the 4 voxel rows of one brick row (wave); loops over the brick's 4 planes.
 // touched != nullptr (z_store_begin a multiple of 4): only the bricks inside integrate bricks marked there are read -- the
 // distances of the others have not been written since their summary bits were formed, and those stand.
 __global__ __launch_bounds__(256) void occupancy_scan_kernel(const float *__restrict__ dist, Geom g, OccGrid occ,
-                                                             uint16_t *__restrict__ bits, const uint8_t *__restrict__ touched,
+                                                             uint16_t *__restrict__ bits, uint8_t *__restrict__ rim_bits,
+                                                             const uint8_t *__restrict__ touched,
                                                              const uint32_t tnx, const uint32_t tny, const uint32_t tnz) {
     __shared__ uint32_t acc[64];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(256) void occupancy_scan_kernel(const float *__rest
     }
     if (threadIdx.x < 64) acc[threadIdx.x] = 0;
     __syncthreads();
-    uint32_t oct = 0, low = 0;
+    uint32_t oct = 0, low = 0, rim = 0;
     if (scan && bx < occ.nbx && y < g.Y) {
         const uint32_t x0 = bx * kBrick;
         const bool vec = (g.X & 3u) == 0;  // rows are 16-byte aligned and a brick never straddles the row end
@@ -153,12 +155,22 @@ __global__ __launch_bounds__(256) void occupancy_scan_kernel(const float *__rest
             if (z < g.z_store_begin || z >= g.z_store_end) continue;  // not resident (or beyond the grid)
             const float *row = dist + ((size_t)g.X * g.Y * (z - g.z_store_begin) + (size_t)g.X * y + x0);
             uint32_t m = 0;  // bit i: voxel x0 + i is not safely positive (also true for NaN)
+            uint32_t nf = 0; // bit i: voxel x0 + i is not flat
             if (vec) {
                 const float4 d = *reinterpret_cast<const float4 *>(row);
                 m = (!(d.x > occ.tau) ? 1u : 0u) | (!(d.y > occ.tau) ? 2u : 0u) | (!(d.z > occ.tau) ? 4u : 0u) | (!(d.w > occ.tau) ? 8u : 0u);
+                nf = (occ.not_flat(d.x) ? 1u : 0u) | (occ.not_flat(d.y) ? 2u : 0u) | (occ.not_flat(d.z) ? 4u : 0u) | (occ.not_flat(d.w) ? 8u : 0u);
             } else {
                 for (uint32_t i = 0; i < (uint32_t)kBrick; i++)
-                    if (x0 + i < g.X && !(row[i] > occ.tau)) m |= 1u << i;
+                    if (x0 + i < g.X) {
+                        if (!(row[i] > occ.tau)) m |= 1u << i;
+                        if (occ.not_flat(row[i])) nf |= 1u << i;
+                    }
+            }
+            if (nf) {
+                const uint32_t zo = j >> 1;
+                if (nf & 3u) rim |= 1u << (0 + 2 * yo + 4 * zo);
+                if (nf & 12u) rim |= 1u << (1 + 2 * yo + 4 * zo);
             }
             if (m) {
                 const uint32_t zo = j >> 1, z0f = j == 0 ? 1u : 0u, fx = m & 1u;
@@ -169,28 +181,33 @@ __global__ __launch_bounds__(256) void occupancy_scan_kernel(const float *__rest
             }
         }
     }
-    const uint32_t both = oct | (low << 8);
+    const uint32_t both = oct | (low << 8) | (rim << 16);
     if (both) atomicOr(&acc[lane], both);
     __syncthreads();
-    if (threadIdx.x < 64 && bx < occ.nbx && scan) bits[((size_t)bz * occ.nby + by) * occ.nbx + bx] = (uint16_t)acc[lane];
+    if (threadIdx.x < 64 && bx < occ.nbx && scan) {
+        bits[((size_t)bz * occ.nby + by) * occ.nbx + bx] = (uint16_t)acc[lane];
+        rim_bits[((size_t)bz * occ.nby + by) * occ.nbx + bx] = (uint8_t)(acc[lane] >> 16);
+    }
 }
 
-__global__ __launch_bounds__(256) void occupancy_flags_kernel(const uint16_t *__restrict__ bits, OccGrid occ, uint32_t size_x,
+__global__ __launch_bounds__(256) void occupancy_flags_kernel(const uint16_t *__restrict__ bits, const uint8_t *__restrict__ rim_bits, OccGrid occ, uint32_t size_x,
                                                               uint32_t size_y, uint32_t size_z, uint8_t *__restrict__ touched,
                                                               const uint32_t n_touched) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (touched && i < n_touched) touched[i] = 0;   // (the scan before this launch has read the marks: they start again)
     if (i >= occ.fine_count()) return;
     const int bx = (int)(i % occ.nbx), by = (int)((i / occ.nbx) % occ.nby), bz = (int)(i / ((size_t)occ.nbx * occ.nby));
+    // a brick touching the grid boundary asks for flat voxels, not just positive ones (OccGrid)
+    const bool boundary = bx == 0 || by == 0 || bz == 0 || bx + 1 == (int)occ.nbx || by + 1 == (int)occ.nby || bz + 1 == (int)occ.nbz;
+    bool fine = false;
     // the permanent marks of occupancy_init_kernel
-    bool fine = bx == 0 || by == 0 || bz == 0 || bx + 1 == (int)occ.nbx || by + 1 == (int)occ.nby || bz + 1 == (int)occ.nbz;
     bool cell = bx * kBrick + kBrick > (int)size_x - 1 || by * kBrick + kBrick > (int)size_y - 1 || bz * kBrick + kBrick > (int)size_z - 1;
     // octants of a neighbour at offset d that lie within 2 voxels of this brick: all (d = 0), the high half (d = -1),
     // the low half (d = +1); per axis, as masks over the octant index xo + 2 yo + 4 zo
     // (No branch around the 27 look-ups -- a neighbour outside the grid is read at a clamped index and masked to 0 -- so that
     // they are all requested before the first is waited for: with `continue` for the outside ones the loads went out one by
     // one, 38 us for 2 M bricks at 512^3.)
-    uint32_t fine_acc = 0, cell_acc = 0;
+    uint32_t fine_acc = 0, cell_acc = 0, rim_acc = 0;
 #pragma unroll
     for (int dz = -1; dz <= 1; dz++) {
         const int z = bz + dz;
@@ -209,6 +226,7 @@ __global__ __launch_bounds__(256) void occupancy_flags_kernel(const uint16_t *__
                 const size_t at = in ? ((size_t)z * occ.nby + y) * occ.nbx + x : i;
                 const uint32_t w = (uint32_t)bits[at] & (in ? 0xffffu : 0u);
                 fine_acc |= w & mx & my & mz;
+                if (boundary) rim_acc |= (uint32_t)rim_bits[at] & (in ? 0xffu : 0u) & mx & my & mz;
                 if (dx >= 0 && dy >= 0 && dz >= 0) {
                     // which summary of the + side neighbour touches [4b, 4b+4]^3: A, Fx, Fy, Exy, Fz, Exz, Eyz, C
                     constexpr uint32_t sel[8] = {1u << 8, 1u << 9, 1u << 10, 1u << 12, 1u << 11, 1u << 13, 1u << 14, 1u << 15};
@@ -217,7 +235,7 @@ __global__ __launch_bounds__(256) void occupancy_flags_kernel(const uint16_t *__
             }
         }
     }
-    fine = fine || fine_acc != 0u;
+    fine = fine_acc != 0u || rim_acc != 0u;
     cell = cell || cell_acc != 0u;
     occ.fine[i] = fine ? 1 : 0;
     occ.cell[i] = cell ? 1 : 0;
@@ -352,6 +370,12 @@ __global__ __launch_bounds__(64) void reach_mip_wave_kernel(OccGrid occ) {
     }
 }
 
+static void set_occupancy_thresholds(tsdf_volume *v) {
+    v->occ.tau = 0.01f * v->g.trunc;
+    v->occ.flat_lo = 0.9375f * v->g.trunc;
+    v->occ.flat_hi = (1.0f + 1.0f / 1024.0f) * v->g.trunc;
+}
+
 static int occupancy_reset(tsdf_volume *v) {
     size_t n = v->occ.fine_count();
     hipLaunchKernelGGL(occupancy_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, v->stream, v->occ, v->g.X, v->g.Y, v->g.Z);
@@ -374,15 +398,16 @@ int occupancy_join(tsdf_volume *v) {
 static int occupancy_rebuild_on(tsdf_volume *v, hipStream_t stream) {
     const size_t n = v->occ.fine_count();
     if (!v->occ_bits) TSDF_HIP(hipMalloc((void **)&v->occ_bits, n * sizeof(uint16_t)), "occupancy scratch alloc");
+    if (!v->occ_rim_bits) TSDF_HIP(hipMalloc((void **)&v->occ_rim_bits, n), "occupancy scratch alloc");
     dim3 grid((v->occ.nbx + 63) / 64, v->occ.nby, v->occ.nbz);
     static const bool always_all = [] { const char *e = getenv("TSDF_OCC_SCAN_ALL"); return e && atoi(e) != 0; }();   // tuning aid
     const bool incremental = !always_all && !v->occ_scan_all && v->touched && (v->g.z_store_begin % kBrick) == 0;
     const uint32_t n_touched = v->touched ? v->touched_nx * v->touched_ny * v->touched_nz : 0u;
     TSDF_REQUIRE(n_touched <= n || !v->touched, "occupancy rebuild: more integrate bricks than occupancy bricks");
-    hipLaunchKernelGGL(occupancy_scan_kernel, grid, dim3(256), 0, stream, v->dist, v->g, v->occ, v->occ_bits,
+    hipLaunchKernelGGL(occupancy_scan_kernel, grid, dim3(256), 0, stream, v->dist, v->g, v->occ, v->occ_bits, v->occ_rim_bits,
                        incremental ? (const uint8_t *)v->touched : (const uint8_t *)nullptr, v->touched_nx, v->touched_ny, v->touched_nz);
     TSDF_HIP(hipGetLastError(), "occupancy scan");
-    hipLaunchKernelGGL(occupancy_flags_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, v->occ_bits, v->occ,
+    hipLaunchKernelGGL(occupancy_flags_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, v->occ_bits, v->occ_rim_bits, v->occ,
                        v->g.X, v->g.Y, v->g.Z, v->touched, n_touched);
     TSDF_HIP(hipGetLastError(), "occupancy rebuild");
     v->occ_scan_all = 0;
@@ -708,7 +733,7 @@ int tsdf_volume_create_slab(uint32_t sx, uint32_t sy, uint32_t sz, float px, flo
     v->occ.nbx = (sx + kBrick - 1) / kBrick;
     v->occ.nby = (sy + kBrick - 1) / kBrick;
     v->occ.nbz = (sz + kBrick - 1) / kBrick;
-    v->occ.tau = 0.01f * g.trunc;
+    set_occupancy_thresholds(v);
     if (v->occ.fine_count() >= ((size_t)1 << 32)) {   // the ray caster indexes bricks with 32 bits (grids beyond ~6500^3)
         delete v;
         set_error("tsdf_volume_create: grid of %u x %u x %u voxels is too large", (unsigned)sx, (unsigned)sy, (unsigned)sz);
@@ -760,6 +785,7 @@ int tsdf_volume_destroy(tsdf_volume *v) {
     if (v->occ.cell) (void)hipFree(v->occ.cell);
     if (v->occ.reach) (void)hipFree(v->occ.reach);
     if (v->occ_bits) (void)hipFree(v->occ_bits);
+    if (v->occ_rim_bits) (void)hipFree(v->occ_rim_bits);
     if (v->touched) (void)hipFree(v->touched);
     if (v->plane_const) (void)hipFree(v->plane_const);
     if (v->tail_entries) (void)hipFree(v->tail_entries);
@@ -848,7 +874,7 @@ int tsdf_volume_set_header(tsdf_volume *v, const float offset[3], float trunc, f
     v->g.offset = {offset[0], offset[1], offset[2]};
     v->g.trunc = trunc;
     v->prepared_valid = 0;
-    v->occ.tau = 0.01f * trunc;
+    set_occupancy_thresholds(v);
     v->occ_dirty = 1;
     v->occ_scan_all = 1;
     int rc = build_t_table(v);
