@@ -347,6 +347,9 @@ np.savez(sys.argv[1], V=V, N=N, D=gv.get_distance_data())
     {"TSDF_RAY_SEGMENTS": "64", "TSDF_RAY_TRIP_BUDGET": "5", "TSDF_RAY_TAIL_LANES": "8"},
     {"TSDF_RAY_RANGE_ORDER": "0"},                                                             # sample ranges dispatched near to far (round 1)
     {"TSDF_RAY_RANGE_ORDER": "2", "TSDF_RAY_SEGMENTS": "5"},                                   # ... last, first, then far to near
+    {"TSDF_RAY_LEARNED_ORDER": "0"},                                                           # tiles in launch order (no order learnt from the previous cast)
+    {"TSDF_RAY_TILE_MAP": "0", "TSDF_RAY_TRIP_BUDGET": "4"},                                   # every eighth tile per XCD; many long waves to order
+    {"TSDF_RAY_TILE_MAP": "1"},                                                                # one contiguous eighth of the image per XCD (round 2)
     {"TSDF_DEBUG_SORT": "1"},                                                                  # integrate: brick list in index order
     {"TSDF_DEBUG_SORT": "2"},                                                                  # ... scattered
     {"TSDF_INT_GRID_PER_CU": "3"},                                                             # integrate: resident grid walking the brick list

@@ -10,11 +10,11 @@ if [ "$mode" = build ]; then
   src=$root
   if [ -n "$rev" ]; then src=$(mktemp -d); git -C $root archive $rev tsdf_amd/csrc include | tar -x -C $src; fi
   objs=""
-  for f in volume integrate raycast bilateral icp mcubes; do
+  for f in $(cd $src/tsdf_amd/csrc && ls *.hip | sed "s/.hip//"); do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I$src/include -I$src/tsdf_amd/csrc -Wall -Wno-unused-function \
         -c $src/tsdf_amd/csrc/$f.hip -o $dst/$f.o 2>&1 | grep -E "error" ; objs="$objs $dst/$f.o"
   done
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $dst/libtsdf_hip.so $objs && rm -f $dst/*.o && ls -la $dst/libtsdf_hip.so
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $dst/libtsdf_hip.so $objs -ldl && rm -f $dst/*.o && ls -la $dst/libtsdf_hip.so
 else
   cmd=$1; shift
   for name in "$@" "$@"; do

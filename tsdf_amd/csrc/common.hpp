@@ -188,6 +188,13 @@ struct tsdf_volume {
     void *tail_entries;
     uint32_t *tail_count;
     size_t tail_cap;
+    // Dispatch order of the first ray-cast kernel, learnt from the previous cast (scheduling only): ray_heavy[range][workgroup] = 1
+    // when a wave of that (sample range, tile) used its whole pass budget, ray_order[z][i] = range << 16 | tile slot that the i-th
+    // workgroup of the z-th slab of the launch takes -- the heavy pairs of its XCD first (raycast.hip: order_ray_tiles).
+    uint8_t *ray_heavy;
+    uint32_t *ray_order;
+    uint32_t ray_order_tiles, ray_order_ranges;   // what the two arrays were sized (and the order was built) for
+    int ray_order_valid;
     // T[k]: the ray parameter of sample k, T[0] = 0, T[k+1] = T[k] + step in fp32 (raycast.hip)
     float *t_table;
     // 1 = dividing by each voxel edge via the 3-instruction reciprocal sequence was verified exhaustively

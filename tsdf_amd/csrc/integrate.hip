@@ -449,8 +449,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         float r1 = 0.f, r2 = 0.f, r3 = 0.f, r4 = 0.f;
         float r4_[kBatchZ] = {};
         uint32_t low_lo = 0, low_hi = 0;   // bit o: my voxel of plane z0 + o got a distance that is not safely positive
-        // voxels a brick at the grid boundary depends on are held to the stricter test of those bricks (flat, not just positive: OccGrid)
+        // Voxels a brick at the grid boundary depends on are held to the stricter test of those bricks (flat, not just positive:
+        // OccGrid).  Both tests are "not (d > lo) or d > hi" with per-lane bounds: (tau, +inf) inside, (the float below flat_lo,
+        // flat_hi) for lanes in the x / y part of the rim zone; the planes of the z part are picked per batch of planes below.
         const bool rim_xy = occ.in_rim_zone(vx, occ.nbx) || occ.in_rim_zone(vy, occ.nby);
+        const float flat_lo_open = __uint_as_float(__float_as_uint(occ.flat_lo) - 1u);   // d >= flat_lo  <=>  d > this  (flat_lo > 0, normal)
+        const float mark_lo = rim_xy ? flat_lo_open : occ.tau, mark_hi = rim_xy ? occ.flat_hi : INFINITY;
         if (!DEFORM) {
             cx = ((((int)vx + 0.5f) * g.vs.x) + g.offset_clear.x) + g.offset.x;
             cy = ((((int)vy + 0.5f) * g.vs.y) + g.offset_clear.y) + g.offset.y;
@@ -558,6 +562,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             }
         };
         auto blend_and_store = [&](const uint32_t zb, const float (&tsdf_)[kBatchZ], const float (&pw_)[kBatchZ], const float (&pd_)[kBatchZ]) {
+            // (uniform) a batch with a plane in the z part of the rim zone -- z < 6 or z >= 4 (nbz - 1) - 2 -- takes the flat test on every lane
+            const bool z_rim = zb < (uint32_t)(kBrick + kBrickGrow) || zb + (uint32_t)kBatchZ - 1u + (uint32_t)kBrickGrow >= (uint32_t)kBrick * (occ.nbz - 1u);
+            const float lo = z_rim ? flat_lo_open : mark_lo, hi = z_rim ? occ.flat_hi : mark_hi;
 #pragma unroll
             for (int j = 0; j < kBatchZ; j++) {
                 if (tsdf_[j] == tsdf_[j]) {
@@ -566,8 +573,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                     const size_t pb = brick_base + plane * (size_t)(zb - z0 + j);
                     (weight + pb)[lane_off] = new_weight;
                     (dist + pb)[lane_off] = new_distance;
-                    const bool rim = rim_xy || occ.in_rim_zone(zb + j, occ.nbz);
-                    if (rim ? occ.not_flat(new_distance) : !(new_distance > occ.tau)) {   // not safely positive (not flat): remember the plane, the bricks are marked when this one is done
+                    if (!(new_distance > lo) || new_distance > hi) {   // not safely positive (rim zone: not flat): remember the plane, the bricks are marked when this one is done
                         const uint32_t o_ = zb + j - z0;
                         if (o_ < 32u) low_lo |= 1u << o_; else low_hi |= 1u << (o_ - 32u);
                     }

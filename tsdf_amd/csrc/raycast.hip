@@ -250,12 +250,12 @@ constexpr int kDone = 0x7fffffff;
 // the APPROXIMATE location used at brick level.
 constexpr float kCellPositive = 1.0e-30f;
 constexpr int kTailLanesDefault = 4;        // lanes per queue entry in the tail kernel
-constexpr int kRaySegmentsDefault = 5;   // sample ranges of a whole-volume march (round 2: 5 ranges / 24 passes, re-tuned with the ranges dispatched far to near; round 1: 6 / 18)
+constexpr int kRaySegmentsDefault = 6;   // sample ranges of a whole-volume march (round 3: 6 ranges / 22 passes, re-tuned with the long waves dispatched first; round 2: 5 / 24 with the ranges dispatched far to near; round 1: 6 / 18)
 constexpr int kTailGridDefault = 256 * 10;   // workgroups of the tail kernel (5 fit a CU at 86 VGPRs: two rounds)
 // What is left of a ray's range when the pass budget runs out is queued in up to kTailPieces pieces of at least
 // kTailPieceMin samples, so that a long stretch is marched by several groups of the tail kernel at once.
 constexpr int kTailPieces = 16, kTailPieceMin = 64;
-constexpr int kTripBudgetDefault = 24;   // passes of the marching loop before a wave hands over to the tail kernel
+constexpr int kTripBudgetDefault = 22;   // passes of the marching loop before a wave hands over to the tail kernel
 static int ray_segments() {
     static const int n = [] {
         const char *e = getenv("TSDF_RAY_SEGMENTS");  // tuning aid
@@ -746,9 +746,16 @@ struct TailQueue {
     uint32_t lanes;        // lanes per ray in the tail kernel (power of two, 4..64)
     uint64_t *best;        // per pixel: {smallest sample index found <= 0 so far, that sample's value}: hit_word (kNoHitWord = none)
     int piece_min;         // shortest piece a handed-over stretch is cut into
+    const uint32_t *order; // dispatch order learnt from the previous cast (nullptr: none): [slot of the range][workgroup] -> range << 16 | workgroup whose tile to take
+    uint8_t *heavy;        // [range][workgroup]: set by a wave that took heavy_passes passes or more, for the next cast's order (nullptr: off)
+    uint32_t heavy_passes;
     unsigned long long *wave_log;   // diagnostics (TSDF_DEBUG_WAVES): per wave of the tail kernel {batches << 32 | rounds, start, end}
 };
 constexpr uint32_t kNoHit = 0xffffffffu;
+// the sample range the z-th slab of workgroups marches (rp.range_order: 0 near to far, 1 far to near, 2 last, first, then far to near)
+__host__ __device__ inline uint32_t ray_range_of_slot(uint32_t z, uint32_t nz, uint32_t order) {
+    return order == 0 ? z : order == 1 ? nz - 1u - z : (z == 0 ? nz - 1u : z == 1 ? 0u : nz - z);
+}
 constexpr uint64_t kNoHitWord = ~0ull;
 // The per-pixel word of the march: the index of the sample in the high half, the bits of its value (<= 0) in the low half.  An
 // unsigned 64-bit minimum orders by the index; two writers of the same index computed the same sample with the same expressions, so
@@ -799,7 +806,19 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
     // passes through the entry rim, none over 23 us) ends last at 89 us.  Any order gives the same picture: the ranges meet in
     // an atomicMin, and the early exit below only ever drops work.
     const uint32_t nz = gridDim.z, bz_ = blockIdx.z;
-    const uint32_t range = rp.range_order == 0 ? bz_ : rp.range_order == 1 ? nz - 1u - bz_ : (bz_ == 0 ? nz - 1u : bz_ == 1 ? 0u : nz - bz_);
+    // Which (sample range, tile) this workgroup takes: its own in launch order, or -- tail.order, scheduling only -- what the order
+    // learnt from the previous cast gives its slot: the pairs in which a wave used its whole pass budget first.  The launch is as long
+    // as its long waves (40-60 us each on the bench scene, 1 400 of 24 000) started late: the chip holds a quarter of the launch,
+    // and the long waves of the second range used to start when the first range's short ones had gone (20 us in), the few of the
+    // near ranges after 40 us.  An entry keeps the workgroup on its XCD (same tile index modulo 8), so locality and balance stay as
+    // the tile map made them.
+    uint32_t lin = blockIdx.y * gridDim.x + blockIdx.x;
+    uint32_t range = ray_range_of_slot(bz_, nz, rp.range_order);
+    if (TAIL && tail.order) {
+        const uint32_t e = tail.order[bz_ * (gridDim.x * gridDim.y) + lin];
+        range = e >> 16;
+        lin = e & 0xffffu;
+    }
     const int k_lo = per_ray_ranges ? 0 : (int)(range * rp.seg_len);
     const int k_hi = (rp.seg_len && !per_ray_ranges) ? min(kMaxSamples, k_lo + (int)rp.seg_len) : kMaxSamples;
     const unsigned long long dbg_entry = (TAIL && !STATS && counters) ? wall_clock64() : 0ull;   // (diagnostics, TSDF_DEBUG_WAVES)
@@ -821,8 +840,10 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
     // blocks of 5 x 5 tiles and each XCD given one block of every block row, in a different column each time (2, when the tile
     // counts divide that way -- 640 x 480 does): 87.5 us.
     uint32_t tile_x = blockIdx.x, tile_y = blockIdx.y;
+    tile_y = lin / gridDim.x;
+    tile_x = lin - tile_y * gridDim.x;
     if (rp.tile_map != 0u) {
-        const uint32_t n_tiles = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const uint32_t n_tiles = gridDim.x * gridDim.y;
         const uint32_t per_xcd = n_tiles / 8;
         if (lin < per_xcd * 8) {   // (the last n_tiles % 8 tiles keep their place)
             const uint32_t xcd = lin & 7u, j = lin >> 3;
@@ -941,6 +962,8 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
     }
 
     if (TAIL) {
+        // (for the next cast's dispatch order: this tile holds a long wave in this range)
+        if (tail.heavy && dbg_trips >= tail.heavy_passes && lane == 0) tail.heavy[range * (gridDim.x * gridDim.y) + lin] = 1;
         // hand over what is left of the unfinished rays, in pieces (one atomic per wave); a ray whose hit is already known
         // to lie at or before its next sample is dropped
         int len = 0;
@@ -997,6 +1020,46 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
     }
 }
 
+// The dispatch order of the next cast's first kernel (TailQueue::order), from the marks this cast's long waves left (heavy[range][tile
+// slot]).  Workgroup i of a launch runs on XCD i % 8; per XCD, its slots in launch order (range slab after range slab) are given
+// first the (range, tile) pairs that held a long wave, then the others, both in launch order.  One wave per XCD; the marks are
+// cleared for the next cast.  Scheduling only: any order gives the same picture.
+struct OrderJob {
+    uint8_t *heavy;
+    uint32_t *order;
+    uint32_t n_tiles, n_ranges, range_order;   // n_ranges == 0: nothing to do
+};
+constexpr uint32_t kOrderWorkgroups = 2;   // workgroups of 4 waves appended to the tail kernel's launch for the 8 XCDs
+__device__ inline void order_ray_tiles(uint32_t xcd, const OrderJob &job) {
+    if (xcd >= 8u || job.n_ranges == 0u) return;
+    const uint32_t lane = threadIdx.x & 63u, n_tiles = job.n_tiles, per_xcd = n_tiles / 8;
+    uint32_t next = 0;   // slots of this XCD filled so far: slot i is workgroup 8 (i % per_xcd) + xcd of range slab i / per_xcd
+    for (int pass = 0; pass < 2; pass++)
+        for (uint32_t z = 0; z < job.n_ranges; z++) {
+            const uint32_t range = ray_range_of_slot(z, job.n_ranges, job.range_order);
+            const uint8_t *h = job.heavy + (size_t)range * n_tiles;
+            for (uint32_t j0 = 0; j0 < per_xcd; j0 += 64) {
+                const uint32_t j = j0 + lane;
+                const bool mine = j < per_xcd && (h[8 * j + xcd] != 0) == (pass == 0);
+                const unsigned long long m = __ballot(mine);
+                if (mine) {
+                    const uint32_t slot = next + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    job.order[(size_t)(slot / per_xcd) * n_tiles + 8 * (slot % per_xcd) + xcd] = (range << 16) | (8 * j + xcd);
+                }
+                next += (uint32_t)__popcll(m);
+            }
+        }
+    for (uint32_t z = 0; z < job.n_ranges; z++) {
+        const uint32_t range = ray_range_of_slot(z, job.n_ranges, job.range_order);
+        for (uint32_t j = lane; j < per_xcd; j += 64) job.heavy[(size_t)range * n_tiles + 8 * j + xcd] = 0;
+        if (xcd == 0)   // the n_tiles % 8 workgroups past the last full round of a slab keep their place
+            for (uint32_t i = per_xcd * 8 + lane; i < n_tiles; i += 64) {
+                job.order[(size_t)z * n_tiles + i] = (range << 16) | i;
+                job.heavy[(size_t)range * n_tiles + i] = 0;
+            }
+    }
+}
+
 // The stretches of rays process_ray_kernel did not finish.  lanes_per_ray lanes per queue entry: the group's lanes take
 // the next samples k .. k+15 of the entry's ray, each classifying / evaluating its own (process_sample without the
 // per-brick memory).  The first lane of the group with a value <= 0 has the stretch's first hit -- everything before it
@@ -1009,8 +1072,12 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
 template <bool SLAB, bool FASTDIV, int LANES>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void process_ray_tail_kernel(const float *__restrict__ dist, const Geom g, const RayParams rp,
                                                                const OccGrid occ, const float *__restrict__ t_table,
-                                                               const TailQueue tail) {
+                                                               const TailQueue tail, const OrderJob order_job) {
     __shared__ float T[kTableLen];
+    if (blockIdx.x >= gridDim.x - kOrderWorkgroups) {   // the last workgroups: the next cast's dispatch order, one wave per XCD (beside the march)
+        if (order_job.n_ranges) order_ray_tiles((blockIdx.x - (gridDim.x - kOrderWorkgroups)) * 4u + (threadIdx.x >> 6), order_job);
+        return;
+    }
     const uint32_t n_entries = tail.count[0];
     const uint32_t lanes_per_ray = LANES ? (uint32_t)LANES : tail.lanes;
     if ((size_t)blockIdx.x * 4u * (64u / lanes_per_ray) >= n_entries) return;   // nothing for this workgroup: skip the staging too
@@ -1024,7 +1091,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     // A wave takes as many consecutive queue entries as it has groups (pieces of one ray, or of rays of one tile and one
     // sample range: alike in length), works on them until all are finished, then takes the next batch: waves round robin.
     const uint32_t groups_per_wave = 64 / lanes_per_ray;
-    const uint32_t n_waves = gridDim.x * 4, wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t n_waves = (gridDim.x - kOrderWorkgroups) * 4, wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
     const unsigned long long dbg_t0 = tail.wave_log ? wall_clock64() : 0ull;
     uint32_t dbg_batches = 0, dbg_rounds = 0;
     for (uint32_t batch = wave_id * groups_per_wave; batch < n_entries; batch += n_waves * groups_per_wave) {
@@ -1141,6 +1208,7 @@ __global__ __launch_bounds__(kResolveThreads) void resolve_normals_kernel(const 
                                                                           uint64_t *__restrict__ best_next, float *__restrict__ V,
                                                                           float *__restrict__ N, uint32_t *__restrict__ reset) {
     constexpr int kT = 16, kS = kT + 1;
+
     static_assert(kS * kS <= kResolveThreads, "one thread per pixel of the tile and its halo");
     __shared__ float vx[kS * kS], vy[kS * kS], vz[kS * kS];
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *reset = 0;
@@ -1418,6 +1486,30 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
     v->ray_best_dirty = 1;
     TailQueue tail = {reinterpret_cast<uint2 *>(v->tail_entries), v->tail_count, (uint32_t)trip_budget(), (uint32_t)tail_lanes(), v->ray_best + (size_t)v->ray_best_side * v->ray_best_cap, tail_piece_min(), nullptr};
     uint64_t *best_next = v->ray_best + (size_t)(1 - v->ray_best_side) * v->ray_best_cap;
+    // the dispatch order learnt from the previous cast (TSDF_RAY_LEARNED_ORDER=0: launch order, tuning aid)
+    static const bool learn_order = [] { const char *e = getenv("TSDF_RAY_LEARNED_ORDER"); return !e || atoi(e) != 0; }();
+    const uint32_t n_tiles = ((rp.width + 15) / 16) * ((rp.height + 15) / 16);
+    OrderJob order_job = {nullptr, nullptr, 0, 0, 0};
+    if (learn_order && n_tiles <= 65535u) {
+        if (!v->ray_heavy || v->ray_order_tiles != n_tiles || v->ray_order_ranges != (uint32_t)n_segments) {
+            if (v->ray_heavy) (void)hipFree(v->ray_heavy);
+            if (v->ray_order) (void)hipFree(v->ray_order);
+            v->ray_heavy = nullptr;
+            v->ray_order = nullptr;
+            v->ray_order_valid = 0;
+            TSDF_HIP(hipMalloc((void **)&v->ray_heavy, (size_t)n_tiles * n_segments), "ray order alloc");
+            TSDF_HIP(hipMalloc((void **)&v->ray_order, (size_t)n_tiles * n_segments * sizeof(uint32_t)), "ray order alloc");
+            TSDF_HIP(hipMemsetAsync(v->ray_heavy, 0, (size_t)n_tiles * n_segments, v->stream), "ray order reset");
+            v->ray_order_tiles = n_tiles;
+            v->ray_order_ranges = (uint32_t)n_segments;
+        }
+        tail.heavy = v->ray_heavy;
+        // "long": half the pass budget or more (only the waves that used ALL of it: no gain -- the waves just under the budget are as long; a
+        // quarter, a twelfth: 1-2 us worse than half)
+        { static const int hp = [] { const char *e = getenv("TSDF_RAY_HEAVY_PASSES"); return e ? atoi(e) : 0; }(); tail.heavy_passes = hp > 0 ? (uint32_t)hp : std::max(1u, tail.trip_budget / 2u); }   // tuning aid
+        tail.order = v->ray_order_valid ? v->ray_order : nullptr;
+        order_job = {v->ray_heavy, v->ray_order, n_tiles, (uint32_t)n_segments, 0};
+    }
     rp.seg_len = (kMaxSamples + n_segments - 1) / n_segments;
     rp.slab_ranges = SLAB ? (uint32_t)n_segments : 0u;
     { static const int map = [] { const char *e = getenv("TSDF_RAY_TILE_MAP"); return e ? atoi(e) : 2; }(); rp.tile_map = (uint32_t)std::min(std::max(map, 0), 2); }   // tuning aid
@@ -1486,15 +1578,16 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
     // persistent workgroups: groups of 16 lanes, fetching queue entries until none is left
     // (the default group width is compiled in; another one, a tuning aid, takes the variant that reads it at run time)
     const bool fixed_lanes = tail_lanes() == kTailLanesDefault;
-    const dim3 tgrid_(tail_grid());
+    order_job.range_order = rp.range_order;
+    const dim3 tgrid_(tail_grid() + kOrderWorkgroups);
     if (v->fast_div && fixed_lanes)
-        TSDF_LAUNCH_TIMED(v, 2, (process_ray_tail_kernel<SLAB, true, kTailLanesDefault>), tgrid_, dim3(256), v->dist, v->g, rp, v->occ, v->t_table, tail);
+        TSDF_LAUNCH_TIMED(v, 2, (process_ray_tail_kernel<SLAB, true, kTailLanesDefault>), tgrid_, dim3(256), v->dist, v->g, rp, v->occ, v->t_table, tail, order_job);
     else if (v->fast_div)
-        TSDF_LAUNCH_TIMED(v, 2, (process_ray_tail_kernel<SLAB, true, 0>), tgrid_, dim3(256), v->dist, v->g, rp, v->occ, v->t_table, tail);
+        TSDF_LAUNCH_TIMED(v, 2, (process_ray_tail_kernel<SLAB, true, 0>), tgrid_, dim3(256), v->dist, v->g, rp, v->occ, v->t_table, tail, order_job);
     else if (fixed_lanes)
-        TSDF_LAUNCH_TIMED(v, 2, (process_ray_tail_kernel<SLAB, false, kTailLanesDefault>), tgrid_, dim3(256), v->dist, v->g, rp, v->occ, v->t_table, tail);
+        TSDF_LAUNCH_TIMED(v, 2, (process_ray_tail_kernel<SLAB, false, kTailLanesDefault>), tgrid_, dim3(256), v->dist, v->g, rp, v->occ, v->t_table, tail, order_job);
     else
-        TSDF_LAUNCH_TIMED(v, 2, (process_ray_tail_kernel<SLAB, false, 0>), tgrid_, dim3(256), v->dist, v->g, rp, v->occ, v->t_table, tail);
+        TSDF_LAUNCH_TIMED(v, 2, (process_ray_tail_kernel<SLAB, false, 0>), tgrid_, dim3(256), v->dist, v->g, rp, v->occ, v->t_table, tail, order_job);
     TSDF_HIP(hipGetLastError(), "process_ray (tail) failed");
     if (debug_waves) {   // diagnostics (synchronises): the tail kernel's waves
         (void)hipStreamSynchronize(v->stream);
@@ -1529,6 +1622,7 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
     } else {
         hipLaunchKernelGGL((resolve_hits_kernel<SLAB>), rgrid, dim3(256), 0, v->stream, v->g, rp, v->t_table, tail.best, best_next, out, v->tail_count);
     }
+    if (order_job.n_ranges) v->ray_order_valid = 1;
     TSDF_HIP(hipGetLastError(), "resolve ray hits failed");
     v->ray_best_side = 1 - v->ray_best_side;
     v->ray_best_dirty = 0;

@@ -790,6 +790,8 @@ int tsdf_volume_destroy(tsdf_volume *v) {
     if (v->plane_const) (void)hipFree(v->plane_const);
     if (v->tail_entries) (void)hipFree(v->tail_entries);
     if (v->tail_count) (void)hipFree(v->tail_count);
+    if (v->ray_heavy) (void)hipFree(v->ray_heavy);
+    if (v->ray_order) (void)hipFree(v->ray_order);
     if (v->t_table) (void)hipFree(v->t_table);
     if (v->ray_best) (void)hipFree(v->ray_best);
     for (int w = 0; w < 3; w++)
