@@ -746,12 +746,14 @@ struct TailQueue {
     uint32_t lanes;        // lanes per ray in the tail kernel (power of two, 4..64)
     uint64_t *best;        // per pixel: {smallest sample index found <= 0 so far, that sample's value}: hit_word (kNoHitWord = none)
     int piece_min;         // shortest piece a handed-over stretch is cut into
-    const uint32_t *order; // dispatch order learnt from the previous cast (nullptr: none): [slot of the range][workgroup] -> range << 16 | workgroup whose tile to take
-    uint8_t *heavy;        // [range][workgroup]: set by a wave that took heavy_passes passes or more, for the next cast's order (nullptr: off)
+    const uint32_t *order; // dispatch order learnt from the previous cast (nullptr: none): [slab of the launch][workgroup] -> last range + 1 << 24 | first range << 16 | workgroup whose tile to take, or kNoSlot
+    uint8_t *heavy;        // for the next cast's order (nullptr: off): [range][workgroup] set by a wave that made a pass at all, and behind those the
+                           // same again for waves that took heavy_passes passes or more
     uint32_t heavy_passes;
     unsigned long long *wave_log;   // diagnostics (TSDF_DEBUG_WAVES): per wave of the tail kernel {batches << 32 | rounds, start, end}
 };
 constexpr uint32_t kNoHit = 0xffffffffu;
+constexpr uint32_t kNoSlot = 0xffffffffu;   // TailQueue::order: a slot of the launch with nothing to do
 // the sample range the z-th slab of workgroups marches (rp.range_order: 0 near to far, 1 far to near, 2 last, first, then far to near)
 __host__ __device__ inline uint32_t ray_range_of_slot(uint32_t z, uint32_t nz, uint32_t order) {
     return order == 0 ? z : order == 1 ? nz - 1u - z : (z == 0 ? nz - 1u : z == 1 ? 0u : nz - z);
@@ -812,15 +814,20 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
     // and the long waves of the second range used to start when the first range's short ones had gone (20 us in), the few of the
     // near ranges after 40 us.  An entry keeps the workgroup on its XCD (same tile index modulo 8), so locality and balance stay as
     // the tile map made them.
+    // The order also MERGES ranges: consecutive ranges of a tile in which no wave made a single pass in the previous cast (free space: a
+    // third of the launch's wave time went into setting their workgroups up) are given to one workgroup, [range, range_hi); any cut of
+    // a ray's samples gives the same picture.  The slots this frees are empty (kNoSlot) and leave at once.
     uint32_t lin = blockIdx.y * gridDim.x + blockIdx.x;
-    uint32_t range = ray_range_of_slot(bz_, nz, rp.range_order);
+    uint32_t range = ray_range_of_slot(bz_, nz, rp.range_order), range_hi = range + 1u;
     if (TAIL && tail.order) {
         const uint32_t e = tail.order[bz_ * (gridDim.x * gridDim.y) + lin];
-        range = e >> 16;
+        if (e == kNoSlot) return;
         lin = e & 0xffffu;
+        range = (e >> 16) & 0xffu;
+        range_hi = e >> 24;
     }
     const int k_lo = per_ray_ranges ? 0 : (int)(range * rp.seg_len);
-    const int k_hi = (rp.seg_len && !per_ray_ranges) ? min(kMaxSamples, k_lo + (int)rp.seg_len) : kMaxSamples;
+    const int k_hi = (rp.seg_len && !per_ray_ranges) ? min(kMaxSamples, (int)(range_hi * rp.seg_len)) : kMaxSamples;
     const unsigned long long dbg_entry = (TAIL && !STATS && counters) ? wall_clock64() : 0ull;   // (diagnostics, TSDF_DEBUG_WAVES)
     // T[0], T[1] (the step) and the part of the table this range reads, T[k_lo .. k_hi], at Ts[2 ..]: 3.5 KB of LDS for a fifth of
     // the table (dynamic allocation, ray_table_lds_bytes) instead of 17.6 KB for all of it.  (Workgroup residency is not what
@@ -873,7 +880,7 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
     if (per_ray_ranges && k_end > k_first) {
         // part blockIdx.z of rp.slab_ranges equal parts of this ray's stretch [k_first, k_end) through the slab
         const int len = k_end - k_first, a = k_first + (int)(((long long)len * range) / rp.slab_ranges);
-        k_end = k_first + (int)(((long long)len * (range + 1)) / rp.slab_ranges);
+        k_end = k_first + (int)(((long long)len * range_hi) / rp.slab_ranges);
         k_first = a;
     }
     const TriConst &tc = rp.tc;
@@ -963,7 +970,12 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
 
     if (TAIL) {
         // (for the next cast's dispatch order: this tile holds a long wave in this range)
-        if (tail.heavy && dbg_trips >= tail.heavy_passes && lane == 0) tail.heavy[range * (gridDim.x * gridDim.y) + lin] = 1;
+        // ([0]: a pass at all -- the range is not free space for this tile; [1]: a long wave.  A merged workgroup speaks for all its ranges)
+        if (tail.heavy && dbg_trips >= 1u && lane < range_hi - range) {
+            const uint32_t n_tiles = gridDim.x * gridDim.y, at = (range + lane) * n_tiles + lin;
+            tail.heavy[at] = 1;
+            if (dbg_trips >= tail.heavy_passes) tail.heavy[gridDim.z * n_tiles + at] = 1;
+        }
         // hand over what is left of the unfinished rays, in pieces (one atomic per wave); a ray whose hit is already known
         // to lie at or before its next sample is dropped
         int len = 0;
@@ -1020,42 +1032,75 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
     }
 }
 
-// The dispatch order of the next cast's first kernel (TailQueue::order), from the marks this cast's long waves left (heavy[range][tile
-// slot]).  Workgroup i of a launch runs on XCD i % 8; per XCD, its slots in launch order (range slab after range slab) are given
-// first the (range, tile) pairs that held a long wave, then the others, both in launch order.  One wave per XCD; the marks are
-// cleared for the next cast.  Scheduling only: any order gives the same picture.
+// The dispatch order of the next cast's first kernel (TailQueue::order), from the marks this cast's waves left: heavy[range][tile
+// slot] = some wave made a pass there, and behind those n_ranges * n_tiles bytes the same for long waves.  Workgroup i of a launch
+// runs on XCD i % 8, so each XCD orders its own tile slots (8 j + xcd) and they stay on it.  Per tile the ranges become entries: one
+// per range that saw a pass, one per RUN of consecutive ranges that saw none (free space: one workgroup marches the run).  Per XCD
+// the entries with a long wave come first, then those with passes, then the runs of free space; what is left of the XCD's slots is
+// empty.  One wave per XCD; the marks are cleared for the next cast.  Scheduling only: any order and any cut give the same picture.
 struct OrderJob {
     uint8_t *heavy;
     uint32_t *order;
     uint32_t n_tiles, n_ranges, range_order;   // n_ranges == 0: nothing to do
 };
 constexpr uint32_t kOrderWorkgroups = 2;   // workgroups of 4 waves appended to the tail kernel's launch for the 8 XCDs
+constexpr uint32_t kOrderMaxRanges = 16;   // (a range index in 8 bits of an entry, a mask of ranges in 32 bits: more ranges, no learnt order)
 __device__ inline void order_ray_tiles(uint32_t xcd, const OrderJob &job) {
     if (xcd >= 8u || job.n_ranges == 0u) return;
-    const uint32_t lane = threadIdx.x & 63u, n_tiles = job.n_tiles, per_xcd = n_tiles / 8;
-    uint32_t next = 0;   // slots of this XCD filled so far: slot i is workgroup 8 (i % per_xcd) + xcd of range slab i / per_xcd
-    for (int pass = 0; pass < 2; pass++)
-        for (uint32_t z = 0; z < job.n_ranges; z++) {
-            const uint32_t range = ray_range_of_slot(z, job.n_ranges, job.range_order);
-            const uint8_t *h = job.heavy + (size_t)range * n_tiles;
-            for (uint32_t j0 = 0; j0 < per_xcd; j0 += 64) {
-                const uint32_t j = j0 + lane;
-                const bool mine = j < per_xcd && (h[8 * j + xcd] != 0) == (pass == 0);
-                const unsigned long long m = __ballot(mine);
-                if (mine) {
-                    const uint32_t slot = next + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                    job.order[(size_t)(slot / per_xcd) * n_tiles + 8 * (slot % per_xcd) + xcd] = (range << 16) | (8 * j + xcd);
+    const uint32_t lane = threadIdx.x & 63u, n_tiles = job.n_tiles, n = job.n_ranges, per_xcd = n_tiles / 8;
+    const bool descending = job.range_order != 0u;   // the far ranges first within a class, as the launch dispatches them
+    const uint8_t *any_ = job.heavy, *long_ = job.heavy + (size_t)n * n_tiles;
+    uint32_t next = 0;   // slots of this XCD filled so far: slot i is workgroup 8 (i % per_xcd) + xcd of slab i / per_xcd of the launch
+    auto slot_address = [&](uint32_t i) { return (size_t)(i / per_xcd) * n_tiles + 8u * (i % per_xcd) + xcd; };
+    for (int cls = 2; cls >= 0; cls--)
+        for (uint32_t j0 = 0; j0 < per_xcd; j0 += 64) {
+            const uint32_t j = j0 + lane, tile = 8u * j + xcd;
+            uint32_t any_m = 0, long_m = 0;
+            if (j < per_xcd)
+                for (uint32_t r = 0; r < n; r++) {
+                    any_m |= (any_[(size_t)r * n_tiles + tile] ? 1u : 0u) << r;
+                    long_m |= (long_[(size_t)r * n_tiles + tile] ? 1u : 0u) << r;
                 }
-                next += (uint32_t)__popcll(m);
+            // this tile's entries of the class, in dispatch order: twice the same walk, first to count, then to write
+            auto walk = [&](uint32_t at, bool write) {
+                uint32_t count = 0;
+                if (j < per_xcd)
+                    for (uint32_t i = 0; i < n;) {
+                        const uint32_t r = descending ? n - 1u - i : i;
+                        const int c = ((long_m >> r) & 1u) ? 2 : ((any_m >> r) & 1u) ? 1 : 0;
+                        uint32_t len = 1;
+                        if (c == 0)   // the run of free space that starts here
+                            while (i + len < n && !((any_m >> (descending ? n - 1u - (i + len) : i + len)) & 1u)) len++;
+                        if (c == cls) {
+                            const uint32_t lo = descending ? r + 1u - len : r, hi = lo + len;
+                            if (write) job.order[slot_address(at + count)] = (hi << 24) | (lo << 16) | tile;
+                            count++;
+                        }
+                        i += len;
+                    }
+                return count;
+            };
+            const uint32_t mine = walk(0, false);
+            uint32_t incl = mine;   // inclusive prefix sum over the wave
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t up = __shfl_up(incl, o);
+                if ((int)lane >= o) incl += up;
             }
+            (void)walk(next + incl - mine, true);
+            next += __shfl(incl, 63);
         }
-    for (uint32_t z = 0; z < job.n_ranges; z++) {
-        const uint32_t range = ray_range_of_slot(z, job.n_ranges, job.range_order);
-        for (uint32_t j = lane; j < per_xcd; j += 64) job.heavy[(size_t)range * n_tiles + 8 * j + xcd] = 0;
-        if (xcd == 0)   // the n_tiles % 8 workgroups past the last full round of a slab keep their place
+    for (uint32_t i = next + lane; i < n * per_xcd; i += 64) job.order[slot_address(i)] = kNoSlot;
+    for (uint32_t r = 0; r < n; r++) {
+        for (uint32_t j = lane; j < per_xcd; j += 64) {
+            job.heavy[(size_t)r * n_tiles + 8 * j + xcd] = 0;
+            job.heavy[(size_t)(n + r) * n_tiles + 8 * j + xcd] = 0;
+        }
+        if (xcd == 0)   // the n_tiles % 8 workgroups past the last full round of a slab keep their place and their one range
             for (uint32_t i = per_xcd * 8 + lane; i < n_tiles; i += 64) {
-                job.order[(size_t)z * n_tiles + i] = (range << 16) | i;
-                job.heavy[(size_t)range * n_tiles + i] = 0;
+                const uint32_t range = ray_range_of_slot(r, n, job.range_order);
+                job.order[(size_t)r * n_tiles + i] = ((range + 1u) << 24) | (range << 16) | i;
+                job.heavy[(size_t)r * n_tiles + i] = 0;
+                job.heavy[(size_t)(n + r) * n_tiles + i] = 0;
             }
     }
 }
@@ -1074,13 +1119,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                                                                const OccGrid occ, const float *__restrict__ t_table,
                                                                const TailQueue tail, const OrderJob order_job) {
     __shared__ float T[kTableLen];
-    if (blockIdx.x >= gridDim.x - kOrderWorkgroups) {   // the last workgroups: the next cast's dispatch order, one wave per XCD (beside the march)
-        if (order_job.n_ranges) order_ray_tiles((blockIdx.x - (gridDim.x - kOrderWorkgroups)) * 4u + (threadIdx.x >> 6), order_job);
+    if (blockIdx.x < kOrderWorkgroups) {   // the first workgroups: the next cast's dispatch order, one wave per XCD (beside the march, from its start)
+        if (order_job.n_ranges) order_ray_tiles(blockIdx.x * 4u + (threadIdx.x >> 6), order_job);
         return;
     }
+    const uint32_t block = blockIdx.x - kOrderWorkgroups;
     const uint32_t n_entries = tail.count[0];
     const uint32_t lanes_per_ray = LANES ? (uint32_t)LANES : tail.lanes;
-    if ((size_t)blockIdx.x * 4u * (64u / lanes_per_ray) >= n_entries) return;   // nothing for this workgroup: skip the staging too
+    if ((size_t)block * 4u * (64u / lanes_per_ray) >= n_entries) return;   // nothing for this workgroup: skip the staging too
     for (int i = (int)threadIdx.x; i < kTableLen; i += 256) T[i] = t_table[i];
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
@@ -1091,7 +1137,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     // A wave takes as many consecutive queue entries as it has groups (pieces of one ray, or of rays of one tile and one
     // sample range: alike in length), works on them until all are finished, then takes the next batch: waves round robin.
     const uint32_t groups_per_wave = 64 / lanes_per_ray;
-    const uint32_t n_waves = (gridDim.x - kOrderWorkgroups) * 4, wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t n_waves = (gridDim.x - kOrderWorkgroups) * 4, wave_id = block * 4 + (threadIdx.x >> 6);
     const unsigned long long dbg_t0 = tail.wave_log ? wall_clock64() : 0ull;
     uint32_t dbg_batches = 0, dbg_rounds = 0;
     for (uint32_t batch = wave_id * groups_per_wave; batch < n_entries; batch += n_waves * groups_per_wave) {
@@ -1493,23 +1539,24 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
     static const bool learn_order = [] { const char *e = getenv("TSDF_RAY_LEARNED_ORDER"); return !e || atoi(e) != 0; }();
     const uint32_t n_tiles = ((rp.width + 15) / 16) * ((rp.height + 15) / 16);
     OrderJob order_job = {nullptr, nullptr, 0, 0, 0};
-    if (learn_order && n_tiles <= 65535u) {
+    if (learn_order && n_tiles <= 65535u && (uint32_t)n_segments <= kOrderMaxRanges) {
         if (!v->ray_heavy || v->ray_order_tiles != n_tiles || v->ray_order_ranges != (uint32_t)n_segments) {
             if (v->ray_heavy) (void)hipFree(v->ray_heavy);
             if (v->ray_order) (void)hipFree(v->ray_order);
             v->ray_heavy = nullptr;
             v->ray_order = nullptr;
             v->ray_order_valid = 0;
-            TSDF_HIP(hipMalloc((void **)&v->ray_heavy, (size_t)n_tiles * n_segments), "ray order alloc");
+            TSDF_HIP(hipMalloc((void **)&v->ray_heavy, (size_t)2 * n_tiles * n_segments), "ray order alloc");
             TSDF_HIP(hipMalloc((void **)&v->ray_order, (size_t)n_tiles * n_segments * sizeof(uint32_t)), "ray order alloc");
-            TSDF_HIP(hipMemsetAsync(v->ray_heavy, 0, (size_t)n_tiles * n_segments, v->stream), "ray order reset");
+            TSDF_HIP(hipMemsetAsync(v->ray_heavy, 0, (size_t)2 * n_tiles * n_segments, v->stream), "ray order reset");
             v->ray_order_tiles = n_tiles;
             v->ray_order_ranges = (uint32_t)n_segments;
         }
+        // "long": three quarters of the pass budget or more.  (With the runs of free space merged and three classes -- long, some pass, none --
+        // any threshold from 14 to 22 of 22 passes gives the same launch, 62-63 us; 12 and below 69-74 us: the waves of a few passes are
+        // many, and listed first they push the long ones back.)
+        { static const int hp = [] { const char *e = getenv("TSDF_RAY_HEAVY_PASSES"); return e ? atoi(e) : 0; }(); tail.heavy_passes = hp > 0 ? (uint32_t)hp : std::max(1u, tail.trip_budget * 3u / 4u); }   // tuning aid
         tail.heavy = v->ray_heavy;
-        // "long": half the pass budget or more (only the waves that used ALL of it: no gain -- the waves just under the budget are as long; a
-        // quarter, a twelfth: 1-2 us worse than half)
-        { static const int hp = [] { const char *e = getenv("TSDF_RAY_HEAVY_PASSES"); return e ? atoi(e) : 0; }(); tail.heavy_passes = hp > 0 ? (uint32_t)hp : std::max(1u, tail.trip_budget / 2u); }   // tuning aid
         tail.order = v->ray_order_valid ? v->ray_order : nullptr;
         order_job = {v->ray_heavy, v->ray_order, n_tiles, (uint32_t)n_segments, 0};
     }
@@ -1525,7 +1572,7 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
         (void)hipMalloc((void **)&wave_log, 3 * n_waves_log * sizeof(unsigned long long));
         (void)hipMemset(wave_log, 0, 3 * n_waves_log * sizeof(unsigned long long));
     }
-    const size_t table_lds = ray_table_lds_bytes(rp, SLAB && rp.slab_ranges > 0);
+    const size_t table_lds = ray_table_lds_bytes(rp, (SLAB && rp.slab_ranges > 0) || tail.order != nullptr);   // (a merged workgroup may read any part of the table)
     if (v->fast_div)
         TSDF_LAUNCH_TIMED_LDS(v, 1, (process_ray_kernel<SLAB, false, true, true, true, true>), grid, dim3(256), table_lds, v->dist, v->g, rp,
                               (float *)nullptr, wave_log, (unsigned int *)nullptr, v->occ, v->t_table, tail);
