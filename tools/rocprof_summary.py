@@ -47,6 +47,23 @@ def pmc_text(db):
     return "\n".join(out)
 
 
+def timeline(db, first=0, count=60):
+    """Kernels in start order with the gap since the previous kernel's end and the overlap with it (ns): where a step's time
+    goes between its launches.  python tools/rocprof_summary.py timeline run.db [first] [count]"""
+    cur = sqlite3.connect(db).cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)").fetchall()]
+    q = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else "0")
+    rows = cur.execute("select name, start, end, %s from kernels order by start" % q).fetchall()
+    out = ["%-58s %6s %12s %10s %10s" % ("kernel", "queue", "start_us", "dur_us", "gap_us")]
+    t0 = rows[0][1] if rows else 0
+    prev_end = None
+    for name, st, en, qid in rows[first:first + count]:
+        gap = (st - prev_end) / 1e3 if prev_end is not None else 0.0
+        out.append("%-58s %6s %12.1f %10.1f %10.1f" % (short(name)[:58], qid, (st - t0) / 1e3, (en - st) / 1e3, gap))
+        prev_end = max(prev_end or en, en)
+    return "\n".join(out)
+
+
 def launches_of(db, counter):
     """{kernel display name: [(start, value, duration)] in dispatch order} for one counter."""
     cur = sqlite3.connect(db).cursor()
@@ -97,6 +114,8 @@ if __name__ == "__main__":
         print(kernel_stats(sys.argv[2]))
     elif mode == "pmc":
         print(pmc_text(sys.argv[2]))
+    elif mode == "timeline":
+        print(timeline(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 0, int(sys.argv[4]) if len(sys.argv) > 4 else 60))
     elif mode == "traffic":
         # traffic FETCH.db WRITE.db [skip take [key=value ...]]   (key=value pairs go into the JSON: tag, steps, warmup, ...)
         skip = int(sys.argv[4]) if len(sys.argv) > 4 else 0
