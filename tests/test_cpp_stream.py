@@ -94,3 +94,43 @@ def test_kinfu_stream_matches_the_oracle_and_the_python_mirror(tmp_path, oracle,
     assert_same_floats(vol.get_distance_data(), ov.dist, "Python mirror: distances vs oracle")
     pipe.close()
     vol.close()
+
+
+@pytest.mark.gpu
+def test_kinfu_stream_tracks_like_the_python_mirror(tmp_path):
+    """kinfu_stream --track: BASELINE configs[4]'s loop from C++ (tsdf_tracker_filter / _align / _integrate + the Camera class) on a TUM
+    directory.  The same entry points through the Python mirror (tsdf_amd.tracking.FrameToModelTracker) on the same frames: the same
+    volume bit for bit when the poses agree bit for bit; the poses agree to the rounding of the one 4 x 4 double product per frame that the two hosts
+    form in different orders (numpy's matmul, a plain loop) -- compared to 1e-4 mm / 1e-7 -- and follow the ground truth."""
+    import torch
+    from tsdf_amd.tracking import FrameToModelTracker
+    n, F = 128, 8
+    d = tmp_path / "tum"
+    synth.write_tum_directory(str(d), F, seed=0x5EED0005, stream_frames=200)
+    out = tmp_path / "out"
+    out.mkdir()
+    r = subprocess.run([BIN, "-d", str(d), "-n", str(n), "-k", str(F), "--track", "--dump", str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["frames"] == F and line["ms_per_frame"] > 0 and line["last_icp_inliers"] > 0.3 * W * H
+    assert line["last_pose_translation_error_mm"] < 25.0          # voxels are 23 mm here, depth noise +-3 mm
+    poses = np.fromfile(str(out / "poses.f32"), np.float32).reshape(F, 4, 4).transpose(0, 2, 1)     # column-major -> usual notation
+
+    frames, _ = tsdf_amd.load_tum_directory(str(d))
+    vol = tsdf_amd.TSDFVolume((n, n, n), (3000.0,) * 3)
+    tracker = FrameToModelTracker(vol, W, H)
+    dev = [torch.from_numpy(f.view(np.int16).copy()).cuda() for f, _ in frames]
+    torch.cuda.synchronize()
+    mine = []
+    for i, (_, cam) in enumerate(frames):
+        truth = cam.pose().astype(np.float64).reshape(4, 4).T
+        mine.append(tracker.process_device(dev[i].data_ptr(), initial_pose=truth if i == 0 else None))
+    tracker.synchronize()
+    mine = np.stack(mine)
+    assert np.array_equal(poses[0].astype(np.float64), mine[0])                     # the first frame: the loader's pose, both sides
+    assert np.abs(poses[:, :3, 3] - mine[:, :3, 3]).max() < 1e-4 * F, np.abs(poses[:, :3, 3] - mine[:, :3, 3]).max()
+    assert np.abs(poses[:, :3, :3] - mine[:, :3, :3]).max() < 1e-6
+    if np.array_equal(poses.astype(np.float64), mine):
+        assert_same_floats(np.fromfile(str(out / "distances.f32"), np.float32), vol.get_distance_data(), "C++ tracked volume vs the Python mirror's")
+    tracker.close()
+    vol.close()

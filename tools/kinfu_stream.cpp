@@ -8,9 +8,14 @@
 // the same entry points from Python: same checksum, same ms per step (tools/compare_drivers.sh).
 //
 //   kinfu_stream -d <tum dir> [-n grid=512] [-p physical_mm=3000] [-k steps=20] [-w warmup=5] [--no-overlap]
-//                [--no-cull-ahead] [--dump <dir>]
+//                [--no-cull-ahead] [--dump <dir>] [--track]
+//   --track: BASELINE configs[4]'s loop instead -- the first frame at its ground-truth pose, every later one tracked against the model
+//           (tsdf_tracker_filter / _align / _integrate: what src/Tools/tsdf_icp.cpp:115-198 does for one frame, composed with kinfu's
+//           integrate; the pose is composed here with the Camera class); the first -k frames of the directory, one JSON line with the
+//           time per frame and the distance of the last pose from its ground truth; --dump writes the tracked poses (poses.f32)
 //   --dump: the last picture (vertices.f32, normals.f32), the final volume (distances.f32, weights.f32) and every frame's
 //           pose (poses.f32, 16 floats each, column-major) as raw files, for tests/test_cpp_stream.py
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -58,7 +63,7 @@ int main(int argc, char **argv) {
     unsigned n = 512;
     float physical = 3000.0f;
     int K = 20, Wu = 5;
-    bool overlap = true, cull_ahead = true;
+    bool overlap = true, cull_ahead = true, track = false;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto value = [&]() -> const char * {
@@ -76,8 +81,9 @@ int main(int argc, char **argv) {
         else if (a == "--no-overlap") overlap = false;
         else if (a == "--no-cull-ahead") cull_ahead = false;
         else if (a == "--dump") dump_dir = value();
+        else if (a == "--track") track = true;
         else {
-            std::fprintf(stderr, "usage: kinfu_stream -d <tum dir> [-n grid] [-p physical_mm] [-k steps] [-w warmup] [--no-overlap] [--no-cull-ahead] [--dump dir]\n");
+            std::fprintf(stderr, "usage: kinfu_stream -d <tum dir> [-n grid] [-p physical_mm] [-k steps] [-w warmup] [--no-overlap] [--no-cull-ahead] [--dump dir] [--track]\n");
             return 2;
         }
     }
@@ -89,6 +95,7 @@ int main(int argc, char **argv) {
     // ---- the stream: every frame of the directory, in millimetres, with its ground-truth pose (kinfu.cpp:32-51) ----------
     std::vector<std::vector<uint16_t>> frames;
     std::vector<tsdf_camera_matrices> cams;
+    std::vector<Eigen::Matrix4f> truth;
     uint32_t W = 0, H = 0;
     try {
         TUMDataLoader loader(dir);
@@ -105,6 +112,7 @@ int main(int argc, char **argv) {
             frames.emplace_back(image->data(), image->data() + (size_t)W * H);
             camera->set_pose(pose);
             cams.push_back(matrices_of(*camera));
+            truth.push_back(pose);
         }
     } catch (const std::exception &e) {
         std::fprintf(stderr, "kinfu_stream: %s\n", e.what());
@@ -128,6 +136,70 @@ int main(int argc, char **argv) {
     tsdf_pipeline *pipe = nullptr;
     ok(tsdf_volume_create(n, n, n, physical, physical, physical, &vol), "volume");
     ok(tsdf_bilateral_create(30.0f, 4.5f, &bil), "bilateral filter");
+
+    if (track) {
+        // ---- the tracked loop: pose[i] = pose[i-1] * T, T from ICP of the filtered frame against the model rendered from pose[i-1] ----
+        std::unique_ptr<Camera> camera(Camera::default_depth_camera());
+        const Eigen::Matrix3f k = camera->k();
+        tsdf_icp *icp = nullptr;
+        tsdf_tracker *trk = nullptr;
+        ok(tsdf_icp_create((int)W, (int)H, k(0, 2), k(1, 2), k(0, 0), k(1, 1), 0.10f, sinf(20.f * 3.14159254f / 180.f), &icp), "ICP");   // ICPOdometry.h:27
+        ok(tsdf_tracker_create(vol, bil, icp, W, H, 20.0f, overlap ? TSDF_PIPELINE_OVERLAP : 0, &trk), "tracker");
+        const size_t n_track = std::min(F, (size_t)K);
+        std::vector<float> tracked;
+        float error = 0.f, inliers = 0.f;
+        camera->set_pose(truth[0]);
+        std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        const size_t first_timed = n_track > 4 ? 4 : 1;     // (the first frames also allocate scratch and build the ray caster's flags)
+        for (size_t i = 0; i < n_track; i++) {
+            if (i == first_timed) {
+                ok(tsdf_tracker_synchronize(trk), "synchronize");
+                t0 = std::chrono::steady_clock::now();
+            }
+            ok(tsdf_tracker_filter(trk, depth_dev + i * n_pix), "filter");
+            if (i > 0) {
+                const tsdf_camera_matrices prev = matrices_of(*camera);
+                double T[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};     // column-major; current camera -> previous camera, metres
+                ok(tsdf_tracker_align(trk, &prev, T, &error, &inliers), "align");
+                // pose <- pose * T with T's translation in millimetres, in double, narrowed once (as tsdf_amd/tracking.py does)
+                Eigen::Matrix4f next;
+                const Eigen::Matrix4f pose = camera->pose();
+                for (int r = 0; r < 4; r++)
+                    for (int c = 0; c < 4; c++) {
+                        double s = 0.0;
+                        for (int j = 0; j < 4; j++) s += (double)pose(r, j) * (T[c * 4 + j] * ((c == 3 && j < 3) ? 1000.0 : 1.0));
+                        next(r, c) = (float)s;
+                    }
+                camera->set_pose(next);
+            }
+            const tsdf_camera_matrices now = matrices_of(*camera);
+            ok(tsdf_tracker_integrate(trk, &now), "integrate");
+            tracked.insert(tracked.end(), now.pose, now.pose + 16);
+        }
+        ok(tsdf_tracker_synchronize(trk), "synchronize");
+        const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        const Eigen::Matrix4f last = camera->pose(), want = truth[n_track - 1];
+        double dt2 = 0.0;
+        for (int r = 0; r < 3; r++) dt2 += ((double)last(r, 3) - want(r, 3)) * ((double)last(r, 3) - want(r, 3));
+        std::printf("{\"driver\": \"tools/kinfu_stream.cpp --track (C++, tsdf_tracker_*)\", \"grid\": %u, \"image\": [%u, %u], \"frames\": %zu, \"overlap\": %s, "
+                    "\"ms_per_frame\": %.4f, \"last_pose_translation_error_mm\": %.4f, \"last_icp_inliers\": %.0f, \"last_icp_error\": %.6g}\n",
+                    n, W, H, n_track, overlap ? "true" : "false", n_track > first_timed ? elapsed * 1e3 / (double)(n_track - first_timed) : 0.0, std::sqrt(dt2),
+                    inliers, error);
+        if (!dump_dir.empty()) {
+            dump(dump_dir + "/poses.f32", tracked.data(), tracked.size() * sizeof(float));
+            std::vector<float> a((size_t)n * n * n);
+            ok(tsdf_volume_get_distance_data(vol, a.data()), "distances");
+            dump(dump_dir + "/distances.f32", a.data(), a.size() * sizeof(float));
+        }
+        ok(tsdf_tracker_destroy(trk), "tracker");
+        tsdf_icp_destroy(icp);
+        ok(tsdf_bilateral_destroy(bil), "bilateral filter");
+        ok(tsdf_volume_destroy(vol), "volume");
+        (void)tsdf_device_free(depth_dev);
+        (void)tsdf_device_free(vert_dev);
+        (void)tsdf_device_free(norm_dev);
+        return 0;
+    }
     ok(tsdf_pipeline_create(vol, bil, W, H, overlap ? TSDF_PIPELINE_OVERLAP : 0, nullptr, &pipe), "pipeline");
 
     auto step = [&](int i) {
