@@ -212,6 +212,11 @@ int tsdf_normals_device(uint32_t width, uint32_t height, const float *device_ver
  * cast missed (NaN) and depths outside 1..65535 give 0 (the reference's conversion of NaN is undefined). */
 int tsdf_vertices_to_depth_device(uint32_t width, uint32_t height, const float *device_vertices,
                                   const float inv_pose[16], uint16_t *device_depth, void *hip_stream);
+/* GPURaycaster::render_to_depth_image (src/RayCaster/GPURaycaster.cu:554-589) in one call on device buffers: the ray cast with the
+ * depth formed from every hit as above, without a vertex map in between (device_vertices may be NULL; when given it is filled
+ * as tsdf_raycast_device fills it).  Asynchronous on the volume's stream. */
+int tsdf_raycast_depth_device(const tsdf_volume *volume, uint32_t width, uint32_t height, const float pose[16],
+                              const float inv_pose[16], const float kinv[9], uint16_t *device_depth, float *device_vertices);
 /* Diagnostics for the roofline model: S = trilinear samples evaluated, T = distinct voxels
  * touched by any tap, of one raycast with these arguments (runs an instrumented kernel). */
 int tsdf_raycast_stats(const tsdf_volume *volume, uint32_t width, uint32_t height, const float pose[16],

@@ -41,6 +41,17 @@ def test_vertices_to_depth_matches_the_class_surface(oracle):
         exp = np.where(np.isfinite(r) & (r > 0) & (r < 65536), r, 0).astype(np.uint16)
     assert np.array_equal(got, exp)
     assert (got > 0).mean() > 0.5
+    # ... and the one-call variant (tsdf_raycast_depth_device: the depth formed in the resolve kernel, no vertex map in between)
+    rc = tsdf_amd.GPURaycaster(W, H)
+    direct = torch.empty((W * H,), dtype=torch.int16, device="cuda")
+    verts = torch.empty((W * H, 3), dtype=torch.float32, device="cuda")
+    for vp in (None, verts.data_ptr()):
+        direct.zero_()
+        rc.render_to_depth_device(vol, cam, direct.data_ptr(), vp)
+        vol.synchronize()
+        assert np.array_equal(direct.cpu().numpy().view(np.uint16), exp)
+    same = (verts.cpu().numpy().view(np.uint32) == V.view(np.uint32)) | (np.isnan(verts.cpu().numpy()) & np.isnan(V))
+    assert same.all()
 
 
 def test_tracking_follows_the_synthetic_trajectory():

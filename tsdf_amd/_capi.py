@@ -105,6 +105,7 @@ _SIGS = {
     "tsdf_volume_get_occupancy_data": (_i, [_vp, C.c_int, _vp, _vp, _vp]),
     "tsdf_raycast_slab_device": (_i, [_vp, _u32, _u32, _fp, _fp, _vp]),
     "tsdf_vertices_to_depth_device": (_i, [_u32, _u32, _vp, _vp, _vp, _vp]),
+    "tsdf_raycast_depth_device": (_i, [_vp, _u32, _u32, _fp, _fp, _fp, _vp, _vp]),
     "tsdf_volume_marching_cubes": (_i, [_vp, _vp, _vp, _vp, C.c_uint64]),
     "tsdf_merge_hits_device": (_i, [_vp, _vp, _u32, _u32, _u32, _fp, _fp, _vp, _vp]),
     "tsdf_merge_hits_normals_device": (_i, [_vp, _vp, _u32, _u32, _u32, _fp, _fp, _vp, _vp, _vp]),

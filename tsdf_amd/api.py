@@ -272,6 +272,12 @@ class GPURaycaster:
                                       C.c_void_p(int(vertices_ptr)),
                                       C.c_void_p(int(normals_ptr)) if normals_ptr else None))
 
+    def render_to_depth_device(self, volume, camera, depth_ptr, vertices_ptr=None):
+        """GPURaycaster::render_to_depth_image on device buffers: uint16 mm per pixel (0 = no hit), the vertex map too when asked for."""
+        pose, ipose, _, kinv = _camera_matrices(camera)
+        check(lib.tsdf_raycast_depth_device(volume._h, self.m_width, self.m_height, _fp(pose), _fp(ipose), _fp(kinv),
+                                            C.c_void_p(int(depth_ptr)), C.c_void_p(int(vertices_ptr)) if vertices_ptr else None))
+
     def raycast_slab_device(self, volume, camera, hits_ptr):
         pose, _, _, kinv = _camera_matrices(camera)
         check(lib.tsdf_raycast_slab_device(volume._h, self.m_width, self.m_height, _fp(pose), _fp(kinv),

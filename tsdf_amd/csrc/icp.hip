@@ -27,6 +27,7 @@ struct tsdf_icp {
     int device;
     hipStream_t stream;
     uint16_t *depth[3];                      // pyramid scratch (used by both init calls)
+    uint16_t *upload;                        // the host variants' image on the device
     float *vmap_prev[3], *nmap_prev[3];      // model
     float *vmap_curr[3], *nmap_curr[3];      // current frame
     float *partial;                          // 2 x kIcpBlocks x 32 floats: per-block sums of the 29 products (two steps)
@@ -69,37 +70,52 @@ __global__ __launch_bounds__(256) void icp_pyr_down_kernel(const uint16_t *__res
     dst[(size_t)y * cols + x] = (uint16_t)(int)(sum / wall);
 }
 
-// computeVmapKernel (Cuda/pyrdown.cu:93-117)
-__global__ __launch_bounds__(256) void icp_vmap_kernel(const uint16_t *__restrict__ depth, int rows, int cols, float fx_inv,
-                                                       float fy_inv, float cx, float cy, float depth_cutoff,
-                                                       float *__restrict__ vmap) {
+// computeVmapKernel (Cuda/pyrdown.cu:93-117) + computeNmapKernel (:135-172; Eigen's normalized(): n / sqrt(n.n) when n.n > 0) for all
+// pyramid levels in ONE launch (blockIdx.z = level): a thread forms its own vertex and the two neighbours' its normal needs from the depth
+// images with the same expressions -- the bits the reference's two kernels exchange through the vertex map -- so initICP is the pyramid (two launches) + this instead of a copy and nine launches
+// (on the tracked loop's critical path for the model image: 18 us of launch chain).  Level 0 reads the caller's image and leaves
+// the copy the pyramid scratch used to get from a memcpy.
+struct IcpLevelMaps {
+    const uint16_t *depth[3];
+    float *vmap[3], *nmap[3];
+    uint16_t *depth0_copy;
+    int rows0, cols0;
+    float fx, fy, cx, cy, depth_cutoff;
+};
+__device__ inline bool icp_vertex(const uint16_t *__restrict__ depth, int cols, int u, int v, float fx_inv, float fy_inv, float cx, float cy,
+                                  float depth_cutoff, float &x, float &y, float &z) {
+    z = depth[(size_t)v * cols + u] / 1000.f;  // mm -> metres
+    if (!(z != 0 && z < depth_cutoff)) return false;
+    x = z * (u - cx) * fx_inv;
+    y = z * (v - cy) * fy_inv;
+    return true;
+}
+__global__ __launch_bounds__(256) void icp_maps_kernel(const IcpLevelMaps m) {
+    const int level = blockIdx.z, rows = m.rows0 >> level, cols = m.cols0 >> level, div = 1 << level;
     const int u = blockIdx.x * 64 + (threadIdx.x & 63), v = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (u >= cols || v >= rows) return;
-    const float z = depth[(size_t)v * cols + u] / 1000.f;  // mm -> metres
-    if (z != 0 && z < depth_cutoff) {
-        vmap[(size_t)v * cols + u] = z * (u - cx) * fx_inv;
-        vmap[(size_t)(v + rows) * cols + u] = z * (v - cy) * fy_inv;
-        vmap[(size_t)(v + rows * 2) * cols + u] = z;
+    // Intr::operator()(level): every intrinsic divided by 2^level (Cuda/internal.h:63-67); 1.f / fx: createVMap (:131)
+    const float fx_inv = 1.f / (m.fx / div), fy_inv = 1.f / (m.fy / div), cx = m.cx / div, cy = m.cy / div;
+    const uint16_t *depth = m.depth[level];
+    float *vmap = m.vmap[level], *nmap = m.nmap[level];
+    if (level == 0) m.depth0_copy[(size_t)v * cols + u] = depth[(size_t)v * cols + u];
+    float a0, a1, a2;
+    const bool a_ok = icp_vertex(depth, cols, u, v, fx_inv, fy_inv, cx, cy, m.depth_cutoff, a0, a1, a2);
+    if (a_ok) {
+        vmap[(size_t)v * cols + u] = a0;
+        vmap[(size_t)(v + rows) * cols + u] = a1;
+        vmap[(size_t)(v + rows * 2) * cols + u] = a2;
     } else {
         vmap[(size_t)v * cols + u] = nan_sentinel();
     }
-}
-
-// computeNmapKernel (Cuda/pyrdown.cu:135-172); Eigen's normalized(): n / sqrt(n.n) when n.n > 0
-__global__ __launch_bounds__(256) void icp_nmap_kernel(int rows, int cols, const float *__restrict__ vmap,
-                                                       float *__restrict__ nmap) {
-    const int u = blockIdx.x * 64 + (threadIdx.x & 63), v = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (u >= cols || v >= rows) return;
     if (u == cols - 1 || v == rows - 1) {
         nmap[(size_t)v * cols + u] = nan_sentinel();
         return;
     }
-    const float a0 = vmap[(size_t)v * cols + u], b0 = vmap[(size_t)v * cols + u + 1], c0 = vmap[(size_t)(v + 1) * cols + u];
-    if (!(a0 != a0) && !(b0 != b0) && !(c0 != c0)) {
-        const float a1 = vmap[(size_t)(v + rows) * cols + u], b1 = vmap[(size_t)(v + rows) * cols + u + 1],
-                    c1 = vmap[(size_t)(v + 1 + rows) * cols + u];
-        const float a2 = vmap[(size_t)(v + 2 * rows) * cols + u], b2 = vmap[(size_t)(v + 2 * rows) * cols + u + 1],
-                    c2 = vmap[(size_t)(v + 1 + 2 * rows) * cols + u];
+    float b0, b1, b2, c0, c1, c2;
+    const bool b_ok = icp_vertex(depth, cols, u + 1, v, fx_inv, fy_inv, cx, cy, m.depth_cutoff, b0, b1, b2);
+    const bool c_ok = icp_vertex(depth, cols, u, v + 1, fx_inv, fy_inv, cx, cy, m.depth_cutoff, c0, c1, c2);
+    if (a_ok && b_ok && c_ok) {
         const float px = b0 - a0, py = b1 - a1, pz = b2 - a2;
         const float qx = c0 - a0, qy = c1 - a1, qz = c2 - a2;
         float rx = py * qz - pz * qy, ry = pz * qx - px * qz, rz = px * qy - py * qx;
@@ -473,27 +489,34 @@ static void free_icp(tsdf_icp *f) {
         if (f->vmap_curr[i]) (void)hipFree(f->vmap_curr[i]);
         if (f->nmap_curr[i]) (void)hipFree(f->nmap_curr[i]);
     }
+    if (f->upload) (void)hipFree(f->upload);
     if (f->partial) (void)hipFree(f->partial);
     if (f->state) (void)hipFree(f->state);
     delete f;
 }
 
-// pyramid + vertex / normal maps of one depth image that is already in f->depth[0]
-static int build_maps(tsdf_icp *f, float **vmaps, float **nmaps, float depth_cutoff) {
+// pyramid + vertex / normal maps of one depth image (device pointer; f->depth[0] gets a copy as a by-product of the maps launch)
+static int build_maps(tsdf_icp *f, const uint16_t *depth0, float **vmaps, float **nmaps, float depth_cutoff) {
     for (int i = 1; i < kIcpLevels; i++) {
         const int src_rows = f->height >> (i - 1), src_cols = f->width >> (i - 1);
         dim3 grid((src_cols / 2 + 63) / 64, (src_rows / 2 + 3) / 4);
-        hipLaunchKernelGGL(icp_pyr_down_kernel, grid, dim3(256), 0, f->stream, f->depth[i - 1], src_rows, src_cols, f->depth[i]);
+        hipLaunchKernelGGL(icp_pyr_down_kernel, grid, dim3(256), 0, f->stream, i == 1 ? depth0 : (const uint16_t *)f->depth[i - 1], src_rows, src_cols,
+                           f->depth[i]);
     }
+    static_assert(kIcpLevels == 3, "icp_maps_kernel carries three levels");
+    IcpLevelMaps m;
+    m.depth[0] = depth0;
+    for (int i = 1; i < kIcpLevels; i++) m.depth[i] = f->depth[i];
     for (int i = 0; i < kIcpLevels; i++) {
-        const int rows = f->height >> i, cols = f->width >> i, div = 1 << i;
-        // Intr::operator()(level): every intrinsic divided by 2^level (Cuda/internal.h:63-67); 1.f / fx: createVMap (:131)
-        const float fx = f->fx / div, fy = f->fy / div, cx = f->cx / div, cy = f->cy / div;
-        dim3 grid((cols + 63) / 64, (rows + 3) / 4);
-        hipLaunchKernelGGL(icp_vmap_kernel, grid, dim3(256), 0, f->stream, f->depth[i], rows, cols, 1.f / fx, 1.f / fy, cx, cy,
-                           depth_cutoff, vmaps[i]);
-        hipLaunchKernelGGL(icp_nmap_kernel, grid, dim3(256), 0, f->stream, rows, cols, vmaps[i], nmaps[i]);
+        m.vmap[i] = vmaps[i];
+        m.nmap[i] = nmaps[i];
     }
+    m.depth0_copy = f->depth[0];
+    m.rows0 = f->height;
+    m.cols0 = f->width;
+    m.fx = f->fx; m.fy = f->fy; m.cx = f->cx; m.cy = f->cy;
+    m.depth_cutoff = depth_cutoff;
+    hipLaunchKernelGGL(icp_maps_kernel, dim3((f->width + 63) / 64, (f->height + 3) / 4, kIcpLevels), dim3(256), 0, f->stream, m);
     TSDF_HIP(hipGetLastError(), "ICP map kernels failed");
     return TSDF_OK;
 }
@@ -568,16 +591,16 @@ int tsdf_icp_set_stream(tsdf_icp *f, void *hip_stream) {
 
 int tsdf_icp_init_device(tsdf_icp *f, int model, const uint16_t *device_depth, float depth_cutoff) {
     TSDF_REQUIRE(f && device_depth, "tsdf_icp_init: null argument");
-    TSDF_HIP(hipMemcpyAsync(f->depth[0], device_depth, (size_t)f->width * f->height * sizeof(uint16_t), hipMemcpyDeviceToDevice,
-                            f->stream), "ICP depth copy");
-    return model ? build_maps(f, f->vmap_prev, f->nmap_prev, depth_cutoff) : build_maps(f, f->vmap_curr, f->nmap_curr, depth_cutoff);
+    TSDF_REQUIRE(device_depth != f->depth[0], "tsdf_icp_init: the image must not be the pyramid's own level 0");
+    return model ? build_maps(f, device_depth, f->vmap_prev, f->nmap_prev, depth_cutoff) : build_maps(f, device_depth, f->vmap_curr, f->nmap_curr, depth_cutoff);
 }
 
 int tsdf_icp_init(tsdf_icp *f, int model, const uint16_t *host_depth, float depth_cutoff) {
     TSDF_REQUIRE(f && host_depth, "tsdf_icp_init: null argument");
-    TSDF_HIP(hipMemcpyAsync(f->depth[0], host_depth, (size_t)f->width * f->height * sizeof(uint16_t), hipMemcpyHostToDevice,
+    if (!f->upload) TSDF_HIP(hipMalloc((void **)&f->upload, (size_t)f->width * f->height * sizeof(uint16_t)), "ICP upload buffer");
+    TSDF_HIP(hipMemcpyAsync(f->upload, host_depth, (size_t)f->width * f->height * sizeof(uint16_t), hipMemcpyHostToDevice,
                             f->stream), "ICP depth upload");
-    int rc = model ? build_maps(f, f->vmap_prev, f->nmap_prev, depth_cutoff) : build_maps(f, f->vmap_curr, f->nmap_curr, depth_cutoff);
+    int rc = model ? build_maps(f, f->upload, f->vmap_prev, f->nmap_prev, depth_cutoff) : build_maps(f, f->upload, f->vmap_curr, f->nmap_curr, depth_cutoff);
     if (rc != TSDF_OK) return rc;
     TSDF_HIP(hipStreamSynchronize(f->stream), "ICP init");  // (the reference synchronises here too)
     return TSDF_OK;

@@ -477,7 +477,6 @@ int tsdf_tracker_create(tsdf_volume *volume, const tsdf_bilateral *filter, tsdf_
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&t->ready, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void **)&t->model, n * sizeof(uint16_t));
-    if (e == hipSuccess) e = hipMalloc((void **)&t->vertices, n * 3 * sizeof(float));
     if (e != hipSuccess) {
         const int rc = hip_fail(e, "tsdf_tracker_create");
         tsdf_tracker_destroy(t);
@@ -543,9 +542,7 @@ int tsdf_tracker_align(tsdf_tracker *t, const tsdf_camera_matrices *previous, do
     TSDF_REQUIRE(t && previous && T_prev_curr, "tsdf_tracker_align: null argument");
     TSDF_REQUIRE(t->have_frame && t->frames > 0, "tsdf_tracker_align: no frame filtered, or nothing integrated to align it to");
     // the model image: the volume rendered from the previous pose (GPURaycaster::render_to_depth_image, src/RayCaster/GPURaycaster.cu:575-579)
-    int rc = tsdf_raycast_device(t->volume, t->width, t->height, previous->pose, previous->kinv, t->vertices, nullptr);
-    if (rc != TSDF_OK) return rc;
-    rc = tsdf_vertices_to_depth_device(t->width, t->height, t->vertices, previous->inv_pose, t->model, t->main);
+    int rc = tsdf_raycast_depth_device(t->volume, t->width, t->height, previous->pose, previous->inv_pose, previous->kinv, t->model, nullptr);
     if (rc != TSDF_OK) return rc;
     rc = tracker_join(t);   // (the model's maps reuse the pyramid scratch of the new frame's)
     if (rc != TSDF_OK) return rc;

@@ -1206,6 +1206,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     }
 }
 
+// render_to_depth_image, per pixel (src/RayCaster/GPURaycaster.cu:575-579 with Camera::world_to_camera, src/Camera.cpp:287-294):
+// camera-space z of the vertex (homogeneous product, divided by w), rounded half away from zero; no hit (NaN) -> 0.
+__device__ inline uint16_t vertex_depth(float x, float y, float z, const Mat44 &ip) {
+    const float cz = ((ip.m31 * x + ip.m32 * y) + ip.m33 * z) + ip.m34 * 1.0f;
+    const float cw = ((ip.m41 * x + ip.m42 * y) + ip.m43 * z) + ip.m44 * 1.0f;
+    const float r = roundf(cz / cw);
+    return (r == r && r > 0.0f && r < 65536.0f) ? (uint16_t)r : (uint16_t)0;
+}
+
 // The vertex of a pixel from best[]: the ray's first sample <= 0 -- its index and the value the march computed for it -- is refined
 // into the hit point as the reference does (process_ray :336-350); no hit -> NaN.
 __device__ inline uint32_t resolve_pixel(uint32_t i, const Geom &g, const RayParams &rp, const float *__restrict__ t_table,
@@ -1228,11 +1237,13 @@ __device__ inline uint32_t resolve_pixel(uint32_t i, const Geom &g, const RayPar
 // one (consumed by the previous march's resolve) for the next march, together with the tail queue's counter -- so a
 // pixel's word may be read by several workgroups (resolve_normals_kernel) without racing against its reset.
 //   SLAB: out = 8-byte records {k, t} (tsdf_hit_record) for the min-k merge across slabs; otherwise packed float3 vertices.
+//   depth != nullptr (whole volume): also, or instead (out == nullptr), the pixel's depth as render_to_depth_image forms it from the vertex
+//   (vertex_depth: src/RayCaster/GPURaycaster.cu:575-579) -- the model image of the tracked loop without a vertex map in between.
 template <bool SLAB>
 __global__ __launch_bounds__(256) void resolve_hits_kernel(const Geom g, const RayParams rp,
                                                            const float *__restrict__ t_table, const uint64_t *__restrict__ best,
                                                            uint64_t *__restrict__ best_next, float *__restrict__ out,
-                                                           uint32_t *__restrict__ reset) {
+                                                           uint32_t *__restrict__ reset, const Mat44 ip, uint16_t *__restrict__ depth) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) *reset = 0;
     if (i >= rp.width * rp.height) return;
@@ -1242,9 +1253,12 @@ __global__ __launch_bounds__(256) void resolve_hits_kernel(const Geom g, const R
     if (SLAB) {
         reinterpret_cast<uint2 *>(out)[i] = make_uint2(kb, __float_as_uint(th));
     } else {
-        out[(size_t)i * 3 + 0] = ix;
-        out[(size_t)i * 3 + 1] = iy;
-        out[(size_t)i * 3 + 2] = iz;
+        if (out) {
+            out[(size_t)i * 3 + 0] = ix;
+            out[(size_t)i * 3 + 1] = iy;
+            out[(size_t)i * 3 + 2] = iz;
+        }
+        if (depth) depth[i] = vertex_depth(ix, iy, iz, ip);
     }
 }
 
@@ -1343,11 +1357,7 @@ __global__ __launch_bounds__(256) void vertices_to_depth_kernel(uint32_t n_pixel
                                                                 uint16_t *__restrict__ depth) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pixels) return;
-    const float x = V[(size_t)i * 3 + 0], y = V[(size_t)i * 3 + 1], z = V[(size_t)i * 3 + 2];
-    const float cz = ((ip.m31 * x + ip.m32 * y) + ip.m33 * z) + ip.m34 * 1.0f;
-    const float cw = ((ip.m41 * x + ip.m42 * y) + ip.m43 * z) + ip.m44 * 1.0f;
-    const float r = roundf(cz / cw);
-    depth[i] = (r == r && r > 0.0f && r < 65536.0f) ? (uint16_t)r : (uint16_t)0;
+    depth[i] = vertex_depth(V[(size_t)i * 3 + 0], V[(size_t)i * 3 + 1], V[(size_t)i * 3 + 2], ip);
 }
 
 // Per pixel, the record {k, t} with the smallest k among n_slabs gathered buffers (layout [slab][pixel]); ties cannot occur: a
@@ -1497,7 +1507,8 @@ static int check_ray_args(const tsdf_volume *v, uint32_t width, uint32_t height,
 // The production march: process_ray_kernel over the sample ranges of every ray with a pass budget, process_ray_tail_kernel
 // for the stretches it handed over, resolve_hits_kernel for the vertices (packed float3, or {k, t} records for a slab).
 template <bool SLAB>
-static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *normals = nullptr) {
+static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *normals = nullptr, const float *depth_inv_pose = nullptr,
+                             uint16_t *depth_out = nullptr) {
     const size_t n_pix = (size_t)rp.width * rp.height;
     const int n_segments = SLAB ? slab_ray_ranges(v) : ray_segments();
     // queue capacity: every range unfinished and cut into all the pieces its length allows (a range holds at most
@@ -1670,7 +1681,11 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
         hipLaunchKernelGGL(resolve_normals_kernel, tgrid, dim3(kResolveThreads), 0, v->stream, v->g, rp, v->t_table, tail.best, best_next, out, normals,
                            v->tail_count);
     } else {
-        hipLaunchKernelGGL((resolve_hits_kernel<SLAB>), rgrid, dim3(256), 0, v->stream, v->g, rp, v->t_table, tail.best, best_next, out, v->tail_count);
+        Mat44 ip;
+        memset(&ip, 0, sizeof(ip));
+        if (depth_inv_pose) memcpy(&ip, depth_inv_pose, sizeof(ip));
+        hipLaunchKernelGGL((resolve_hits_kernel<SLAB>), rgrid, dim3(256), 0, v->stream, v->g, rp, v->t_table, tail.best, best_next, out, v->tail_count, ip,
+                           SLAB ? (uint16_t *)nullptr : depth_out);
     }
     if (order_job.n_ranges) v->ray_order_valid = 1;
     TSDF_HIP(hipGetLastError(), "resolve ray hits failed");
@@ -1720,6 +1735,18 @@ int tsdf_raycast(const tsdf_volume *cv, uint32_t width, uint32_t height, const f
         TSDF_HIP(hipMemcpyAsync(host_normals, v->norm_buf, bytes, hipMemcpyDeviceToHost, v->stream), "Normals Memcpy failed");
     TSDF_HIP(hipStreamSynchronize(v->stream), "process_ray failed");
     return TSDF_OK;
+}
+
+int tsdf_raycast_depth_device(const tsdf_volume *v, uint32_t width, uint32_t height, const float pose[16], const float inv_pose[16],
+                              const float kinv[9], uint16_t *device_depth, float *device_vertices) {
+    int rc = check_ray_args(v, width, height, pose, kinv);
+    if (rc != TSDF_OK) return rc;
+    TSDF_REQUIRE(device_depth && inv_pose, "tsdf_raycast_depth: null argument");
+    TSDF_REQUIRE(v->z_begin == 0 && v->z_end == v->g.Z, "tsdf_raycast_depth needs a whole volume");
+    rc = occupancy_refresh(const_cast<tsdf_volume *>(v));
+    if (rc != TSDF_OK) return rc;
+    RayParams rp = make_params(v, width, height, pose, kinv);
+    return march_and_resolve<false>(const_cast<tsdf_volume *>(v), rp, device_vertices, nullptr, inv_pose, device_depth);
 }
 
 int tsdf_normals_device(uint32_t width, uint32_t height, const float *device_vertices, float *device_normals,
