@@ -65,7 +65,7 @@ template <typename PIX, int R>
 __global__ __launch_bounds__(256) void bilateral_kernel(const PIX *__restrict__ in, PIX *__restrict__ out,
                                                         int width, int height, int radius_arg,
                                                         const float *__restrict__ kernel,
-                                                        const float *__restrict__ similarity, const int debug_skip,
+                                                        const float *__restrict__ similarity,
                                                         uint16_t *__restrict__ tile_max) {
     constexpr bool STAGED = R > 0;
     // tile_max != nullptr: the workgroup also leaves the largest value of its 16 x 16 output tile in tile_max[tile] -- what
@@ -115,7 +115,6 @@ __global__ __launch_bounds__(256) void bilateral_kernel(const PIX *__restrict__ 
     // accumulators exactly as they are (sum + 0 * 0 and total + 0 are exact).
     const int wy0 = (blockIdx.y * kBTile + (ly & ~3)) - radius;      // first tap row of the wave's first pixel row
     const bool interior = tx0 >= 0 && tx0 + span <= width && wy0 >= 0 && wy0 + 4 + 2 * radius <= height;
-    if (debug_skip && !tile_max && (debug_skip == 1) == !interior) return;   // (timing experiments only: 1 = rim waves leave, 2 = interior waves leave)
     const bool inside = x < width && y < height;
     const int i0 = max(0, radius - x), i1 = inside ? min(n - 1, width - 1 - x + radius) : -1;
     const int j0 = max(0, radius - y), j1 = inside ? min(n - 1, height - 1 - y + radius) : -1;
@@ -234,17 +233,15 @@ static int launch_bilateral(const tsdf_bilateral *f, const PIX *in, PIX *out, in
                             uint16_t *tile_max = nullptr) {
     dim3 grid((width + kBTile - 1) / kBTile, (height + kBTile - 1) / kBTile);
     const int span = kBTile + 2 * f->radius, n = 2 * f->radius + 1;
-    static const int variant = [] { const char *e = getenv("TSDF_BIL_VARIANT"); return e ? atoi(e) : 1; }();   // tuning aid: 0 = plain loops
-    static const int debug_skip = [] { const char *e = getenv("TSDF_BIL_DEBUG_SKIP"); return e ? atoi(e) : 0; }();
-    const bool staged = f->radius == 7 && variant >= 1;      // the depth filter of the pipeline: sigma_space 4.5 -> 15 x 15 taps
+    const bool staged = f->radius == 7;      // the depth filter of the pipeline: sigma_space 4.5 -> 15 x 15 taps (other radii: the plain loops)
     size_t smem = (size_t)span * span * ((staged ? 0 : sizeof(double)) + sizeof(uint32_t)) + (size_t)n * n * sizeof(float) +
                   (staged ? kSimLds * sizeof(float) : 0);
     if (staged)
         hipLaunchKernelGGL((bilateral_kernel<PIX, 7>), grid, dim3(256), smem, s, in, out, width, height, f->radius, f->kernel_dev,
-                           f->similarity_dev, debug_skip, tile_max);
+                           f->similarity_dev, tile_max);
     else
         hipLaunchKernelGGL((bilateral_kernel<PIX, 0>), grid, dim3(256), smem, s, in, out, width, height, f->radius, f->kernel_dev,
-                           f->similarity_dev, debug_skip, tile_max);
+                           f->similarity_dev, tile_max);
     TSDF_HIP(hipGetLastError(), "bilateral filter kernel failed");
     return TSDF_OK;
 }

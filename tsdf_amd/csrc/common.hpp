@@ -35,6 +35,30 @@ constexpr int kIntBrickX = 64, kIntBrickY = 4, kIntBrickZ = TSDF_CHUNK_Z;
 // ---- error plumbing ----------------------------------------------------------------------
 void set_error(const char *fmt, ...);
 int hip_fail(hipError_t e, const char *what);
+// Every environment variable the library reads, in one place, read once per process (volume.hip: tuning()).  None of them can change a
+// result: they move work between launches, lanes and streams (tests/test_parity_raycast.py::test_schedule_knobs_do_not_change_a_bit),
+// or switch diagnostics on.  DESIGN.md 5 has the table.
+struct Tuning {
+    int ray_segments;        // TSDF_RAY_SEGMENTS       sample ranges a whole-volume ray march is cut into (6)
+    int ray_slab_ranges;     // TSDF_RAY_SLAB_RANGES    parts of a ray's stretch through a Z-slab (0: by the slab's share of the grid)
+    int ray_trip_budget;     // TSDF_RAY_TRIP_BUDGET    passes before a wave hands its unfinished rays to the tail kernel (22)
+    int ray_tail_lanes;      // TSDF_RAY_TAIL_LANES     lanes per queue entry in the tail kernel (4)
+    int ray_tail_grid;       // TSDF_RAY_TAIL_GRID      workgroups of the tail kernel (2560)
+    int ray_tail_piece;      // TSDF_RAY_TAIL_PIECE     shortest piece an unfinished stretch is cut into (64)
+    int ray_range_order;     // TSDF_RAY_RANGE_ORDER    0 near to far, 1 far to near (default), 2 last, first, then far to near
+    int ray_tile_map;        // TSDF_RAY_TILE_MAP       which tiles an XCD gets: 0 every eighth, 1 a contiguous eighth, 2 one block per block row (default)
+    int ray_learned_order;   // TSDF_RAY_LEARNED_ORDER  0: launch order, one workgroup per (range, tile) (default 1: the order learnt from the previous cast)
+    int ray_heavy_passes;    // TSDF_RAY_HEAVY_PASSES   passes from which a wave counts as long for that order (0: three quarters of the budget)
+    int occ_rebuild_period;  // TSDF_OCC_REBUILD_PERIOD integrations between tightenings of the ray caster's flags (16; 0: never)
+    int occ_scan_all;        // TSDF_OCC_SCAN_ALL       1: every tightening reads the whole distance array
+    int reach_lds;           // TSDF_REACH_LDS          1: the workgroup variant of the reach summary on every grid
+    int int_grid_per_cu;     // TSDF_INT_GRID_PER_CU    integrate: n > 0 = a resident grid of n workgroups per CU walking the brick list
+    int timing_bracket;      // TSDF_TIMING_BRACKET     1: tsdf_volume_set_timing brackets launches with hipEventRecord
+    int verbose;             // TSDF_VERBOSE            the reference's chatter
+    int debug_waves;         // TSDF_DEBUG_WAVES        per-wave clocks of the two ray kernels (synchronises)
+    int debug_rays;          // TSDF_DEBUG_RAYS         how many pieces went through the tail queue (synchronises)
+};
+const Tuning &tuning();
 int occupancy_rebuild(struct ::tsdf_volume *v);  // volume.hip
 int occupancy_join(struct ::tsdf_volume *v);     // volume.hip: the volume's stream waits for a tightening enqueued elsewhere
 int occupancy_tighten_on(struct ::tsdf_volume *v, hipStream_t stream);  // volume.hip: the periodic rebuild on another stream

@@ -140,14 +140,7 @@ __device__ inline void mark_low_voxels(const OccGrid &occ, const uint32_t bits_l
 constexpr int kDepthTile = TSDF_DEPTH_TILE;  // pixels per side of a depth tile (16)
 constexpr int kCullTilesLds = 4096;  // tile maxima brick_cull_kernel keeps in LDS (1200 at 640x480)
 
-static uint32_t occupancy_rebuild_period() {
-    static const uint32_t n = [] {
-        const char *e = getenv("TSDF_OCC_REBUILD_PERIOD");  // tuning aid; 0 = never
-        int v = e ? atoi(e) : 16;
-        return (uint32_t)(v < 0 ? 0 : v);
-    }();
-    return n;
-}
+static uint32_t occupancy_rebuild_period() { return (uint32_t)tuning().occ_rebuild_period; }
 
 // Max depth per 16x16 pixel tile (0 = the tile holds no valid depth).  One wave per tile.
 __global__ __launch_bounds__(64) void depth_tile_max_kernel(const uint16_t *__restrict__ depth, uint32_t width,
@@ -721,7 +714,7 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
     // whichever compute unit frees a slot, which balances the uneven bricks better than a resident grid walking the list
     // with a fixed stride did (0.136 vs 0.144 ms: 5 300 bricks over 1 536 resident workgroups are 3.3 rounds).
     // TSDF_INT_GRID_PER_CU = n > 0 restores a resident grid of n workgroups per compute unit (tuning aid).
-    static const int grid_per_cu = [] { const char *e = getenv("TSDF_INT_GRID_PER_CU"); return e ? atoi(e) : 0; }();
+    const int grid_per_cu = tuning().int_grid_per_cu;
     dim3 grid((unsigned)(grid_per_cu > 0 ? std::min<size_t>(n_bricks, (size_t)256 * grid_per_cu) : n_bricks));
     bool finite = true;
     for (int i = 0; i < 16; i++) finite = finite && std::isfinite(inv_pose[i]);

@@ -249,66 +249,26 @@ constexpr int kDone = 0x7fffffff;
 // value the reference computes is > 0 whatever the rounding.  No margin like occ.tau is needed here -- that one covers
 // the APPROXIMATE location used at brick level.
 constexpr float kCellPositive = 1.0e-30f;
-constexpr int kTailLanesDefault = 4;        // lanes per queue entry in the tail kernel
-constexpr int kRaySegmentsDefault = 6;   // sample ranges of a whole-volume march (round 3: 6 ranges / 22 passes, re-tuned with the long waves dispatched first; round 2: 5 / 24 with the ranges dispatched far to near; round 1: 6 / 18)
-constexpr int kTailGridDefault = 256 * 10;   // workgroups of the tail kernel (5 fit a CU at 86 VGPRs: two rounds)
+constexpr int kTailLanesDefault = 4;        // lanes per queue entry in the tail kernel (the variant compiled with the group width fixed)
+// Defaults of the schedule (common.hpp: Tuning, read from the environment in volume.hip): 6 sample ranges / 22 passes before a wave hands
+// over (round 3, re-tuned with the long waves dispatched first and the runs of free space merged; round 2: 5 / 24 with the ranges
+// dispatched far to near; round 1: 6 / 18); 2 560 workgroups of the tail kernel; pieces of at least 64 samples.
 // What is left of a ray's range when the pass budget runs out is queued in up to kTailPieces pieces of at least
-// kTailPieceMin samples, so that a long stretch is marched by several groups of the tail kernel at once.
-constexpr int kTailPieces = 16, kTailPieceMin = 64;
-constexpr int kTripBudgetDefault = 22;   // passes of the marching loop before a wave hands over to the tail kernel
-static int ray_segments() {
-    static const int n = [] {
-        const char *e = getenv("TSDF_RAY_SEGMENTS");  // tuning aid
-        int v = e ? atoi(e) : kRaySegmentsDefault;
-        return v < 1 ? 1 : (v > 64 ? 64 : v);
-    }();
-    return n;
-}
-static int tail_lanes() {
-    static const int n = [] {
-        const char *e = getenv("TSDF_RAY_TAIL_LANES");  // tuning aid: a power of two, 1..64
-        int v = e ? atoi(e) : kTailLanesDefault;
-        return (v >= 1 && v <= 64 && (v & (v - 1)) == 0) ? v : kTailLanesDefault;
-    }();
-    return n;
-}
-static int tail_grid() {
-    static const int n = [] {
-        const char *e = getenv("TSDF_RAY_TAIL_GRID");  // tuning aid
-        int v = e ? atoi(e) : kTailGridDefault;
-        return v < 1 ? 1 : v;
-    }();
-    return n;
-}
+// tail_piece_min() samples, so that a long stretch is marched by several groups of the tail kernel at once.
+constexpr int kTailPieces = 16;
+static int ray_segments() { return tuning().ray_segments; }
+static int tail_lanes() { return tuning().ray_tail_lanes; }
+static int tail_grid() { return tuning().ray_tail_grid; }
 // Parts a ray's stretch through a slab is cut into: in proportion to the slab's share of the grid (a whole volume
 // uses ray_segments() ranges), at least 2.
 static int slab_ray_ranges(const tsdf_volume *v) {
-    static const int forced = [] {
-        const char *e = getenv("TSDF_RAY_SLAB_RANGES");  // tuning aid
-        int n = e ? atoi(e) : 0;
-        return n < 0 ? 0 : (n > 64 ? 64 : n);
-    }();
-    if (forced) return forced;
+    if (tuning().ray_slab_ranges) return tuning().ray_slab_ranges;
     const uint32_t planes = v->z_end - v->z_begin, Z = v->g.Z ? v->g.Z : 1;
     const int n = (int)(((uint64_t)ray_segments() * planes + Z - 1) / Z);
     return n < 2 ? 2 : (n > 64 ? 64 : n);
 }
-static int tail_piece_min() {
-    static const int n = [] {
-        const char *e = getenv("TSDF_RAY_TAIL_PIECE");  // tuning aid
-        int v = e ? atoi(e) : kTailPieceMin;
-        return v < 1 ? 1 : v;
-    }();
-    return n;
-}
-static int trip_budget() {
-    static const int n = [] {
-        const char *e = getenv("TSDF_RAY_TRIP_BUDGET");  // tuning aid
-        int v = e ? atoi(e) : kTripBudgetDefault;
-        return v < 1 ? 1 : v;
-    }();
-    return n;
-}
+static int tail_piece_min() { return tuning().ray_tail_piece; }
+static int trip_budget() { return tuning().ray_trip_budget; }
 
 // Per-ray constants of the skipping arithmetic.  Everything here is APPROXIMATE on purpose (hardware
 // reciprocals, no care for rounding): it only decides how far k may jump, and the slack of the occupancy
@@ -1547,7 +1507,7 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
     TailQueue tail = {reinterpret_cast<uint2 *>(v->tail_entries), v->tail_count, (uint32_t)trip_budget(), (uint32_t)tail_lanes(), v->ray_best + (size_t)v->ray_best_side * v->ray_best_cap, tail_piece_min(), nullptr};
     uint64_t *best_next = v->ray_best + (size_t)(1 - v->ray_best_side) * v->ray_best_cap;
     // the dispatch order learnt from the previous cast (TSDF_RAY_LEARNED_ORDER=0: launch order, tuning aid)
-    static const bool learn_order = [] { const char *e = getenv("TSDF_RAY_LEARNED_ORDER"); return !e || atoi(e) != 0; }();
+    const bool learn_order = tuning().ray_learned_order != 0;
     const uint32_t n_tiles = ((rp.width + 15) / 16) * ((rp.height + 15) / 16);
     OrderJob order_job = {nullptr, nullptr, 0, 0, 0};
     if (learn_order && n_tiles <= 65535u && (uint32_t)n_segments <= kOrderMaxRanges) {
@@ -1566,17 +1526,17 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
         // "long": three quarters of the pass budget or more.  (With the runs of free space merged and three classes -- long, some pass, none --
         // any threshold from 14 to 22 of 22 passes gives the same launch, 62-63 us; 12 and below 69-74 us: the waves of a few passes are
         // many, and listed first they push the long ones back.)
-        { static const int hp = [] { const char *e = getenv("TSDF_RAY_HEAVY_PASSES"); return e ? atoi(e) : 0; }(); tail.heavy_passes = hp > 0 ? (uint32_t)hp : std::max(1u, tail.trip_budget * 3u / 4u); }   // tuning aid
+        tail.heavy_passes = tuning().ray_heavy_passes > 0 ? (uint32_t)tuning().ray_heavy_passes : std::max(1u, tail.trip_budget * 3u / 4u);
         tail.heavy = v->ray_heavy;
         tail.order = v->ray_order_valid ? v->ray_order : nullptr;
         order_job = {v->ray_heavy, v->ray_order, n_tiles, (uint32_t)n_segments, 0};
     }
     rp.seg_len = (kMaxSamples + n_segments - 1) / n_segments;
     rp.slab_ranges = SLAB ? (uint32_t)n_segments : 0u;
-    { static const int map = [] { const char *e = getenv("TSDF_RAY_TILE_MAP"); return e ? atoi(e) : 2; }(); rp.tile_map = (uint32_t)std::min(std::max(map, 0), 2); }   // tuning aid
-    { static const int order = [] { const char *e = getenv("TSDF_RAY_RANGE_ORDER"); return e ? atoi(e) : 1; }(); rp.range_order = (uint32_t)std::min(std::max(order, 0), 2); }
+    rp.tile_map = (uint32_t)tuning().ray_tile_map;
+    rp.range_order = (uint32_t)tuning().ray_range_order;
     dim3 grid((rp.width + 15) / 16, (rp.height + 15) / 16, n_segments);
-    static const bool debug_waves = getenv("TSDF_DEBUG_WAVES") != nullptr;
+    const bool debug_waves = tuning().debug_waves != 0;
     unsigned long long *wave_log = nullptr;
     const size_t n_waves_log = (size_t)grid.x * grid.y * grid.z * 4;
     if (debug_waves) {
@@ -1671,7 +1631,7 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
         for (int q = 0; q < 16; q++) fprintf(stderr, " %zu", alive[q]);
         fprintf(stderr, "\n");
     }
-    if (getenv("TSDF_DEBUG_RAYS")) {   // diagnostics: how much went through the tail queue (synchronises)
+    if (tuning().debug_rays) {   // diagnostics: how much went through the tail queue (synchronises)
         uint32_t n_tail = 0;
         (void)hipMemcpy(&n_tail, v->tail_count, sizeof(n_tail), hipMemcpyDeviceToHost);
         fprintf(stderr, "tsdf: %u pieces of the %zu (ray, range) pairs finished by the tail kernel\n", n_tail, n_pix * n_segments);

@@ -25,6 +25,35 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+const Tuning &tuning() {
+    static const Tuning t = [] {
+        auto num = [](const char *name, int fallback) { const char *e = getenv(name); return e ? atoi(e) : fallback; };
+        auto clamp = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+        Tuning u;
+        u.ray_segments = clamp(num("TSDF_RAY_SEGMENTS", 6), 1, 64);
+        u.ray_slab_ranges = clamp(num("TSDF_RAY_SLAB_RANGES", 0), 0, 64);
+        u.ray_trip_budget = std::max(num("TSDF_RAY_TRIP_BUDGET", 22), 1);
+        u.ray_tail_lanes = num("TSDF_RAY_TAIL_LANES", 4);
+        if (!(u.ray_tail_lanes >= 1 && u.ray_tail_lanes <= 64 && (u.ray_tail_lanes & (u.ray_tail_lanes - 1)) == 0)) u.ray_tail_lanes = 4;
+        u.ray_tail_grid = std::max(num("TSDF_RAY_TAIL_GRID", 256 * 10), 1);
+        u.ray_tail_piece = std::max(num("TSDF_RAY_TAIL_PIECE", 64), 1);
+        u.ray_range_order = clamp(num("TSDF_RAY_RANGE_ORDER", 1), 0, 2);
+        u.ray_tile_map = clamp(num("TSDF_RAY_TILE_MAP", 2), 0, 2);
+        u.ray_learned_order = num("TSDF_RAY_LEARNED_ORDER", 1) != 0;
+        u.ray_heavy_passes = std::max(num("TSDF_RAY_HEAVY_PASSES", 0), 0);
+        u.occ_rebuild_period = std::max(num("TSDF_OCC_REBUILD_PERIOD", 16), 0);
+        u.occ_scan_all = num("TSDF_OCC_SCAN_ALL", 0) != 0;
+        u.reach_lds = num("TSDF_REACH_LDS", 0) != 0;
+        u.int_grid_per_cu = num("TSDF_INT_GRID_PER_CU", 0);
+        u.timing_bracket = num("TSDF_TIMING_BRACKET", 0) != 0;
+        u.verbose = getenv("TSDF_VERBOSE") != nullptr;
+        u.debug_waves = getenv("TSDF_DEBUG_WAVES") != nullptr;
+        u.debug_rays = getenv("TSDF_DEBUG_RAYS") != nullptr;
+        return u;
+    }();
+    return t;
+}
+
 int hip_fail(hipError_t e, const char *what) {
     set_error("%s: %s", what, hipGetErrorString(e));
     return e == hipErrorOutOfMemory ? TSDF_ERR_NOMEM : TSDF_ERR_DEVICE;
@@ -400,8 +429,7 @@ static int occupancy_rebuild_on(tsdf_volume *v, hipStream_t stream) {
     if (!v->occ_bits) TSDF_HIP(hipMalloc((void **)&v->occ_bits, n * sizeof(uint16_t)), "occupancy scratch alloc");
     if (!v->occ_rim_bits) TSDF_HIP(hipMalloc((void **)&v->occ_rim_bits, n), "occupancy scratch alloc");
     dim3 grid((v->occ.nbx + 63) / 64, v->occ.nby, v->occ.nbz);
-    static const bool always_all = [] { const char *e = getenv("TSDF_OCC_SCAN_ALL"); return e && atoi(e) != 0; }();   // tuning aid
-    const bool incremental = !always_all && !v->occ_scan_all && v->touched && (v->g.z_store_begin % kBrick) == 0;
+    const bool incremental = !tuning().occ_scan_all && !v->occ_scan_all && v->touched && (v->g.z_store_begin % kBrick) == 0;
     const uint32_t n_touched = v->touched ? v->touched_nx * v->touched_ny * v->touched_nz : 0u;
     TSDF_REQUIRE(n_touched <= n || !v->touched, "occupancy rebuild: more integrate bricks than occupancy bricks");
     hipLaunchKernelGGL(occupancy_scan_kernel, grid, dim3(256), 0, stream, v->dist, v->g, v->occ, v->occ_bits, v->occ_rim_bits,
@@ -445,7 +473,7 @@ int occupancy_refresh(tsdf_volume *v) {
     }
     if (v->reach_dirty) {
         dim3 grid((v->occ.nbx + kSuper - 1) / kSuper, (v->occ.nby + kSuper - 1) / kSuper, (v->occ.nbz + kSuper - 1) / kSuper);
-        static const bool lds_variant = [] { const char *e = getenv("TSDF_REACH_LDS"); return e && atoi(e) != 0; }();   // tuning aid: the workgroup variant always
+        const bool lds_variant = tuning().reach_lds != 0;   // (tuning aid: the workgroup variant always)
         const bool whole_blocks = v->occ.nbx % kSuper == 0 && v->occ.nby % kSuper == 0 && v->occ.nbz % kSuper == 0 &&
                                   (reinterpret_cast<uintptr_t>(v->occ.fine) & 15u) == 0 && (reinterpret_cast<uintptr_t>(v->occ.reach) & 15u) == 0;
         if (whole_blocks && !lds_variant)
@@ -511,14 +539,11 @@ int verify_fast_division(tsdf_volume *v) {
     TSDF_HIP(hipStreamSynchronize(v->stream), "fast division check");
     v->fast_div = (bad == 0) ? 1 : 0;
     v->fast_div_mismatches = bad;
-    if (bad && getenv("TSDF_VERBOSE")) fprintf(stderr, "tsdf: fast division not verified (%llu mismatches)\n", bad);
+    if (bad && tuning().verbose) fprintf(stderr, "tsdf: fast division not verified (%llu mismatches)\n", bad);
     return TSDF_OK;
 }
 
-static bool timing_brackets() {
-    static const bool b = [] { const char *e = getenv("TSDF_TIMING_BRACKET"); return e && atoi(e) != 0; }();
-    return b;
-}
+static bool timing_brackets() { return tuning().timing_bracket != 0; }
 
 // Start / stop events for the next launch of kernel `which` (filled by hipExtLaunchKernel with the dispatch's timestamps);
 // false when this launch is not to be timed, or when the brackets are asked for.
