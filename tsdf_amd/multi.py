@@ -216,14 +216,33 @@ class SlabExchange:
             return
         path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so").encode()
         uid = (C.c_uint8 * 128)()
+        # Every rank must leave this constructor the same way -- with a communicator or with an exception -- or the caller's fallback
+        # (bench.py: torch's collective) would be taken by some ranks only and the next collective would hang.  So rank 0's failure to
+        # make an id travels with the id (a status byte in front), and the ranks agree on the outcome of the communicator's creation.
+        id_error = None
         if self.rank == 0:
-            check(lib.tsdf_slab_exchange_unique_id(uid, path))
-        # the id travels as 128 bytes through the process group that exists already (nccl: on the device; gloo: on the host)
+            try:
+                check(lib.tsdf_slab_exchange_unique_id(uid, path))
+            except Exception as e_:
+                id_error = e_
+        # the id travels as 1 + 128 bytes through the process group that exists already (nccl: on the device; gloo: on the host)
         dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
-        t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).clone().to(dev)
+        t = torch.frombuffer(bytearray(bytes([0 if id_error else 1]) + bytes(uid)), dtype=torch.uint8).clone().to(dev)
         dist.broadcast(t, src=0, group=group)
-        C.memmove(uid, bytes(t.cpu().numpy().tobytes()), 128)
-        check(lib.tsdf_slab_exchange_create(self.rank, self.world, uid, path, C.byref(self._h)))
+        got = bytes(t.cpu().numpy().tobytes())
+        if got[0] == 0:
+            raise RuntimeError("rank 0 could not make an RCCL id%s" % (": %s" % id_error if id_error else ""))
+        C.memmove(uid, got[1:], 128)
+        created = None
+        try:
+            check(lib.tsdf_slab_exchange_create(self.rank, self.world, uid, path, C.byref(self._h)))
+        except Exception as e_:
+            created = e_
+        agree = torch.tensor([0 if created else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN, group=group)
+        if int(agree.item()) == 0:
+            self.close()
+            raise RuntimeError("the RCCL communicator of the slab exchange could not be built on every rank%s" % (": %s" % created if created else ""))
 
     def all_gather(self, send, recv, stream):
         if not (send.is_cuda and recv.is_cuda and send.is_contiguous() and recv.is_contiguous()):
