@@ -129,7 +129,6 @@ struct tsdf_tracker {
     hipStream_t main, side;
     hipStream_t volume_stream_before;
     uint16_t *filtered[2], *tile_max[2], *model;
-    float *vertices;
     hipEvent_t integrated[2];   // [b]: the integrate that read buffer b is done
     hipEvent_t ready;           // the frame in buffer `cur` has been filtered (and its ICP maps built)
     bool ready_pending;         // ... and the step's stream has not waited for that yet
@@ -438,7 +437,6 @@ int tsdf_tracker_destroy(tsdf_tracker *t) {
     }
     if (t->ready) (void)hipEventDestroy(t->ready);
     if (t->model) (void)hipFree(t->model);
-    if (t->vertices) (void)hipFree(t->vertices);
     if (t->side) (void)hipStreamDestroy(t->side);
     if (t->main) (void)hipStreamDestroy(t->main);
     delete t;
