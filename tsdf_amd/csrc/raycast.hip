@@ -348,21 +348,33 @@ __device__ inline int wave_min(int v) {
 
 
 // Look-ahead after an evaluated sample.  Inside one dual cell the interpolant f is trilinear in the cell coordinates
-// (u,v,w), so |df/du| <= Rx = the largest difference along the cell's four x edges (a convex combination of them), same for
-// v and w: n samples further on, still inside the cell, f has dropped by at most n * (su*Rx + sv*Ry + sw*Rz).  The sample
-// just evaluated is `val` > 0 (the reference's fp32 value); the values the reference would compute for the next samples
-// differ from f at the exact positions by its rounding (a few 1e-6 * largest |corner|; 2e-5 is allowed) and the positions are known
-// to 2*eps in each coordinate.  So while  val - margin - n * 1.01 * per_sample > 0  sample k+n cannot be <= 0.  Returns
-// that n, at most `limit` (the samples known to stay inside the cell); 0 when anything is NaN or infinite.
+// (u,v,w), so df/du lies between the smallest and the largest difference along the cell's four x edges (it is a convex combination
+// of them), same for v and w.  A sample moves the ray by (du, dv, dw) -- signed -- so one sample further on, still inside the cell, f has
+// changed by at least  L = min_e(du * Dx_e) + min_e(dv * Dy_e) + min_e(dw * Dz_e):  n samples on it is >= val + n * L.  (Round 1-2
+// used |du| * max_e |Dx_e| + ...: the same number for a ray that descends onto a surface, but a ray that skims past a silhouette
+// spends half its way RECEDING from it -- f grows -- and was still evaluated sample by sample.)  The sample just evaluated is `val` > 0
+// (the reference's fp32 value); the values the reference would compute for the next samples differ from f at the exact positions by
+// its rounding (a few 1e-6 * largest |corner|; 2e-5 is allowed) and the positions are known to 2*eps in each coordinate, the step
+// to 1 % (the approximate reciprocals; T[k+1] - T[k] is the step to 5e-4).  So while  val - margin + n * 1.01 * min(L, 0) > 0
+// sample k+n cannot be <= 0.  Returns that n, at most `limit` (the samples known to stay inside the cell); 0 when anything is NaN
+// or infinite.
 __device__ inline int lipschitz_lookahead(float val, float c000, float c100, float c010, float c110, float c001, float c101, float c011,
                                           float c111, const SkipCtx &sc, int limit) {
-    const float rx = fmaxf(fmaxf(fabsf(c100 - c000), fabsf(c110 - c010)), fmaxf(fabsf(c101 - c001), fabsf(c111 - c011)));
-    const float ry = fmaxf(fmaxf(fabsf(c010 - c000), fabsf(c110 - c100)), fmaxf(fabsf(c011 - c001), fabsf(c111 - c101)));
-    const float rz = fmaxf(fmaxf(fabsf(c001 - c000), fabsf(c101 - c100)), fmaxf(fabsf(c011 - c010), fabsf(c111 - c110)));
+    const float x0 = c100 - c000, x1 = c110 - c010, x2 = c101 - c001, x3 = c111 - c011;
+    const float y0 = c010 - c000, y1 = c110 - c100, y2 = c011 - c001, y3 = c111 - c101;
+    const float z0 = c001 - c000, z1 = c101 - c100, z2 = c011 - c010, z3 = c111 - c110;
+    const float rx = fmaxf(fmaxf(fabsf(x0), fabsf(x1)), fmaxf(fabsf(x2), fabsf(x3)));
+    const float ry = fmaxf(fmaxf(fabsf(y0), fabsf(y1)), fmaxf(fabsf(y2), fabsf(y3)));
+    const float rz = fmaxf(fmaxf(fabsf(z0), fabsf(z1)), fmaxf(fabsf(z2), fabsf(z3)));
     const float rsum = (rx + ry) + rz;
     const float margin = 4.0f * sc.eps * rsum + 2.0e-5f * (fabsf(c000) + rsum);   // |corner| <= |c000| + rsum
-    const float per_sample = 1.01f * ((sc.su * rx + sc.sv * ry) + sc.sw * rz);
-    const float x = 0.99f * (val - margin) * __builtin_amdgcn_rcpf(per_sample);   // (inf when the cell is flat: limit applies)
+    // the ray's movement per sample in cell units, signed (posx = 1 when it moves towards +x)
+    const float du = sc.posx != 0.0f ? sc.su : -sc.su, dv = sc.posy != 0.0f ? sc.sv : -sc.sv, dw = sc.posz != 0.0f ? sc.sw : -sc.sw;
+    const float lx = fminf(fminf(du * x0, du * x1), fminf(du * x2, du * x3));
+    const float ly = fminf(fminf(dv * y0, dv * y1), fminf(dv * y2, dv * y3));
+    const float lz = fminf(fminf(dw * z0, dw * z1), fminf(dw * z2, dw * z3));
+    const float drop = 1.01f * fmaxf(-((lx + ly) + lz), 0.0f);                   // the most f can fall per sample
+    const float x = 0.99f * (val - margin) * __builtin_amdgcn_rcpf(drop);        // (inf when f cannot fall: limit applies)
     // (a NaN corner makes val, hence x, NaN -- fmaxf / fminf would drop it from the slopes; an infinite one makes rsum infinite)
     if (!(rsum < INFINITY) || !(x > 0.0f)) return 0;
     return (int)fminf(x, (float)limit);
