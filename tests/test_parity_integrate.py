@@ -330,3 +330,47 @@ def test_slab_with_caller_tile_maxima(oracle):
     a, b = whole.get_distance_data().reshape(96, 64, 64), slab.get_distance_data().reshape(-1, 64, 64)
     z0 = 30
     assert_same_floats(a[z0:z0 + b.shape[0]].reshape(-1), b.reshape(-1), "slab distances")
+
+
+# ---- round 4: bricks that straddle the camera plane are culled against the double cone of the image's side planes ----------------
+
+@pytest.mark.parametrize("ypr", [(0.0, 0.0, 0.0), (0.35, -0.2, 0.15), (1.2, 0.4, -0.7), (3.0, 0.1, 0.0), (-1.57, 1.3, 2.0)])
+def test_camera_inside_a_grid_of_many_bricks(oracle, ypr):
+    # 192 x 96 x 128 voxels = 3 x 24 x 4 integrate bricks; the camera plane cuts through most of them at every angle
+    d, _ = synth.depth_frame(1, 7, seed=21)
+    cam = camera_at((1310.0, 1490.0, 1720.0), yaw_pitch_roll=ypr)
+    gv, ov, up = run_both(oracle, (192, 96, 128), (3000, 3000, 3000), [(d, cam), (synth.wall_depth(700), cam)])
+    check(gv, ov, up, "camera inside, ypr %s" % (ypr,))
+    assert up[0][1] > 0 and up[1][1] > 0
+    # voxels BEHIND the camera are updated too (Q2): the oracle's weights say so, and the GPU agreed above
+    w = ov.weight.reshape(128, 96, 192)
+    ip = cam.inverse_pose().astype(np.float64).reshape(4, 4).T
+    zz, yy, xx = np.nonzero(w > 0)
+    vs = np.array([3000 / 192, 3000 / 96, 3000 / 128])
+    camz = ip[2, 0] * (xx + 0.5) * vs[0] + ip[2, 1] * (yy + 0.5) * vs[1] + ip[2, 2] * (zz + 0.5) * vs[2] + ip[2, 3]
+    assert (camz < 0).any(), "no voxel behind the camera was updated: the case does not reach the back half of the cone"
+
+
+def test_camera_exactly_on_a_voxel_centre(oracle):
+    # the voxel under the camera projects to 0 / 0: NaN -> pixel (0, 0) (Q3); its brick straddles the camera plane
+    n, phys = 128, 3200.0            # voxel size 25: centres are exact floats
+    depth = synth.wall_depth(900)
+    for voxel in ((70, 40, 50), (64, 4, 32), (0, 0, 0), (127, 127, 127)):
+        pos = tuple((v + 0.5) * 25.0 for v in voxel)
+        cam = camera_at(pos)
+        gv, ov, up = run_both(oracle, (n, n, n), (phys, phys, phys), [(depth, cam)])
+        check(gv, ov, up, "camera on voxel %s" % (voxel,))
+        assert ov.weight.reshape(n, n, n)[voxel[2], voxel[1], voxel[0]] == 1.0, "the voxel under the camera takes pixel (0, 0)"
+
+
+def test_camera_inside_with_a_general_projection(oracle):
+    # skewed intrinsics and a projective last row: the straddlers' test is on the signs of affine forms and holds for any matrices
+    d, _ = synth.depth_frame(2, 7, seed=23)
+    cam0 = camera_at((1500.0, 1400.0, 1600.0), yaw_pitch_roll=(0.5, 0.3, -0.2))
+    k = cam0.k().copy(); k[3] = 7.5; k[1] = -3.0          # column-major: m12, m21
+    ip = cam0.inverse_pose().copy(); ip[3] = 1.0e-5; ip[7] = -2.0e-5
+    from tests.helpers import Cam
+    cam = Cam(cam0.pose(), ip, k, oracle.mat3_inverse(k))
+    gv, ov, up = run_both(oracle, (192, 64, 96), (3000, 3000, 3000), [(d, cam)])
+    check(gv, ov, up, "camera inside, general projection")
+    assert up[0][1] > 0

@@ -163,7 +163,8 @@ __global__ __launch_bounds__(256) void brick_cull_kernel(const Geom g, const Bri
                                                          const int depth_test, uint32_t *__restrict__ list,
                                                          uint4 *__restrict__ boxes, uint32_t *__restrict__ count,
                                                          uint32_t *__restrict__ count_next,
-                                                         float4 *__restrict__ plane_const, const uint32_t n_plane_const) {
+                                                         float4 *__restrict__ plane_const, const uint32_t n_plane_const,
+                                                         const float cone_mx, const float cone_my) {
     // One lane per corner: 8 consecutive lanes share a brick and combine their corners with 3 butterfly steps (a thread per brick
     // walked its 8 corners one after the other on a quarter of the chip's compute units: 12 us of dependent arithmetic).
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
@@ -221,6 +222,21 @@ __global__ __launch_bounds__(256) void brick_cull_kernel(const Geom g, const Bri
     // bits that must hold for ALL corners: 0 divisor positive, 1 divisor negative, 2 left of the image, 3 right, 4 above, 5 below
     uint32_t all = ((sign_ok && p.iz > 0.0f) ? 1u : 0u) | ((sign_ok && p.iz < 0.0f) ? 2u : 0u) | ((qx + mqx < -1.0f) ? 4u : 0u) |
                    ((qx - mqx > (float)width) ? 8u : 0u) | ((qy + mqy < -1.0f) ? 16u : 0u) | ((qy - mqy > (float)height) ? 32u : 0u);
+    // Bricks that straddle the camera plane (the camera is inside the volume: a whole layer of them) have no hull to bound, but the
+    // reference's frustum test (:349) still is a statement about signs.  With a = image.x, b = image.z, c = image.y as the reference
+    // computes them, a pixel column in [0, W-1] needs -1 < a / b < W (the rounded IEEE quotient cannot differ from a / b by 1/2), i.e.
+    //   b > 0:  L1 = a + b > 0  and  L2 = W b - a > 0        b < 0:  L1 < 0  and  L2 < 0        b == 0:  a == 0 (NaN -> pixel 0, Q3)
+    // and the same for rows with L3 = c + b, L4 = H b - c: a voxel is in the image only inside the double cone
+    // {all L > 0} u {all L < 0} u {all L == 0}.  Each L is an affine function of the position, so over the brick it stays under the
+    // largest corner value: if some L_i is < 0 at all 8 corners (beyond the margin: cone_mx / cone_my, the host's bound on what the
+    // fp32 evaluation of a, b, c can be off by anywhere in the grid, both at the corner and at the voxel) no voxel of the brick has all
+    // L > 0 or all L == 0, and if some L_j is > 0 at all corners none has all L < 0: the brick updates nothing.
+    {
+        const float fw = (float)width, fh = (float)height;
+        const float l1 = p.ix + p.iz, l2 = fw * p.iz - p.ix, l3 = p.iy + p.iz, l4 = fh * p.iz - p.iy;   // (NaN: no bit)
+        all |= ((l1 < -cone_mx) ? 64u : 0u) | ((l2 < -cone_mx) ? 128u : 0u) | ((l3 < -cone_my) ? 256u : 0u) | ((l4 < -cone_my) ? 512u : 0u) |
+               ((l1 > cone_mx) ? 1024u : 0u) | ((l2 > cone_mx) ? 2048u : 0u) | ((l3 > cone_my) ? 4096u : 0u) | ((l4 > cone_my) ? 8192u : 0u);
+    }
     float qx_lo = qx - mqx, qx_hi = qx + mqx, qy_lo = qy - mqy, qy_hi = qy + mqy;
     float camz_lo = p.cam_z - p.ecz, ecz_max = p.ecz;
 #pragma unroll
@@ -270,6 +286,7 @@ __global__ __launch_bounds__(256) void brick_cull_kernel(const Geom g, const Bri
                 keep = false;
         }
     }
+    else if ((all & 960u) && (all & 15360u)) keep = false;   // straddles the camera plane, but lies outside both halves of the cone
     // One atomic on the list's length per workgroup (a few thousand of them on one address, from 8 XCDs, were most of this
     // kernel's time), the workgroup's survivors in brick order behind it: neighbouring bricks stay neighbours in the list, so
     // that they are in flight together in integrate_kernel (rows of the volume they share stay open in memory).
@@ -687,12 +704,29 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
         // the depth tests need surface z == depth and w == 1 exactly (rigid pose, standard intrinsics)
         const int depth_test = (ip.m41 == 0.0f && ip.m42 == 0.0f && ip.m43 == 0.0f && ip.m44 == 1.0f &&
                                 mkinv.m31 == 0.0f && mkinv.m32 == 0.0f && mkinv.m33 == 1.0f) ? 1 : 0;
+        // brick_cull_kernel's margins for the bricks that straddle the camera plane: what the fp32 values of image.x / .y / .z can be
+        // off by anywhere in the resident grid (the kernel's own corner bounds, with every coordinate at its largest magnitude)
+        float cone_mx, cone_my;
+        {
+            const double u = 6.0e-7;
+            auto centre = [](uint32_t i, float vs, float oc, float o) { return (double)((((int)i + 0.5f) * vs + oc) + o); };
+            const double PX = std::max(std::fabs(centre(0, g.vs.x, g.offset_clear.x, g.offset.x)), std::fabs(centre(g.X - 1, g.vs.x, g.offset_clear.x, g.offset.x)));
+            const double PY = std::max(std::fabs(centre(0, g.vs.y, g.offset_clear.y, g.offset.y)), std::fabs(centre(g.Y - 1, g.vs.y, g.offset_clear.y, g.offset.y)));
+            const double PZ = std::max(std::fabs(centre(g.z_store_begin, g.vs.z, g.offset_clear.z, g.offset.z)), std::fabs(centre(g.z_store_end - 1, g.vs.z, g.offset_clear.z, g.offset.z)));
+            auto row = [&](float a, float b, float c, float d) { return std::fabs((double)a) * PX + std::fabs((double)b) * PY + std::fabs((double)c) * PZ + std::fabs((double)d); };
+            const double CX = row(ip.m11, ip.m12, ip.m13, ip.m14), CY = row(ip.m21, ip.m22, ip.m23, ip.m24), CZ = row(ip.m31, ip.m32, ip.m33, ip.m34);
+            auto img = [&](float a, float b, float c) { return 2.0 * u * (std::fabs((double)a) * CX + std::fabs((double)b) * CY + std::fabs((double)c) * CZ); };
+            const double ex = img(mk.m11, mk.m12, mk.m13), ey = img(mk.m21, mk.m22, mk.m23), ez = img(mk.m31, mk.m32, mk.m33);
+            // at the corner + at the voxel + forming L itself, doubled; not finite (wild matrices): NaN margins switch the test off
+            cone_mx = (float)(8.0 * (ex + (double)width * ez) + 1.0e-3);
+            cone_my = (float)(8.0 * (ey + (double)height * ez) + 1.0e-3);
+        }
         if (!caller_tile_max)
             hipLaunchKernelGGL(depth_tile_max_kernel, dim3(tiles_x, tiles_y), dim3(64), 0, cull_stream, d_depth, width, height,
                                tiles_x, v->tile_max);
         hipLaunchKernelGGL(brick_cull_kernel, dim3((unsigned)((8 * n_bricks + 255) / 256)), dim3(256), 0, cull_stream, g, bg, ip, mk,
                            width, height, caller_tile_max ? caller_tile_max : v->tile_max, tiles_x, depth_test, v->brick_list, boxes, count,
-                           count_next, plane_const, n_plane_const);
+                           count_next, plane_const, n_plane_const, cone_mx, cone_my);
         v->brick_count_side = 1u - v->brick_count_side;
         if (phase == kIntPrepare) {
             TSDF_HIP(hipGetLastError(), "Integrate culling failed");
