@@ -68,6 +68,12 @@ def parse():
                     help="take the stream from a TUM-layout directory (depth/*.png + ground_truth.txt) through the host library's "
                          "TUMDataLoader instead of synthesising it: the frames tools/kinfu_stream.cpp sees (tools/compare_drivers.sh)")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the K-step timed region (barrier + synchronise on both sides, MAX over ranks) is run this many times, each on a freshly "
+                         "cleared volume fed the same warm-up and the same K frames; ms_per_step / value are the MEDIAN region, every region is "
+                         "listed in ms_per_step_runs")
+    ap.add_argument("--parity-grid", type=int, default=None,
+                    help="grid of the parity gate (default: the benchmarked grid, first and last timed frame against the oracle)")
     ap.add_argument("--path-only", action="store_true",
                     help="only the timed hot path and its roofline (no ICP / tracking / host-buffer legs): what the profiling passes run")
     a = ap.parse_args()
@@ -101,15 +107,30 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` started plainly (the shape of the driver's N = 1 command): become the launcher -- the same
+        # torch.distributed.run command the driver uses, one rank per GPU, rendezvous on 127.0.0.1; rank 0 of it prints the line
+        import socket
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        os.dup2(json_fd, 1)
+        if os.environ.get("BENCH_LAUNCH_DRYRUN") == "1":     # (tests/test_bench_launcher.py: the command, not the run)
+            print(json.dumps([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                              "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]))
+            return
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     if world != args.gpus:
-        # launched without torchrun for N>1 is a usage error; N=1 runs standalone
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run" % args.gpus)
+        raise SystemExit("bench.py --gpus %d inside a world of %d ranks" % (args.gpus, world))
     # Debug aid for a 1-GPU box: TSDF_BENCH_SHARE_GPU=1 puts every rank on device 0 and uses gloo for the
     # collective, so the N>1 code path can be exercised (the numbers mean nothing then).
     share = os.environ.get("TSDF_BENCH_SHARE_GPU") == "1"
     if share:
         local_rank = 0
+    elif world > torch.cuda.device_count():
+        raise SystemExit("bench.py --gpus %d: this node shows %d GPU(s) (TSDF_BENCH_SHARE_GPU=1 walks the N > 1 path with every rank on "
+                         "GPU 0 over gloo; its numbers mean nothing)" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     sharded = world > 1 or args.one_rank_slab_path
     if world == 1 and sharded:   # (a world of one, without torchrun)
@@ -333,29 +354,37 @@ def main():
     del pool
 
     trace("event pool grown")
-    # ---- warmup, then the timed region -------------------------------------------------------------
-    for i in range(Wu):
-        step(i, False)
-    torch.cuda.synchronize()
+    # ---- warmup, then the timed region; R times, each on a freshly cleared volume fed the same frames (the spread is the box's noise,
+    # not a different workload) --------------------------------------------------------------------------
     period = args.event_period if args.event_period > 0 else 0
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(Wu, Wu + K):
-        step(i, period > 0 and (i - Wu) % period == 0, period > 0 and (i + 1 - Wu) % period == 0 and i + 1 < Wu + K)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if sharded:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    R = max(1, args.repeats)
+    runs, run_bits = [], []
+    for rep in range(R):
+        if rep:
+            vol.clear()
+        for i in range(Wu):
+            step(i, False)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(Wu, Wu + K):
+            step(i, period > 0 and (i - Wu) % period == 0, period > 0 and (i + 1 - Wu) % period == 0 and i + 1 < Wu + K)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        elapsed_r = time.perf_counter() - t0
+        if sharded:
+            t = torch.tensor([elapsed_r], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed_r = float(t.item())
+        runs.append(elapsed_r)
+        # order-independent, exact: the sum of the 32-bit patterns of every word of the maps, as signed integers (what tools/kinfu_stream.cpp prints)
+        run_bits.append((int(vert_dev.view(torch.int32).to(torch.int64).sum().item()), int(norm_dev.view(torch.int32).to(torch.int64).sum().item())))
+    elapsed = float(np.median(runs))
     checksum = float(torch.nan_to_num(vert_dev.double(), nan=0.0).sum().item())   # the picture of the last timed frame
     last_vertices = vert_dev.clone()
-    # order-independent, exact: the sum of the 32-bit patterns of every word of the maps, as signed integers (what tools/kinfu_stream.cpp prints)
-    bits_v = int(vert_dev.view(torch.int32).to(torch.int64).sum().item())
-    bits_n = int(norm_dev.view(torch.int32).to(torch.int64).sum().item())
+    bits_v, bits_n = run_bits[-1]
 
     trace("timed region done")
     # ---- untimed replays of the SAME K frames: (1) every stage and every launch of the dominant kernels bracketed with HIP
@@ -364,6 +393,10 @@ def main():
     # src/TSDF/TSDFVolume.cu:355,366 -- so the byte model prices exactly the launches that were timed)
     for s_ in stage_names:
         ev[s_].clear()
+    vol.clear()                    # the replay starts from the state the timed regions started from: cleared + the warm-up frames
+    for i in range(Wu):
+        step(i, False)
+    torch.cuda.synchronize()
     vol.set_timing(1)
     for i in range(Wu, Wu + K):
         step(i, True, True)
@@ -403,9 +436,12 @@ def main():
         "steps": K,
         "warmup": Wu,
         "event_period": period,     # HIP events inside the timed region on every n-th step (0 = none)
-        "stage_and_kernel_times_from": "untimed replay of the %d timed frames, one stage after the other (no overlap), every launch bracketed with "
-                                       "HIP events on the launch stream" % K,
+        "stage_and_kernel_times_from": "untimed replay of the %d timed frames from the same volume state (cleared + the warm-up frames), one stage "
+                                       "after the other (no overlap), every launch bracketed with HIP events on the launch stream" % K,
         "ms_per_step": round(ms_per_step, 4),
+        "ms_per_step_is": "median of %d timed regions of %d steps, each on a freshly cleared volume fed the same %d warm-up + %d timed frames" % (R, K, Wu, K),
+        "ms_per_step_runs": [round(r_ * 1e3 / K, 4) for r_ in runs],
+        "picture_bits_equal_across_runs": bool(all(b_ == run_bits[0] for b_ in run_bits)),
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
@@ -486,7 +522,7 @@ def main():
             out["icp"] = icp_tracking(tsdf_amd, synth, depth_dev, frames, stream, not args.no_cpu_baseline)
             out["tracking"] = tracking_loop(tsdf_amd, synth, n, args.physical, args.stream_frames)
         if not args.no_parity:
-            out["parity"] = parity_gate(tsdf_amd, synth, n_small=96)
+            out["parity"] = parity_gate(tsdf_amd, frames, cams, args.parity_grid or n, args.physical, Wu, K)
             out["parity"]["note"] = ("GPU vs oracle, bit for bit.  The oracle's integrate / ray-cast legs are a line-by-line restatement "
                                      "(the reference holds no vectors for them: parity unpinned); the 16-bit bilateral follows semantics "
                                      "defined here (the reference's 16-bit path is undefined behaviour), its 8-bit path is pinned on the "
@@ -682,39 +718,62 @@ def load_traffic(args):
     return d.get("bytes_per_launch", {}), meta
 
 
-def parity_gate(tsdf_amd, synth, n_small):
-    """GPU vs CPU oracle on a reduced grid (first and last frame of a short stream), as SURVEY.md 8d asks.
-    The oracle is the checker here, nothing it computes is timed or reported as a result."""
+def parity_gate(tsdf_amd, frames, cams, n, physical, Wu, K):
+    """GPU vs CPU oracle on the BENCHMARKED grid and frames: both replay the warm-up and the K timed frames
+    (bilateral -> integrate, host-buffer calls); after the first and after the last timed frame the whole volume is compared bit
+    for bit and every 4th image row is ray cast by both.  The oracle is the checker here, nothing it computes is timed or reported
+    as a result."""
     import oracle as O
-    gv = tsdf_amd.TSDFVolume((n_small,) * 3, (3000.0,) * 3)
-    ov = O.Volume((n_small,) * 3, (3000.0,) * 3)
+    threads = O.max_threads()
+    gv = tsdf_amd.TSDFVolume((n,) * 3, (physical,) * 3)
+    ov = O.Volume((n,) * 3, (physical,) * 3)
     bil = tsdf_amd.BilateralFilter(30.0, 4.5)
-    res = {"grid": n_small, "frames": 3}
-    for i in (0, 1, 2):
-        d, cam = synth.depth_frame(i, 200, seed=SEED)
-        f = d.copy()
+    row_step = 4
+    res = {"grid": n, "frames": Wu + K, "compared_after_frames": [Wu + 1, Wu + K], "ray_rows": "every %dth" % row_step,
+           "bilateral_mismatch": 0, "weight_mismatch": 0, "dist_bit_mismatch": 0, "dist_max_rel_err": 0.0,
+           "nan_mask_mismatch": 0, "vertex_bit_mismatch": 0, "vertex_max_rel_err": 0.0, "normal_max_abs_err": 0.0, "rays_compared": 0}
+    t0 = time.perf_counter()
+    for i in range(Wu + K):
+        f = frames[i].copy()
         bil.filter(f, W, H)
-        fo = O.bilateral_u16(d, W, H, 30.0, 4.5, nthreads=O.max_threads()).reshape(-1)
-        res["bilateral_mismatch"] = res.get("bilateral_mismatch", 0) + int((f != fo).sum())
-        gv.integrate(f, W, H, cam)
-        ov.integrate(fo, W, H, cam.inverse_pose(), cam.k(), cam.kinv(), nthreads=O.max_threads())
-    gd, gw = gv.get_distance_data(), gv.get_weight_data()
-    res["weight_mismatch"] = int((gw != ov.weight).sum())
-    m = ov.weight > 0
-    rel = np.abs(gd[m] - ov.dist[m]) / np.maximum(np.abs(ov.dist[m]), 1e-6)
-    res["dist_max_rel_err"] = float(rel.max()) if m.any() else 0.0
-    res["dist_bit_mismatch"] = int((gd.view(np.uint32) != ov.dist.view(np.uint32)).sum())
-    d, cam = synth.depth_frame(0, 200, seed=SEED)
-    V, Nn = gv.raycast(W, H, cam)
-    Vo, No = ov.raycast(W, H, cam.pose(), cam.kinv(), nthreads=O.max_threads())
-    res["nan_mask_mismatch"] = int((np.isnan(V) != np.isnan(Vo)).sum())
-    ok = ~np.isnan(Vo)
-    res["vertex_max_rel_err"] = float((np.abs(V[ok] - Vo[ok]) / np.maximum(np.abs(Vo[ok]), 1e-6)).max()) if ok.any() else 0.0
-    okn = np.isfinite(No)
-    res["normal_max_abs_err"] = float(np.abs(Nn[okn] - No[okn]).max()) if okn.any() else 0.0
+        fo = O.bilateral_u16(frames[i], W, H, 30.0, 4.5, nthreads=threads).reshape(-1)
+        res["bilateral_mismatch"] += int((f != fo).sum())
+        gv.integrate(f, W, H, cams[i])
+        ov.integrate(fo, W, H, cams[i].inverse_pose(), cams[i].k(), cams[i].kinv(), nthreads=threads)
+        if i not in (Wu, Wu + K - 1):
+            continue
+        gd, gw = gv.get_distance_data(), gv.get_weight_data()
+        res["weight_mismatch"] += int((gw != ov.weight).sum())
+        res["dist_bit_mismatch"] += int((gd.view(np.uint32) != ov.dist.view(np.uint32)).sum())
+        m = ov.weight > 0
+        if m.any():
+            res["dist_max_rel_err"] = max(res["dist_max_rel_err"], float((np.abs(gd[m] - ov.dist[m]) / np.maximum(np.abs(ov.dist[m]), 1e-6)).max()))
+        del gd, gw, m
+        V, Nn = gv.raycast(W, H, cams[i])
+        Vo, _ = ov.raycast_rows(W, H, cams[i].pose(), cams[i].kinv(), 0, H, row_step, nthreads=threads)
+        rows = np.arange(0, H, row_step)
+        Vg = V.reshape(H, W, 3)[rows].reshape(-1, 3)
+        Vo = np.asarray(Vo, np.float32).reshape(H, W, 3)[rows].reshape(-1, 3)
+        res["rays_compared"] += int(Vo.shape[0])
+        res["nan_mask_mismatch"] += int((np.isnan(Vg) != np.isnan(Vo)).sum())
+        same = (Vg.view(np.uint32) == Vo.view(np.uint32)) | (np.isnan(Vg) & np.isnan(Vo))
+        res["vertex_bit_mismatch"] += int((~same).sum())
+        ok = ~np.isnan(Vo) & ~np.isnan(Vg)
+        if ok.any():
+            res["vertex_max_rel_err"] = max(res["vertex_max_rel_err"], float((np.abs(Vg[ok] - Vo[ok]) / np.maximum(np.abs(Vo[ok]), 1e-6)).max()))
+        # normals of the compared rows whose lower neighbour row was cast too would need consecutive rows: the oracle's normals of
+        # the GPU's own vertex map instead (compute_normals is a function of the vertex map alone, GPURaycaster.cu:393-427)
+        No = O.normals(W, H, V)
+        okn = np.isfinite(No)
+        res["nan_mask_mismatch"] += int((np.isnan(Nn) != np.isnan(No)).sum())
+        if okn.any():
+            res["normal_max_abs_err"] = max(res["normal_max_abs_err"], float(np.abs(Nn[okn] - No[okn]).max()))
+    res["seconds"] = round(time.perf_counter() - t0, 2)
+    res["oracle_threads"] = threads
     res["pass"] = bool(res["weight_mismatch"] == 0 and res["dist_max_rel_err"] <= 1e-4 and res["nan_mask_mismatch"] == 0
                        and res["vertex_max_rel_err"] <= 1e-4 and res["normal_max_abs_err"] <= 1e-4
                        and res["bilateral_mismatch"] == 0)
+    gv.close()
     return res
 
 

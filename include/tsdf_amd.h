@@ -80,6 +80,8 @@ int tsdf_device_alloc(size_t bytes, void **device_ptr);
 int tsdf_device_free(void *device_ptr);
 int tsdf_device_upload(void *device_dst, const void *host_src, size_t bytes);
 int tsdf_device_download(void *host_dst, const void *device_src, size_t bytes);
+/* hipStreamSynchronize for the same callers (e.g. a tsdf_exchange_fn that stages the records through the host). */
+int tsdf_stream_synchronize(void *hip_stream);
 
 /* ---- volume lifecycle ------------------------------------------------------------------ */
 /* Replaces TSDFVolume::TSDFVolume / set_size (src/TSDF/TSDFVolume.cu:430-457, 679-722):
@@ -97,6 +99,7 @@ int tsdf_volume_create_slab(uint32_t size_x, uint32_t size_y, uint32_t size_z, f
 int tsdf_volume_destroy(tsdf_volume *volume);
 /* HIP stream (hipStream_t) used by this volume's kernels and copies; NULL = default stream. */
 int tsdf_volume_set_stream(tsdf_volume *volume, void *hip_stream);
+int tsdf_volume_stream(const tsdf_volume *volume, void **hip_stream);   /* the stream the volume's kernels are enqueued on now */
 int tsdf_volume_synchronize(const tsdf_volume *volume);
 /* Replaces TSDFVolume::clear (src/TSDF/TSDFVolume.cu:812-845): weights <- 0,
  * distances <- truncation distance, deformation grid <- voxel centres + current offset. */
@@ -122,7 +125,10 @@ int tsdf_volume_set_header(tsdf_volume *volume, const float offset[3], float tru
  * same float expression as initialise_deformation, src/TSDF/TSDFVolume.cu:783-785). */
 int tsdf_volume_distances(const tsdf_volume *volume, float **device_ptr);
 /* Call after writing distances through the raw device pointer (the reference only ever reads through it):
- * the ray caster's brick-occupancy summary is rebuilt before the next ray cast. */
+ * the ray caster's brick-occupancy summary is rebuilt before the next ray cast.  Writes through the raw pointers must be
+ * ORDERED ON THE VOLUME'S STREAM (tsdf_volume_set_stream / tsdf_pipeline_streams), after the tsdf_volume_distances /
+ * tsdf_volume_weights / tsdf_volume_mark_dirty call that precedes them: those calls make that stream wait for a tightening of
+ * the occupancy flags that tsdf_pipeline_step may have left running on its second stream (it reads the distances). */
 int tsdf_volume_mark_dirty(tsdf_volume *volume);
 int tsdf_volume_weights(const tsdf_volume *volume, float **device_ptr);
 int tsdf_volume_deformation(tsdf_volume *volume, tsdf_deformation_node **device_ptr);
@@ -299,7 +305,10 @@ int tsdf_slab_exchange_destroy(tsdf_slab_exchange *exchange);
  * and the merge to a third stream so that the next frame's integrate need not wait for the collective (results are then
  * ordered behind tsdf_pipeline_synchronize only).  The pipeline owns its streams, events, the two filtered frames + tile
  * maxima and the record buffers; while it lives the volume's stream is the pipeline's (tsdf_pipeline_streams), restored
- * by tsdf_pipeline_destroy.  All pointers are device pointers: width * height uint16 depth (it must stay valid until the step
+ * by tsdf_pipeline_destroy.  A volume takes ONE pipeline or tracker at a time: tsdf_pipeline_create / tsdf_tracker_create on a
+ * volume that is still attached return TSDF_ERR_INVALID (destroy the previous one first).  A frame announced as `next` is
+ * recognised in the following step BY ITS DEVICE POINTER: every frame in flight needs a buffer of its own -- refilling one staging
+ * buffer between the announcement and the step integrates the image that was filtered ahead, not the new contents.  All pointers are device pointers: width * height uint16 depth (it must stay valid until the step
  * after the one it was announced to has run), 3 * width * height floats per map (device_normals may be NULL). */
 typedef struct tsdf_pipeline tsdf_pipeline;
 typedef struct tsdf_camera_matrices {   /* camera.pose(), inverse_pose(), k(), kinv(): column-major, as everywhere in this header */
@@ -352,6 +361,7 @@ int tsdf_icp_create(int width, int height, float cx, float cy, float fx, float f
                     tsdf_icp **out);
 void tsdf_icp_destroy(tsdf_icp *icp);
 int tsdf_icp_set_stream(tsdf_icp *icp, void *hip_stream);
+int tsdf_icp_stream(const tsdf_icp *icp, void **hip_stream);   /* the stream its kernels are enqueued on now */
 /* ICPOdometry::initICP (model = 0, ICPOdometry.cpp:64-78) / initICPModel (model = 1, :80-95): upload the depth (uint16 mm),
  * pyrDown twice, createVMap + createNMap per level (Cuda/pyrdown.cu).  The host variant synchronises like the reference;
  * the _device variant takes a device pointer and does not. */

@@ -38,6 +38,21 @@ def test_tum_directory_read_back_through_the_host_loader(tmp_path):
         tsdf_amd.load_tum_directory(str(tmp_path / "missing"))
 
 
+def test_a_missing_or_corrupt_frame_is_an_error_not_the_end_of_the_stream(tmp_path):
+    """ADVICE r03: the C wrapper of TUMDataLoader::next told exhaustion, a missing PNG and a corrupt PNG apart by nothing; a
+    truncated stream would have become a different workload without a word."""
+    synth.write_tum_directory(str(tmp_path), 4, seed=0x5EED0002)
+    pngs = sorted(os.listdir(tmp_path / "depth"))
+    os.rename(tmp_path / "depth" / pngs[2], tmp_path / "depth" / "moved_away.png")
+    with pytest.raises(ValueError, match="record 2"):
+        tsdf_amd.load_tum_directory(str(tmp_path))
+    os.rename(tmp_path / "depth" / "moved_away.png", tmp_path / "depth" / pngs[2])
+    with open(tmp_path / "depth" / pngs[1], "wb") as f:
+        f.write(b"not a png at all")
+    with pytest.raises(ValueError, match="record 1"):
+        tsdf_amd.load_tum_directory(str(tmp_path))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("overlap", [True, False])
 def test_kinfu_stream_matches_the_oracle_and_the_python_mirror(tmp_path, oracle, overlap):
@@ -134,3 +149,33 @@ def test_kinfu_stream_tracks_like_the_python_mirror(tmp_path):
         assert_same_floats(np.fromfile(str(out / "distances.f32"), np.float32), vol.get_distance_data(), "C++ tracked volume vs the Python mirror's")
     tracker.close()
     vol.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_kinfu_stream_ranks_gives_the_single_volume_picture(tmp_path, ranks):
+    """kinfu_stream --ranks P (round 4): the sharded step of SURVEY.md 8e from C++ -- one forked process per Z-slab, slab integrate +
+    slab ray cast + all-gather of the hit records + min-k merge through tsdf_pipeline_step -- with no Python in it.  On a box with
+    fewer GPUs than ranks the ranks share GPU 0 and the records travel through host shared memory (a tsdf_exchange_fn); with P GPUs
+    the same command runs ncclAllGather.  The merged picture and the slabs' distances must be the single-volume run's, bit for bit."""
+    n, F, Wu, K = 96, 5, 2, 5
+    d = tmp_path / "tum"
+    synth.write_tum_directory(str(d), F, seed=0x5EED0003, stream_frames=40)
+    one, many = tmp_path / "one", tmp_path / "many"
+    one.mkdir(); many.mkdir()
+    base = [BIN, "-d", str(d), "-n", str(n), "-k", str(K), "-w", str(Wu)]
+    r1 = subprocess.run(base + ["--dump", str(one)], capture_output=True, text=True, timeout=300)
+    assert r1.returncode == 0, r1.stdout + r1.stderr
+    rp = subprocess.run(base + ["--ranks", str(ranks), "--dump", str(many)], capture_output=True, text=True, timeout=600)
+    assert rp.returncode == 0, rp.stdout + rp.stderr
+    lines = [l for l in rp.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly one JSON line"
+    a, b = json.loads(r1.stdout.strip().splitlines()[-1]), json.loads(lines[0])
+    assert b["ranks"] == ranks and b["ranks_hold_the_same_picture"] is True and b["steps"] == K
+    assert b["last_frame_vertex_bits"] == a["last_frame_vertex_bits"] and b["last_frame_normal_bits"] == a["last_frame_normal_bits"]
+    assert b["last_frame_hits"] == a["last_frame_hits"] > 1000
+    assert_same_floats(np.fromfile(str(many / "vertices.f32"), np.float32), np.fromfile(str(one / "vertices.f32"), np.float32), "merged picture")
+    whole = np.fromfile(str(one / "distances.f32"), np.float32).reshape(n, n * n)
+    for r in range(ranks):
+        z0, z1 = n * r // ranks, n * (r + 1) // ranks
+        assert_same_floats(np.fromfile(str(many / ("distances.rank%d.f32" % r)), np.float32), whole[z0:z1], "slab %d distances" % r)

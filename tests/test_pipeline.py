@@ -218,3 +218,36 @@ def test_a_prepared_brick_list_does_not_outlive_the_state_it_was_culled_for(orac
                  nthreads=oracle.max_threads())
     assert_same_floats(gv.get_weight_data(), ov.weight, "image rewritten after the preparation: weights")
     assert_same_floats(gv.get_distance_data(), ov.dist, "image rewritten after the preparation: distances")
+
+
+def test_a_volume_takes_one_pipeline_or_tracker_at_a_time():
+    """two attachments restored each other's (destroyed) streams.  A second one is refused now; once the
+    first has gone the volume is back on the stream it had, and the next attachment works."""
+    from tsdf_amd.pipeline import FusionPipeline
+    from tsdf_amd.tracking import FrameToModelTracker
+    vol = tsdf_amd.TSDFVolume((32, 32, 32), (3000.0,) * 3)
+    bil, rc = tsdf_amd.BilateralFilter(30.0, 4.5), tsdf_amd.GPURaycaster(W, H)
+    before = vol.stream_ptr()
+    a = FusionPipeline(vol, bil, rc, W, H)
+    assert vol.stream_ptr() == a.main.cuda_stream != before
+    with pytest.raises((ValueError, tsdf_amd.TsdfError), match="attached"):
+        FusionPipeline(vol, bil, rc, W, H)
+    with pytest.raises((ValueError, tsdf_amd.TsdfError), match="attached"):
+        FrameToModelTracker(vol, W, H)
+    assert vol.stream_ptr() == a.main.cuda_stream          # the refused attempts changed nothing
+    a.close()
+    assert vol.stream_ptr() == before
+    t = FrameToModelTracker(vol, W, H)
+    with pytest.raises((ValueError, tsdf_amd.TsdfError), match="attached"):
+        FusionPipeline(vol, bil, rc, W, H)
+    t.close()
+    assert vol.stream_ptr() == before
+    b = FusionPipeline(vol, bil, rc, W, H)                  # rebinding after an explicit close is fine
+    d, cam = synth.depth_frame(0, 10, seed=3)
+    import torch
+    dd = torch.from_numpy(d.view(np.int16)).cuda()
+    v = torch.empty((H * W, 3), dtype=torch.float32, device="cuda")
+    b.step(dd.data_ptr(), cam, v.data_ptr())
+    b.synchronize()
+    b.close()
+    vol.close()

@@ -8,13 +8,25 @@
 // the same entry points from Python: same checksum, same ms per step (tools/compare_drivers.sh).
 //
 //   kinfu_stream -d <tum dir> [-n grid=512] [-p physical_mm=3000] [-k steps=20] [-w warmup=5] [--no-overlap]
-//                [--no-cull-ahead] [--dump <dir>] [--track]
+//                [--no-cull-ahead] [--dump <dir>] [--track] [--ranks P] [--share-gpu]
+//   --ranks P: the volume in P Z-slabs, one PROCESS per slab (fork, before anything touches the GPU), each on its own GPU: slab
+//           integrate + slab ray cast, the frame's all-gather of 8-byte hit records (tsdf_slab_exchange_*: RCCL on the step's
+//           stream, the 128-byte id from rank 0 through shared memory) and the min-k merge on every rank, all through
+//           tsdf_pipeline_step -- SURVEY.md 8e with no Python and no torch anywhere.  Rank 0 prints the line; the merged picture's
+//           checksum must be the single-volume run's.  With fewer GPUs than ranks (or --share-gpu) every rank uses GPU 0 and the
+//           records travel through host shared memory (a tsdf_exchange_fn): the N > 1 code path on a one-GPU box, timings meaningless.
 //   --track: BASELINE configs[4]'s loop instead -- the first frame at its ground-truth pose, every later one tracked against the model
 //           (tsdf_tracker_filter / _align / _integrate: what src/Tools/tsdf_icp.cpp:115-198 does for one frame, composed with kinfu's
 //           integrate; the pose is composed here with the Camera class); the first -k frames of the directory, one JSON line with the
 //           time per frame and the distance of the last pose from its ground truth; --dump writes the tracked poses (poses.f32)
 //   --dump: the last picture (vertices.f32, normals.f32), the final volume (distances.f32, weights.f32) and every frame's
 //           pose (poses.f32, 16 floats each, column-major) as raw files, for tests/test_cpp_stream.py
+#include <pthread.h>
+#include <signal.h>
+#include <sys/mman.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -58,8 +70,35 @@ static tsdf_camera_matrices matrices_of(const Camera &cam) {
     return m;
 }
 
+// ---- --ranks P: what the processes share (one anonymous shared mapping made before the fork) -------------------------------
+constexpr int kMaxRanks = 64;
+struct Shared {
+    pthread_barrier_t barrier;
+    uint8_t id[TSDF_EXCHANGE_ID_BYTES];
+    double elapsed[kMaxRanks];
+    long long bits_v[kMaxRanks], bits_n[kMaxRanks];
+    int use_rccl;
+};
+struct ShmGather {   // user data of the host-staged all-gather (one GPU shared by every rank)
+    Shared *shared;
+    tsdf_hit_record *records;   // world x n_pixels, in the shared mapping
+    int rank, world;
+};
+// tsdf_exchange_fn: rank r's records to slot r of the shared mapping, everybody's back to the device.  Blocking; correctness only.
+static int shm_all_gather(void *user, const tsdf_hit_record *device_mine, tsdf_hit_record *device_all, uint32_t n_pixels, void *hip_stream) {
+    ShmGather *g = (ShmGather *)user;
+    if (tsdf_stream_synchronize(hip_stream) != TSDF_OK) return TSDF_ERR_DEVICE;
+    if (tsdf_device_download(g->records + (size_t)g->rank * n_pixels, device_mine, (size_t)n_pixels * sizeof(tsdf_hit_record)) != TSDF_OK) return TSDF_ERR_DEVICE;
+    pthread_barrier_wait(&g->shared->barrier);
+    if (tsdf_device_upload(device_all, g->records, (size_t)n_pixels * g->world * sizeof(tsdf_hit_record)) != TSDF_OK) return TSDF_ERR_DEVICE;
+    pthread_barrier_wait(&g->shared->barrier);   // (nobody overwrites its slot before everybody has read it)
+    return TSDF_OK;
+}
+
 int main(int argc, char **argv) {
     std::string dir, dump_dir;
+    int ranks = 1;
+    bool share_gpu = false;
     unsigned n = 512;
     float physical = 3000.0f;
     int K = 20, Wu = 5;
@@ -82,13 +121,15 @@ int main(int argc, char **argv) {
         else if (a == "--no-cull-ahead") cull_ahead = false;
         else if (a == "--dump") dump_dir = value();
         else if (a == "--track") track = true;
+        else if (a == "--ranks") ranks = std::atoi(value());
+        else if (a == "--share-gpu") share_gpu = true;
         else {
-            std::fprintf(stderr, "usage: kinfu_stream -d <tum dir> [-n grid] [-p physical_mm] [-k steps] [-w warmup] [--no-overlap] [--no-cull-ahead] [--dump dir] [--track]\n");
+            std::fprintf(stderr, "usage: kinfu_stream -d <tum dir> [-n grid] [-p physical_mm] [-k steps] [-w warmup] [--no-overlap] [--no-cull-ahead] [--dump dir] [--track] [--ranks P] [--share-gpu]\n");
             return 2;
         }
     }
-    if (dir.empty() || K < 1 || Wu < 0 || n < 1) {
-        std::fprintf(stderr, "kinfu_stream: -d <tum dir>, -k >= 1, -w >= 0, -n >= 1\n");
+    if (dir.empty() || K < 1 || Wu < 0 || n < 1 || ranks < 1 || ranks > kMaxRanks || (unsigned)ranks > n || (track && ranks > 1)) {
+        std::fprintf(stderr, "kinfu_stream: -d <tum dir>, -k >= 1, -w >= 0, -n >= 1, 1 <= --ranks <= min(%d, grid), --track is single-volume\n", kMaxRanks);
         return 2;
     }
 
@@ -124,6 +165,60 @@ int main(int argc, char **argv) {
     }
     const size_t F = frames.size(), n_pix = (size_t)W * H;
 
+    // ---- --ranks P: one process per Z-slab, forked here -- nothing has touched the GPU yet, every child starts its own HIP runtime
+    int rank = 0;
+    Shared *shared = nullptr;
+    tsdf_hit_record *shared_records = nullptr;
+    if (ranks > 1) {
+        const size_t bytes = sizeof(Shared) + n_pix * (size_t)ranks * sizeof(tsdf_hit_record);
+        void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+        if (m == MAP_FAILED) {
+            std::perror("kinfu_stream: mmap");
+            return 1;
+        }
+        shared = new (m) Shared();
+        shared_records = (tsdf_hit_record *)((char *)m + sizeof(Shared));
+        pthread_barrierattr_t attr;
+        pthread_barrierattr_init(&attr);
+        pthread_barrierattr_setpshared(&attr, PTHREAD_PROCESS_SHARED);
+        pthread_barrier_init(&shared->barrier, &attr, (unsigned)ranks);
+        std::fflush(stdout);
+        std::fflush(stderr);
+        std::vector<pid_t> kids;
+        bool child = false;
+        for (int r = 0; r < ranks && !child; r++) {
+            const pid_t pid = fork();
+            if (pid < 0) {
+                std::perror("kinfu_stream: fork");
+                for (pid_t k_ : kids) kill(k_, SIGKILL);
+                return 1;
+            }
+            if (pid == 0) {
+                rank = r;
+                child = true;
+            } else {
+                kids.push_back(pid);
+            }
+        }
+        if (!child) {   // the launcher: wait for the ranks; one failing takes the others (blocked in a barrier) with it
+            int failed = 0;
+            for (size_t left = kids.size(); left > 0; left--) {
+                int status = 0;
+                const pid_t done = wait(&status);
+                if (done < 0) break;
+                if (!(WIFEXITED(status) && WEXITSTATUS(status) == 0) && !failed) {
+                    failed = 1;
+                    for (pid_t k_ : kids) if (k_ != done) kill(k_, SIGKILL);
+                }
+            }
+            return failed;
+        }
+    }
+    int n_devices = 0;
+    ok(tsdf_device_count(&n_devices), "device count");
+    const bool use_rccl = ranks > 1 && !share_gpu && ranks <= n_devices;
+    if (ranks > 1) ok(tsdf_set_device(use_rccl ? rank : 0), "set device");
+
     // ---- everything resident in HBM before the clock starts ---------------------------------------------------------------
     uint16_t *depth_dev = nullptr;
     float *vert_dev = nullptr, *norm_dev = nullptr;
@@ -134,7 +229,21 @@ int main(int argc, char **argv) {
     tsdf_volume *vol = nullptr;
     tsdf_bilateral *bil = nullptr;
     tsdf_pipeline *pipe = nullptr;
-    ok(tsdf_volume_create(n, n, n, physical, physical, physical, &vol), "volume");
+    tsdf_slab_exchange *exch = nullptr;
+    ShmGather shm_gather = {shared, shared_records, rank, ranks};
+    const uint32_t z_begin = (uint32_t)((uint64_t)n * rank / ranks), z_end = (uint32_t)((uint64_t)n * (rank + 1) / ranks);   // equal plane counts
+    if (ranks == 1) {
+        ok(tsdf_volume_create(n, n, n, physical, physical, physical, &vol), "volume");
+    } else {
+        ok(tsdf_volume_create_slab(n, n, n, physical, physical, physical, z_begin, z_end, &vol), "slab volume");
+        if (use_rccl) {
+            if (rank == 0) ok(tsdf_slab_exchange_unique_id(shared->id, nullptr), "RCCL unique id");
+            pthread_barrier_wait(&shared->barrier);
+            ok(tsdf_slab_exchange_create(rank, ranks, shared->id, nullptr, &exch), "slab exchange (RCCL)");
+        } else {
+            ok(tsdf_slab_exchange_create_callback(rank, ranks, shm_all_gather, &shm_gather, &exch), "slab exchange (shared memory)");
+        }
+    }
     ok(tsdf_bilateral_create(30.0f, 4.5f, &bil), "bilateral filter");
 
     if (track) {
@@ -200,7 +309,7 @@ int main(int argc, char **argv) {
         (void)tsdf_device_free(norm_dev);
         return 0;
     }
-    ok(tsdf_pipeline_create(vol, bil, W, H, overlap ? TSDF_PIPELINE_OVERLAP : 0, nullptr, &pipe), "pipeline");
+    ok(tsdf_pipeline_create(vol, bil, W, H, overlap ? TSDF_PIPELINE_OVERLAP : 0, exch, &pipe), "pipeline");
 
     auto step = [&](int i) {
         const size_t f = (size_t)i % F, g = (size_t)(i + 1) % F;
@@ -209,10 +318,12 @@ int main(int argc, char **argv) {
     };
     for (int i = 0; i < Wu; i++) step(i);
     ok(tsdf_pipeline_synchronize(pipe), "synchronize");
+    if (shared) pthread_barrier_wait(&shared->barrier);
     const auto t0 = std::chrono::steady_clock::now();
     for (int i = Wu; i < Wu + K; i++) step(i);
     ok(tsdf_pipeline_synchronize(pipe), "synchronize");
-    const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (shared) pthread_barrier_wait(&shared->barrier);
+    double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 
     // ---- the last picture: checksum = sum of the 32-bit patterns of every word, as signed integers (order independent, exact) --
     std::vector<float> V(n_pix * 3), N(n_pix * 3);
@@ -227,13 +338,43 @@ int main(int argc, char **argv) {
         bits_n += w;
     }
     for (size_t i = 0; i < n_pix; i++) hits += !std::isnan(V[3 * i]);
+    bool ranks_agree = true;
+    if (shared) {   // the step is as long as its slowest rank; every rank holds the merged picture: the checksums must agree
+        shared->elapsed[rank] = elapsed;
+        shared->bits_v[rank] = bits_v;
+        shared->bits_n[rank] = bits_n;
+        pthread_barrier_wait(&shared->barrier);
+        for (int r = 0; r < ranks; r++) {
+            elapsed = std::max(elapsed, shared->elapsed[r]);
+            ranks_agree = ranks_agree && shared->bits_v[r] == bits_v && shared->bits_n[r] == bits_n;
+        }
+    }
     const double ms = elapsed * 1e3 / K, voxels = (double)n * n * n;
-    std::printf("{\"driver\": \"tools/kinfu_stream.cpp (C++, tsdf_pipeline_step)\", \"grid\": %u, \"image\": [%u, %u], \"frames_in_directory\": %zu, "
-                "\"steps\": %d, \"warmup\": %d, \"overlap\": %s, \"cull_ahead\": %s, \"ms_per_step\": %.4f, \"value\": %.3f, \"unit\": \"Mvoxels/s\", "
-                "\"last_frame_vertex_bits\": %lld, \"last_frame_normal_bits\": %lld, \"last_frame_hits\": %lld}\n",
-                n, W, H, F, K, Wu, overlap ? "true" : "false", cull_ahead ? "true" : "false", ms, voxels * K / elapsed / 1e6, bits_v, bits_n, hits);
+    if (rank == 0) {
+        if (ranks > 1)
+            std::printf("{\"driver\": \"tools/kinfu_stream.cpp --ranks (C++, one process per Z-slab, tsdf_pipeline_step + tsdf_slab_exchange)\", \"ranks\": %d, "
+                        "\"exchange\": \"%s\", \"slab_planes\": %u, \"ranks_hold_the_same_picture\": %s, ",
+                        ranks, use_rccl ? "ncclAllGather on the step's stream (librccl, id through shared memory)" : "host shared memory, every rank on GPU 0 (timings meaningless)",
+                        z_end - z_begin, ranks_agree ? "true" : "false");
+        else
+            std::printf("{\"driver\": \"tools/kinfu_stream.cpp (C++, tsdf_pipeline_step)\", ");
+        std::printf("\"grid\": %u, \"image\": [%u, %u], \"frames_in_directory\": %zu, "
+                    "\"steps\": %d, \"warmup\": %d, \"overlap\": %s, \"cull_ahead\": %s, \"ms_per_step\": %.4f, \"value\": %.3f, \"unit\": \"Mvoxels/s\", "
+                    "\"last_frame_vertex_bits\": %lld, \"last_frame_normal_bits\": %lld, \"last_frame_hits\": %lld}\n",
+                    n, W, H, F, K, Wu, overlap ? "true" : "false", cull_ahead ? "true" : "false", ms, voxels * K / elapsed / 1e6, bits_v, bits_n, hits);
+    }
 
-    if (!dump_dir.empty()) {
+    if (!dump_dir.empty() && ranks > 1) {   // the merged picture (rank 0) and every rank's slab of the volume (its own planes, without the halo)
+        if (rank == 0) {
+            dump(dump_dir + "/vertices.f32", V.data(), V.size() * sizeof(float));
+            dump(dump_dir + "/normals.f32", N.data(), N.size() * sizeof(float));
+        }
+        tsdf_volume_info info;
+        ok(tsdf_volume_get_info(vol, &info), "volume info");
+        std::vector<float> a((size_t)n * n * (info.z_store_end - info.z_store_begin));
+        ok(tsdf_volume_get_distance_data(vol, a.data()), "distances");
+        dump(dump_dir + "/distances.rank" + std::to_string(rank) + ".f32", a.data(), (size_t)n * n * (z_end - z_begin) * sizeof(float));
+    } else if (!dump_dir.empty()) {
         dump(dump_dir + "/vertices.f32", V.data(), V.size() * sizeof(float));
         dump(dump_dir + "/normals.f32", N.data(), N.size() * sizeof(float));
         std::vector<float> a((size_t)n * n * n);
@@ -247,10 +388,12 @@ int main(int argc, char **argv) {
     }
 
     ok(tsdf_pipeline_destroy(pipe), "pipeline");
+    if (exch) ok(tsdf_slab_exchange_destroy(exch), "slab exchange");
     ok(tsdf_bilateral_destroy(bil), "bilateral filter");
     ok(tsdf_volume_destroy(vol), "volume");
     (void)tsdf_device_free(depth_dev);
     (void)tsdf_device_free(vert_dev);
     (void)tsdf_device_free(norm_dev);
-    return 0;
+    std::fflush(stdout);
+    return (shared && !ranks_agree) ? 1 : 0;
 }

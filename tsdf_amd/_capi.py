@@ -62,10 +62,12 @@ _SIGS = {
     "tsdf_device_free": (_i, [_vp]),
     "tsdf_device_upload": (_i, [_vp, _vp, C.c_size_t]),
     "tsdf_device_download": (_i, [_vp, _vp, C.c_size_t]),
+    "tsdf_stream_synchronize": (_i, [_vp]),
     "tsdf_volume_create": (_i, [_u32, _u32, _u32, _f, _f, _f, C.POINTER(_vp)]),
     "tsdf_volume_create_slab": (_i, [_u32, _u32, _u32, _f, _f, _f, _u32, _u32, C.POINTER(_vp)]),
     "tsdf_volume_destroy": (_i, [_vp]),
     "tsdf_volume_set_stream": (_i, [_vp, _vp]),
+    "tsdf_volume_stream": (_i, [_vp, C.POINTER(_vp)]),
     "tsdf_volume_synchronize": (_i, [_vp]),
     "tsdf_volume_clear": (_i, [_vp]),
     "tsdf_volume_get_info": (_i, [_vp, C.POINTER(VolumeInfo)]),
@@ -132,6 +134,7 @@ _SIGS = {
     "tsdf_icp_create": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, C.POINTER(_vp)]),
     "tsdf_icp_destroy": (None, [_vp]),
     "tsdf_icp_set_stream": (_i, [_vp, _vp]),
+    "tsdf_icp_stream": (_i, [_vp, C.POINTER(_vp)]),
     "tsdf_icp_init": (_i, [_vp, _i, _vp, _f]),
     "tsdf_icp_init_device": (_i, [_vp, _i, _vp, _f]),
     "tsdf_icp_estimate_step": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -111,6 +111,12 @@ class TSDFVolume:
     def set_stream(self, hip_stream):
         check(lib.tsdf_volume_set_stream(self._h, C.c_void_p(int(hip_stream) if hip_stream else 0)))
 
+    def stream_ptr(self):
+        """The HIP stream (as an integer, 0 = the null stream) the volume's kernels are enqueued on now."""
+        p = C.c_void_p()
+        check(lib.tsdf_volume_stream(self._h, C.byref(p)))
+        return p.value or 0
+
     def synchronize(self):
         check(lib.tsdf_volume_synchronize(self._h))
 
@@ -576,13 +582,20 @@ def load_tum_directory(directory):
     h = opened()       # the first frame's size (nothing is copied without a buffer)
     got = _capi.host.tsdf_host_tum_next(h, None, 0, size, _fp(pose))
     _capi.host.tsdf_host_tum_close(h)
+    if got < 0:
+        raise ValueError("%s: the first record's depth image is missing or unreadable" % directory)
     if not got:
         return [], (0, 0)
     w, hh = int(size[0]), int(size[1])
     buf, frames = np.zeros(w * hh, np.uint16), []
     h = opened()
     try:
-        while _capi.host.tsdf_host_tum_next(h, buf.ctypes.data, buf.size, size, _fp(pose)):
+        while True:
+            got = _capi.host.tsdf_host_tum_next(h, buf.ctypes.data, buf.size, size, _fp(pose))
+            if got == 0:
+                break
+            if got < 0:     # (a truncated stream would silently become another workload)
+                raise ValueError("%s: record %d of ground_truth.txt has no readable depth image" % (directory, len(frames)))
             if (int(size[0]), int(size[1])) != (w, hh):
                 raise ValueError("depth images of different sizes in %s" % directory)
             cam = Camera.default_depth_camera()

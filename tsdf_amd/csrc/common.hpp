@@ -192,6 +192,9 @@ struct tsdf_volume {
     float global_rotation[3];
     int device;
     hipStream_t stream;
+    // the tsdf_pipeline / tsdf_tracker that has put this volume on its own stream (nullptr: none).  One at a time: a second
+    // attachment is refused, and only the owner's destroy restores the stream the volume had before (pipeline.hip)
+    const void *attached;
     float *dist;
     float *weight;
     tsdf_deformation_node *nodes;  // nullptr while implicit

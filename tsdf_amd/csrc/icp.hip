@@ -583,6 +583,12 @@ void tsdf_icp_destroy(tsdf_icp *f) {
     if (f) free_icp(f);
 }
 
+int tsdf_icp_stream(const tsdf_icp *f, void **hip_stream) {
+    TSDF_REQUIRE(f && hip_stream, "null argument");
+    *hip_stream = f->stream;
+    return TSDF_OK;
+}
+
 int tsdf_icp_set_stream(tsdf_icp *f, void *hip_stream) {
     TSDF_REQUIRE(f, "null ICP handle");
     f->stream = (hipStream_t)hip_stream;

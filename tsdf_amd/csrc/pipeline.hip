@@ -127,7 +127,7 @@ struct tsdf_tracker {
     uint32_t width, height;
     float depth_cutoff;
     hipStream_t main, side;
-    hipStream_t volume_stream_before;
+    hipStream_t volume_stream_before, icp_stream_before;
     uint16_t *filtered[2], *tile_max[2], *model;
     hipEvent_t integrated[2];   // [b]: the integrate that read buffer b is done
     hipEvent_t ready;           // the frame in buffer `cur` has been filtered (and its ICP maps built)
@@ -246,7 +246,11 @@ int tsdf_pipeline_destroy(tsdf_pipeline *p) {
     if (p->main) (void)hipStreamSynchronize(p->main);
     if (p->side) (void)hipStreamSynchronize(p->side);
     if (p->xstream) (void)hipStreamSynchronize(p->xstream);
-    if (p->volume) (void)tsdf_volume_set_stream(p->volume, p->volume_stream_before);
+    if (p->volume && p->volume->attached == p) {   // (this pipeline did put the volume on its stream)
+        (void)tsdf_integrate_discard_prepared(p->volume);
+        (void)tsdf_volume_set_stream(p->volume, p->volume_stream_before);
+        p->volume->attached = nullptr;
+    }
     for (int b = 0; b < 2; b++) {
         if (p->filtered[b]) (void)hipFree(p->filtered[b]);
         if (p->tile_max[b]) (void)hipFree(p->tile_max[b]);
@@ -271,6 +275,9 @@ int tsdf_pipeline_create(tsdf_volume *volume, const tsdf_bilateral *filter, uint
     TSDF_REQUIRE(volume && filter && width > 0 && height > 0 && width <= 65535 && height <= 65535, "tsdf_pipeline_create: bad argument");
     const bool slab = volume->z_begin != 0 || volume->z_end != volume->g.Z;
     TSDF_REQUIRE(exchange || !slab, "tsdf_pipeline_create: a Z-slab needs a slab exchange");
+    // one pipeline or tracker per volume at a time: each puts the volume on its own stream and restores the previous one when it
+    // goes -- two of them would restore each other's (destroyed) streams
+    TSDF_REQUIRE(!volume->attached, "tsdf_pipeline_create: the volume is attached to another pipeline or tracker (destroy that one first)");
     tsdf_pipeline *p = new (std::nothrow) tsdf_pipeline();
     if (!p) {
         set_error("out of host memory");
@@ -311,13 +318,13 @@ int tsdf_pipeline_create(tsdf_volume *volume, const tsdf_bilateral *filter, uint
     }
     if (e != hipSuccess) {
         const int rc = hip_fail(e, "tsdf_pipeline_create");
-        p->volume = nullptr;   // (its stream was not changed yet)
-        tsdf_pipeline_destroy(p);
+        tsdf_pipeline_destroy(p);   // (the volume is not attached yet: its stream stays)
         return rc;
     }
     // whatever the volume has in flight on its previous stream comes before the pipeline's first launch
     (void)hipStreamSynchronize(volume->stream);
     (void)tsdf_volume_set_stream(volume, p->main);
+    volume->attached = p;
     *out = p;
     return TSDF_OK;
 }
@@ -428,8 +435,11 @@ int tsdf_tracker_destroy(tsdf_tracker *t) {
     if (!t) return TSDF_OK;
     if (t->main) (void)hipStreamSynchronize(t->main);
     if (t->side) (void)hipStreamSynchronize(t->side);
-    if (t->volume) (void)tsdf_volume_set_stream(t->volume, t->volume_stream_before);
-    if (t->icp) (void)tsdf_icp_set_stream(t->icp, t->volume_stream_before);
+    if (t->volume && t->volume->attached == t) {
+        (void)tsdf_volume_set_stream(t->volume, t->volume_stream_before);
+        t->volume->attached = nullptr;
+        if (t->icp) (void)tsdf_icp_set_stream(t->icp, t->icp_stream_before);   // (the ICP's own previous stream, not the volume's)
+    }
     for (int b = 0; b < 2; b++) {
         if (t->filtered[b]) (void)hipFree(t->filtered[b]);
         if (t->tile_max[b]) (void)hipFree(t->tile_max[b]);
@@ -449,6 +459,7 @@ int tsdf_tracker_create(tsdf_volume *volume, const tsdf_bilateral *filter, tsdf_
     *out = nullptr;
     TSDF_REQUIRE(volume && filter && icp && width > 0 && height > 0 && width <= 65535 && height <= 65535, "tsdf_tracker_create: bad argument");
     TSDF_REQUIRE(volume->z_begin == 0 && volume->z_end == volume->g.Z, "tsdf_tracker_create: tracking needs a whole volume");
+    TSDF_REQUIRE(!volume->attached, "tsdf_tracker_create: the volume is attached to another pipeline or tracker (destroy that one first)");
     tsdf_tracker *t = new (std::nothrow) tsdf_tracker();
     if (!t) {
         set_error("out of host memory");
@@ -483,8 +494,14 @@ int tsdf_tracker_create(tsdf_volume *volume, const tsdf_bilateral *filter, tsdf_
     (void)hipStreamSynchronize(volume->stream);   // whatever the volume has in flight comes before the tracker's first launch
     t->volume = volume;
     t->icp = icp;
+    {
+        void *before = nullptr;
+        (void)tsdf_icp_stream(icp, &before);
+        t->icp_stream_before = (hipStream_t)before;
+    }
     (void)tsdf_volume_set_stream(volume, t->main);
     (void)tsdf_icp_set_stream(icp, t->main);
+    volume->attached = t;
     *out = t;
     return TSDF_OK;
 }

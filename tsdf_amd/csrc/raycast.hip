@@ -355,7 +355,7 @@ __device__ inline int wave_min(int v) {
 // spends half its way RECEDING from it -- f grows -- and was still evaluated sample by sample.)  The sample just evaluated is `val` > 0
 // (the reference's fp32 value); the values the reference would compute for the next samples differ from f at the exact positions by
 // its rounding (a few 1e-6 * largest |corner|; 2e-5 is allowed) and the positions are known to 2*eps in each coordinate, the step
-// to 1 % (the approximate reciprocals; T[k+1] - T[k] is the step to 5e-4).  So while  val - margin + n * 1.01 * min(L, 0) > 0
+// to 1 % (the approximate reciprocals; T[k+1] - T[k] is the step to 5e-4).  So while  val - margin - n * drop > 0 (drop: the bound with that 1 % applied term by term, below)
 // sample k+n cannot be <= 0.  Returns that n, at most `limit` (the samples known to stay inside the cell); 0 when anything is NaN
 // or infinite.
 __device__ inline int lipschitz_lookahead(float val, float c000, float c100, float c010, float c110, float c001, float c101, float c011,
@@ -373,7 +373,11 @@ __device__ inline int lipschitz_lookahead(float val, float c000, float c100, flo
     const float lx = fminf(fminf(du * x0, du * x1), fminf(du * x2, du * x3));
     const float ly = fminf(fminf(dv * y0, dv * y1), fminf(dv * y2, dv * y3));
     const float lz = fminf(fminf(dw * z0, dw * z1), fminf(dw * z2, dw * z3));
-    const float drop = 1.01f * fmaxf(-((lx + ly) + lz), 0.0f);                   // the most f can fall per sample
+    // the most f can fall per sample.  The per-sample movements su, sv, sw are known to 1 %: a falling term may really be 1.01 x
+    // as large, a rising one only 0.99 x -- -(1.01 N + 0.99 P) with N / P the sums of the negative / positive terms, written as
+    // 1.01 (-(N + P)) + 0.02 P so that rising terms cannot cancel more of the fall than they are sure to
+    const float rising = (fmaxf(lx, 0.0f) + fmaxf(ly, 0.0f)) + fmaxf(lz, 0.0f);
+    const float drop = fmaxf(__builtin_fmaf(1.01f, -((lx + ly) + lz), 0.02f * rising), 0.0f);
     const float x = 0.99f * (val - margin) * __builtin_amdgcn_rcpf(drop);        // (inf when f cannot fall: limit applies)
     // (a NaN corner makes val, hence x, NaN -- fmaxf / fminf would drop it from the slopes; an infinite one makes rsum infinite)
     if (!(rsum < INFINITY) || !(x > 0.0f)) return 0;

@@ -720,6 +720,11 @@ int tsdf_device_download(void *host_dst, const void *device_src, size_t bytes) {
     return TSDF_OK;
 }
 
+int tsdf_stream_synchronize(void *hip_stream) {
+    TSDF_HIP(hipStreamSynchronize((hipStream_t)hip_stream), "stream synchronize");
+    return TSDF_OK;
+}
+
 int tsdf_volume_create_slab(uint32_t sx, uint32_t sy, uint32_t sz, float px, float py, float pz,
                             uint32_t z_begin, uint32_t z_end, tsdf_volume **out) {
     TSDF_REQUIRE(out, "tsdf_volume_create: null out pointer");
@@ -834,6 +839,12 @@ int tsdf_volume_destroy(tsdf_volume *v) {
 int tsdf_volume_set_stream(tsdf_volume *v, void *hip_stream) {
     TSDF_REQUIRE(v, "null volume");
     v->stream = (hipStream_t)hip_stream;
+    return TSDF_OK;
+}
+
+int tsdf_volume_stream(const tsdf_volume *v, void **hip_stream) {
+    TSDF_REQUIRE(v && hip_stream, "null argument");
+    *hip_stream = v->stream;
     return TSDF_OK;
 }
 
@@ -1002,6 +1013,10 @@ int tsdf_volume_deform_points(const tsdf_volume *v, int num_points, float *host_
 
 int tsdf_volume_mark_dirty(tsdf_volume *v) {
     TSDF_REQUIRE(v, "null volume");
+    // (a tightening of the flags still running beside the last ray cast reads the distances: what follows on the volume's stream --
+    // the caller's next writes, ordered on it -- comes after that scan)
+    const int rcj = occupancy_join(v);
+    if (rcj != TSDF_OK) return rcj;
     v->occ_dirty = 1;
     v->occ_scan_all = 1;   // (written from outside: anywhere)
     return TSDF_OK;
@@ -1009,12 +1024,18 @@ int tsdf_volume_mark_dirty(tsdf_volume *v) {
 
 int tsdf_volume_distances(const tsdf_volume *v, float **p) {
     TSDF_REQUIRE(v && p, "null argument");
+    // The pointer may be written through.  A tightening of the ray caster's flags enqueued on another stream (tsdf_pipeline_step)
+    // reads the distances: the volume's stream waits for it here, so that work the caller orders on that stream comes after the scan.
+    const int rcj = occupancy_join(const_cast<tsdf_volume *>(v));
+    if (rcj != TSDF_OK) return rcj;
     *p = v->dist;
     return TSDF_OK;
 }
 
 int tsdf_volume_weights(const tsdf_volume *v, float **p) {
     TSDF_REQUIRE(v && p, "null argument");
+    const int rcj = occupancy_join(const_cast<tsdf_volume *>(v));
+    if (rcj != TSDF_OK) return rcj;
     *p = v->weight;
     return TSDF_OK;
 }

@@ -18,6 +18,10 @@ public:
     // The caller deletes the image.
     DepthImage *next(Eigen::Matrix4f &pose);
 
+    // records of ground_truth.txt not consumed yet (not in the reference's class: lets a caller tell "exhausted" from "this
+    // record's PNG is missing", which next() answers with nullptr alike, as the reference does)
+    size_t records_left() const { return m_frames.size() - m_next; }
+
 private:
     struct Frame {
         std::string png;   // <dir>/depth/<stem>.png

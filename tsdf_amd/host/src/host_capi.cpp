@@ -103,15 +103,19 @@ tsdf_tum_loader *tsdf_host_tum_open(const char *directory) {
         return nullptr;
     }
 }
+// 1: a frame; 0: the sequence is exhausted; -1: the next record was consumed but its frame is missing or unreadable (the
+// reference's loader answers nullptr for both of the last two; a caller that stops at the first nullptr must know which)
 int tsdf_host_tum_next(tsdf_tum_loader *l, uint16_t *depth, size_t capacity, unsigned size[2], float pose[16]) {
     Eigen::Matrix4f p;
     DepthImage *image = nullptr;
+    TUMDataLoader *loader = reinterpret_cast<TUMDataLoader *>(l);
+    if (loader->records_left() == 0) return 0;
     try {
-        image = reinterpret_cast<TUMDataLoader *>(l)->next(p);
+        image = loader->next(p);
     } catch (const std::exception &) {
-        return 0;
+        return -1;
     }
-    if (!image) return 0;
+    if (!image) return -1;
     size[0] = image->width();
     size[1] = image->height();
     const size_t n = (size_t)image->width() * image->height();
