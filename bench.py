@@ -693,29 +693,36 @@ def kernel_source_sha():
 
 
 def load_traffic(args):
-    """HBM bytes per launch from the PMC passes (profiles/traffic.json, written by tools/profile_round.sh from separate
+    """HBM bytes per launch from the PMC passes (profiles/traffic*.json, written by tools/profile_round.sh from separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, averaged over the K timed launches only).  The counters
-    cannot be read inside this process, so the figure is reported only when the profile was taken on the same kernel sources
-    with the same --steps / --warmup / --grid; otherwise `traffic` is null and the reason is stated."""
-    p = os.path.join(ROOT, "profiles", "traffic.json")
+    cannot be read inside this process, so the figure is reported only when a profile was taken on the same kernel sources
+    with the same --steps / --warmup / --grid (one file per profiled configuration); otherwise `traffic` is null and the reason
+    is stated."""
+    import glob
     meta = {"traffic_source": None}
-    if not os.path.exists(p):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic*.json")))
+    if not files:
         meta["traffic_note"] = "no counter profile committed"
         return {}, meta
-    try:
-        d = json.load(open(p))
-    except Exception:
-        meta["traffic_note"] = "profiles/traffic.json unreadable"
-        return {}, meta
     want = {"steps": args.steps, "warmup": args.warmup, "grid": args.grid, "gpus": args.gpus}
-    if d.get("kernel_source_sha") != kernel_source_sha():
-        meta["traffic_note"] = "profiles/traffic.json was taken on other kernel sources (%s): not reported" % d.get("tag")
-        return {}, meta
-    if d.get("bench_args") != want:
-        meta["traffic_note"] = "profiles/traffic.json was taken with %s, this run is %s: not reported" % (d.get("bench_args"), want)
-        return {}, meta
-    meta["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, mean over the %d timed launches of the same command)" % (d.get("tag"), args.steps)
-    return d.get("bytes_per_launch", {}), meta
+    sha, notes = kernel_source_sha(), []
+    for p in files:
+        try:
+            d = json.load(open(p))
+        except Exception:
+            notes.append("%s unreadable" % os.path.basename(p))
+            continue
+        if d.get("bench_args") != want:
+            notes.append("%s was taken with %s, this run is %s" % (os.path.basename(p), d.get("bench_args"), want))
+            continue
+        if d.get("kernel_source_sha") != sha:
+            notes.append("%s was taken on other kernel sources (%s)" % (os.path.basename(p), d.get("tag")))
+            continue
+        meta["traffic_source"] = "profiles/%s (%s: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, mean over the %d timed launches of the same command)" % (
+            os.path.basename(p), d.get("tag"), args.steps)
+        return d.get("bytes_per_launch", {}), meta
+    meta["traffic_note"] = "; ".join(notes) + ": not reported"
+    return {}, meta
 
 
 def parity_gate(tsdf_amd, frames, cams, n, physical, Wu, K):

@@ -355,6 +355,8 @@ np.savez(sys.argv[1], V=V, N=N, D=gv.get_distance_data())
     {"TSDF_INT_GRID_PER_CU": "3"},                                                             # integrate: resident grid walking the brick list
     {"TSDF_OCC_REBUILD_PERIOD": "0"},                                                          # sticky flags only
     {"TSDF_OCC_REBUILD_PERIOD": "1"},                                                          # flags rebuilt every frame
+    {"TSDF_RAY_ENTRY_BOUND": "0"},                                                             # no per-tile entry bound (round 4)
+    {"TSDF_RAY_ENTRY_BOUND": "0", "TSDF_RAY_LEARNED_ORDER": "0"},
 ])
 def test_schedule_knobs_do_not_change_a_bit(oracle, tmp_path, env):
     """How the march is cut into sample ranges, passes and lane groups, and when the occupancy flags are refreshed, is
@@ -430,3 +432,96 @@ def test_bricks_at_the_grid_boundary_are_skipped_only_when_their_voxels_are_flat
     for pos, look in (((-300.0, c + 7, c - 5), (c, c, c)), ((c + 3, c - 8, -250.0), (c, c, c)), ((c, phys + 280.0, c + 11), (c, c, c)),
                       ((-200.0, -180.0, -150.0), (c, c, c)), ((c, c, c), (0.0, c + 40, c - 30))):
         compare(oracle, gv, ov, camera_at(pos, look_at=look), what="%s from %s" % (case, pos))
+
+
+
+# ---- round 4: the per-tile entry bound (EntryParams, tsdf_amd/csrc/common.hpp) --------------------------------------------------
+
+def _cast_both(oracle, gv, ov, cam, width=W, height=H, what=""):
+    V, N = gv.raycast(width, height, cam)
+    Vo, No = ov.raycast(width, height, cam.pose(), cam.kinv(), nthreads=oracle.max_threads())
+    assert_same_floats(V, Vo, what + " vertices")
+    assert_same_floats(N, No, what + " normals")
+    return Vo
+
+
+@pytest.mark.parametrize("n", [64, 72, 100])      # whole super blocks of bricks (wave summary), and grids that are not (workgroup summary)
+def test_entry_bound_views_from_outside_inside_and_along_the_faces(oracle, n):
+    """Rays start at the nearest flagged unit of 4^3 bricks their 16 x 16 tile can see.  Views for which the bound is made (camera in
+    front of everything flagged), views that switch it off (a flagged unit straddles the camera plane), and views that graze the
+    grid's faces; the same volume is cast from one pose after the other, so each cast's launch also resets the words of the next."""
+    frames = [synth.depth_frame(i, 12, seed=0x5EED0002) for i in range(4)]
+    gv = tsdf_amd.TSDFVolume((n, n, n), (3000, 3000, 3000))
+    ov = oracle.Volume((n, n, n), (3000, 3000, 3000))
+    for d, cam in frames:
+        gv.integrate(d, W, H, cam)
+        ov.integrate(d, W, H, cam.inverse_pose(), cam.k(), cam.kinv(), nthreads=oracle.max_threads())
+    hits = 0
+    for name, cam in (("outside", frames[0][1]),
+                      ("outside, rolled", camera_at((1400, 1300, -900), yaw_pitch_roll=(0.1, -0.05, 0.8))),
+                      ("far away", camera_at((1500, 1500, -6000))),
+                      ("inside, in front of the sphere", camera_at((1500, 1400, 900))),
+                      ("inside the sphere's shell", camera_at((1500, 1400, 1460))),
+                      ("from behind the wall", camera_at((1500, 1500, 3600), look_at=(1500, 1400, 1800))),
+                      ("along the x = 0 face", camera_at((5, 1500, -300))),
+                      ("from a corner", camera_at((-800, -700, -900), look_at=(1500, 1400, 1900))),
+                      ("outside again", frames[2][1])):
+        Vo = _cast_both(oracle, gv, ov, cam, what="%d^3, %s:" % (n, name))
+        hits += int((~np.isnan(Vo[:, 0])).sum())
+    assert hits > 200000
+
+
+def test_entry_bound_small_images_and_images_that_are_not_whole_tiles(oracle):
+    n = 64
+    d, cam0 = synth.depth_frame(0, 5, seed=3)
+    gv = tsdf_amd.TSDFVolume((n, n, n), (3000, 3000, 3000))
+    ov = oracle.Volume((n, n, n), (3000, 3000, 3000))
+    gv.integrate(d, W, H, cam0)
+    ov.integrate(d, W, H, cam0.inverse_pose(), cam0.k(), cam0.kinv(), nthreads=oracle.max_threads())
+    for (w, h) in ((640, 480), (33, 17), (1, 1), (250, 131), (640, 480), (16, 16)):
+        cam = tsdf_amd.Camera(591.1 * w / 640.0, 590.1 * w / 640.0, w / 2.0 + 1.0, h / 2.0 - 0.4)
+        cam.move_to(1500, 1300, -600)
+        cam.look_at(1500, 1400, 1900)
+        _cast_both(oracle, gv, ov, cam, w, h, what="%dx%d:" % (w, h))
+
+
+def test_entry_bound_cameras_that_do_not_qualify_cast_without_it(oracle):
+    """K^-1 whose last row is not (0, 0, 1), a sheared / scaled pose block: the camera depth of a sample is not near + t (or the
+    host cannot invert the pose): those views march as before."""
+    n = 64
+    d, cam0 = synth.depth_frame(0, 5, seed=3)
+    gv = tsdf_amd.TSDFVolume((n, n, n), (3000, 3000, 3000))
+    ov = oracle.Volume((n, n, n), (3000, 3000, 3000))
+    gv.integrate(d, W, H, cam0)
+    ov.integrate(d, W, H, cam0.inverse_pose(), cam0.k(), cam0.kinv(), nthreads=oracle.max_threads())
+    kinv = cam0.kinv().copy(); kinv[2] = 1.0e-5; kinv[8] = 1.01                  # last row (m31, m32, m33), column-major
+    _cast_both(oracle, gv, ov, Cam(cam0.pose(), cam0.inverse_pose(), cam0.k(), kinv), what="projective K^-1:")
+    pose = cam0.pose().copy(); pose[0:3] *= 1.3; pose[4] += 0.2                   # scaled first column, a shear: still invertible
+    _cast_both(oracle, gv, ov, Cam(pose, cam0.inverse_pose(), cam0.k(), cam0.kinv()), what="sheared pose:")
+    pose = cam0.pose().copy(); pose[8:11] = pose[0:3]                             # singular 3 x 3 block
+    _cast_both(oracle, gv, ov, Cam(pose, cam0.inverse_pose(), cam0.k(), cam0.kinv()), what="singular pose:")
+    _cast_both(oracle, gv, ov, cam0, what="and the plain camera after them:")
+
+
+def test_entry_bound_a_surface_on_the_entry_face_and_speckles_in_free_space(oracle):
+    """Set distances by hand: negative voxels in the first planes the rays meet (the bound of those tiles is the entry itself),
+    single low voxels scattered through free space (every one flags its unit and pulls the bound of the tiles that see it forward)
+    and an untouched half of the image (no unit at all: the rays of those tiles are done at once)."""
+    n, phys = 96, 960.0
+    rng = np.random.default_rng(5)
+    probe = tsdf_amd.TSDFVolume((n, n, n), (phys,) * 3)
+    trunc = np.float32(probe.truncation_distance())
+    probe.close()
+    D = np.full((n, n, n), trunc, np.float32)
+    D[0:2, 10:40, 10:50] = -0.4 * trunc                          # on the z = 0 face
+    D[60, 20:70, 5:45] = -0.2 * trunc; D[59, 20:70, 5:45] = 0.3 * trunc
+    for _ in range(40):
+        z, y, x = rng.integers(3, n - 3, size=3)
+        if x < 48:
+            D[z, y, x] = rng.choice([-0.5, 0.0, 0.004]) * trunc
+    gv = tsdf_amd.TSDFVolume((n, n, n), (phys,) * 3)
+    ov = oracle.Volume((n, n, n), (phys,) * 3)
+    gv.set_distance_data(D.reshape(-1)); ov.set_distance_data(D.reshape(-1))
+    for pos, look in (((480, 480, -700), (480, 480, 480)), ((200, 300, -400), (600, 500, 900)), ((480, 480, 300), (480, 480, 900))):
+        cam = camera_at(pos, look_at=look)
+        _cast_both(oracle, gv, ov, cam, what="hand-made field from %s:" % (pos,))

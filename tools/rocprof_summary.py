@@ -64,6 +64,49 @@ def timeline(db, first=0, count=60):
     return "\n".join(out)
 
 
+def overlaps(db, skip_first=0):
+    """What runs BESIDE each kernel (other queues): per kernel name, launches, mean duration, and per overlapping kernel name the mean
+    overlap per launch -- for two-stream schedules (tsdf_pipeline_step).  Also the mean gap between a kernel's end and the start of
+    the next kernel on the same queue.  python tools/rocprof_summary.py overlap run.db [skip the first n kernels]"""
+    cur = sqlite3.connect(db).cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)").fetchall()]
+    q = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else "0")
+    rows = cur.execute("select name, start, end, %s from kernels order by start" % q).fetchall()[skip_first:]
+    rows = [(short(n).split("<")[0], s, e, qq) for n, s, e, qq in rows]
+    stat, gaps = {}, {}
+    by_queue = {}
+    for r in rows:
+        by_queue.setdefault(r[3], []).append(r)
+    for qq, lst in by_queue.items():
+        for a, b in zip(lst, lst[1:]):
+            g = gaps.setdefault((a[0], b[0]), [0, 0.0])
+            g[0] += 1; g[1] += (b[1] - a[2]) / 1e3
+    j0 = 0
+    for i, (n, s, e, qq) in enumerate(rows):
+        st = stat.setdefault(n, {"n": 0, "dur": 0.0, "beside": {}, "queues": set()})
+        st["n"] += 1; st["dur"] += (e - s) / 1e3; st["queues"].add(qq)
+        while j0 < len(rows) and rows[j0][2] < s - 2_000_000:
+            j0 += 1
+        for n2, s2, e2, q2 in rows[j0:]:
+            if s2 > e:
+                break
+            if q2 == qq:
+                continue
+            ov = min(e, e2) - max(s, s2)
+            if ov > 0:
+                st["beside"][n2] = st["beside"].get(n2, 0.0) + ov / 1e3
+    out = ["%-30s %6s %8s %10s   %s" % ("kernel", "calls", "queues", "avg_us", "mean overlap per launch with kernels of other queues (us)")]
+    for n, st in sorted(stat.items(), key=lambda kv: -kv[1]["dur"]):
+        bes = ", ".join("%s %.1f" % (k, v / st["n"]) for k, v in sorted(st["beside"].items(), key=lambda kv: -kv[1]) if v / st["n"] >= 0.05)
+        out.append("%-30s %6d %8s %10.1f   %s" % (n[:30], st["n"], ",".join(str(x) for x in sorted(st["queues"])), st["dur"] / st["n"], bes or "-"))
+    out.append("")
+    out.append("%-62s %6s %10s" % ("same queue: end of A -> start of B", "pairs", "mean_gap_us"))
+    for (a, b), (c, g) in sorted(gaps.items(), key=lambda kv: -kv[1][0]):
+        if c >= 3:
+            out.append("%-62s %6d %10.1f" % ((a[:30] + " -> " + b[:28]), c, g / c))
+    return "\n".join(out)
+
+
 def launches_of(db, counter):
     """{kernel display name: [(start, value, duration)] in dispatch order} for one counter."""
     cur = sqlite3.connect(db).cursor()
@@ -116,6 +159,8 @@ if __name__ == "__main__":
         print(pmc_text(sys.argv[2]))
     elif mode == "timeline":
         print(timeline(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 0, int(sys.argv[4]) if len(sys.argv) > 4 else 60))
+    elif mode == "overlap":
+        print(overlaps(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 0))
     elif mode == "traffic":
         # traffic FETCH.db WRITE.db [skip take [key=value ...]]   (key=value pairs go into the JSON: tag, steps, warmup, ...)
         skip = int(sys.argv[4]) if len(sys.argv) > 4 else 0

@@ -49,6 +49,7 @@ struct Tuning {
     int ray_tile_map;        // TSDF_RAY_TILE_MAP       which tiles an XCD gets: 0 every eighth, 1 a contiguous eighth, 2 one block per block row (default)
     int ray_learned_order;   // TSDF_RAY_LEARNED_ORDER  0: launch order, one workgroup per (range, tile) (default 1: the order learnt from the previous cast)
     int ray_heavy_passes;    // TSDF_RAY_HEAVY_PASSES   passes from which a wave counts as long for that order (0: three quarters of the budget)
+    int ray_entry_bound;     // TSDF_RAY_ENTRY_BOUND    0: no per-tile entry bound (default 1: rays start at the nearest flagged block their 16 x 16 tile can see)
     int occ_rebuild_period;  // TSDF_OCC_REBUILD_PERIOD integrations between tightenings of the ray caster's flags (16; 0: never)
     int occ_scan_all;        // TSDF_OCC_SCAN_ALL       1: every tightening reads the whole distance array
     int reach_lds;           // TSDF_REACH_LDS          1: the workgroup variant of the reach summary on every grid
@@ -62,7 +63,10 @@ const Tuning &tuning();
 int occupancy_rebuild(struct ::tsdf_volume *v);  // volume.hip
 int occupancy_join(struct ::tsdf_volume *v);     // volume.hip: the volume's stream waits for a tightening enqueued elsewhere
 int occupancy_tighten_on(struct ::tsdf_volume *v, hipStream_t stream);  // volume.hip: the periodic rebuild on another stream
-int occupancy_refresh(struct ::tsdf_volume *v);  // volume.hip: bring fine + reach up to date
+struct EntryParams;
+// volume.hip: bring fine + reach up to date; with `entry` (a whole-volume ray cast whose camera allows it) the same launch also leaves
+// the per-tile entry bound of that view (EntryParams)
+int occupancy_refresh(struct ::tsdf_volume *v, const EntryParams *entry = nullptr);
 int build_t_table(struct ::tsdf_volume *v);      // volume.hip
 // timing helpers (volume.hip).  When timing is on, a launch of kernel `which` carries a start and a stop event that take the
 // dispatch's own begin / end timestamps (hipExtLaunchKernel: what rocprofv3's kernel trace reads), TSDF_LAUNCH_TIMED below.
@@ -172,6 +176,32 @@ struct OccGrid {
     __host__ __device__ size_t fine_count() const { return (size_t)nbx * nby * nbz; }
 };
 
+// Entry bound of a whole-volume ray cast (round 4; tried in round 2 when the grid's rim bricks were flagged for good, which ate
+// the gain).  Most of a ray's passes are hops through the free space between the grid's face and the first surface (13.9 of 22.9
+// per ray on the bench scene).  For a view with camera depth == ray parameter (K^-1 with last row (0, 0, 1), pose [R t; 0 0 0 1])
+// that free space is bounded once per 16 x 16 pixel tile instead: the reach summary's launch projects every aligned unit of 4^3
+// bricks (16^3 voxels) that holds a flagged brick -- grown by a voxel, by its 8 corners -- and lowers, with atomicMin, the word of
+// every tile its pixel rectangle (grown by 2 pixels) touches to the unit's smallest camera depth minus two voxels.  A sample of a
+// ray through pixel (u, v) that lies in such a unit projects to (u, v), inside the unit's rectangle, and is no nearer than the
+// unit's nearest corner (depth is linear, the unit convex, all its corners in front of the camera): so a sample whose depth
+// near + T[k] is below its tile's word lies in no flagged brick -- which is exactly the condition under which the march itself
+// passes it unevaluated (SkipCtx / locate in raycast.hip; off-grid samples within rounding of a face read clamped taps of boundary
+// bricks, whose clear flag means flat voxels).  A unit wholly behind the camera holds no sample; one that straddles the camera
+// plane switches the bound off for the view (word [tiles]).  Scheduling only: the picture is the same bits with or without it
+// (TSDF_RAY_ENTRY_BOUND=0), CPU estimate tools/dbg_reach_estimate.py: 13.9 -> 6.1 hops per ray.
+constexpr int kEntryTile = 16;                  // pixels per side of a tile (= a workgroup of process_ray_kernel)
+constexpr uint32_t kEntryFar = 0x7f7f7f7fu;     // "no unit": what a byte-wise fill leaves (3.4e38 as a float)
+struct EntryParams {
+    float r[3][4];        // world -> camera, rows 1-3 (the inverse of the pose the ray directions are formed with)
+    float k[2][3];        // pixel = k * camera / camera.z (the inverse of kinv), rows 1-2
+    F3 vs, offset;        // voxel size, grid origin (the ray caster's space_min)
+    uint32_t width, height, tiles_x, tiles_y;
+    float slack_z;        // subtracted from a unit's nearest corner (two voxels, mm)
+    uint32_t *ztile;      // tiles_x * tiles_y words + the on/off word, all kEntryFar / 1 when the launch starts
+    uint32_t *ztile_next; // the copy the NEXT cast uses: this launch resets it
+    uint32_t units_x, units_y, units_z;   // units (whole or partial) per axis
+};
+
 // float -> int with the reference target's semantics (CUDA cvt.rzi: saturating, NaN -> 0);
 // written out so the result does not depend on what an out-of-range fptosi lowers to.
 __host__ __device__ inline int f2i_sat(float f) {
@@ -222,6 +252,11 @@ struct tsdf_volume {
     uint32_t *ray_order;
     uint32_t ray_order_tiles, ray_order_ranges;   // what the two arrays were sized (and the order was built) for
     int ray_order_valid;
+    // per-tile entry bound of a whole-volume cast (EntryParams): two copies of ztile_words words used alternately -- the launch that
+    // fills one resets the other
+    uint32_t *ztile;
+    size_t ztile_words;
+    int ztile_side;
     // T[k]: the ray parameter of sample k, T[0] = 0, T[k+1] = T[k] + step in fp32 (raycast.hip)
     float *t_table;
     // 1 = dividing by each voxel edge via the 3-instruction reciprocal sequence was verified exhaustively

@@ -12,7 +12,10 @@ constexpr int kChunkZ = kIntBrickZ; // planes walked by one workgroup
 #define TSDF_BATCH_Z 4
 #endif
 constexpr int kBatchZ = TSDF_BATCH_Z;  // planes whose loads are issued together
-constexpr int kTilePixels = 8192;  // LDS depth tile of a brick: 16 KiB
+#ifndef TSDF_TILE_PIXELS
+#define TSDF_TILE_PIXELS 8192
+#endif
+constexpr int kTilePixels = TSDF_TILE_PIXELS;  // LDS depth tile of a brick: 16 KiB
 
 struct BrickGrid {
     uint32_t nx, ny, nz;  // bricks per axis over the resident planes

@@ -53,6 +53,9 @@ struct RayParams {
     uint32_t tile_map;        // which image tiles an XCD gets (see process_ray_kernel): 0 every eighth tile, 1 one contiguous eighth of the image, 2 one 5x5-tile block per block row
     uint32_t range_order;     // order in which the sample ranges are dispatched (see process_ray_kernel): 0 ascending, 1 descending (default), 2 last, first, then descending
     TriConst tc;              // loop-invariant pieces of the interpolation, formed once on the host (same IEEE operations)
+    // entry bound of this view (EntryParams, common.hpp): one word per 16 x 16 tile + the on/off word at [ztile_count]; nullptr = none
+    const uint32_t *ztile;
+    uint32_t ztile_pitch, ztile_count;
 };
 
 // Division by a loop-invariant voxel edge.  The reference divides (IEEE, correctly rounded); when FASTDIV is
@@ -620,7 +623,7 @@ __device__ inline float process_sample_eager(float t, const RayState &r, const S
 
 // Ray set-up: direction and start point (ray_geometry), and the range of sample indices [k_first, k_end) of the
 // sample range [k_lo, k_hi] that the reference's loop evaluates unless it hits earlier (setup_ray).  T = the staged table.
-__device__ inline bool ray_geometry(int imx, int imy, bool in_image, const RayParams &rp, RayState &ray, float &max_t) {
+__device__ inline bool ray_geometry(int imx, int imy, bool in_image, const RayParams &rp, RayState &ray, float &max_t, float *near_out = nullptr) {
     // compute_ray_direction_at_pixel (:24-44); f3_normalise is a no-op (by-value argument): Q6
     uint16_t pix_x = (uint16_t)imx, pix_y = (uint16_t)imy;
     float rcx = pix_x * rp.kinv.m11 + pix_y * rp.kinv.m12 + rp.kinv.m13;
@@ -640,16 +643,17 @@ __device__ inline bool ray_geometry(int imx, int imy, bool in_image, const RayPa
     const float sz = ((near_t * dir.z) + rp.origin.z) - rp.space_min.z;
     ray = {dir.x, dir.y, dir.z, sx, sy, sz};
     max_t = far_t - near_t;
+    if (near_out) *near_out = near_t;
     return intersects;
 }
 
 template <bool SLAB>
 __device__ inline void setup_ray(int imx, int imy, bool in_image, int k_lo, int k_hi, const float *Ts, const int t_off, const RayParams &rp,
-                                 const Geom &g, float step_size, RayState &ray, int &k_first, int &k_end) {
+                                 const Geom &g, float step_size, RayState &ray, int &k_first, int &k_end, float *near_out = nullptr) {
     // Ts[k + t_off] = T[k] for k_lo <= k <= k_hi (the staged part of the table)
     auto T = [&](int k) { return Ts[k + t_off]; };
     float max_t;
-    const bool intersects = ray_geometry(imx, imy, in_image, rp, ray, max_t);
+    const bool intersects = ray_geometry(imx, imy, in_image, rp, ray, max_t, near_out);
     const float sz = ray.sz;
     const F3 dir = {ray.dx, ray.dy, ray.dz};
 
@@ -852,7 +856,8 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
 
     RayState ray;
     int k_first, k_end;
-    setup_ray<SLAB>(imx, imy, in_image, k_lo, k_hi, Ts, t_off, rp, g, step_size, ray, k_first, k_end);
+    float near_t = 0.f;
+    setup_ray<SLAB>(imx, imy, in_image, k_lo, k_hi, Ts, t_off, rp, g, step_size, ray, k_first, k_end, &near_t);
     if (per_ray_ranges && k_end > k_first) {
         // part blockIdx.z of rp.slab_ranges equal parts of this ray's stretch [k_first, k_end) through the slab
         const int len = k_end - k_first, a = k_first + (int)(((long long)len * range) / rp.slab_ranges);
@@ -866,6 +871,17 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
     const size_t idx = (size_t)imy * rp.width + imx;
     int k = (k_end <= k_first) ? kDone : k_first;  // next sample of this lane's ray (kDone when finished)
     if (SEG && range > 0 && k != kDone && load_best(&tail.best[idx]) <= (uint32_t)k_first) k = kDone;
+    // Entry bound (EntryParams, common.hpp): no flagged brick holds a sample of this tile's rays whose camera depth -- near + T[k] for
+    // the views the bound is made for -- is below the tile's word, so those samples are passed as the hops below would pass them, in one go:
+    // the ray goes on with the first sample at or beyond the bound (or is done with this range).
+    if (SKIP && !SLAB && !STATS && rp.ztile && k != kDone && sc.skip_ok && rp.ztile[rp.ztile_count] != 0u) {
+        const float t_safe = (__uint_as_float(rp.ztile[tile_y * rp.ztile_pitch + tile_x]) - near_t) * 0.9999f;   // (the tile's word: uniform)
+        // the last sample of [k, k_end) with T[ks] < t_safe: T[k] is k * step up to the rounding of its k additions (under a sample
+        // over the whole table), so the walk down from the estimate is a few entries
+        int ks = min(f2i_sat(t_safe * sc.inv_step) + 2, k_end - 1);
+        while (ks >= k && !(T(ks) < t_safe)) ks--;
+        if (ks >= k) k = ks + 1 >= k_end ? kDone : ks + 1;
+    }
     BrickCache bc = {0, 0, false};
     SampleWork work = {0, 0, 0, 0};
     const unsigned long long dbg_setup = (TAIL && !STATS && counters) ? wall_clock64() : 0ull;
@@ -1462,6 +1478,8 @@ static RayParams make_params(const tsdf_volume *v, uint32_t width, uint32_t heig
     rp.range_order = 0;
     rp.tile_map = 1;
     rp.tc = make_tri_const(g);
+    rp.ztile = nullptr;
+    rp.ztile_pitch = rp.ztile_count = 0;
     return rp;
 }
 
@@ -1477,6 +1495,77 @@ static int check_ray_args(const tsdf_volume *v, uint32_t width, uint32_t height,
     // the reference's raycaster stores width/height as uint16_t (src/include/Raycaster.hpp:35-36)
     TSDF_REQUIRE(width > 0 && height > 0 && width <= 65535 && height <= 65535, "tsdf_raycast: bad image size");
     return TSDF_OK;
+}
+
+// The entry bound of a whole-volume ray cast (EntryParams, common.hpp): usable when the camera depth of a sample is near + t --
+// K^-1 with last row (0, 0, 1) -- and the pose's 3 x 3 block has an inverse.  Fills `ep` and rp's fields and returns true, or leaves
+// rp.ztile null.  The launch that fills the words is the reach summary's (occupancy_refresh(v, &ep)).
+static bool prepare_entry_bound(tsdf_volume *v, RayParams &rp, EntryParams &ep, int &rc) {
+    rc = TSDF_OK;
+    if (!tuning().ray_entry_bound) return false;
+    const Geom &g = v->g;
+    const Mat33 &ki = rp.kinv;
+    if (ki.m31 != 0.0f || ki.m32 != 0.0f || ki.m33 != 1.0f) return false;   // the ray's camera z must be 1 per unit of t
+    // pose = [R t; 0 0 0 1] (rp.rot, rp.origin), kinv = [a s c; e b d; 0 0 1]: the inverses in double
+    const double R[3][3] = {{rp.rot.m11, rp.rot.m12, rp.rot.m13}, {rp.rot.m21, rp.rot.m22, rp.rot.m23}, {rp.rot.m31, rp.rot.m32, rp.rot.m33}};
+    const double det = R[0][0] * (R[1][1] * R[2][2] - R[1][2] * R[2][1]) - R[0][1] * (R[1][0] * R[2][2] - R[1][2] * R[2][0]) +
+                       R[0][2] * (R[1][0] * R[2][1] - R[1][1] * R[2][0]);
+    if (!(std::fabs(det) > 1e-9) || !std::isfinite(det)) return false;
+    double Ri[3][3];
+    Ri[0][0] = (R[1][1] * R[2][2] - R[1][2] * R[2][1]) / det; Ri[0][1] = (R[0][2] * R[2][1] - R[0][1] * R[2][2]) / det; Ri[0][2] = (R[0][1] * R[1][2] - R[0][2] * R[1][1]) / det;
+    Ri[1][0] = (R[1][2] * R[2][0] - R[1][0] * R[2][2]) / det; Ri[1][1] = (R[0][0] * R[2][2] - R[0][2] * R[2][0]) / det; Ri[1][2] = (R[0][2] * R[1][0] - R[0][0] * R[1][2]) / det;
+    Ri[2][0] = (R[1][0] * R[2][1] - R[1][1] * R[2][0]) / det; Ri[2][1] = (R[0][1] * R[2][0] - R[0][0] * R[2][1]) / det; Ri[2][2] = (R[0][0] * R[1][1] - R[0][1] * R[1][0]) / det;
+    const double t[3] = {rp.origin.x, rp.origin.y, rp.origin.z};
+    memset(&ep, 0, sizeof(ep));
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) ep.r[i][j] = (float)Ri[i][j];
+        ep.r[i][3] = (float)-(Ri[i][0] * t[0] + Ri[i][1] * t[1] + Ri[i][2] * t[2]);
+    }
+    const double kd = (double)ki.m11 * ki.m22 - (double)ki.m12 * ki.m21;
+    if (!(std::fabs(kd) > 1e-12) || !std::isfinite(kd)) return false;
+    // inverse of [a s c; e b d; 0 0 1], rows 1-2
+    ep.k[0][0] = (float)(ki.m22 / kd); ep.k[0][1] = (float)(-ki.m12 / kd); ep.k[0][2] = (float)((ki.m12 * (double)ki.m23 - ki.m22 * (double)ki.m13) / kd);
+    ep.k[1][0] = (float)(-ki.m21 / kd); ep.k[1][1] = (float)(ki.m11 / kd); ep.k[1][2] = (float)((ki.m21 * (double)ki.m13 - ki.m11 * (double)ki.m23) / kd);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 4; j++)
+            if (!std::isfinite(ep.r[i][j])) return false;
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 3; j++)
+            if (!std::isfinite(ep.k[i][j])) return false;
+    ep.vs = g.vs;
+    ep.offset = g.offset;
+    ep.width = rp.width; ep.height = rp.height;
+    ep.tiles_x = (rp.width + kEntryTile - 1) / kEntryTile; ep.tiles_y = (rp.height + kEntryTile - 1) / kEntryTile;
+    ep.slack_z = 2.0f * std::max(g.vs.x, std::max(g.vs.y, g.vs.z));
+    ep.units_x = (v->occ.nbx + 3) / 4; ep.units_y = (v->occ.nby + 3) / 4; ep.units_z = (v->occ.nbz + 3) / 4;
+    const size_t n_words = (size_t)ep.tiles_x * ep.tiles_y + 1;
+    if (v->ztile_words != n_words) {   // (first use, or another image size: both copies start reset)
+        if (v->ztile) (void)hipFree(v->ztile);
+        v->ztile = nullptr;
+        v->ztile_words = 0;
+        if (hipMalloc((void **)&v->ztile, 2 * n_words * sizeof(uint32_t)) != hipSuccess) { rc = hip_fail(hipErrorOutOfMemory, "entry bound alloc"); return false; }
+        std::vector<uint32_t> init(2 * n_words, kEntryFar);
+        init[n_words - 1] = init[2 * n_words - 1] = 1u;
+        if (hipMemcpyAsync(v->ztile, init.data(), init.size() * sizeof(uint32_t), hipMemcpyHostToDevice, v->stream) != hipSuccess ||
+            hipStreamSynchronize(v->stream) != hipSuccess) { rc = hip_fail(hipErrorUnknown, "entry bound reset"); return false; }
+        v->ztile_words = n_words;
+        v->ztile_side = 0;
+    }
+    ep.ztile = v->ztile + (size_t)v->ztile_side * n_words;
+    ep.ztile_next = v->ztile + (size_t)(1 - v->ztile_side) * n_words;
+    v->ztile_side = 1 - v->ztile_side;
+    rp.ztile = ep.ztile;
+    rp.ztile_pitch = ep.tiles_x;
+    rp.ztile_count = ep.tiles_x * ep.tiles_y;
+    return true;
+}
+// occupancy_refresh for a whole-volume cast, with the view's entry bound when the camera allows one
+static int refresh_for_cast(tsdf_volume *v, RayParams &rp) {
+    EntryParams ep;
+    int rc;
+    const bool bound = prepare_entry_bound(v, rp, ep, rc);
+    if (rc != TSDF_OK) return rc;
+    return occupancy_refresh(v, bound ? &ep : nullptr);
 }
 
 // The production march: process_ray_kernel over the sample ranges of every ray with a pass budget, process_ray_tail_kernel
@@ -1681,9 +1770,9 @@ int tsdf_raycast_device(const tsdf_volume *v, uint32_t width, uint32_t height, c
     if (rc != TSDF_OK) return rc;
     TSDF_REQUIRE(device_vertices, "tsdf_raycast: null vertex buffer");
     TSDF_REQUIRE(v->z_begin == 0 && v->z_end == v->g.Z, "tsdf_raycast on a slab: use tsdf_raycast_slab_device");
-    rc = occupancy_refresh(const_cast<tsdf_volume *>(v));
-    if (rc != TSDF_OK) return rc;
     RayParams rp = make_params(v, width, height, pose, kinv);
+    rc = refresh_for_cast(const_cast<tsdf_volume *>(v), rp);
+    if (rc != TSDF_OK) return rc;
     return march_and_resolve<false>(const_cast<tsdf_volume *>(v), rp, device_vertices, device_normals);
 }
 
@@ -1718,9 +1807,9 @@ int tsdf_raycast_depth_device(const tsdf_volume *v, uint32_t width, uint32_t hei
     if (rc != TSDF_OK) return rc;
     TSDF_REQUIRE(device_depth && inv_pose, "tsdf_raycast_depth: null argument");
     TSDF_REQUIRE(v->z_begin == 0 && v->z_end == v->g.Z, "tsdf_raycast_depth needs a whole volume");
-    rc = occupancy_refresh(const_cast<tsdf_volume *>(v));
-    if (rc != TSDF_OK) return rc;
     RayParams rp = make_params(v, width, height, pose, kinv);
+    rc = refresh_for_cast(const_cast<tsdf_volume *>(v), rp);
+    if (rc != TSDF_OK) return rc;
     return march_and_resolve<false>(const_cast<tsdf_volume *>(v), rp, device_vertices, nullptr, inv_pose, device_depth);
 }
 

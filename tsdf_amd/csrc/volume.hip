@@ -41,6 +41,7 @@ const Tuning &tuning() {
         u.ray_tile_map = clamp(num("TSDF_RAY_TILE_MAP", 2), 0, 2);
         u.ray_learned_order = num("TSDF_RAY_LEARNED_ORDER", 1) != 0;
         u.ray_heavy_passes = std::max(num("TSDF_RAY_HEAVY_PASSES", 0), 0);
+        u.ray_entry_bound = num("TSDF_RAY_ENTRY_BOUND", 1) != 0;
         u.occ_rebuild_period = std::max(num("TSDF_OCC_REBUILD_PERIOD", 16), 0);
         u.occ_scan_all = num("TSDF_OCC_SCAN_ALL", 0) != 0;
         u.reach_lds = num("TSDF_REACH_LDS", 0) != 0;
@@ -276,7 +277,53 @@ __global__ __launch_bounds__(256) void occupancy_flags_kernel(const uint16_t *__
 // brick looks up its ancestors.  Bricks outside the grid count as flagged, so blocks that stick out are never
 // reported empty.  O(1) work per brick, ~2 x 2 MiB of traffic at 512^3.
 constexpr int kSuper = 16;  // bricks per side of a super block = 2^(kReachLevels - 1)
-__global__ __launch_bounds__(256) void reach_mip_kernel(OccGrid occ) {
+
+// ---- entry bound of a whole-volume ray cast (EntryParams, common.hpp): side job of the reach summary's launch, which holds the
+// OR of `fine` over every aligned unit of 4^3 bricks anyway.  One lane per flagged unit.
+__device__ inline void entry_reset_next(const EntryParams &ep, uint32_t global_thread, uint32_t n_threads) {
+    const uint32_t n = ep.tiles_x * ep.tiles_y;
+    for (uint32_t i = global_thread; i <= n; i += n_threads) ep.ztile_next[i] = i < n ? kEntryFar : 1u;
+}
+__device__ inline void entry_project_unit(const EntryParams &ep, uint32_t ux, uint32_t uy, uint32_t uz) {
+    constexpr int kUnit = kBrick * 4;   // voxels per side
+    const float lo_x = (float)((int)(ux * kUnit) - 1), hi_x = (float)(ux * kUnit + kUnit + 1);   // voxel coordinates, grown by one
+    const float lo_y = (float)((int)(uy * kUnit) - 1), hi_y = (float)(uy * kUnit + kUnit + 1);
+    const float lo_z = (float)((int)(uz * kUnit) - 1), hi_z = (float)(uz * kUnit + kUnit + 1);
+    float zmin = INFINITY, zmax = -INFINITY, umin = INFINITY, umax = -INFINITY, vmin = INFINITY, vmax = -INFINITY;
+    bool nan = false;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const float wx = ((c & 1) ? hi_x : lo_x) * ep.vs.x + ep.offset.x;
+        const float wy = ((c & 2) ? hi_y : lo_y) * ep.vs.y + ep.offset.y;
+        const float wz = ((c & 4) ? hi_z : lo_z) * ep.vs.z + ep.offset.z;
+        const float cx = ep.r[0][0] * wx + ep.r[0][1] * wy + ep.r[0][2] * wz + ep.r[0][3];
+        const float cy = ep.r[1][0] * wx + ep.r[1][1] * wy + ep.r[1][2] * wz + ep.r[1][3];
+        const float cz = ep.r[2][0] * wx + ep.r[2][1] * wy + ep.r[2][2] * wz + ep.r[2][3];
+        nan = nan || !(cz == cz);
+        zmin = fminf(zmin, cz);
+        zmax = fmaxf(zmax, cz);
+        const float rz = 1.0f / cz;
+        const float u = (ep.k[0][0] * cx + ep.k[0][1] * cy + ep.k[0][2] * cz) * rz, w = (ep.k[1][0] * cx + ep.k[1][1] * cy + ep.k[1][2] * cz) * rz;
+        umin = fminf(umin, u); umax = fmaxf(umax, u);
+        vmin = fminf(vmin, w); vmax = fmaxf(vmax, w);
+    }
+    // wholly behind the camera, with room to spare: a sample's depth is near + t >= 0, none lies in it
+    if (!nan && zmax < -4.0f * ep.slack_z) return;
+    const float bound = zmin - ep.slack_z;
+    // a corner that is not safely in front of the camera (the hull argument needs one sign), or NaN anywhere: no bound for this view
+    if (nan || !(bound > 4.0f * ep.slack_z) || !(umin <= umax) || !(vmin <= vmax)) {
+        ep.ztile[ep.tiles_x * ep.tiles_y] = 0u;
+        return;
+    }
+    const float u0 = umin - 2.0f, u1 = umax + 2.0f, v0 = vmin - 2.0f, v1 = vmax + 2.0f;
+    if (u1 < 0.0f || v1 < 0.0f || u0 > (float)(ep.width - 1) || v0 > (float)(ep.height - 1)) return;   // off the image
+    const uint32_t tx0 = (uint32_t)fmaxf(u0, 0.0f) / kEntryTile, tx1 = min((uint32_t)fminf(u1, (float)(ep.width - 1)) / kEntryTile, ep.tiles_x - 1);
+    const uint32_t ty0 = (uint32_t)fmaxf(v0, 0.0f) / kEntryTile, ty1 = min((uint32_t)fminf(v1, (float)(ep.height - 1)) / kEntryTile, ep.tiles_y - 1);
+    const uint32_t word = __float_as_uint(bound);   // (positive floats order like their bit patterns)
+    for (uint32_t ty = ty0; ty <= ty1; ty++)
+        for (uint32_t tx = tx0; tx <= tx1; tx++) atomicMin(&ep.ztile[ty * ep.tiles_x + tx], word);
+}
+__global__ __launch_bounds__(256) void reach_mip_kernel(OccGrid occ, const EntryParams ep) {
     __shared__ __align__(16) unsigned char f[kSuper * kSuper * kSuper];  // 4096
     __shared__ unsigned char l1[8 * 8 * 8], l2[4 * 4 * 4], l3[2 * 2 * 2], l4[1];
     const uint32_t ox = blockIdx.x * kSuper, oy = blockIdx.y * kSuper, oz = blockIdx.z * kSuper;
@@ -307,6 +354,15 @@ __global__ __launch_bounds__(256) void reach_mip_kernel(OccGrid occ) {
         l2[i] = o;
     }
     __syncthreads();
+    if (ep.ztile) {   // the entry bound of the cast this summary is made for: one thread per flagged unit of 4^3 bricks
+        entry_reset_next(ep, ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 256u + threadIdx.x, gridDim.x * gridDim.y * gridDim.z * 256u);
+        if (threadIdx.x < 64) {
+            // (units partly beyond the grid count as flagged here -- bricks outside it do, above -- and are projected like any other:
+            // conservative; units wholly beyond it are left out)
+            const uint32_t i = threadIdx.x, ux = ox / 4 + (i & 3), uy = oy / 4 + ((i >> 2) & 3), uz = oz / 4 + (i >> 4);
+            if (l2[i] && ux < ep.units_x && uy < ep.units_y && uz < ep.units_z) entry_project_unit(ep, ux, uy, uz);
+        }
+    }
     if (threadIdx.x < 8) {
         const uint32_t i = threadIdx.x, x = (i & 1) * 2, y = ((i >> 1) & 1) * 2, z = (i >> 2) * 2;
         unsigned char o = 0;
@@ -365,7 +421,7 @@ __global__ __launch_bounds__(256) void reach_mip_kernel(OccGrid occ) {
 __device__ inline uint32_t or_x2(uint32_t w) { const uint32_t a = (w | (w >> 8)) & 0x00ff00ffu; return a | (a << 8); }   // byte pairs (x, x ^ 1)
 __device__ inline uint32_t or_x4(uint32_t w) { const uint32_t a = (w | (w >> 16)) & 0x0000ffffu; return a | (a << 16); }   // (of a pair-uniform word)
 __device__ inline uint32_t or_lanes(uint32_t v, int mask) { return v | (uint32_t)__shfl_xor((int)v, mask); }
-__global__ __launch_bounds__(64) void reach_mip_wave_kernel(OccGrid occ) {
+__global__ __launch_bounds__(64) void reach_mip_wave_kernel(OccGrid occ, const EntryParams ep) {
     // blockIdx.x counts the super blocks along Z, blockIdx.z those along X: workgroups go to the 8 XCDs round robin in launch order
     // (x fastest), and the super blocks that are neighbours along X read the same 128-byte lines -- with X as the fastest launch
     // index every line was fetched by up to 8 XCDs (16.8 MB fetched for 2 MiB of flags at 512^3)
@@ -390,6 +446,14 @@ __global__ __launch_bounds__(64) void reach_mip_wave_kernel(OccGrid occ) {
 #pragma unroll
     for (int h = 0; h < 2; h++) l3[h] = or_lanes(or_lanes(l2[2 * h] | l2[2 * h + 1], 4), 16);
     l4 = or_lanes(or_lanes(l3[0] | l3[1], 8), 32);
+    if (ep.ztile) {
+        // The entry bound of the cast this summary is made for.  l2[k] of lane (y, zg) is the OR over the unit of 4^3 bricks (k, y / 4, zg)
+        // of this super block: the lane with y % 4 == k projects it -- 64 units, one per lane.
+        entry_reset_next(ep, ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 64u + lane, gridDim.x * gridDim.y * gridDim.z * 64u);
+        const uint32_t kx = lane & 3u;
+        const uint32_t w = kx == 0u ? l2[0] : kx == 1u ? l2[1] : kx == 2u ? l2[2] : l2[3];
+        if (w != 0u) entry_project_unit(ep, blockIdx.z * 4u + kx, blockIdx.y * 4u + ((lane & 15u) >> 2), blockIdx.x * 4u + (lane >> 4));
+    }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         uint32_t o[4];
@@ -466,20 +530,23 @@ int occupancy_tighten_on(tsdf_volume *v, hipStream_t stream) {
     return TSDF_OK;
 }
 
-int occupancy_refresh(tsdf_volume *v) {
+int occupancy_refresh(tsdf_volume *v, const EntryParams *entry) {
     if (v->occ_dirty || v->occ_tighten_due) {
         int rc = occupancy_rebuild(v);
         if (rc != TSDF_OK) return rc;
     }
-    if (v->reach_dirty) {
+    EntryParams ep;
+    memset(&ep, 0, sizeof(ep));   // (ztile == nullptr: no entry bound asked for)
+    if (entry) ep = *entry;
+    if (v->reach_dirty || entry) {   // (an entry bound is per view: the summary's launch is repeated for it even when `reach` is current)
         dim3 grid((v->occ.nbx + kSuper - 1) / kSuper, (v->occ.nby + kSuper - 1) / kSuper, (v->occ.nbz + kSuper - 1) / kSuper);
         const bool lds_variant = tuning().reach_lds != 0;   // (tuning aid: the workgroup variant always)
         const bool whole_blocks = v->occ.nbx % kSuper == 0 && v->occ.nby % kSuper == 0 && v->occ.nbz % kSuper == 0 &&
                                   (reinterpret_cast<uintptr_t>(v->occ.fine) & 15u) == 0 && (reinterpret_cast<uintptr_t>(v->occ.reach) & 15u) == 0;
         if (whole_blocks && !lds_variant)
-            hipLaunchKernelGGL(reach_mip_wave_kernel, dim3(grid.z, grid.y, grid.x), dim3(64), 0, v->stream, v->occ);
+            hipLaunchKernelGGL(reach_mip_wave_kernel, dim3(grid.z, grid.y, grid.x), dim3(64), 0, v->stream, v->occ, ep);
         else
-            hipLaunchKernelGGL(reach_mip_kernel, grid, dim3(256), 0, v->stream, v->occ);
+            hipLaunchKernelGGL(reach_mip_kernel, grid, dim3(256), 0, v->stream, v->occ, ep);
         TSDF_HIP(hipGetLastError(), "occupancy summary");
         v->reach_dirty = 0;
     }
@@ -822,6 +889,7 @@ int tsdf_volume_destroy(tsdf_volume *v) {
     if (v->tail_count) (void)hipFree(v->tail_count);
     if (v->ray_heavy) (void)hipFree(v->ray_heavy);
     if (v->ray_order) (void)hipFree(v->ray_order);
+    if (v->ztile) (void)hipFree(v->ztile);
     if (v->t_table) (void)hipFree(v->t_table);
     if (v->ray_best) (void)hipFree(v->ray_best);
     for (int w = 0; w < 3; w++)
