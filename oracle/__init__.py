@@ -16,7 +16,7 @@ _REF = os.path.join(_HERE, "_ref", "libref_bilateral.so")
 
 def build(force=False):
     """(Re)build the oracle .so (and oracle/_ref when /root/reference is mounted)."""
-    if force or not os.path.exists(_LIB) or \
+    if force or not os.path.exists(_LIB) or not os.path.exists(_FMAD) or \
             os.path.getmtime(_LIB) < max(os.path.getmtime(os.path.join(_HERE, f))
                                          for f in ("tsdf_oracle.c", "icp_oracle.c", "mc_oracle.c", "tsdf_oracle.h")):
         subprocess.check_call(["make", "-C", _HERE, "-s", "all"])
@@ -33,14 +33,34 @@ class RayStats(C.Structure):
     _fields_ = [("samples", C.c_int64), ("touched", C.c_int64), ("hits", C.c_int64)]
 
 
-_lib = None
+_libs = {}
+_variant = "exact"
+_FMAD = os.path.join(_HERE, "libtsdf_oracle_fmad.so")
+
+
+class variant:
+    """with oracle.variant("fmad"): ... -- the same restatement compiled with -ffp-contract=fast -mfma, i.e. with every multiply
+    feeding an add fused as nvcc's default -fmad=true may fuse them in a real CUDA build of the reference (oracle/Makefile).
+    Only for the study of what that difference can flip (tests/test_fmad_sensitivity.py); never the parity oracle."""
+
+    def __init__(self, name):
+        assert name in ("exact", "fmad")
+        self.name = name
+
+    def __enter__(self):
+        global _variant
+        self.prev, _variant = _variant, self.name
+        return self
+
+    def __exit__(self, *a):
+        global _variant
+        _variant = self.prev
 
 
 def lib():
-    global _lib
-    if _lib is None:
+    if _variant not in _libs:
         build()
-        L = C.CDLL(_LIB)
+        L = C.CDLL(_LIB if _variant == "exact" else _FMAD)
         fp = C.POINTER(C.c_float)
         L.orc_geom_init.argtypes = [C.POINTER(Geom), C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float]
         L.orc_clear.argtypes = [fp, fp, C.c_size_t, C.c_float]
@@ -90,8 +110,8 @@ def lib():
         L.orc_mc_tables.argtypes = [C.POINTER(C.c_int8), C.POINTER(C.c_uint8)]
         L.orc_marching_cubes.restype = C.c_int64
         L.orc_marching_cubes.argtypes = [fp, C.c_uint32, C.c_uint32, C.c_uint32, fp, fp, fp, C.c_int64, C.c_int]
-        _lib = L
-    return _lib
+        _libs[_variant] = L
+    return _libs[_variant]
 
 
 def _fp(a):

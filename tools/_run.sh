@@ -1,18 +1,5 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r04g
-for rep in 1 2 3; do for k in 1 8; do
-  TSDF_PLACE_VERBOSE=1 TSDF_PLACE_TRIES=$k timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity --path-only --repeats 3 > gpurun_out/r04g/config3_k${k}_$rep.json 2> gpurun_out/r04g/config3_k${k}_$rep.err
-  grep "placement" gpurun_out/r04g/config3_k${k}_$rep.err
-done; done
-for k in 1 6; do
-  TSDF_PLACE_VERBOSE=1 TSDF_PLACE_TRIES=$k timeout 600 python bench.py --workload config4 --steps 20 --warmup 5 --no-cpu-baseline --no-parity --path-only --repeats 3 > gpurun_out/r04g/config4_k${k}.json 2> gpurun_out/r04g/config4_k${k}.err
-  grep "placement" gpurun_out/r04g/config4_k${k}.err
-done
-python - <<'PY'
-import json,glob
-for f in sorted(glob.glob("gpurun_out/r04g/*.json")):
-    try:
-        d=json.load(open(f)); r=d["roofline"] if d["roofline"]["kernel"]=="integrate_kernel" else d["roofline_other"]
-        print(f, d["ms_per_step"], r["avg_launch_ms"], r["frac"], r.get("measured_inplace_update_gbs"))
-    except Exception as e: print(f, "ERR", e)
-PY
+bash tools/profile_round.sh r04h 20 5 > gpurun_out/r04h.log 2>&1
+bash tools/profile_round.sh r04h_config4 20 5 "--workload config4 --no-parity --no-cpu-baseline" 1024 > gpurun_out/r04h_config4.log 2>&1
+bash tools/profile_round.sh r04h_grid256 20 5 "--grid 256 --stream-frames 50 --no-cpu-baseline" 256 > gpurun_out/r04h_grid256.log 2>&1
+ls gpurun_out/profiles_r04h*; tail -3 gpurun_out/r04h*.log

@@ -14,12 +14,8 @@ for wl in ${WORKLOADS:-config3 config4}; do
   for n in 1 2 4 8; do
     if [ "$n" -gt "$have" ] && [ -z "$TSDF_BENCH_SHARE_GPU" ]; then echo "$wl N=$n skipped: $have GPU(s) visible"; continue; fi
     port=$((29500 + n)); f=$out/scale_${wl}_N$n
-    if [ "$n" -eq 1 ]; then
-      timeout 900 python $root/bench.py --gpus 1 --steps $steps --warmup $warmup --workload $wl "$@" > $f.json 2> $f.err
-    else
-      timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $port \
-          $root/bench.py --gpus $n --steps $steps --warmup $warmup --workload $wl "$@" > $f.json 2> $f.err
-    fi
+    # (bench.py --gpus N started plainly re-executes itself under torch.distributed.run, one rank per GPU, 127.0.0.1 rendezvous)
+    timeout 1200 python $root/bench.py --gpus $n --steps $steps --warmup $warmup --workload $wl "$@" > $f.json 2> $f.err
     echo "$wl N=$n rc=$? $(tail -c 300 $f.json | head -c 300)"
   done
 done
