@@ -116,3 +116,44 @@ def test_bad_arguments():
         icp.init_icp(np.zeros(10, np.uint16))
     with pytest.raises(ValueError):
         icp.estimate_step(3, np.eye(3), np.zeros(3))
+
+
+_PERSIST_PROBE = r"""
+import sys, numpy as np
+import tsdf_amd
+from tsdf_amd import synth
+W, H = synth.WIDTH, synth.HEIGHT
+out = []
+for (i0, i1) in ((0, 2), (5, 6), (10, 14)):
+    d0, _ = synth.depth_frame(i0, 200, seed=0x5EED0005, noise=False)
+    d1, _ = synth.depth_frame(i1, 200, seed=0x5EED0005, noise=False)
+    icp = tsdf_amd.ICPOdometry(W, H, 331.0, 234.6, 591.1, 590.1)
+    for rep in range(2):                      # twice on one object: the barrier's counter carries on from launch to launch
+        icp.init_icp_model(d0); icp.init_icp(d1)
+        T = icp.get_incremental_transformation()
+        out.append(np.asarray(T, np.float64).reshape(-1))
+        out.append(np.array([icp.last_error, icp.last_inliers], np.float64))
+np.save(sys.argv[1], np.concatenate(out))
+"""
+
+
+def test_one_persistent_launch_gives_the_chain_of_launches_bit_for_bit(tmp_path):
+    """Round 4: getIncrementalTransformation as ONE launch whose 256 workgroups stay through all 19 iterations and meet in a grid
+    barrier (icp_persistent_kernel), in its two variants (TSDF_ICP_PERSISTENT=1 / 2), against the chain of 20 launches of rounds 1-3 (0, the default: the persistent
+    launches measured slower): the same fixed-order
+    sums, the same solve, so the same pose, residual and inlier count to the last bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for mode in ("1", "2", "0"):
+        out = str(tmp_path / ("icp_%s.npy" % mode))
+        e = dict(os.environ, TSDF_ICP_PERSISTENT=mode)
+        e["PYTHONPATH"] = root + os.pathsep + e.get("PYTHONPATH", "")
+        subprocess.run([sys.executable, "-c", _PERSIST_PROBE, out], check=True, env=e, cwd=root, timeout=600)
+        got[mode] = np.load(out)
+    assert got["1"].shape == got["0"].shape == got["2"].shape and got["1"].size == 3 * 2 * 18
+    assert np.array_equal(got["1"].view(np.uint64), got["0"].view(np.uint64))          # every workgroup finishes each step
+    assert np.array_equal(got["2"].view(np.uint64), got["0"].view(np.uint64))          # workgroup 0 finishes it and publishes the pose
+    assert np.abs(got["0"][:16].reshape(4, 4)[:3, 3]).max() > 1e-4      # (a real motion was estimated)

@@ -34,6 +34,9 @@ struct tsdf_icp {
     double *state;                           // device, 2 x kIcpStateDoubles: [0..15] T (column-major), [16..17] residual,
                                              //         inliers, [18..53] A (float values), [54..59] b
     int side;                                // which copy of state / partial holds the latest step
+    unsigned long long *arrivals;            // icp_persistent_kernel's grid barrier: a counter that only grows ...
+    unsigned long long arrivals_base;        // ... and the value it will have when the next launch starts
+    unsigned long long published_base;       // (leader variant: [1] = last published step, [2..] the published poses)
 };
 
 namespace tsdf {
@@ -145,32 +148,16 @@ __device__ inline int float2int_rn(float f) {
 // Reduction::operator() (Cuda/estimate.cu:139-209): projective association of the current frame's vertices into the
 // model, distance / angle gates, the 27 upper-triangular products of the row (n, v x n, n.(v_prev - v)) + inlier count.
 // The pose is read from the device state (T as doubles, narrowed to float like `rotationMatrix().cast<float>()`).
+template <bool COHERENT = false>
 __device__ __forceinline__ void icp_finish_step(const float *partial, int n_blocks, const double *state_in, int update, double *pose_out,
                                        double *state_out);
 
-// One Gauss-Newton step's sums.  `pending` != 0: the previous launch left its per-workgroup sums in partial_prev and the
-// pose they were taken at in state_in; EVERY workgroup finishes that step first (second reduction stage, solve, pose
-// update: icp_finish_step, the same fixed-order arithmetic, so all arrive at the same pose) and workgroup 0 records
-// it in state_out.  The kernel boundary orders the two launches -- no fence, no ticket, no workgroup waiting for the others
-// across the chip's eight L2s (that hand-over cost more than the whole reduction: 24 -> 14 us per step).
-__global__ __launch_bounds__(kIcpThreads) void icp_reduce_kernel(const double *__restrict__ state_in, double *__restrict__ state_out,
-                                                                const float *__restrict__ partial_prev, int pending,
-                                                                const float *__restrict__ vmap_curr,
-                                                                const float *__restrict__ nmap_curr,
-                                                                const float *__restrict__ vmap_prev,
-                                                                const float *__restrict__ nmap_prev, int rows, int cols,
-                                                                float fx, float fy, float cx, float cy, float dist_thresh,
-                                                                float angle_thresh, float *__restrict__ partial) {
-    __shared__ double pose[16];
-    if (pending) {
-        icp_finish_step(partial_prev, (int)gridDim.x, state_in, 1, pose, blockIdx.x == 0 ? state_out : nullptr);
-    } else {
-        if (threadIdx.x < 16) {
-            pose[threadIdx.x] = state_in[threadIdx.x];
-            if (blockIdx.x == 0) state_out[threadIdx.x] = state_in[threadIdx.x];
-        }
-    }
-    __syncthreads();
+// The sums of one Gauss-Newton step over this workgroup's share of the pixels, at the pose in `pose` (shared memory, doubles): per-thread
+// fp32 partial sums as the reference's, wave64 shuffle tree, the four waves in a fixed order -> partial_out[29] of this workgroup.
+__device__ __forceinline__ void icp_accumulate(const double *pose, const float *__restrict__ vmap_curr, const float *__restrict__ nmap_curr,
+                                               const float *__restrict__ vmap_prev, const float *__restrict__ nmap_prev, int rows, int cols,
+                                               float fx, float fy, float cx, float cy, float dist_thresh, float angle_thresh,
+                                               float *__restrict__ partial_out, float (*shared)[32]) {
     float R[9], t[3];  // column-major
     for (int c = 0; c < 3; c++)
         for (int r = 0; r < 3; r++) R[c * 3 + r] = (float)pose[c * 4 + r];
@@ -222,7 +209,6 @@ __global__ __launch_bounds__(kIcpThreads) void icp_reduce_kernel(const double *_
         }
     }
     // wave64 shuffle tree, then the four waves of the workgroup in a fixed order
-    __shared__ float shared[4][32];
 #pragma unroll
     for (int i = 0; i < 29; i++) {
         float v = sum[i];
@@ -236,9 +222,37 @@ __global__ __launch_bounds__(kIcpThreads) void icp_reduce_kernel(const double *_
     }
     __syncthreads();
     if (threadIdx.x < 29) {
-        partial[blockIdx.x * 32 + threadIdx.x] =
+        partial_out[threadIdx.x] =
             ((shared[0][threadIdx.x] + shared[1][threadIdx.x]) + shared[2][threadIdx.x]) + shared[3][threadIdx.x];
     }
+}
+
+// One Gauss-Newton step's sums.  `pending` != 0: the previous launch left its per-workgroup sums in partial_prev and the
+// pose they were taken at in state_in; EVERY workgroup finishes that step first (second reduction stage, solve, pose
+// update: icp_finish_step, the same fixed-order arithmetic, so all arrive at the same pose) and workgroup 0 records
+// it in state_out.  The kernel boundary orders the two launches -- no fence, no ticket, no workgroup waiting for the others
+// across the chip's eight L2s (that hand-over cost more than the whole reduction: 24 -> 14 us per step).
+__global__ __launch_bounds__(kIcpThreads) void icp_reduce_kernel(const double *__restrict__ state_in, double *__restrict__ state_out,
+                                                                const float *__restrict__ partial_prev, int pending,
+                                                                const float *__restrict__ vmap_curr,
+                                                                const float *__restrict__ nmap_curr,
+                                                                const float *__restrict__ vmap_prev,
+                                                                const float *__restrict__ nmap_prev, int rows, int cols,
+                                                                float fx, float fy, float cx, float cy, float dist_thresh,
+                                                                float angle_thresh, float *__restrict__ partial) {
+    __shared__ double pose[16];
+    if (pending) {
+        icp_finish_step(partial_prev, (int)gridDim.x, state_in, 1, pose, blockIdx.x == 0 ? state_out : nullptr);
+    } else {
+        if (threadIdx.x < 16) {
+            pose[threadIdx.x] = state_in[threadIdx.x];
+            if (blockIdx.x == 0) state_out[threadIdx.x] = state_in[threadIdx.x];
+        }
+    }
+    __syncthreads();
+    __shared__ float shared[4][32];
+    icp_accumulate(pose, vmap_curr, nmap_curr, vmap_prev, nmap_prev, rows, cols, fx, fy, cx, cy, dist_thresh, angle_thresh,
+                   partial + blockIdx.x * 32, shared);
 }
 
 // Finishes the last step of a sequence (nothing follows whose prologue would): one workgroup.
@@ -412,7 +426,10 @@ __device__ inline void se3_exp(const double *a, double *E) {
 // Second stage of the reduction (reduceSum<29>, Cuda/estimate.cu:70-85) + the host part of estimateStep /
 // getIncrementalTransformation: A, b, residual, inliers; when `update` != 0 also x = A^-1 b and T <- exp(x) * T.
 // Run by all 256 threads of a workgroup; the pose after the step goes to pose_out (shared memory, for the caller's
-// __syncthreads), the whole state to state_out when that is not null.  The sums were written by the previous launch.
+// __syncthreads), the whole state to state_out when that is not null.  The sums were written by the previous launch -- or, COHERENT,
+// by the other workgroups of THIS launch before a grid barrier (icp_persistent_kernel): then they are read past the caches that are
+// not coherent across the chip's eight L2s.
+template <bool COHERENT>
 __device__ __forceinline__ void icp_finish_step(const float *partial, int n_blocks, const double *state_in, int update, double *pose_out,
                                        double *state_out) {
     // 29 entries x 8 groups of blocks: thread (entry, group) adds its 32 blocks in order (loads issued together), then
@@ -432,7 +449,10 @@ __device__ __forceinline__ void icp_finish_step(const float *partial, int n_bloc
 #pragma unroll
         for (int i = 0; i < 32; i++) {
             const int b = group * 32 + i;
-            v[i] = b < n_blocks ? partial[b * 32 + entry] : 0.0f;
+            if (COHERENT)
+                v[i] = b < n_blocks ? __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t *>(partial) + b * 32 + entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.0f;
+            else
+                v[i] = b < n_blocks ? partial[b * 32 + entry] : 0.0f;
         }
         double s = 0.0;
 #pragma unroll
@@ -481,6 +501,89 @@ __device__ __forceinline__ void icp_finish_step(const float *partial, int n_bloc
     }
 }
 
+// ---- the whole of getIncrementalTransformation in ONE launch (round 4) ---------------------------------------------------------
+// The chain above costs ~20 us per iteration for 5-13 us of sums: a kernel boundary, then every workgroup fetching the 256 partial
+// sums and the pose the previous launch left.  Here the 256 workgroups stay resident through all 19 iterations and meet in a grid
+// barrier instead: sums -> partial[buffer] -> barrier -> every workgroup finishes the step itself (icp_finish_step, the same
+// fixed-order arithmetic as the chain: the same pose bit for bit) -> next iteration at the new pose, into the other buffer.  One
+// barrier per iteration is enough: a workgroup that writes buffer s for iteration i + 2 has passed the barrier of iteration i + 1,
+// which every workgroup reaches only after it has read buffer s of iteration i.  The barrier is an arrival counter that only
+// grows (its base is a kernel argument, so nothing has to be reset between launches).  256 workgroups of 256 threads are one per
+// compute unit: all resident at once on an idle chip; beside other kernels the late ones are waited for, nothing waits for them.
+struct IcpRun {
+    const float *vmap_curr[3], *nmap_curr[3], *vmap_prev[3], *nmap_prev[3];
+    int rows0, cols0;
+    float fx, fy, cx, cy, dist_thresh, angle_thresh;
+    int iterations[3];                 // per pyramid level (ICPOdometry.cpp:99-101: 10, 5, 4), coarsest level first
+    const double *state_in;            // [0..15] the pose to start from
+    double *state_out;                 // the state after the last step (pose, residual, inliers, A, b)
+    float *partial;                    // 2 x gridDim.x x 32
+    unsigned long long *arrivals;      // the barrier's counter
+    unsigned long long arrivals_base;  // its value when the launch starts
+    int leader;                        // 1: workgroup 0 finishes each step alone and publishes the pose (pose_pub, published)
+    double *pose_pub;                  // 2 x 16
+    unsigned long long *published;     // the last step whose pose is out (+ published_base)
+    unsigned long long published_base;
+};
+__global__ __launch_bounds__(kIcpThreads) void icp_persistent_kernel(const IcpRun run) {
+    __shared__ double pose[16];
+    __shared__ float shared[4][32];
+    if (threadIdx.x < 16) pose[threadIdx.x] = run.state_in[threadIdx.x];
+    __syncthreads();
+    unsigned long long step = 0;
+    int buf = 0;
+    int total = 0;
+    for (int l = 0; l < kIcpLevels; l++) total += run.iterations[l];
+    for (int level = kIcpLevels - 1; level >= 0; level--) {
+        const int rows = run.rows0 >> level, cols = run.cols0 >> level;
+        const float div = (float)(1 << level);
+        const float fx = run.fx / div, fy = run.fy / div, cx = run.cx / div, cy = run.cy / div;
+        for (int it = 0; it < run.iterations[level]; it++) {
+            float *partial = run.partial + (size_t)buf * gridDim.x * 32;
+            icp_accumulate(pose, run.vmap_curr[level], run.nmap_curr[level], run.vmap_prev[level], run.nmap_prev[level], rows, cols, fx, fy, cx, cy,
+                           run.dist_thresh, run.angle_thresh, partial + blockIdx.x * 32, shared);
+            // this workgroup's sums are out (release) ...
+            __syncthreads();
+            step++;
+            const unsigned long long want = run.arrivals_base + step * gridDim.x;
+            const bool last = (int)step == total;
+            if (threadIdx.x == 0) __hip_atomic_fetch_add(run.arrivals, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (run.leader) {
+                // ... workgroup 0 waits for everybody's, finishes the step alone and publishes the pose; the others wait for that word
+                // (256 workgroups fetching the 30 KB of partial sums each, past the caches, cost more than the launch boundary they replace)
+                double *pub = run.pose_pub + (size_t)buf * 16;
+                if (blockIdx.x == 0) {
+                    if (threadIdx.x == 0)
+                        while (__hip_atomic_load(run.arrivals, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(1);
+                    __syncthreads();
+                    icp_finish_step<true>(partial, (int)gridDim.x, pose, 1, pose, last ? run.state_out : nullptr);
+                    __syncthreads();
+                    if (threadIdx.x < 16) pub[threadIdx.x] = pose[threadIdx.x];
+                    __syncthreads();
+                    if (threadIdx.x == 0) __hip_atomic_store(run.published, run.published_base + step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    if (threadIdx.x == 0)
+                        while (__hip_atomic_load(run.published, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < run.published_base + step) __builtin_amdgcn_s_sleep(1);
+                    __syncthreads();
+                    if (threadIdx.x < 16) {
+                        const unsigned long long bits = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(pub) + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        pose[threadIdx.x] = __longlong_as_double((long long)bits);
+                    }
+                    __syncthreads();
+                }
+            } else {
+                // ... grid barrier: wait for everybody's (acquire), then every workgroup finishes the step itself
+                if (threadIdx.x == 0)
+                    while (__hip_atomic_load(run.arrivals, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(2);
+                __syncthreads();
+                icp_finish_step<true>(partial, (int)gridDim.x, pose, 1, pose, (last && blockIdx.x == 0) ? run.state_out : nullptr);
+                __syncthreads();
+            }
+            buf ^= 1;
+        }
+    }
+}
+
 static void free_icp(tsdf_icp *f) {
     for (int i = 0; i < kIcpLevels; i++) {
         if (f->depth[i]) (void)hipFree(f->depth[i]);
@@ -492,6 +595,7 @@ static void free_icp(tsdf_icp *f) {
     if (f->upload) (void)hipFree(f->upload);
     if (f->partial) (void)hipFree(f->partial);
     if (f->state) (void)hipFree(f->state);
+    if (f->arrivals) (void)hipFree(f->arrivals);
     delete f;
 }
 
@@ -571,6 +675,8 @@ int tsdf_icp_create(int width, int height, float cx, float cy, float fx, float f
     if (e == hipSuccess) e = hipMalloc((void **)&f->partial, (size_t)2 * kIcpBlocks * 32 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&f->state, 2 * kIcpStateDoubles * sizeof(double));
     if (e == hipSuccess) e = hipMemset(f->state, 0, 2 * kIcpStateDoubles * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&f->arrivals, (2 + 32) * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(f->arrivals, 0, (2 + 32) * sizeof(unsigned long long));
     if (e != hipSuccess) {
         free_icp(f);
         return hip_fail(e, "ICP alloc failed");
@@ -656,13 +762,39 @@ int tsdf_icp_get_incremental_transformation(tsdf_icp *f, double T_prev_curr[16],
     TSDF_HIP(hipMemcpyAsync(f->state + f->side * kIcpStateDoubles, T_prev_curr, 16 * sizeof(double), hipMemcpyHostToDevice, f->stream),
              "ICP pose upload");
     const int iterations[kIcpLevels] = {10, 5, 4};  // ICPOdometry.cpp:99-101
-    int pending = 0;   // every launch finishes the step before it, the last step gets a launch of its own
-    for (int i = kIcpLevels - 1; i >= 0; i--)
-        for (int j = 0; j < iterations[i]; j++) {
-            launch_step(f, i, pending);
-            pending = 1;
+    if (tuning().icp_persistent) {
+        // one launch: the workgroups stay through all 19 iterations and meet in a grid barrier (icp_persistent_kernel)
+        IcpRun run;
+        for (int i = 0; i < kIcpLevels; i++) {
+            run.vmap_curr[i] = f->vmap_curr[i]; run.nmap_curr[i] = f->nmap_curr[i];
+            run.vmap_prev[i] = f->vmap_prev[i]; run.nmap_prev[i] = f->nmap_prev[i];
+            run.iterations[i] = iterations[i];
         }
-    launch_finish(f, 1);
+        run.rows0 = f->height; run.cols0 = f->width;
+        run.fx = f->fx; run.fy = f->fy; run.cx = f->cx; run.cy = f->cy;
+        run.dist_thresh = f->dist_thresh; run.angle_thresh = f->angle_thresh;
+        run.state_in = f->state + f->side * kIcpStateDoubles;
+        run.state_out = f->state + (1 - f->side) * kIcpStateDoubles;
+        run.partial = f->partial;
+        run.arrivals = f->arrivals;
+        run.arrivals_base = f->arrivals_base;
+        f->arrivals_base += (unsigned long long)kIcpBlocks * (iterations[0] + iterations[1] + iterations[2]);
+        run.leader = tuning().icp_persistent == 2 ? 1 : 0;
+        run.pose_pub = reinterpret_cast<double *>(f->arrivals + 2);
+        run.published = f->arrivals + 1;
+        run.published_base = f->published_base;
+        f->published_base += (unsigned long long)(iterations[0] + iterations[1] + iterations[2]);
+        hipLaunchKernelGGL(icp_persistent_kernel, dim3(kIcpBlocks), dim3(kIcpThreads), 0, f->stream, run);
+        f->side = 1 - f->side;
+    } else {
+        int pending = 0;   // every launch finishes the step before it, the last step gets a launch of its own
+        for (int i = kIcpLevels - 1; i >= 0; i--)
+            for (int j = 0; j < iterations[i]; j++) {
+                launch_step(f, i, pending);
+                pending = 1;
+            }
+        launch_finish(f, 1);
+    }
     TSDF_HIP(hipGetLastError(), "ICP kernels failed");
     double out[18];
     TSDF_HIP(hipMemcpyAsync(out, f->state + f->side * kIcpStateDoubles, sizeof(out), hipMemcpyDeviceToHost, f->stream), "ICP pose download");

@@ -42,6 +42,7 @@ const Tuning &tuning() {
         u.ray_learned_order = num("TSDF_RAY_LEARNED_ORDER", 1) != 0;
         u.ray_heavy_passes = std::max(num("TSDF_RAY_HEAVY_PASSES", 0), 0);
         u.ray_entry_bound = num("TSDF_RAY_ENTRY_BOUND", 1) != 0;
+        u.icp_persistent = num("TSDF_ICP_PERSISTENT", 0);
         u.occ_rebuild_period = std::max(num("TSDF_OCC_REBUILD_PERIOD", 16), 0);
         u.occ_scan_all = num("TSDF_OCC_SCAN_ALL", 0) != 0;
         u.reach_lds = num("TSDF_REACH_LDS", 0) != 0;
