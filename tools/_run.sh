@@ -1,14 +1,4 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r04j
-timeout 1200 python -m pytest tests/test_parity_icp.py -m gpu -x -q 2>&1 | tail -8 > gpurun_out/r04j/pytest2.log
-cat gpurun_out/r04j/pytest2.log
-for rep in 1 2; do for m in 0 1 2; do
-  TSDF_ICP_PERSISTENT=$m timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity --repeats 1 > gpurun_out/r04j/b_icp${m}_$rep.json 2> gpurun_out/r04j/b_icp${m}_$rep.err
-done; done
-python - <<'PY'
-import json,glob
-for f in sorted(glob.glob("gpurun_out/r04j/b_icp*.json")):
-    try:
-        d=json.load(open(f)); print(f, "icp ms/frame", d["icp"]["ms_per_frame"], "tracking ms/frame", d["tracking"]["ms_per_frame"], d["tracking"]["max_translation_error_mm"])
-    except Exception as e: print(f, "ERR", e)
-PY
+bash tools/pmc_bound.sh r04l > gpurun_out/r04l_pmc.log 2>&1
+bash tools/pmc_cmd.sh r04l "python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-parity --path-only --repeats 1 --steps 40 --warmup 8" "integrate_kernel<false, false\|process_ray_kernel<false, false\|process_ray_tail\|bilateral_kernel" "l2:TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" "mem:TA_TA_BUSY_sum TA_BUSY_avr SQ_LDS_BANK_CONFLICT SQ_INST_LEVEL_VMEM" >> gpurun_out/r04l_pmc.log 2>&1
+tail -40 gpurun_out/r04l_pmc.log

@@ -8,7 +8,7 @@
 tag=${1:-r02x}
 root=$(pwd); out=$root/gpurun_out; mkdir -p $out/profiles_$tag
 cd /tmp && export TMPDIR=/tmp
-cmd="python $root/bench.py --no-cpu-baseline --no-parity --path-only --steps 40 --warmup 8"
+cmd="python $root/bench.py --no-cpu-baseline --no-parity --path-only --repeats 1 --steps 40 --warmup 8"
 run() {  # name, counters...
   name=$1; shift
   timeout 300 rocprofv3 --kernel-trace --pmc "$@" -d $out/prof_$name -o bench -- $cmd > $out/prof_$name.log 2>&1
