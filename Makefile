@@ -11,7 +11,7 @@ CSRC      = tsdf_amd/csrc
 ifeq ($(DIAG),1)
 HIPFLAGS += -DTSDF_DIAGNOSTICS
 endif
-HIP_SRCS  = $(CSRC)/diagnostics.hip $(CSRC)/volume.hip $(CSRC)/integrate.hip $(CSRC)/raycast.hip $(CSRC)/bilateral.hip $(CSRC)/icp.hip $(CSRC)/mcubes.hip $(CSRC)/pipeline.hip
+HIP_SRCS  = $(CSRC)/diagnostics.hip $(CSRC)/volume.hip $(CSRC)/integrate.hip $(CSRC)/integrate_packed.hip $(CSRC)/weights.hip $(CSRC)/raycast.hip $(CSRC)/bilateral.hip $(CSRC)/icp.hip $(CSRC)/mcubes.hip $(CSRC)/pipeline.hip
 HIP_OBJS  = $(HIP_SRCS:.hip=.o)
 LIBDIR    = tsdf_amd/lib
 

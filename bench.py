@@ -475,10 +475,18 @@ def main():
     int_ms = kern["integrate"][1] or stage_ms["integrate"]
     int_gbs = int_bytes / (int_ms * 1e-3) / 1e9
     traffic, traffic_meta = load_traffic(args)
-    roof_int = {"kernel": "integrate_kernel", "bound": "hbm", "achieved": round(int_gbs, 2), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(int_gbs / HBM_PEAK_GBS, 5), "traffic": traffic.get("integrate_kernel"),
+    # How the weights are stored decides which kernel ran and what it moves per updated voxel: the algorithmic figure stays SURVEY 8d's
+    # (the reference's two fp32 arrays read and written: 16 B); with weights kept as 8- / 16-bit counts the kernel moves 10 / 12 B.
+    wbits = vol.weight_storage()[0]
+    int_kernel = "integrate_kernel" if wbits == 32 else "integrate_packed_kernel"
+    moved_per_voxel = {32: 16, 16: 12, 8: 10}[wbits]
+    roof_int = {"kernel": int_kernel, "bound": "hbm", "achieved": round(int_gbs, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(int_gbs / HBM_PEAK_GBS, 5), "traffic": traffic.get(int_kernel),
                 "algorithmic_bytes": int_bytes, "avg_launch_ms": round(int_ms, 4), "launches_timed": kern["integrate"][0],
-                "U_voxels_updated": U, "U_min_max": [int(min(U_frames)), int(max(U_frames))], "dense_bytes": 16 * N_vox}
+                "U_voxels_updated": U, "U_min_max": [int(min(U_frames)), int(max(U_frames))], "dense_bytes": 16 * N_vox,
+                "weight_storage_bits": wbits, "bytes_moved_per_updated_voxel": moved_per_voxel,
+                "moved_bytes_model": moved_per_voxel * U + 2 * W * H,
+                "moved_gbs": round((moved_per_voxel * U + 2 * W * H) / (int_ms * 1e-3) / 1e9, 2)}
     roof_int.update(traffic_meta)
     if not sharded:
         st = rc.stats(vol, cams[last - 1])             # S samples, T distinct voxels touched at the end state

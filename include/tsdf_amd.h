@@ -130,7 +130,14 @@ int tsdf_volume_distances(const tsdf_volume *volume, float **device_ptr);
  * tsdf_volume_weights / tsdf_volume_mark_dirty call that precedes them: those calls make that stream wait for a tightening of
  * the occupancy flags that tsdf_pipeline_step may have left running on its second stream (it reads the distances). */
 int tsdf_volume_mark_dirty(tsdf_volume *volume);
+/* weight_data(): a device pointer to one fp32 weight per resident voxel, the reference's layout.  Until this is called a volume may
+ * hold its weights more compactly (integrate only ever adds 1 to a weight, src/TSDF/TSDFVolume.cu:375-377: 8- or 16-bit counts,
+ * tsdf_volume_weight_storage); the call converts them and the volume keeps fp32 weights from then on, clear() included, because the
+ * caller may hold the pointer.  set_weight_data / get_weight_data speak fp32 whatever the storage and do not pin it. */
 int tsdf_volume_weights(const tsdf_volume *volume, float **device_ptr);
+/* How the weights are stored now: 8 or 16 (bits per voxel, counts) or 32 (fp32); *pinned (may be NULL) = 1 once tsdf_volume_weights
+ * has handed the fp32 pointer out.  Integration computes the same bits in every storage ((float)count is exact). */
+int tsdf_volume_weight_storage(const tsdf_volume *volume, int *bits_per_weight, int *pinned);
 int tsdf_volume_deformation(tsdf_volume *volume, tsdf_deformation_node **device_ptr);
 /* Replace set_distance_data/set_weight_data/set_deformation (src/TSDF/TSDFVolume.cu:731-757):
  * blocking H2D of every resident voxel. */

@@ -131,6 +131,12 @@ class TSDFVolume:
         check(lib.tsdf_volume_weights(self._h, C.byref(p)))
         return p.value
 
+    def weight_storage(self):
+        """(bits per stored weight: 8 / 16 = packed counts, 32 = the reference's fp32 array; pinned to fp32 by weight_data())"""
+        bits, pinned = C.c_int(), C.c_int()
+        check(lib.tsdf_volume_weight_storage(self._h, C.byref(bits), C.byref(pinned)))
+        return bits.value, bool(pinned.value)
+
     def deformation(self):
         p = C.c_void_p()
         check(lib.tsdf_volume_deformation(self._h, C.byref(p)))

@@ -89,6 +89,14 @@ void timing_end(struct ::tsdf_volume *v, int which);
     } while (0)
 #define TSDF_LAUNCH_TIMED(v, which, kernel, grid, block, ...) TSDF_LAUNCH_TIMED_LDS(v, which, kernel, grid, block, 0, __VA_ARGS__)
 int verify_fast_division(struct ::tsdf_volume *v);  // volume.hip
+// weights.hip: how the weights are stored
+int weights_create(struct ::tsdf_volume *v);
+void weights_destroy(struct ::tsdf_volume *v);
+int weights_clear(struct ::tsdf_volume *v);
+int weights_require_f32(struct ::tsdf_volume *v);
+int weights_make_room(struct ::tsdf_volume *v);
+int weights_upload(struct ::tsdf_volume *v, const float *host);
+int weights_download(const struct ::tsdf_volume *v, float *host);
 
 #define TSDF_HIP(call, what)                                  \
     do {                                                      \
@@ -227,7 +235,13 @@ struct tsdf_volume {
     // attachment is refused, and only the owner's destroy restores the stream the volume had before (pipeline.hip)
     const void *attached;
     float *dist;
+    // weights.hip: wmode 0 = the reference's fp32 array `weight` (wpacked null); 8 / 16 = counts of that many bits in `wpacked`
+    // (weight null), the planes of one integrate batch of a lane in one dword
     float *weight;
+    uint32_t *wpacked;
+    int wmode;
+    uint32_t weight_bound;   // packed modes: no count exceeds this (integrations since the weights were last known + their maximum then)
+    int weight_pinned;       // the caller holds the fp32 device pointer (tsdf_volume_weights): the volume keeps the reference's layout
     tsdf_deformation_node *nodes;  // nullptr while implicit
     // cached per-call temporaries (the reference mallocs/frees these every call)
     uint16_t *depth_buf;
@@ -298,6 +312,10 @@ struct tsdf_volume {
     uint16_t *tile_max;
     size_t tile_max_cap;
     float *plane_const;      // float4 per resident plane (+ padding): z-only terms of the projection
+    // the depth image of the brick list on the device inside a ring of zeros, (w + 2) x (h + 2): brick_cull_kernel's side job when the
+    // weights are packed; integrate_packed_kernel's bricks without an LDS tile look their depths up in it
+    uint16_t *depth_pad;
+    uint32_t depth_pad_w, depth_pad_h;
     // optional HIP-event timing of the two dominant kernels on the volume's stream (tsdf_volume_set_timing)
     int timing;                   // 0 = off, n = every n-th launch of each kernel is bracketed
     uint32_t timing_launches[3];

@@ -88,54 +88,10 @@ __device__ inline void mark_occupied(const OccGrid &occ, uint32_t vx, uint32_t v
             for (uint32_t bx = cx0; bx <= cx1; bx++) occ.cell[((size_t)bz * occ.nby + by) * occ.nbx + bx] = 1;
 }
 
-// Occupancy marks of integrate_kernel.  Each lane keeps one bit per plane of its brick ("my voxel of that plane got a new
-// distance that is not safely positive"); when the brick is done, mark_low_voxels() turns the bits of a wave row (64 voxels along x
-// from voxel 4 * bx0, at vy, planes z0 .. z0 + 63 at most) into exactly the bricks mark_occupied() flags voxel by voxel: per layer
-// of bricks along z, the ballot of the lanes with a bit among the planes that reach the layer, grown along x with scalar mask
-// arithmetic, written by at most 18 lanes.  Called by the whole wave.
-__device__ inline uint64_t plane_range_mask(int lo, int hi) {   // bits lo .. hi (any ints) of a 64-bit mask
-    lo = max(lo, 0);
-    hi = min(hi, 63);
-    return hi < lo ? 0ull : ((~0ull >> (63 - hi)) & (~0ull << lo));
-}
-__device__ inline void mark_low_voxels(const OccGrid &occ, const uint32_t bits_lo, const uint32_t bits_hi, const uint32_t bx0,
-                                       const uint32_t vy, const uint32_t z0, const uint32_t z_first, const uint32_t z_last, const uint32_t lane) {
-    const int bxl = (int)bx0 - 1 + (int)lane;   // lane l looks after brick bx0 - 1 + l
-    const bool in_grid = bxl >= 0 && bxl < (int)occ.nbx && lane < 18u;
-    const uint32_t sh = 4u * ((lane - 1u) & 15u);
-    // y: the row's voxels reach the bricks holding vy-2 .. vy+2 (fine) and vy / 4, plus the one before when vy is a multiple of 4 (cell)
-    const uint32_t by0 = (max(vy, (uint32_t)kBrickGrow) - kBrickGrow) >> kBrickShift, by1 = min((vy + kBrickGrow) >> kBrickShift, occ.nby - 1);
-    const uint32_t cy1 = vy >> kBrickShift, cy0 = ((vy & (kBrick - 1)) == 0 && cy1 > 0) ? cy1 - 1 : cy1;
-    const uint32_t zb_first = (max(z_first, (uint32_t)kBrickGrow) - kBrickGrow) >> kBrickShift, zb_last = min((z_last + kBrickGrow) >> kBrickShift, occ.nbz - 1);
-#pragma unroll 1
-    for (uint32_t zb = zb_first; zb <= zb_last; zb++) {
-        // fine[zb] takes voxels with (z-2)/4 <= zb <= (z+2)/4, i.e. z in [4 zb - 2, 4 zb + 5]; cell[zb] those with z / 4 == zb or
-        // z == 4 (zb + 1), i.e. z in [4 zb, 4 zb + 4]  (mark_occupied's ranges, solved for the brick)
-        const int rel = (int)(zb << kBrickShift) - (int)z0;
-        const uint64_t zf = plane_range_mask(rel - 2, rel + 5), zc = plane_range_mask(rel, rel + 4);
-        const uint64_t low = __ballot(((bits_lo & (uint32_t)zf) | (bits_hi & (uint32_t)(zf >> 32))) != 0u);
-        if (low) {
-            // x, fine: the bricks holding v-2 .. v+2.  Inside the row that is the mask grown by two lanes either way, nibble by
-            // nibble; lanes 0, 1 also reach the brick before the row, lanes 62, 63 the one after it
-            const uint64_t grown = low | (low << 1) | (low << 2) | (low >> 1) | (low >> 2);
-            const bool f_fine = in_grid && (lane == 0u ? (low & 3ull) != 0 : lane == 17u ? (low >> 62) != 0 : ((grown >> sh) & 15ull) != 0);
-            if (f_fine) {   // (by1 - by0 is 0 or 1: two stores, possibly to the same byte)
-                occ.fine[((size_t)zb * occ.nby + by0) * occ.nbx + bxl] = 1;
-                occ.fine[((size_t)zb * occ.nby + by1) * occ.nbx + bxl] = 1;
-            }
-        }
-        const uint64_t lowc = __ballot(((bits_lo & (uint32_t)zc) | (bits_hi & (uint32_t)(zc >> 32))) != 0u);
-        if (lowc) {
-            // x, cell: brick v / 4, and the one before it when v is a multiple of 4
-            const uint64_t with_prev = lowc | ((lowc & 0x1111111111111111ull) >> 1);
-            const bool f_cell = in_grid && lane < 17u && (lane == 0u ? (lowc & 1ull) != 0 : ((with_prev >> sh) & 15ull) != 0);
-            if (f_cell) {
-                occ.cell[((size_t)zb * occ.nby + cy0) * occ.nbx + bxl] = 1;
-                occ.cell[((size_t)zb * occ.nby + cy1) * occ.nbx + bxl] = 1;
-            }
-        }
-    }
-}
+// integrate_packed.hip
+int launch_integrate_packed_kernel(tsdf_volume *v, dim3 grid, const BrickGrid &bg, const Mat44 &ip, const Mat33 &mk, uint32_t width,
+                                   uint32_t height, const uint16_t *d_depth, unsigned long long *counter_arg, const uint4 *boxes,
+                                   const uint32_t *count, const float4 *plane_const);
 
 constexpr int kDepthTile = TSDF_DEPTH_TILE;  // pixels per side of a depth tile (16)
 constexpr int kCullTilesLds = 4096;  // tile maxima brick_cull_kernel keeps in LDS (1200 at 640x480)
@@ -164,7 +120,8 @@ __global__ __launch_bounds__(256) void brick_cull_kernel(const Geom g, const Bri
                                                          uint4 *__restrict__ boxes, uint32_t *__restrict__ count,
                                                          uint32_t *__restrict__ count_next,
                                                          float4 *__restrict__ plane_const, const uint32_t n_plane_const,
-                                                         const float cone_mx, const float cone_my) {
+                                                         const float cone_mx, const float cone_my,
+                                                         const uint16_t *__restrict__ depth, uint16_t *__restrict__ depth_pad) {
     // One lane per corner: 8 consecutive lanes share a brick and combine their corners with 3 butterfly steps (a thread per brick
     // walked its 8 corners one after the other on a quarter of the chip's compute units: 12 us of dependent arithmetic).
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
@@ -179,6 +136,13 @@ __global__ __launch_bounds__(256) void brick_cull_kernel(const Geom g, const Bri
         const float cz = ((((int)vz + 0.5f) * g.vs.z) + g.offset_clear.z) + g.offset.z;
         plane_const[p] = make_float4(cz, ip.m13 * cz, ip.m23 * cz, ip.m33 * cz);
     }
+    // side job (volumes with packed weights): the image inside a ring of zeros, for integrate_packed_kernel's bricks without a tile
+    // (the ring was zeroed when the buffer was allocated)
+    if (depth_pad)
+        for (uint32_t p = t; p < width * height; p += gridDim.x * 256) {
+            const uint32_t y = p / width, x = p - y * width;
+            depth_pad[(size_t)(y + 1u) * (width + 2u) + (x + 1u)] = depth[p];
+        }
     // the tile maxima in LDS (when they fit): the depth test below reads up to 256 of them per brick
     __shared__ uint16_t tmax_lds[kCullTilesLds];
     __shared__ uint32_t wave_count[4], wg_base;   // survivors per wave of this workgroup, the workgroup's first slot in the list
@@ -341,13 +305,6 @@ __device__ inline void round_quotients(float a1, float a2, float b, float near_h
         if (rx != rx) rx = 0.0f;
         if (ry != ry) ry = 0.0f;
     }
-}
-
-// float -> int as the hardware converts: saturating, NaN -> 0 (defined for every float, unlike the C cast)
-__device__ inline int cvt_i32_sat(float f) {
-    int i;
-    asm("v_cvt_i32_f32 %0, %1" : "=v"(i) : "v"(f));
-    return i;
 }
 
 // Per z plane, the terms of the projection that depend on z only (the same fp32 products the reference forms per voxel):
@@ -673,6 +630,16 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
         TSDF_HIP(hipMalloc((void **)&v->tile_max, (size_t)tiles_x * tiles_y * sizeof(uint16_t)), "depth tile alloc");
         v->tile_max_cap = (size_t)tiles_x * tiles_y;
     }
+    if (v->wmode != 0 && !v->nodes && (!v->depth_pad || v->depth_pad_w != width || v->depth_pad_h != height)) {
+        // (re)allocated between frames only: the culling that fills it and the integrate_packed_kernel that reads it belong to one frame
+        if (v->depth_pad) (void)hipFree(v->depth_pad);
+        v->depth_pad = nullptr;
+        v->prepared_valid = 0;
+        const size_t pad_bytes = (size_t)(width + 2u) * (height + 2u) * sizeof(uint16_t);
+        TSDF_HIP(hipMalloc((void **)&v->depth_pad, pad_bytes), "padded depth alloc");
+        TSDF_HIP(hipMemset(v->depth_pad, 0, pad_bytes), "padded depth alloc");
+        v->depth_pad_w = width; v->depth_pad_h = height;
+    }
     // the list's length: the last two slots, used alternately (see brick_cull_kernel)
     // (a prepared list: its length is behind the word the culling of the prepare call used)
     PreparedCull sig;
@@ -726,7 +693,7 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
                                tiles_x, v->tile_max);
         hipLaunchKernelGGL(brick_cull_kernel, dim3((unsigned)((8 * n_bricks + 255) / 256)), dim3(256), 0, cull_stream, g, bg, ip, mk,
                            width, height, caller_tile_max ? caller_tile_max : v->tile_max, tiles_x, depth_test, v->brick_list, boxes, count,
-                           count_next, plane_const, n_plane_const, cone_mx, cone_my);
+                           count_next, plane_const, n_plane_const, cone_mx, cone_my, d_depth, v->wmode != 0 ? v->depth_pad : nullptr);
         v->brick_count_side = 1u - v->brick_count_side;
         if (phase == kIntPrepare) {
             TSDF_HIP(hipGetLastError(), "Integrate culling failed");
@@ -761,10 +728,23 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
     brick_log = diag_brick_log_alloc(v, n_bricks);   // TSDF_DEBUG_BRICKS=3: per-brick clocks of the launch (diagnostics.hip)
 #endif
     unsigned long long *counter_arg = brick_log ? brick_log : (v->counting ? v->counter_dev : nullptr);
+    // Weights kept as packed counts (weights.hip) go with integrate_packed_kernel, which is written for the standard camera and
+    // implicit nodes; anything else takes the reference's fp32 layout first (and keeps it until clear()).
+    if (v->wmode != 0) {
+        // (integrate_packed_kernel addresses a brick's planes with 32-bit byte offsets)
+        const bool planes_fit = (size_t)g.X * g.Y * sizeof(float) * (kChunkZ + kBatchZ) < ((size_t)1 << 31);
+        int rcw = (v->nodes || !std_camera || brick_log || !planes_fit) ? weights_require_f32(v) : weights_make_room(v);
+        if (rcw != TSDF_OK) return rcw;
+    }
 #define LAUNCH(DEF, CNT, STDC)                                                                                       \
     TSDF_LAUNCH_TIMED(v, 0, (integrate_kernel<DEF, CNT, STDC>), grid, block, v->dist, v->weight, v->nodes,          \
                       g, bg, ip, mk, mkinv, width, height, d_depth, counter_arg, v->occ, v->brick_list, boxes, count, plane_const, v->touched)
-    if (v->nodes) {
+    if (v->wmode != 0) {
+        const int rcp = launch_integrate_packed_kernel(v, dim3((unsigned)n_bricks), bg,   // (one brick per workgroup, always)
+                                                        ip, mk, width, height, d_depth, counter_arg, boxes, count, plane_const);
+        if (rcp != TSDF_OK) return rcp;
+        v->weight_bound++;
+    } else if (v->nodes) {
         if (v->counting) LAUNCH(true, true, false); else LAUNCH(true, false, false);
     } else if (std_camera) {
         if (v->counting) LAUNCH(false, true, true); else LAUNCH(false, false, true);

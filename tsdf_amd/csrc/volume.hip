@@ -63,22 +63,15 @@ int hip_fail(hipError_t e, const char *what) {
 
 // ---- fill kernels ------------------------------------------------------------------------
 // clear() is a pure streaming write: 16 B per lane per store, grid-stride, 2048 blocks.
-__global__ __launch_bounds__(256) void fill2_kernel(float *__restrict__ dist, float *__restrict__ weight,
-                                                    size_t n, float dval, float wval) {
+// (the weights are zeroed by weights_clear, weights.hip: a memset of however many bytes they take)
+__global__ __launch_bounds__(256) void fill_kernel(float *__restrict__ dist, size_t n, float dval) {
     size_t n4 = n >> 2;
     float4 d4 = make_float4(dval, dval, dval, dval);
-    float4 w4 = make_float4(wval, wval, wval, wval);
     size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        reinterpret_cast<float4 *>(dist)[i] = d4;
-        reinterpret_cast<float4 *>(weight)[i] = w4;
-    }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) reinterpret_cast<float4 *>(dist)[i] = d4;
     // tail (n not a multiple of 4)
     size_t t = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) {
-        dist[t] = dval;
-        weight[t] = wval;
-    }
+    if (t < n) dist[t] = dval;
 }
 
 // float4 streaming copy, one 16-byte element per thread and four per loop trip (tsdf_measure_copy_bandwidth)
@@ -843,7 +836,6 @@ int tsdf_volume_create_slab(uint32_t sx, uint32_t sy, uint32_t sz, float px, flo
     if (e == hipSuccess) e = hipMalloc((void **)&v->occ.reach, v->occ.fine_count());
     size_t bytes = v->resident_voxels() * sizeof(float);
     if (e == hipSuccess) e = hipMalloc((void **)&v->dist, bytes);
-    if (e == hipSuccess) e = hipMalloc((void **)&v->weight, bytes);
     if (e == hipSuccess) e = hipMalloc((void **)&v->counter_dev, 4 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(v->counter_dev, 0, 4 * sizeof(unsigned long long));
     if (e != hipSuccess) {
@@ -851,7 +843,8 @@ int tsdf_volume_create_slab(uint32_t sx, uint32_t sy, uint32_t sz, float px, flo
         tsdf_volume_destroy(v);
         return rc;
     }
-    int rc = build_t_table(v);
+    int rc = weights_create(v);
+    if (rc == TSDF_OK) rc = build_t_table(v);
     if (rc == TSDF_OK) rc = verify_fast_division(v);
     if (rc == TSDF_OK) rc = tsdf_volume_clear(v);
     if (rc == TSDF_OK) rc = tsdf_volume_synchronize(v);
@@ -873,7 +866,7 @@ int tsdf_volume_destroy(tsdf_volume *v) {
     if (v->occ_tighten_pending) (void)hipEventSynchronize(v->occ_tightened);
     if (v->occ_tightened) (void)hipEventDestroy(v->occ_tightened);
     if (v->dist) (void)hipFree(v->dist);
-    if (v->weight) (void)hipFree(v->weight);
+    weights_destroy(v);
     if (v->nodes) (void)hipFree(v->nodes);
     if (v->depth_buf) (void)hipFree(v->depth_buf);
     if (v->vert_buf) (void)hipFree(v->vert_buf);
@@ -886,6 +879,7 @@ int tsdf_volume_destroy(tsdf_volume *v) {
     if (v->occ_rim_bits) (void)hipFree(v->occ_rim_bits);
     if (v->touched) (void)hipFree(v->touched);
     if (v->plane_const) (void)hipFree(v->plane_const);
+    if (v->depth_pad) (void)hipFree(v->depth_pad);
     if (v->tail_entries) (void)hipFree(v->tail_entries);
     if (v->tail_count) (void)hipFree(v->tail_count);
     if (v->ray_heavy) (void)hipFree(v->ray_heavy);
@@ -930,7 +924,11 @@ int tsdf_volume_clear(tsdf_volume *v) {
         if (rcj != TSDF_OK) return rcj;
     }
     size_t n = v->resident_voxels();
-    hipLaunchKernelGGL(fill2_kernel, dim3(2048), dim3(256), 0, v->stream, v->dist, v->weight, n, v->g.trunc, 0.0f);
+    {
+        const int rcw = weights_clear(v);
+        if (rcw != TSDF_OK) return rcw;
+    }
+    hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, v->stream, v->dist, n, v->g.trunc);
     TSDF_HIP(hipGetLastError(), "Couldn't clear TSDF data");
     // every distance is +trunc again: only the permanent boundary marks remain
     int rc0 = occupancy_reset(v);
@@ -1105,6 +1103,11 @@ int tsdf_volume_weights(const tsdf_volume *v, float **p) {
     TSDF_REQUIRE(v && p, "null argument");
     const int rcj = occupancy_join(const_cast<tsdf_volume *>(v));
     if (rcj != TSDF_OK) return rcj;
+    // the reference's weight_data(): a device pointer to fp32 weights.  The volume takes the reference's layout and keeps it
+    // (weights.hip): the caller may hold the pointer and write through it.
+    const int rcw = weights_require_f32(const_cast<tsdf_volume *>(v));
+    if (rcw != TSDF_OK) return rcw;
+    const_cast<tsdf_volume *>(v)->weight_pinned = 1;
     *p = v->weight;
     return TSDF_OK;
 }
@@ -1147,7 +1150,9 @@ int tsdf_volume_set_distance_data(tsdf_volume *v, const float *host) {
 
 int tsdf_volume_set_weight_data(tsdf_volume *v, const float *host) {
     TSDF_REQUIRE(v, "null volume");
-    return copy_in(v, v->weight, host, v->resident_voxels() * sizeof(float), "Couldn't set weight data");
+    TSDF_REQUIRE(host, "null argument");
+    v->prepared_valid = 0;   // (the storage of the weights may change, and with it what a brick list prepared ahead came with)
+    return weights_upload(v, host);
 }
 
 int tsdf_volume_set_deformation(tsdf_volume *v, const tsdf_deformation_node *host) {
@@ -1172,7 +1177,8 @@ int tsdf_volume_get_distance_data(const tsdf_volume *v, float *host) {
 
 int tsdf_volume_get_weight_data(const tsdf_volume *v, float *host) {
     TSDF_REQUIRE(v, "null volume");
-    return copy_out(v, host, v->weight, v->resident_voxels() * sizeof(float), "Couldn't read weight data");
+    TSDF_REQUIRE(host, "null argument");
+    return weights_download(v, host);
 }
 
 int tsdf_volume_get_deformation_planes(const tsdf_volume *v, uint32_t plane_begin, uint32_t plane_count,

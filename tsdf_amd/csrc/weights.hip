@@ -1,0 +1,282 @@
+// How a volume stores its weights.
+//
+// The reference keeps one float per voxel (m_weights, src/include/TSDFVolume.hpp) and integrate_kernel only ever adds 1 to it (the
+// clamp to max_weight is commented out, src/TSDF/TSDFVolume.cu:375-377): unless a caller uploads something else, a weight is the
+// number of frames that have updated the voxel.  Integration is a read-modify-write of distance and weight of every updated voxel
+// and is bound by that traffic, so the count is kept as narrow as it can be:
+//   wmode 8   one byte per voxel, the bytes of planes 4g .. 4g + 3 (counted from the first resident plane) of one (x, y) in one dword
+//             at wpacked[g * X * Y + y * X + x] -- the four planes a lane of integrate_packed_kernel walks as one batch;
+//   wmode 16  two bytes per voxel, planes 2g, 2g + 1 in one dword;
+//   wmode 0   the reference's layout: fp32, `weight`, index x + y X + z X Y.
+// A volume starts at wmode 8 (TSDF_WEIGHT_PACK = 8 | 16 | 0 picks the starting mode), moves to 16 before the integration that could
+// take a count past 255, and to fp32 before the one that could pass 65535 (`weight_bound` counts integrations since the weights were
+// last known) -- or at once when it needs the general kernel (custom deformation nodes, a camera that is not of the standard shape),
+// when weights that are not such counts are uploaded, or when the caller asks for the device pointer (tsdf_volume_weights: the
+// reference's weight_data(); from then on the volume keeps the reference's layout, "pinned").  clear() returns an unpinned volume to
+// the starting mode.  Every accessor speaks fp32 whatever the mode; the arithmetic of integration is the same exact fp32 expression in
+// all three ((float)count is exact), tests/test_weight_storage.py.
+#include <algorithm>
+
+#include "common.hpp"
+
+namespace tsdf {
+
+static size_t packed_words(const tsdf_volume *v, int bits) {
+    const size_t per = 32 / bits, planes = v->g.z_store_end - v->g.z_store_begin;
+    return (size_t)v->g.X * v->g.Y * ((planes + per - 1) / per);
+}
+
+// one thread per dword of the packed array: its planes out as floats
+template <int BITS>
+__global__ __launch_bounds__(256) void weights_expand_kernel(const uint32_t *__restrict__ wp, float *__restrict__ w, size_t xy, uint32_t planes, size_t n_words) {
+    constexpr uint32_t kPer = 32 / BITS, kMask = BITS == 8 ? 0xffu : 0xffffu;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (size_t)gridDim.x * 256) {
+        const size_t grp = i / xy, in_plane = i - grp * xy;
+        const uint32_t word = wp[i];
+#pragma unroll
+        for (uint32_t s = 0; s < kPer; s++) {
+            const size_t z = grp * kPer + s;
+            if (z < planes) w[z * xy + in_plane] = (float)((word >> (BITS * s)) & kMask);
+        }
+    }
+}
+// 8 -> 16 bits: one thread per dword of the 8-bit array, two dwords out
+__global__ __launch_bounds__(256) void weights_widen_kernel(const uint32_t *__restrict__ w8, uint32_t *__restrict__ w16, size_t xy, size_t n_words8, size_t n_words16) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_words8; i += (size_t)gridDim.x * 256) {
+        const size_t grp = i / xy, in_plane = i - grp * xy;
+        const uint32_t word = w8[i];
+        const size_t o = (2 * grp) * xy + in_plane;
+        w16[o] = (word & 0xffu) | ((word & 0xff00u) << 8);
+        if (o + xy < n_words16) w16[o + xy] = ((word >> 16) & 0xffu) | ((word >> 24) << 16);
+    }
+}
+// fp32 -> packed: one thread per dword out.  stats[0] |= 1 when a weight is not an integer in [0, 65535]; stats[1] = the largest weight
+// (as the bits of a non-negative float: they order like the values)
+template <int BITS>
+__global__ __launch_bounds__(256) void weights_pack_kernel(const float *__restrict__ w, uint32_t *__restrict__ wp, size_t xy, uint32_t planes, size_t n_words) {
+    constexpr uint32_t kPer = 32 / BITS;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (size_t)gridDim.x * 256) {
+        const size_t grp = i / xy, in_plane = i - grp * xy;
+        uint32_t word = 0;
+#pragma unroll
+        for (uint32_t s = 0; s < kPer; s++) {
+            const size_t z = grp * kPer + s;
+            if (z < planes) word |= (uint32_t)w[z * xy + in_plane] << (BITS * s);
+        }
+        wp[i] = word;
+    }
+}
+__global__ __launch_bounds__(256) void weights_survey_kernel(const float *__restrict__ w, size_t n, uint32_t *__restrict__ stats) {
+    uint32_t bad = 0, top = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float x = w[i];
+        // a count: an integer in [0, 65535] (-0 is not: its bits differ from +0's)
+        const bool ok = x >= 0.0f && x <= 65535.0f && x == truncf(x) && __float_as_uint(x) != 0x80000000u;
+        bad |= ok ? 0u : 1u;
+        if (ok) top = max(top, (uint32_t)x);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        bad |= (uint32_t)__shfl_down((int)bad, o);
+        top = max(top, (uint32_t)__shfl_down((int)top, o));
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        if (bad) atomicOr(&stats[0], 1u);
+        if (top) atomicMax(&stats[1], top);
+    }
+}
+
+static int weight_pack_start() {
+    static const int m = [] {
+        const char *e = getenv("TSDF_WEIGHT_PACK");
+        const int v = e ? atoi(e) : 8;
+        return (v == 0 || v == 16) ? v : 8;
+    }();
+    return m;
+}
+
+// the packed array for `bits`, zeroed or not
+static int alloc_packed(tsdf_volume *v, int bits, uint32_t **out) {
+    const size_t words = packed_words(v, bits);
+    TSDF_HIP(hipMalloc((void **)out, words * sizeof(uint32_t)), "Couldn't allocate space for TSDF weights");
+    return TSDF_OK;
+}
+
+int weights_create(tsdf_volume *v) {
+    v->wmode = weight_pack_start();
+    v->weight_bound = 0;
+    v->weight_pinned = 0;
+    if (v->wmode == 0) {
+        TSDF_HIP(hipMalloc((void **)&v->weight, v->resident_voxels() * sizeof(float)), "Couldn't allocate space for TSDF weights");
+        return TSDF_OK;
+    }
+    return alloc_packed(v, v->wmode, &v->wpacked);
+}
+
+void weights_destroy(tsdf_volume *v) {
+    if (v->weight) (void)hipFree(v->weight);
+    if (v->wpacked) (void)hipFree(v->wpacked);
+    v->weight = nullptr;
+    v->wpacked = nullptr;
+}
+
+// fp32 weights out of the packed array into `dst` (resident_voxels() floats), on the volume's stream
+static int expand_into(const tsdf_volume *v, float *dst) {
+    const size_t xy = (size_t)v->g.X * v->g.Y, words = packed_words(v, v->wmode);
+    const uint32_t planes = v->g.z_store_end - v->g.z_store_begin;
+    const dim3 grid((unsigned)std::min<size_t>((words + 255) / 256, 4096));
+    if (v->wmode == 8) hipLaunchKernelGGL(weights_expand_kernel<8>, grid, dim3(256), 0, v->stream, v->wpacked, dst, xy, planes, words);
+    else hipLaunchKernelGGL(weights_expand_kernel<16>, grid, dim3(256), 0, v->stream, v->wpacked, dst, xy, planes, words);
+    TSDF_HIP(hipGetLastError(), "Couldn't expand the weights");
+    return TSDF_OK;
+}
+
+// The reference's layout from here on (until clear(), unless pinned).
+int weights_require_f32(tsdf_volume *v) {
+    if (v->wmode == 0) return TSDF_OK;
+    float *w = nullptr;
+    TSDF_HIP(hipMalloc((void **)&w, v->resident_voxels() * sizeof(float)), "Couldn't allocate space for TSDF weights");
+    const int rc = expand_into(v, w);
+    if (rc != TSDF_OK) {
+        (void)hipFree(w);
+        return rc;
+    }
+    TSDF_HIP(hipStreamSynchronize(v->stream), "Couldn't expand the weights");
+    (void)hipFree(v->wpacked);
+    v->wpacked = nullptr;
+    v->weight = w;
+    v->wmode = 0;
+    return TSDF_OK;
+}
+
+// Before an integration in a packed mode: no count may pass what the mode holds.
+int weights_make_room(tsdf_volume *v) {
+    if (v->wmode == 8 && v->weight_bound >= 255u) {
+        uint32_t *w16 = nullptr;
+        int rc = alloc_packed(v, 16, &w16);
+        if (rc != TSDF_OK) return rc;
+        const size_t xy = (size_t)v->g.X * v->g.Y, n8 = packed_words(v, 8), n16 = packed_words(v, 16);
+        hipLaunchKernelGGL(weights_widen_kernel, dim3((unsigned)std::min<size_t>((n8 + 255) / 256, 4096)), dim3(256), 0, v->stream, v->wpacked, w16, xy, n8, n16);
+        TSDF_HIP(hipGetLastError(), "Couldn't widen the weights");
+        TSDF_HIP(hipStreamSynchronize(v->stream), "Couldn't widen the weights");
+        (void)hipFree(v->wpacked);
+        v->wpacked = w16;
+        v->wmode = 16;
+    }
+    if (v->wmode == 16 && v->weight_bound >= 65535u) return weights_require_f32(v);
+    return TSDF_OK;
+}
+
+// clear(): every weight 0 (on the volume's stream); an unpinned volume goes back to its starting mode
+int weights_clear(tsdf_volume *v) {
+    const int start = v->weight_pinned ? 0 : weight_pack_start();
+    if (v->wmode != start) {
+        TSDF_HIP(hipStreamSynchronize(v->stream), "clear");
+        weights_destroy(v);
+        v->wmode = start;
+        if (start == 0) TSDF_HIP(hipMalloc((void **)&v->weight, v->resident_voxels() * sizeof(float)), "Couldn't allocate space for TSDF weights");
+        else {
+            const int rc = alloc_packed(v, start, &v->wpacked);
+            if (rc != TSDF_OK) return rc;
+        }
+    }
+    v->weight_bound = 0;
+    if (v->wmode == 0) TSDF_HIP(hipMemsetAsync(v->weight, 0, v->resident_voxels() * sizeof(float), v->stream), "Couldn't clear TSDF weights");
+    else TSDF_HIP(hipMemsetAsync(v->wpacked, 0, packed_words(v, v->wmode) * sizeof(uint32_t), v->stream), "Couldn't clear TSDF weights");
+    return TSDF_OK;
+}
+
+// set_weight_data(): counts are packed (into the narrowest mode from the starting one that holds them), anything else is kept as fp32
+int weights_upload(tsdf_volume *v, const float *host) {
+    const size_t n = v->resident_voxels();
+    float *w = nullptr;
+    TSDF_HIP(hipStreamSynchronize(v->stream), "Couldn't set weight data");
+    if (v->wmode == 0) w = v->weight;
+    else TSDF_HIP(hipMalloc((void **)&w, n * sizeof(float)), "Couldn't allocate space for TSDF weights");
+    hipError_t e = hipMemcpyAsync(w, host, n * sizeof(float), hipMemcpyHostToDevice, v->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(v->stream);
+    if (e != hipSuccess) {
+        if (w != v->weight) (void)hipFree(w);
+        return hip_fail(e, "Couldn't set weight data");
+    }
+    if (v->wmode == 0 && (v->weight_pinned || weight_pack_start() == 0)) return TSDF_OK;
+    // are they counts?
+    uint32_t stats[2] = {0, 0};
+    e = hipMemsetAsync(v->counter_dev + 3, 0, sizeof(stats), v->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(weights_survey_kernel, dim3(2048), dim3(256), 0, v->stream, w, n, reinterpret_cast<uint32_t *>(v->counter_dev + 3));
+        e = hipMemcpyAsync(stats, v->counter_dev + 3, sizeof(stats), hipMemcpyDeviceToHost, v->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(v->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(v->counter_dev + 3, 0, sizeof(stats), v->stream);   // (scratch slot shared with verify_fast_division)
+    if (e != hipSuccess) {
+        if (w != v->weight) (void)hipFree(w);
+        return hip_fail(e, "Couldn't set weight data");
+    }
+    const int want = stats[0] ? 0 : (stats[1] <= 255u && weight_pack_start() == 8 ? 8 : 16);
+    if (want == 0) {   // not counts: the reference's layout
+        if (v->wmode != 0) {
+            (void)hipFree(v->wpacked);
+            v->wpacked = nullptr;
+            v->weight = w;
+            v->wmode = 0;
+        }
+        return TSDF_OK;
+    }
+    if (v->wmode != want) {
+        if (v->wpacked) (void)hipFree(v->wpacked);
+        v->wpacked = nullptr;
+        const int rc = alloc_packed(v, want, &v->wpacked);
+        if (rc != TSDF_OK) {
+            if (w != v->weight) (void)hipFree(w);
+            return rc;
+        }
+    }
+    const size_t xy = (size_t)v->g.X * v->g.Y, words = packed_words(v, want);
+    const uint32_t planes = v->g.z_store_end - v->g.z_store_begin;
+    const dim3 grid((unsigned)std::min<size_t>((words + 255) / 256, 4096));
+    if (want == 8) hipLaunchKernelGGL(weights_pack_kernel<8>, grid, dim3(256), 0, v->stream, w, v->wpacked, xy, planes, words);
+    else hipLaunchKernelGGL(weights_pack_kernel<16>, grid, dim3(256), 0, v->stream, w, v->wpacked, xy, planes, words);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(v->stream);
+    (void)hipFree(w);
+    if (w == v->weight) v->weight = nullptr;
+    v->wmode = want;
+    v->weight_bound = stats[1];
+    if (e != hipSuccess) return hip_fail(e, "Couldn't set weight data");
+    return TSDF_OK;
+}
+
+// get_weight_data(): fp32 on the host whatever the mode
+int weights_download(const tsdf_volume *v, float *host) {
+    const size_t n = v->resident_voxels();
+    if (v->wmode == 0) {
+        TSDF_HIP(hipMemcpyAsync(host, v->weight, n * sizeof(float), hipMemcpyDeviceToHost, v->stream), "Couldn't read weight data");
+        TSDF_HIP(hipStreamSynchronize(v->stream), "Couldn't read weight data");
+        return TSDF_OK;
+    }
+    float *w = nullptr;
+    TSDF_HIP(hipMalloc((void **)&w, n * sizeof(float)), "Couldn't read weight data");
+    int rc = expand_into(v, w);
+    hipError_t e = hipSuccess;
+    if (rc == TSDF_OK) e = hipMemcpyAsync(host, w, n * sizeof(float), hipMemcpyDeviceToHost, v->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(v->stream);
+    (void)hipFree(w);
+    if (rc != TSDF_OK) return rc;
+    if (e != hipSuccess) return hip_fail(e, "Couldn't read weight data");
+    return TSDF_OK;
+}
+
+}  // namespace tsdf
+
+using namespace tsdf;
+
+extern "C" {
+
+int tsdf_volume_weight_storage(const tsdf_volume *v, int *bits_per_weight, int *pinned) {
+    TSDF_REQUIRE(v && bits_per_weight, "null argument");
+    *bits_per_weight = v->wmode == 0 ? 32 : v->wmode;
+    if (pinned) *pinned = v->weight_pinned;
+    return TSDF_OK;
+}
+
+}  // extern "C"
