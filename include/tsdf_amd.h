@@ -138,6 +138,11 @@ int tsdf_volume_weights(const tsdf_volume *volume, float **device_ptr);
 /* How the weights are stored now: 8 or 16 (bits per voxel, counts) or 32 (fp32); *pinned (may be NULL) = 1 once tsdf_volume_weights
  * has handed the fp32 pointer out.  Integration computes the same bits in every storage ((float)count is exact). */
 int tsdf_volume_weight_storage(const tsdf_volume *volume, int *bits_per_weight, int *pinned);
+/* Self-test of the kernel arithmetic behind packed weights: integrate divides by (count + 1) with a short exact sequence instead of
+ * the division instruction sequence (integrate_packed.hip: div_by_count, with the proof); this compares the two bit for bit for every
+ * mantissa of the dividend (both signs, three exponents) and every divisor in [b_begin, b_end), 1 <= b_begin < b_end <= 2^17 + 1, and
+ * returns the number of differences (0).  About a second for all 65536 divisors the 16-bit counts can reach. */
+int tsdf_selftest_count_division(uint32_t b_begin, uint32_t b_end, unsigned long long *mismatches);
 int tsdf_volume_deformation(tsdf_volume *volume, tsdf_deformation_node **device_ptr);
 /* Replace set_distance_data/set_weight_data/set_deformation (src/TSDF/TSDFVolume.cu:731-757):
  * blocking H2D of every resident voxel. */

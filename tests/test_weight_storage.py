@@ -201,6 +201,17 @@ def test_a_slab_packs_from_its_first_resident_plane(oracle):
         assert_same_floats(s.get_distance_data().reshape(b - a, -1), wd[a:b], "slab [%d, %d) distances" % (lo, hi))
 
 
+def test_the_short_division_by_a_count_is_the_division():
+    """integrate_packed_kernel forms (d w + tsdf) / (w + 1) with rcp + mul + two fmas (div_by_count, proof in integrate_packed.hip);
+    here against the division's own instruction sequence for every mantissa, both signs, three exponents, every divisor 1 .. 65536
+    (16-bit counts + 1), and the special values that take the long sequence."""
+    import ctypes as C
+    from tsdf_amd import _capi
+    bad = C.c_uint64(123)
+    assert _capi.lib.tsdf_selftest_count_division(1, 65537, C.byref(bad)) == 0
+    assert bad.value == 0
+
+
 SCRIPT = r"""
 import sys, hashlib, numpy as np
 sys.path.insert(0, %r)

@@ -51,6 +51,27 @@ __device__ inline float max3_abs_keep_nan(float acc, float a, float b) {
 }
 __device__ inline float med3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 
+// a / b as the IEEE division rounds it, for b an integer-valued float in [1, 2^17] (a weight count + 1) and any float a.
+//   y = rcp(b) (relative error e, |e| <= 2^-22 and far less in practice), q0 = fl(a y), r = a - q0 b, q1 = fl(q0 + r y).
+//   * |q0 - a / b| < 2.5 ulp of the quotient, so r = b (a / b - q0) is a multiple of ulp(q) / 2 below 2^24 of them: the fma forms it
+//     exactly;
+//   * q0 + r y = a / b + (a / b - q0) e, off the true quotient by less than 2.5 * 2^-22 ulp;
+//   * a quotient by an integer is never a rounding midpoint m (b m would need a 25th significant bit) and a - b m is a multiple of
+//     ulp(q) / 2, so a / b stays ulp / (2 b) >= 2^-18 ulp away from every midpoint: rounding the perturbed value rounds like the true
+//     one, q1 = RN(a / b).
+// That needs every intermediate normal: |a| in [2^-90, 2^90].  Anything else (zeros, denormals, huge values, infinities, NaN -- what a
+// caller may have uploaded) takes the division instruction sequence.  tsdf_selftest_count_division compares the two for every
+// mantissa of a and every b (tests/test_weight_storage.py).
+__device__ inline float div_by_count(float a, float b) {
+    const float y = __builtin_amdgcn_rcpf(b);
+    const float q0 = a * y;
+    const float r = __builtin_fmaf(-q0, b, a);
+    float q = __builtin_fmaf(r, y, q0);
+    const float aa = __builtin_fabsf(a);
+    if (__builtin_expect(!(aa >= 0x1p-90f && aa <= 0x1p90f), 0)) q = a / b;
+    return q;
+}
+
 constexpr int kPairFloats = 8;   // LDS per pair of planes: {cz, cz', m13 cz, m13 cz', m23 cz, m23 cz', m33 cz, m33 cz'}
 
 // WBITS = 8 or 16: bits per weight; 32 / WBITS planes of one (x, y) share a dword, group g of planes at wpk + g * X * Y.
@@ -193,7 +214,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TSDF_PACKED
         // branch filled the destination registers -- and the batches stopped overlapping.
         auto walk = [&](auto staged_c) {
         constexpr bool kStaged = decltype(staged_c)::value;
-        auto project_and_load = [&](const uint32_t o, float (&tsdf_)[kBatchZ], float (&pd_)[kBatchZ], uint32_t (&pw_)[kWords]) {
+        auto project_and_load = [&](const uint32_t o, bool (&upd_)[kBatchZ], float (&tsdf_)[kBatchZ], float (&pd_)[kBatchZ], uint32_t (&pw_)[kWords]) {
             // o = first plane of the batch relative to z0 (a multiple of 4)
             f2 rx_[2], ry_[2], camz_[2];
 #pragma unroll
@@ -250,9 +271,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TSDF_PACKED
                 const float sdf = (float)d_[j] - camz;
                 // depth > 0 (:355) and sdf >= -trunc (:366); NaN camz (planes / lanes past the grid): false
                 const bool update = d_[j] != 0 && sdf >= neg_trunc;
-                // (sdf > 0) ? min(sdf, trunc) : sdf  ==  sdf < trunc ? sdf : trunc   (trunc > 0); NaN = this frame does not update the voxel
-                tsdf_[j] = update ? (sdf < g.trunc ? sdf : g.trunc) : NAN;
-                pd_[j] = 0.f;
+                // (sdf > 0) ? min(sdf, trunc) : sdf  ==  min(sdf, trunc)   (trunc > 0, sdf not NaN under `update`)
+                upd_[j] = update;
+                asm("v_min_f32 %0, %1, %2" : "=v"(tsdf_[j]) : "s"(g.trunc), "v"(sdf));   // (the plain instruction: fminf would first canonicalise both operands)
                 if (update DIAG_NOLOAD) pd_[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(drsrc, lane_off4, dsoff(o + j), 0));
                 any = any || update;
                 if (kPlanesPerWord == 2 && (j & 1)) {
@@ -266,7 +287,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TSDF_PACKED
                 if (any DIAG_NOLOAD) pw_[0] = __builtin_amdgcn_raw_buffer_load_b32(wrsrc, lane_off4, wsoff(o), 0);
             }
         };
-        auto blend_and_store = [&](const uint32_t o, const float (&tsdf_)[kBatchZ], const float (&pd_)[kBatchZ], const uint32_t (&pw_)[kWords]) {
+        auto blend_and_store = [&](const uint32_t o, const bool (&upd_)[kBatchZ], const float (&tsdf_)[kBatchZ], const float (&pd_)[kBatchZ], const uint32_t (&pw_)[kWords]) {
             const uint32_t zb = z0 + o;
             // (uniform) a batch with a plane in the z part of the rim zone takes the flat test on every lane
             const bool z_rim = zb < (uint32_t)(kBrick + kBrickGrow) || zb + (uint32_t)kBatchZ - 1u + (uint32_t)kBrickGrow >= (uint32_t)kBrick * (occ.nbz - 1u);
@@ -276,13 +297,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TSDF_PACKED
             for (int w = 0; w < kWords; w++) nw_[w] = pw_[w];
 #pragma unroll
             for (int j = 0; j < kBatchZ; j++) {
-                if (tsdf_[j] == tsdf_[j]) {
+                if (upd_[j]) {
                     constexpr uint32_t kMask = WBITS == 8 ? 0xffu : 0xffffu;
                     const int w = j / kPlanesPerWord, s = (j % kPlanesPerWord) * WBITS;
                     float prior_weight = (float)((pw_[w] >> s) & kMask);
                     asm("" : "+v"(prior_weight));   // (opaque: the compiler otherwise forms count + 1 in integers and converts a second time)
                     const float new_weight = prior_weight + 1.0f;                                                   // :375-376
-                    const float new_distance = ((pd_[j] * prior_weight) + (tsdf_[j] * 1.0f)) / new_weight;        // :381
+                    const float new_distance = div_by_count((pd_[j] * prior_weight) + (tsdf_[j] * 1.0f), new_weight);   // :381
                     nw_[w] += 1u << s;   // (the caller has made room: weights.hip, weights_make_room)
                     if (true DIAG_NOSTORE_D) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, new_distance), drsrc, lane_off4, dsoff(o + j), 0);
                     if (!(new_distance > lo) || new_distance > hi) {   // not safely positive (rim zone: not flat): remember the plane
@@ -299,18 +320,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TSDF_PACKED
         static_assert(kChunkZ % (2 * kBatchZ) == 0, "the pipeline alternates two register sets");
         float tsdf_a[kBatchZ], pd_a[kBatchZ], tsdf_b[kBatchZ], pd_b[kBatchZ];
         uint32_t pw_a[kWords], pw_b[kWords];
-        project_and_load(0, tsdf_a, pd_a, pw_a);
+        bool upd_a[kBatchZ], upd_b[kBatchZ];   // (lane masks in scalar registers)
+        project_and_load(0, upd_a, tsdf_a, pd_a, pw_a);
 #pragma unroll
         for (uint32_t o = 0; o < (uint32_t)kChunkZ; o += 2 * kBatchZ) {
             // (batches past z1 -- the last bricks of a grid whose depth is not a multiple of kChunkZ -- are all NaN planes)
-            project_and_load(o + kBatchZ, tsdf_b, pd_b, pw_b);
-            blend_and_store(o, tsdf_a, pd_a, pw_a);
-            if (o + 2 * kBatchZ < (uint32_t)kChunkZ) project_and_load(o + 2 * kBatchZ, tsdf_a, pd_a, pw_a);
-            blend_and_store(o + kBatchZ, tsdf_b, pd_b, pw_b);
+            project_and_load(o + kBatchZ, upd_b, tsdf_b, pd_b, pw_b);
+            blend_and_store(o, upd_a, tsdf_a, pd_a, pw_a);
+            if (o + 2 * kBatchZ < (uint32_t)kChunkZ) project_and_load(o + 2 * kBatchZ, upd_a, tsdf_a, pd_a, pw_a);
+            blend_and_store(o + kBatchZ, upd_b, tsdf_b, pd_b, pw_b);
         }
         if (z_extra != 0) {   // (uniform; after the pipeline, not inside it)
-            project_and_load(kChunkZ, tsdf_a, pd_a, pw_a);
-            blend_and_store(kChunkZ, tsdf_a, pd_a, pw_a);
+            project_and_load(kChunkZ, upd_a, tsdf_a, pd_a, pw_a);
+            blend_and_store(kChunkZ, upd_a, tsdf_a, pd_a, pw_a);
         }
         };
         if (staged) walk(std::true_type{}); else walk(std::false_type{});
@@ -343,4 +365,55 @@ int launch_integrate_packed_kernel(tsdf_volume *v, dim3 grid, const BrickGrid &b
     return TSDF_OK;
 }
 
+// div_by_count against the division it replaces: one workgroup per divisor, every mantissa of the dividend, both signs
+__global__ __launch_bounds__(256) void count_division_check_kernel(uint32_t b0, float scale, unsigned long long *__restrict__ bad) {
+    const float b = (float)(b0 + blockIdx.x);
+    uint32_t n = 0;
+    for (uint32_t m = threadIdx.x; m < (1u << 23); m += 256) {
+        const float a = __uint_as_float(0x3f800000u | m) * scale;   // (a power of two: exact)
+        n += __float_as_uint(div_by_count(a, b)) != __float_as_uint(a / b);
+        n += __float_as_uint(div_by_count(-a, b)) != __float_as_uint(-a / b);
+    }
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o);
+    if ((threadIdx.x & 63u) == 0 && n) atomicAdd(bad, (unsigned long long)n);
+}
+__global__ void count_division_special_kernel(const float *__restrict__ a, uint32_t n_a, uint32_t b_end, unsigned long long *__restrict__ bad) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_a * b_end) return;
+    const float x = a[t % n_a], b = (float)(t / n_a + 1u);
+    const float q = div_by_count(x, b), r = x / b;
+    if (__float_as_uint(q) != __float_as_uint(r) && !(q != q && r != r)) atomicAdd(bad, 1ull);
+}
+
 }  // namespace tsdf
+
+extern "C" int tsdf_selftest_count_division(uint32_t b_begin, uint32_t b_end, unsigned long long *mismatches) {
+    using namespace tsdf;
+    TSDF_REQUIRE(mismatches && b_begin >= 1 && b_begin < b_end && b_end <= (1u << 17) + 1u, "tsdf_selftest_count_division: divisors are 1 .. 2^17");
+    unsigned long long *bad = nullptr;
+    TSDF_HIP(hipMalloc((void **)&bad, sizeof(*bad)), "selftest alloc");
+    hipError_t e = hipMemset(bad, 0, sizeof(*bad));
+    // every mantissa at three scales: 1, the bottom and the top of the range the short sequence is taken in
+    for (float scale : {1.0f, 0x1p-90f, 0x1p89f})
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(count_division_check_kernel, dim3(b_end - b_begin), dim3(256), 0, nullptr, b_begin, scale, bad);
+            e = hipGetLastError();
+        }
+    // and the values outside it (the division's own instruction sequence is taken: equal by construction, checked all the same)
+    const float special[] = {0.0f, -0.0f, 1.0e-45f, -1.0e-40f, 0x1p-126f, 0x1p-91f, 0x1.fffffep-91f, 0x1.000002p90f, 0x1p100f, -0x1p127f,
+                             3.4028235e38f, INFINITY, -INFINITY, NAN};
+    const uint32_t n_a = sizeof(special) / sizeof(special[0]);
+    float *a_dev = nullptr;
+    if (e == hipSuccess) e = hipMalloc((void **)&a_dev, sizeof(special));
+    if (e == hipSuccess) e = hipMemcpy(a_dev, special, sizeof(special), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        const uint32_t n = n_a * (b_end - 1u);
+        hipLaunchKernelGGL(count_division_special_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, a_dev, n_a, b_end - 1u, bad);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(mismatches, bad, sizeof(*bad), hipMemcpyDeviceToHost);
+    (void)hipFree(bad);
+    if (a_dev) (void)hipFree(a_dev);
+    if (e != hipSuccess) return hip_fail(e, "tsdf_selftest_count_division");
+    return TSDF_OK;
+}
