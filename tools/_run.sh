@@ -1,6 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for rep in 1 2 3; do 
-TAG=cz32 timeout 300 python tools/dbg_integrate_only.py 2>&1 | tail -1
-for n in cz16 cz64; do
-TAG=$n TSDF_HIP_LIB=$GRAFT_REPO_ROOT/build/variants/$n/libtsdf_hip.so timeout 300 python tools/dbg_integrate_only.py 2>&1 | tail -1
-done; done | tee gpurun_out/r04q/chunkz.txt
+bash tools/profile_round.sh r04s 20 5 2>&1 | tail -12
+bash tools/profile_round.sh r04s_config4 20 5 "--workload config4" 1024 2>&1 | tail -8
+bash tools/profile_round.sh r04s_grid256 20 5 "--grid 256" 256 2>&1 | tail -8
+ls gpurun_out/profiles_r04s gpurun_out/profiles_r04s_config4 gpurun_out/profiles_r04s_grid256

@@ -55,6 +55,8 @@ struct Tuning {
     int occ_scan_all;        // TSDF_OCC_SCAN_ALL       1: every tightening reads the whole distance array
     int reach_lds;           // TSDF_REACH_LDS          1: the workgroup variant of the reach summary on every grid
     int int_grid_per_cu;     // TSDF_INT_GRID_PER_CU    integrate: n > 0 = a resident grid of n workgroups per CU walking the brick list
+    int pipe_release;        // TSDF_PIPE_RELEASE       when tsdf_pipeline_step lets the next frame's filter + culling start on the side stream: 0 after
+                             //                          this frame's integrate (beside the bulk ray kernel), 1 after the bulk ray kernel (beside the tail kernel)
     int timing_bracket;      // TSDF_TIMING_BRACKET     1: tsdf_volume_set_timing brackets launches with hipEventRecord
     int verbose;             // TSDF_VERBOSE            the reference's chatter
     int debug_waves;         // TSDF_DEBUG_WAVES        per-wave clocks of the two ray kernels (synchronises)
@@ -251,6 +253,7 @@ struct tsdf_volume {
     size_t ray_cap;
     // per pixel: {the smallest sample index found <= 0 so far by the ray march, that sample's value} in one 64-bit word (all ones
     // = none); every kernel of the march lowers it with atomicMin, resolve_hits_kernel turns it into the vertex and resets it (raycast.hip)
+    hipEvent_t after_bulk;   // when set: recorded on the volume's stream right behind the bulk ray kernel's launch (tsdf_pipeline_step, scheduling)
     uint64_t *ray_best;      // two copies of ray_best_cap words, used alternately (ray_best_side)
     size_t ray_best_cap;
     int ray_best_side;

@@ -104,6 +104,7 @@ struct tsdf_pipeline {
     // events are made once and recorded again every other frame (creating one per frame makes the runtime grow its pool of
     // signals now and then: a stall of tens of milliseconds in the middle of a stream)
     hipEvent_t done[2], ready[2];   // [b]: the integrate that read buffer b has finished; buffer b has been filtered (and culled) ahead
+    hipEvent_t bulk;                // the bulk ray kernel of this frame's cast has ended (TSDF_PIPE_RELEASE=1)
     hipEvent_t cast, merged;        // third-stream exchange: the slab cast has left its records; the merge has consumed them
     bool merged_pending;
     const uint16_t *ahead_depth;    // the frame filtered ahead into buffer ahead_buf (nullptr: none)
@@ -257,6 +258,7 @@ int tsdf_pipeline_destroy(tsdf_pipeline *p) {
         if (p->done[b]) (void)hipEventDestroy(p->done[b]);
         if (p->ready[b]) (void)hipEventDestroy(p->ready[b]);
     }
+    if (p->bulk) (void)hipEventDestroy(p->bulk);
     if (p->cast) (void)hipEventDestroy(p->cast);
     if (p->merged) (void)hipEventDestroy(p->merged);
     if (p->hits_mine) (void)hipFree(p->hits_mine);
@@ -310,6 +312,7 @@ int tsdf_pipeline_create(tsdf_volume *volume, const tsdf_bilateral *filter, uint
         if (e == hipSuccess) e = hipEventCreateWithFlags(&p->done[b], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ready[b], hipEventDisableTiming);
     }
+    if (e == hipSuccess && overlap) e = hipEventCreateWithFlags(&p->bulk, hipEventDisableTiming);
     if (e == hipSuccess && p->xstream) e = hipEventCreateWithFlags(&p->cast, hipEventDisableTiming);
     if (e == hipSuccess && p->xstream) e = hipEventCreateWithFlags(&p->merged, hipEventDisableTiming);
     if (e == hipSuccess && exchange) {
@@ -364,6 +367,21 @@ int tsdf_pipeline_step(tsdf_pipeline *p, const uint16_t *device_depth, const tsd
     p->ahead_depth = nullptr;
     rc = tsdf_integrate_device_tiles(p->volume, p->filtered[b], W, H, cam->pose, cam->inv_pose, cam->k, cam->kinv, p->tile_max[b]);
     if (rc != TSDF_OK) return rc;
+    bool late_release = false;
+    auto filter_ahead = [&](hipEvent_t release) -> int {
+        TSDF_HIP(hipStreamWaitEvent(p->side, release, 0), "pipeline: release the next frame's filter");
+        int rc_ = run_filter(p, next_device_depth, 1 - b, p->side);
+        if (rc_ != TSDF_OK) return rc_;
+        if (next_cam) {
+            rc_ = tsdf_integrate_prepare_device_tiles(p->volume, p->filtered[1 - b], W, H, next_cam->pose, next_cam->inv_pose, next_cam->k,
+                                                      next_cam->kinv, p->tile_max[1 - b], p->side);
+            if (rc_ != TSDF_OK) return rc_;
+        }
+        TSDF_HIP(hipEventRecord(p->ready[1 - b], p->side), "pipeline: next frame ready");
+        p->ahead_depth = next_device_depth;
+        p->ahead_buf = 1 - b;
+        return TSDF_OK;
+    };
     if (p->side) {
         TSDF_HIP(hipEventRecord(p->done[b], p->main), "pipeline: integrate done");
         if (p->volume->occ_tighten_due && !p->volume->occ_dirty && !(p->flags & TSDF_PIPELINE_NO_TIGHTEN_AHEAD)) {
@@ -374,26 +392,25 @@ int tsdf_pipeline_step(tsdf_pipeline *p, const uint16_t *device_depth, const tsd
             rc = occupancy_tighten_on(p->volume, p->side);
             if (rc != TSDF_OK) return rc;
         }
-        if (next_device_depth) {
-            // released by THIS frame's integrate (never beside integrate_kernel); the other buffer was last read by the previous
-            // frame's integrate, which lies before it on the step's stream; the brick list, the boxes and the plane constants
-            // are free once this frame's integrate_kernel is done
-            TSDF_HIP(hipStreamWaitEvent(p->side, p->done[b], 0), "pipeline: release the next frame's filter");
-            rc = run_filter(p, next_device_depth, 1 - b, p->side);
+        // The next frame's filter + culling on the side stream: released by THIS frame's integrate (never beside integrate_kernel; the
+        // other buffer was last read by the previous frame's integrate, which lies before it on the step's stream; the brick list, the
+        // boxes and the plane constants are free once this frame's integrate_kernel is done) -- or, TSDF_PIPE_RELEASE=1, only by the end
+        // of this frame's bulk ray kernel, so that it runs beside the tail kernel instead (whole-volume casts).
+        late_release = next_device_depth && !p->exchange && tuning().pipe_release == 1;
+        if (next_device_depth && !late_release) {
+            rc = filter_ahead(p->done[b]);
             if (rc != TSDF_OK) return rc;
-            if (next_cam) {
-                rc = tsdf_integrate_prepare_device_tiles(p->volume, p->filtered[1 - b], W, H, next_cam->pose, next_cam->inv_pose, next_cam->k,
-                                                         next_cam->kinv, p->tile_max[1 - b], p->side);
-                if (rc != TSDF_OK) return rc;
-            }
-            TSDF_HIP(hipEventRecord(p->ready[1 - b], p->side), "pipeline: next frame ready");
-            p->ahead_depth = next_device_depth;
-            p->ahead_buf = 1 - b;
         }
     }
     if (!p->exchange) {
+        p->volume->after_bulk = late_release ? p->bulk : nullptr;
         rc = tsdf_raycast_device(p->volume, W, H, cam->pose, cam->kinv, device_vertices, device_normals);
+        p->volume->after_bulk = nullptr;
         if (rc != TSDF_OK) return rc;
+        if (late_release) {
+            rc = filter_ahead(p->bulk);
+            if (rc != TSDF_OK) return rc;
+        }
     } else {
         if (p->xstream && p->merged_pending)   // the previous frame's merge still reads hits_all / the collective hits_mine
             TSDF_HIP(hipStreamWaitEvent(p->main, p->merged, 0), "pipeline: wait for the previous exchange");

@@ -1655,6 +1655,7 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
         TSDF_LAUNCH_TIMED_LDS(v, 1, (process_ray_kernel<SLAB, false, true, false, true, true>), grid, dim3(256), table_lds, v->dist, v->g, rp,
                               (float *)nullptr, (unsigned long long *)nullptr, (unsigned int *)nullptr, v->occ, v->t_table, tail);
     TSDF_HIP(hipGetLastError(), "process_ray failed");
+    if (v->after_bulk) TSDF_HIP(hipEventRecord(v->after_bulk, v->stream), "process_ray: bulk kernel event");
     if (debug_waves) {   // diagnostics (synchronises): the bulk kernel's waves by sample range
         (void)hipStreamSynchronize(v->stream);
         std::vector<unsigned long long> log(3 * n_waves_log);
