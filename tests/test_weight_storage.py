@@ -89,6 +89,26 @@ def test_counts_widen_before_they_could_pass_255_and_again_before_65535(oracle):
     step(oracle, gv, ov, *fr[3]); same(gv, ov, "after clear")
 
 
+def test_a_camera_that_moves_on_keeps_the_bytes_beyond_255_frames(oracle):
+    """The bound that triggers widening counts integrations; before widening the library looks at the counts themselves.  Two views
+    of disjoint halves of a small grid, alternating for 270 frames: no voxel is updated more than 135 times, the weights stay bytes
+    and equal the oracle's."""
+    size, phys = (64, 40, 36), (1920.0, 1200.0, 1080.0)
+    gv, ov = pair(oracle, size, phys)
+    k_cam = tsdf_amd.Camera.default_depth_camera()
+    views = []
+    for x in (480.0, 1440.0):             # over the left half, over the right half, looking down +z with a narrow image
+        cam = camera_at((x, 600.0, -700.0))
+        d = np.zeros((H, W), np.uint16)
+        d[:, W // 2 - 60:W // 2 + 60] = 1200
+        views.append((d.reshape(-1), cam))
+    for i in range(270):
+        step(oracle, gv, ov, *views[i & 1])
+    assert ov.weight.max() == 135.0
+    assert gv.weight_storage() == (8, False)
+    same(gv, ov, "270 alternating frames")
+
+
 def test_sixteen_bit_counts_walk_every_plane_position(oracle):
     """Planes 2g and 2g + 1 share a dword in the 16-bit mode, 4g .. 4g + 3 in the 8-bit one: a weight pattern that differs plane by
     plane comes back, and integrates, exactly."""

@@ -10,7 +10,8 @@
 //   wmode 0   the reference's layout: fp32, `weight`, index x + y X + z X Y.
 // A volume starts at wmode 8 (TSDF_WEIGHT_PACK = 8 | 16 | 0 picks the starting mode), moves to 16 before the integration that could
 // take a count past 255, and to fp32 before the one that could pass 65535 (`weight_bound` counts integrations since the weights were
-// last known) -- or at once when it needs the general kernel (custom deformation nodes, a camera that is not of the standard shape),
+// last known; when it reaches the mode's limit the counts themselves are looked at first, so a stream whose camera moves on keeps its
+// bytes far beyond 255 frames) -- or at once when it needs the general kernel (custom deformation nodes, a camera that is not of the standard shape),
 // when weights that are not such counts are uploaded, or when the caller asks for the device pointer (tsdf_volume_weights: the
 // reference's weight_data(); from then on the volume keeps the reference's layout, "pinned").  clear() returns an unpinned volume to
 // the starting mode.  Every accessor speaks fp32 whatever the mode; the arithmetic of integration is the same exact fp32 expression in
@@ -148,8 +149,40 @@ int weights_require_f32(tsdf_volume *v) {
     return TSDF_OK;
 }
 
+// the largest count in the packed array (one streaming read: 30 us at 512^3)
+template <int BITS>
+__global__ __launch_bounds__(256) void weights_max_kernel(const uint32_t *__restrict__ wp, size_t n_words, uint32_t *__restrict__ top_out) {
+    uint32_t top = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (size_t)gridDim.x * 256) {
+        const uint32_t w = wp[i];
+        if (BITS == 8) top = max(max(top, w & 0xffu), max(max((w >> 8) & 0xffu, (w >> 16) & 0xffu), w >> 24));
+        else top = max(top, max(w & 0xffffu, w >> 16));
+    }
+    for (int o = 32; o > 0; o >>= 1) top = max(top, (uint32_t)__shfl_down((int)top, o));
+    if ((threadIdx.x & 63u) == 0 && top) atomicMax(top_out, top);
+}
+// `weight_bound` counts integrations, not updates of one voxel: when it reaches what the mode holds, look at the counts themselves --
+// a camera that moves on leaves every voxel far below the number of frames, and the volume keeps its narrow counts.
+static int refresh_bound(tsdf_volume *v) {
+    uint32_t *slot = reinterpret_cast<uint32_t *>(v->counter_dev + 3);   // (scratch slot shared with verify_fast_division)
+    TSDF_HIP(hipMemsetAsync(slot, 0, sizeof(uint32_t), v->stream), "weights: bound");
+    const size_t words = packed_words(v, v->wmode);
+    const dim3 grid((unsigned)std::min<size_t>((words + 255) / 256, 4096));
+    if (v->wmode == 8) hipLaunchKernelGGL(weights_max_kernel<8>, grid, dim3(256), 0, v->stream, v->wpacked, words, slot);
+    else hipLaunchKernelGGL(weights_max_kernel<16>, grid, dim3(256), 0, v->stream, v->wpacked, words, slot);
+    uint32_t top = 0;
+    TSDF_HIP(hipMemcpyAsync(&top, slot, sizeof(top), hipMemcpyDeviceToHost, v->stream), "weights: bound");
+    TSDF_HIP(hipStreamSynchronize(v->stream), "weights: bound");
+    v->weight_bound = top;
+    return TSDF_OK;
+}
+
 // Before an integration in a packed mode: no count may pass what the mode holds.
 int weights_make_room(tsdf_volume *v) {
+    if ((v->wmode == 8 && v->weight_bound >= 255u) || (v->wmode == 16 && v->weight_bound >= 65535u)) {
+        const int rc = refresh_bound(v);
+        if (rc != TSDF_OK) return rc;
+    }
     if (v->wmode == 8 && v->weight_bound >= 255u) {
         uint32_t *w16 = nullptr;
         int rc = alloc_packed(v, 16, &w16);
