@@ -352,6 +352,15 @@ int tsdf_pipeline_step(tsdf_pipeline *p, const uint16_t *device_depth, const tsd
     const uint32_t W = p->width, H = p->height;
     const int b = (int)(p->frames & 1u);
     int rc;
+    // TSDF_PIPE_RELEASE=2 (experiment): the next frame's FILTER is released by the end of the previous step already and runs beside
+    // this frame's integrate (its buffers were last read by the integrate before that); its culling still waits for this integrate.
+    const bool early_filter = p->side && next_device_depth && !p->exchange && tuning().pipe_release == 2;
+    if (early_filter) {
+        TSDF_HIP(hipEventRecord(p->bulk, p->main), "pipeline: previous step done");
+        TSDF_HIP(hipStreamWaitEvent(p->side, p->bulk, 0), "pipeline: release the next frame's filter");
+        rc = run_filter(p, next_device_depth, 1 - b, p->side);
+        if (rc != TSDF_OK) return rc;
+    }
     if (p->ahead_depth && p->ahead_depth == device_depth && p->ahead_buf == b) {
         TSDF_HIP(hipStreamWaitEvent(p->main, p->ready[b], 0), "pipeline: wait for the frame filtered ahead");
     } else {
@@ -370,7 +379,7 @@ int tsdf_pipeline_step(tsdf_pipeline *p, const uint16_t *device_depth, const tsd
     bool late_release = false;
     auto filter_ahead = [&](hipEvent_t release) -> int {
         TSDF_HIP(hipStreamWaitEvent(p->side, release, 0), "pipeline: release the next frame's filter");
-        int rc_ = run_filter(p, next_device_depth, 1 - b, p->side);
+        int rc_ = early_filter ? TSDF_OK : run_filter(p, next_device_depth, 1 - b, p->side);
         if (rc_ != TSDF_OK) return rc_;
         if (next_cam) {
             rc_ = tsdf_integrate_prepare_device_tiles(p->volume, p->filtered[1 - b], W, H, next_cam->pose, next_cam->inv_pose, next_cam->k,

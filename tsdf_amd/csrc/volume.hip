@@ -47,7 +47,7 @@ const Tuning &tuning() {
         u.occ_scan_all = num("TSDF_OCC_SCAN_ALL", 0) != 0;
         u.reach_lds = num("TSDF_REACH_LDS", 0) != 0;
         u.int_grid_per_cu = num("TSDF_INT_GRID_PER_CU", 0);
-        u.pipe_release = clamp(num("TSDF_PIPE_RELEASE", 0), 0, 1);
+        u.pipe_release = clamp(num("TSDF_PIPE_RELEASE", 0), 0, 2);
         u.timing_bracket = num("TSDF_TIMING_BRACKET", 0) != 0;
         u.verbose = getenv("TSDF_VERBOSE") != nullptr;
         u.debug_waves = getenv("TSDF_DEBUG_WAVES") != nullptr;
