@@ -57,6 +57,7 @@ struct Tuning {
     int int_grid_per_cu;     // TSDF_INT_GRID_PER_CU    integrate: n > 0 = a resident grid of n workgroups per CU walking the brick list
     int pipe_release;        // TSDF_PIPE_RELEASE       when tsdf_pipeline_step lets the next frame's filter + culling start on the side stream: 0 after
                              //                          this frame's integrate (beside the bulk ray kernel), 1 after the bulk ray kernel (beside the tail kernel), 2 the filter already after the previous step (beside integrate); both measured slower
+    int pipe_host_wait;      // TSDF_PIPE_HOST_WAIT     1: tsdf_pipeline_step waits on the HOST for the frame filtered ahead instead of putting a wait packet into the step's stream
     int timing_bracket;      // TSDF_TIMING_BRACKET     1: tsdf_volume_set_timing brackets launches with hipEventRecord
     int verbose;             // TSDF_VERBOSE            the reference's chatter
     int debug_waves;         // TSDF_DEBUG_WAVES        per-wave clocks of the two ray kernels (synchronises)

@@ -362,7 +362,14 @@ int tsdf_pipeline_step(tsdf_pipeline *p, const uint16_t *device_depth, const tsd
         if (rc != TSDF_OK) return rc;
     }
     if (p->ahead_depth && p->ahead_depth == device_depth && p->ahead_buf == b) {
-        TSDF_HIP(hipStreamWaitEvent(p->main, p->ready[b], 0), "pipeline: wait for the frame filtered ahead");
+        // The frame filtered (and culled) ahead on the side stream.  A wait packet in the step's stream costs it 6-12 us even when the
+        // event completed long ago (the packet breaks the back-to-back dispatch of resolve -> integrate); when the event is already
+        // complete at this call no packet is needed, and with TSDF_PIPE_HOST_WAIT=1 the host waits for it here instead (it completes while
+        // the previous frame's tail kernel runs: the host then enqueues this step beside the rest of the previous one).
+        if (hipEventQuery(p->ready[b]) != hipSuccess) {
+            if (tuning().pipe_host_wait) TSDF_HIP(hipEventSynchronize(p->ready[b]), "pipeline: wait for the frame filtered ahead");
+            else TSDF_HIP(hipStreamWaitEvent(p->main, p->ready[b], 0), "pipeline: wait for the frame filtered ahead");
+        }
     } else {
         if (p->ahead_depth) {
             // Another frame than the one announced: the side stream may still be writing a filtered buffer, its tile maxima and

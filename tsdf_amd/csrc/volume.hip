@@ -48,6 +48,7 @@ const Tuning &tuning() {
         u.reach_lds = num("TSDF_REACH_LDS", 0) != 0;
         u.int_grid_per_cu = num("TSDF_INT_GRID_PER_CU", 0);
         u.pipe_release = clamp(num("TSDF_PIPE_RELEASE", 0), 0, 2);
+        u.pipe_host_wait = num("TSDF_PIPE_HOST_WAIT", 0) != 0;
         u.timing_bracket = num("TSDF_TIMING_BRACKET", 0) != 0;
         u.verbose = getenv("TSDF_VERBOSE") != nullptr;
         u.debug_waves = getenv("TSDF_DEBUG_WAVES") != nullptr;
