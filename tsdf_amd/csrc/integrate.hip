@@ -637,7 +637,10 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
         v->prepared_valid = 0;
         const size_t pad_bytes = (size_t)(width + 2u) * (height + 2u) * sizeof(uint16_t);
         TSDF_HIP(hipMalloc((void **)&v->depth_pad, pad_bytes), "padded depth alloc");
-        TSDF_HIP(hipMemset(v->depth_pad, 0, pad_bytes), "padded depth alloc");
+        // (zeroed on the stream the culling that fills it runs on, and waited for: the ring must be there before, not after, the interior)
+        const hipStream_t pad_stream = phase == kIntPrepare ? prepare_stream : v->stream;
+        TSDF_HIP(hipMemsetAsync(v->depth_pad, 0, pad_bytes, pad_stream), "padded depth alloc");
+        TSDF_HIP(hipStreamSynchronize(pad_stream), "padded depth alloc");
         v->depth_pad_w = width; v->depth_pad_h = height;
     }
     // the list's length: the last two slots, used alternately (see brick_cull_kernel)
