@@ -109,6 +109,41 @@ def test_a_camera_that_moves_on_keeps_the_bytes_beyond_255_frames(oracle):
     same(gv, ov, "270 alternating frames")
 
 
+def test_counts_widen_in_the_middle_of_a_pipeline_run(oracle):
+    """A camera that does not move: every voxel in view is updated by every frame, so the 256th frame needs 16-bit counts.  The
+    widening happens inside tsdf_pipeline_step (two streams, no host round trip between the steps); volume and last picture are
+    the oracle's."""
+    import torch
+    from tsdf_amd.pipeline import FusionPipeline
+    size, phys = (64, 40, 36), (1920.0, 1200.0, 1080.0)
+    gv, ov = pair(oracle, size, phys)
+    cam = camera_at((960.0, 600.0, -700.0))
+    d = np.zeros((H, W), np.uint16)
+    d[120:360, 160:480] = 1250
+    d = d.reshape(-1)
+    threads = oracle.max_threads()
+    f = oracle.bilateral_u16(d, W, H, 30.0, 4.5, nthreads=threads).reshape(-1)
+    n_frames = 262
+    pipe = FusionPipeline(gv, tsdf_amd.BilateralFilter(30.0, 4.5), tsdf_amd.GPURaycaster(W, H), W, H, overlap=True)
+    depth = torch.from_numpy(d.view(np.int16)).cuda()
+    depth2 = depth.clone()                                   # (a distinct buffer per in-flight frame)
+    vert = torch.empty((H * W, 3), dtype=torch.float32, device="cuda")
+    norm = torch.empty_like(vert)
+    bufs = (depth, depth2)
+    for i in range(n_frames):
+        nxt = bufs[(i + 1) & 1].data_ptr() if i + 1 < n_frames else None
+        pipe.step(bufs[i & 1].data_ptr(), cam, vert.data_ptr(), norm.data_ptr(), nxt, cam if nxt else None)
+        ov.integrate(f, W, H, cam.inverse_pose(), cam.k(), cam.kinv(), nthreads=threads)
+    pipe.synchronize()
+    assert ov.weight.max() == float(n_frames)
+    assert gv.weight_storage() == (16, False)
+    same(gv, ov, "262 frames from one pose through the pipeline")
+    Vo, No = ov.raycast(W, H, cam.pose(), cam.kinv(), nthreads=threads)
+    assert_same_floats(vert.cpu().numpy(), Vo, "last picture")
+    assert_same_floats(norm.cpu().numpy(), No, "last normals")
+    pipe.close()
+
+
 def test_sixteen_bit_counts_walk_every_plane_position(oracle):
     """Planes 2g and 2g + 1 share a dword in the 16-bit mode, 4g .. 4g + 3 in the 8-bit one: a weight pattern that differs plane by
     plane comes back, and integrates, exactly."""
