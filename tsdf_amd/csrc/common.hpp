@@ -55,6 +55,7 @@ struct Tuning {
     int occ_scan_all;        // TSDF_OCC_SCAN_ALL       1: every tightening reads the whole distance array
     int reach_lds;           // TSDF_REACH_LDS          1: the workgroup variant of the reach summary on every grid
     int int_grid_per_cu;     // TSDF_INT_GRID_PER_CU    integrate: n > 0 = a resident grid of n workgroups per CU walking the brick list
+    int weight_pack;         // TSDF_WEIGHT_PACK        how a volume's weights are stored to begin with (weights.hip): 8 (default) / 16-bit counts, 0 = the reference's fp32 array
     int pipe_release;        // TSDF_PIPE_RELEASE       when tsdf_pipeline_step lets the next frame's filter + culling start on the side stream: 0 after
                              //                          this frame's integrate (beside the bulk ray kernel), 1 after the bulk ray kernel (beside the tail kernel), 2 the filter already after the previous step (beside integrate); both measured slower
     int pipe_host_wait;      // TSDF_PIPE_HOST_WAIT     1: tsdf_pipeline_step waits on the HOST for the frame filtered ahead instead of putting a wait packet into the step's stream

@@ -47,6 +47,8 @@ const Tuning &tuning() {
         u.occ_scan_all = num("TSDF_OCC_SCAN_ALL", 0) != 0;
         u.reach_lds = num("TSDF_REACH_LDS", 0) != 0;
         u.int_grid_per_cu = num("TSDF_INT_GRID_PER_CU", 0);
+        u.weight_pack = num("TSDF_WEIGHT_PACK", 8);
+        if (u.weight_pack != 0 && u.weight_pack != 16) u.weight_pack = 8;
         u.pipe_release = clamp(num("TSDF_PIPE_RELEASE", 0), 0, 2);
         u.pipe_host_wait = num("TSDF_PIPE_HOST_WAIT", 0) != 0;
         u.timing_bracket = num("TSDF_TIMING_BRACKET", 0) != 0;

@@ -86,14 +86,7 @@ __global__ __launch_bounds__(256) void weights_survey_kernel(const float *__rest
     }
 }
 
-static int weight_pack_start() {
-    static const int m = [] {
-        const char *e = getenv("TSDF_WEIGHT_PACK");
-        const int v = e ? atoi(e) : 8;
-        return (v == 0 || v == 16) ? v : 8;
-    }();
-    return m;
-}
+static int weight_pack_start() { return tuning().weight_pack; }
 
 // the packed array for `bits`, zeroed or not
 static int alloc_packed(tsdf_volume *v, int bits, uint32_t **out) {
