@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for i in 1 2 3; do for n in w6 w7; do
-echo $n $(TSDF_HIP_LIB=$GRAFT_REPO_ROOT/build/variants/$n/libtsdf_hip.so python tools/dbg_integrate_only.py 2>&1 | tail -1)
-done; done
+mkdir -p gpurun_out/r04zz
+timeout 900 python -m pytest tests/test_parity_icp.py tests/test_tracking.py -m gpu -x -q 2>&1 | tail -4
+for i in 1 2 3; do python tools/dbg_icp.py 2>&1 | tail -1; done | tee gpurun_out/r04zz/icp.txt
+for i in 1 2; do python tools/dbg_tracking.py 2>&1 | grep "ms per frame"; done | tee -a gpurun_out/r04zz/icp.txt

@@ -445,18 +445,21 @@ __device__ __forceinline__ void icp_finish_step(const float *partial, int n_bloc
         for (int i = 0; i < 16; i++) T[i] = state_in[i];
     }
     if (entry < 29) {
+        // (The loads are unconditional -- a block past n_blocks re-reads block 0 and its value is replaced by 0 afterwards: with the
+        // test in front of each load the compiler made 32 branches, each load waited for on its own: 32 dependent round trips, 8 of
+        // the 9.5 us this step took, profiles/r04zz_icp_finish_phases.txt.)
         float v[32];
 #pragma unroll
         for (int i = 0; i < 32; i++) {
-            const int b = group * 32 + i;
+            const int b = group * 32 + i, bb = b < n_blocks ? b : 0;
             if (COHERENT)
-                v[i] = b < n_blocks ? __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t *>(partial) + b * 32 + entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.0f;
+                v[i] = __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t *>(partial) + bb * 32 + entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             else
-                v[i] = b < n_blocks ? partial[b * 32 + entry] : 0.0f;
+                v[i] = partial[bb * 32 + entry];
         }
         double s = 0.0;
 #pragma unroll
-        for (int i = 0; i < 32; i++) s += (double)v[i];
+        for (int i = 0; i < 32; i++) s += (double)(group * 32 + i < n_blocks ? v[i] : 0.0f);
         group_sum[group][entry] = s;
     }
     __syncthreads();
