@@ -1,4 +1,16 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_parity_icp.py tests/test_tracking.py tests/test_fuzz_parity.py -k "icp or track" -m gpu -x -q 2>&1 | tail -4
-for i in 1 2 3; do python tools/dbg_icp.py 2>&1 | tail -1; done
-for i in 1 2; do python tools/dbg_tracking.py 2>&1 | grep "ms per frame"; done
+mkdir -p gpurun_out/r04final
+timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > gpurun_out/r04final/pytest_gpu.log
+cat gpurun_out/r04final/pytest_gpu.log
+timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee gpurun_out/r04final/smoke.log
+bash tools/profile_round.sh r04zz 20 5 2>&1 | tail -2
+bash tools/profile_round.sh r04zz_config4 20 5 "--workload config4" 1024 2>&1 | tail -2
+bash tools/profile_round.sh r04zz_grid256 20 5 "--grid 256" 256 2>&1 | tail -2
+cp profiles/traffic_r04zz*.json gpurun_out/r04final/ 2>/dev/null
+dir=/tmp/tsdf_tum_trk
+python - <<PY
+import sys; sys.path.insert(0, "$GRAFT_REPO_ROOT")
+from tsdf_amd import synth
+synth.write_tum_directory("$dir", 26, seed=0x5EED0003, stream_frames=200)
+PY
+for i in 1 2 3; do build/kinfu_stream -d $dir -n 512 -k 24 --track | tail -1; python tools/dbg_tracking.py 2>&1 | grep "ms per frame"; python tools/dbg_icp.py 2>&1 | tail -1; done | tee gpurun_out/r04final/track.txt
