@@ -1,16 +1,14 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r04final
-timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > gpurun_out/r04final/pytest_gpu.log
-cat gpurun_out/r04final/pytest_gpu.log
-timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee gpurun_out/r04final/smoke.log
-bash tools/profile_round.sh r04zz 20 5 2>&1 | tail -2
-bash tools/profile_round.sh r04zz_config4 20 5 "--workload config4" 1024 2>&1 | tail -2
-bash tools/profile_round.sh r04zz_grid256 20 5 "--grid 256" 256 2>&1 | tail -2
-cp profiles/traffic_r04zz*.json gpurun_out/r04final/ 2>/dev/null
-dir=/tmp/tsdf_tum_trk
-python - <<PY
-import sys; sys.path.insert(0, "$GRAFT_REPO_ROOT")
-from tsdf_amd import synth
-synth.write_tum_directory("$dir", 26, seed=0x5EED0003, stream_frames=200)
+mkdir -p gpurun_out/r05a
+for rep in 1 2 3; do for n in base rayprio; do
+if [ $n = base ]; then unset TSDF_HIP_LIB; else export TSDF_HIP_LIB=$GRAFT_REPO_ROOT/build/variants/$n/libtsdf_hip.so; fi
+timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity --path-only --repeats 3 > gpurun_out/r05a/c3_${n}_$rep.json 2>/dev/null
+timeout 600 python bench.py --workload config4 --steps 20 --warmup 5 --no-cpu-baseline --no-parity --path-only --repeats 3 > gpurun_out/r05a/c4_${n}_$rep.json 2>/dev/null
+done; done
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob("gpurun_out/r05a/*.json")):
+    try:
+        d=json.load(open(f)); print(f, d["ms_per_step"], d.get("ms_per_step_runs"), d.get("last_frame_vertex_bits"))
+    except Exception as e: print(f, "ERR", e)
 PY
-for i in 1 2 3; do build/kinfu_stream -d $dir -n 512 -k 24 --track | tail -1; python tools/dbg_tracking.py 2>&1 | grep "ms per frame"; python tools/dbg_icp.py 2>&1 | tail -1; done | tee gpurun_out/r04final/track.txt
