@@ -1,2 +1,6 @@
 cd $GRAFT_REPO_ROOT
-TSDF_RAY_DBG=1 python tools/dbg_ray_only.py 3 2>&1 | grep "long waves" | tail -4
+timeout 900 python -m pytest tests/test_parity_integrate.py -m gpu -x -q 2>&1 | tail -2
+for i in 1 2 3 4; do
+echo new $(python tools/dbg_integrate_only.py 2>&1 | tail -1)
+echo old $(TSDF_HIP_LIB=$GRAFT_REPO_ROOT/build/variants/intold/libtsdf_hip.so python tools/dbg_integrate_only.py 2>&1 | tail -1)
+done

@@ -98,9 +98,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TSDF_PACKED
     // over bricks: what the prologue needs of the kernel's arguments is dead once the planes are walked, which the scalar register
     // file needs (with a loop around it the compiler kept it all live and spilled scalars into vector lanes: a v_readlane per use).
     {
+        // (the list's entry and its box are requested together with the list's length -- both arrays hold an entry for every brick of the
+        // grid, so reading past the length is harmless -- instead of one round trip after it)
         const uint32_t i = blockIdx.x;
-        if (i >= n_active) return;
         const uint32_t b = list[i];
+        const uint4 box = boxes[i];
+        if (i >= n_active) return;
         const uint32_t bx = b % bg.nx, by = (b / bg.nx) % bg.ny, bz = b / (bg.nx * bg.ny);
         if (tid == 0) touched[b] = 1;   // for the next occupancy rebuild: this brick's distances may change (volume.hip)
         const uint32_t vx = bx * kTileX + threadIdx.x;
@@ -112,7 +115,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TSDF_PACKED
         // box itself is written as 0 (the ring).  The box holds every pixel a voxel of this brick can project to and lies inside the
         // image (brick_cull_kernel), so a voxel that misses the box fails the reference's frustum test (:349): its look-up, clamped
         // onto the ring, finds depth 0 = no update (:355).
-        const uint4 box = boxes[i];
         const uint32_t lead = bg.pair_loads ? 2u : 1u;
         const uint32_t pitch = box.z + 2u * lead, rows = box.w + 2u;
         const bool staged = box.z != 0 && pitch * rows <= (uint32_t)kTilePixels;
@@ -135,20 +137,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TSDF_PACKED
                 uint32_t *tile2 = reinterpret_cast<uint32_t *>(tile);
                 // pair index of tile slot (0, 0) -- may lie before the image (box.y == 0 or box.x == 0); the clamped slots below do not
                 const int64_t org2 = (((int64_t)box.y - 1) * (int64_t)width + (int64_t)box.x - 2) / 2;
+                // slot p = tid + 256 u of the tile as (row, pair): one division per thread, then steps of 256 slots = (dq rows, dr pairs)
+                // (eight divisions by `half` per batch, twice, were a quarter of the prologue's instructions)
+                const uint32_t dq = (kTileX * kTileY) / half, dr = (kTileX * kTileY) - dq * half;
+                uint32_t ty_ = tid / half, tx_ = tid - ty_ * half;
                 for (uint32_t p0 = tid; p0 < total2; p0 += kTileX * kTileY * kStageBatch) {
-                    uint32_t px[kStageBatch];
+                    uint32_t px[kStageBatch], row_[kStageBatch], col_[kStageBatch];
 #pragma unroll
                     for (uint32_t u = 0; u < kStageBatch; u++) {
-                        const uint32_t p = min(p0 + u * (kTileX * kTileY), total2 - 1u);
-                        const uint32_t ty = p / half, tx2 = p - ty * half;
-                        const uint32_t cy = min(max(ty, 1u), rows - 2u), cx2 = min(max(tx2, 1u), half - 2u);   // (inside the box)
+                        row_[u] = ty_; col_[u] = tx_;
+                        const uint32_t cy = min(max(ty_, 1u), rows - 2u), cx2 = min(max(tx_, 1u), half - 2u);   // (inside the box, whatever the slot)
                         px[u] = depth2[org2 + (int64_t)cy * (int64_t)(width >> 1) + (int64_t)cx2];
+                        tx_ += dr; ty_ += dq;
+                        if (tx_ >= half) { tx_ -= half; ty_ += 1u; }
                     }
 #pragma unroll
                     for (uint32_t u = 0; u < kStageBatch; u++) {
                         const uint32_t p = p0 + u * (kTileX * kTileY);
-                        const uint32_t ty = p / half, tx2 = p - ty * half;
-                        const bool ring = ty == 0u || ty == rows - 1u || tx2 == 0u || tx2 == half - 1u;
+                        const bool ring = row_[u] == 0u || row_[u] == rows - 1u || col_[u] == 0u || col_[u] == half - 1u;
                         if (p < total2) tile2[p] = ring ? 0u : px[u];
                     }
                 }
