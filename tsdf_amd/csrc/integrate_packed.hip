@@ -179,8 +179,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TSDF_PACKED
                 }
             }
         }
-        __syncthreads();
-        if (vy >= g.Y) return;   // (a whole wave)
+        // (the per-lane constants of the walk are formed while the tile's pixels are on their way, in front of the barrier)
 
         // distance / weight addressing: one buffer descriptor per array based at this brick's first row (scalar registers), the plane as
         // the instruction's scalar byte offset, one 32-bit lane offset in bytes: no address arithmetic on the vector unit (the flat
@@ -215,6 +214,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TSDF_PACKED
         const float fy_hi = staged ? (float)(box.w + 1u) : (float)(height + 1u);
         const float pitch2 = 2.0f * (float)(staged ? pitch : width + 2u);
 
+        __syncthreads();
+        if (vy >= g.Y) return;   // (a whole wave)
         // The walk over the brick's planes exists twice in the kernel, once per kind of look-up (a workgroup takes one): with both
         // kinds in one body every LDS read after the join waited for all outstanding memory loads -- the compiler cannot tell which
         // branch filled the destination registers -- and the batches stopped overlapping.
