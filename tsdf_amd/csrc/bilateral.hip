@@ -84,18 +84,48 @@ __global__ __launch_bounds__(256) void bilateral_kernel(const PIX *__restrict__ 
     uint32_t *tile4 = reinterpret_cast<uint32_t *>(sim_lds + (STAGED ? kSimLds : 0));
     const int tx0 = blockIdx.x * kBTile - radius;
     const int ty0 = blockIdx.y * kBTile - radius;
-    for (int i = threadIdx.x; i < span * span; i += 256) {
-        int ly = i / span, lx = i - ly * span;
-        int gx = tx0 + lx, gy = ty0 + ly;
-        unsigned v = 0;
-        if (gx >= 0 && gx < width && gy >= 0 && gy < height) v = in[(size_t)gy * width + gx];
-        tile4[i] = v * 4u;
-        if (!STAGED) tile_d[i] = (double)(int)v;
+    // Everything the workgroup stages -- its tile with the apron, the spatial kernel, the head of the similarity table -- is requested
+    // in batches and waited for once per batch.  (As plain loops these were 4 + 1 + 8 dependent memory round trips in front of the
+    // first tap: a fifth of the kernel.  Pixels outside the image: the load goes to a clamped address, the value is replaced by 0.)
+    {
+        constexpr int kAhead = 4;
+        for (int i0 = threadIdx.x; i0 < span * span; i0 += 256 * kAhead) {
+            unsigned v_[kAhead];
+#pragma unroll
+            for (int u = 0; u < kAhead; u++) {
+                const int i = min(i0 + u * 256, span * span - 1);
+                const int ly = i / span, lx = i - ly * span;
+                const int gx = min(max(tx0 + lx, 0), width - 1), gy = min(max(ty0 + ly, 0), height - 1);
+                v_[u] = in[(size_t)gy * width + gx];
+            }
+#pragma unroll
+            for (int u = 0; u < kAhead; u++) {
+                const int i = i0 + u * 256;
+                const int ly = i / span, lx = i - ly * span;
+                const int gx = tx0 + lx, gy = ty0 + ly;
+                const unsigned v = (gx >= 0 && gx < width && gy >= 0 && gy < height) ? v_[u] : 0u;
+                if (i < span * span) {
+                    tile4[i] = v * 4u;
+                    if (!STAGED) tile_d[i] = (double)(int)v;
+                }
+            }
+        }
     }
-    for (int i = threadIdx.x; i < n * n; i += 256) kern_lds[i] = kernel[i];
-    if (STAGED) {
-        const int n_sim = sizeof(PIX) == 1 ? 256 : kSimLds;
-        for (int i = threadIdx.x; i < n_sim; i += 256) sim_lds[i] = similarity[i];
+    {
+        const int n_sim = !STAGED ? 0 : (sizeof(PIX) == 1 ? 256 : kSimLds);
+        constexpr int kAhead = 16;
+        float k_ = 0.0f;
+        if ((int)threadIdx.x < n * n) k_ = kernel[threadIdx.x];                  // (n * n <= 256 for the staged radii; the loop below takes the rest)
+        for (int i0 = threadIdx.x; i0 < n_sim; i0 += 256 * kAhead) {
+            float s_[kAhead];
+#pragma unroll
+            for (int u = 0; u < kAhead; u++) s_[u] = similarity[min(i0 + u * 256, n_sim - 1)];
+#pragma unroll
+            for (int u = 0; u < kAhead; u++)
+                if (i0 + u * 256 < n_sim) sim_lds[i0 + u * 256] = s_[u];
+        }
+        if ((int)threadIdx.x < n * n) kern_lds[threadIdx.x] = k_;
+        for (int i = threadIdx.x + 256; i < n * n; i += 256) kern_lds[i] = kernel[i];
     }
     __syncthreads();
 
