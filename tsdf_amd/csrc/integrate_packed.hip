@@ -4,7 +4,7 @@
 // the vector instructions and 10 (12) instead of 16 bytes moved per updated voxel.
 //
 // Why (round 4, knock-out builds of integrate_kernel, `profiles/r04n_*`): with every distance / weight access removed the kernel still
-// took 0.097 of its 0.118 ms -- its vector instruction stream (93 issue slots per 64-voxel row x 6 waves per SIMD = the 31 us a brick
+// took 0.097 of its 0.118 ms -- its vector instruction stream (80 issue slots per 64-voxel row x 6 waves per SIMD = the 31 us a brick
 // takes) -- and the read-modify-write of 558 MB at the 5-6 TB/s an in-place walk reaches is 0.093-0.11 ms: two equal bounds, so that
 // halving either alone changed nothing (what rounds 2 and 3 measured).  This kernel lowers both.
 //   * weights: the reference only ever adds 1 to a weight (the clamp to max_weight is commented out, TSDFVolume.cu:377), so a
@@ -12,8 +12,8 @@
 //     (two) planes of a batch of one lane in ONE dword ("z-packed"): a wave still moves whole 256-byte rows, one per batch instead of
 //     four.  Dense walks in this shape: 0.237 (0.274) ms against 0.360 for two fp32 arrays (tools/ubench_layout.hip).
 //   * arithmetic: two planes at a time with packed fp32 (v_pk_add / v_pk_mul: separately rounded lanes, no contraction); one test
-//     per batch of four planes for "some quotient is near a rounding boundary" (v_maximum3, NaN-propagating) instead of a branch per
-//     plane; the depth look-up addressed in fp32 into a tile with a ring of zeros (v_med3 clamps what misses the pixel box onto the
+//     per pair of planes for "some quotient is near a rounding boundary" (v_maximum3, NaN-propagating) instead of a branch per
+//     plane; (d w + tsdf) / (w + 1) as rcp + mul + two fmas (div_by_count, proven and checked exhaustively); the depth look-up addressed in fp32 into a tile with a ring of zeros (v_med3 clamps what misses the pixel box onto the
 //     ring: no range tests, no select; bricks without a tile look up a copy of the whole image inside such a ring that
 //     brick_cull_kernel leaves in memory); distance rows addressed as wave-uniform base + one 32-bit lane offset.
 #include <type_traits>
