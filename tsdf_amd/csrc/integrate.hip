@@ -91,7 +91,7 @@ __device__ inline void mark_occupied(const OccGrid &occ, uint32_t vx, uint32_t v
 // integrate_packed.hip
 int launch_integrate_packed_kernel(tsdf_volume *v, dim3 grid, const BrickGrid &bg, const Mat44 &ip, const Mat33 &mk, uint32_t width,
                                    uint32_t height, const uint16_t *d_depth, unsigned long long *counter_arg, const uint4 *boxes,
-                                   const uint32_t *count, const float4 *plane_const);
+                                   const uint2 *coords, const uint32_t *count, const float4 *plane_const);
 
 constexpr int kDepthTile = TSDF_DEPTH_TILE;  // pixels per side of a depth tile (16)
 constexpr int kCullTilesLds = 4096;  // tile maxima brick_cull_kernel keeps in LDS (1200 at 640x480)
@@ -121,7 +121,8 @@ __global__ __launch_bounds__(256) void brick_cull_kernel(const Geom g, const Bri
                                                          uint32_t *__restrict__ count_next,
                                                          float4 *__restrict__ plane_const, const uint32_t n_plane_const,
                                                          const float cone_mx, const float cone_my,
-                                                         const uint16_t *__restrict__ depth, uint16_t *__restrict__ depth_pad) {
+                                                         const uint16_t *__restrict__ depth, uint16_t *__restrict__ depth_pad,
+                                                         uint2 *__restrict__ coords) {
     // One lane per corner: 8 consecutive lanes share a brick and combine their corners with 3 butterfly steps (a thread per brick
     // walked its 8 corners one after the other on a quarter of the chip's compute units: 12 us of dependent arithmetic).
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
@@ -269,6 +270,7 @@ __global__ __launch_bounds__(256) void brick_cull_kernel(const Geom g, const Bri
         for (uint32_t w = 0; w < wave; w++) slot += wave_count[w];
         list[slot] = b;
         boxes[slot] = box;
+        coords[slot] = make_uint2(bx | (by << 16), bz);   // (bx < 2^10, by < 2^14: the grid's sides fit 16 bits)
     }
 }
 
@@ -657,10 +659,11 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
         if (v->brick_boxes) (void)hipFree(v->brick_boxes);
         v->brick_boxes = nullptr;
         v->brick_box_cap = 0;
-        TSDF_HIP(hipMalloc((void **)&v->brick_boxes, n_bricks * 4 * sizeof(uint32_t)), "brick box alloc");
+        TSDF_HIP(hipMalloc((void **)&v->brick_boxes, n_bricks * 6 * sizeof(uint32_t)), "brick box alloc");   // (boxes, then the bricks' coordinates)
         v->brick_box_cap = n_bricks;
     }
     uint4 *boxes = reinterpret_cast<uint4 *>(v->brick_boxes);
+    uint2 *coords = reinterpret_cast<uint2 *>(v->brick_boxes + 4 * v->brick_box_cap);   // per listed brick: {bx | by << 16, bz}, for integrate_packed_kernel
     const uint32_t n_plane_const = g.z_store_end - g.z_store_begin + kBatchZ;  // padded: a batch may run past the last plane
     if (!v->plane_const) TSDF_HIP(hipMalloc((void **)&v->plane_const, n_plane_const * 4 * sizeof(float)), "plane constants alloc");
     float4 *plane_const = reinterpret_cast<float4 *>(v->plane_const);
@@ -696,7 +699,7 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
                                tiles_x, v->tile_max);
         hipLaunchKernelGGL(brick_cull_kernel, dim3((unsigned)((8 * n_bricks + 255) / 256)), dim3(256), 0, cull_stream, g, bg, ip, mk,
                            width, height, caller_tile_max ? caller_tile_max : v->tile_max, tiles_x, depth_test, v->brick_list, boxes, count,
-                           count_next, plane_const, n_plane_const, cone_mx, cone_my, d_depth, v->wmode != 0 ? v->depth_pad : nullptr);
+                           count_next, plane_const, n_plane_const, cone_mx, cone_my, d_depth, v->wmode != 0 ? v->depth_pad : nullptr, coords);
         v->brick_count_side = 1u - v->brick_count_side;
         if (phase == kIntPrepare) {
             TSDF_HIP(hipGetLastError(), "Integrate culling failed");
@@ -744,7 +747,7 @@ static int launch_integrate(tsdf_volume *v, const uint16_t *d_depth, uint32_t wi
                       g, bg, ip, mk, mkinv, width, height, d_depth, counter_arg, v->occ, v->brick_list, boxes, count, plane_const, v->touched)
     if (v->wmode != 0) {
         const int rcp = launch_integrate_packed_kernel(v, dim3((unsigned)n_bricks), bg,   // (one brick per workgroup, always)
-                                                        ip, mk, width, height, d_depth, counter_arg, boxes, count, plane_const);
+                                                        ip, mk, width, height, d_depth, counter_arg, boxes, coords, count, plane_const);
         if (rcp != TSDF_OK) return rcp;
         v->weight_bound++;
     } else if (v->nodes) {

@@ -79,7 +79,7 @@ template <bool COUNT, int WBITS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TSDF_PACKED_WAVES, TSDF_PACKED_WAVES))) void integrate_packed_kernel(
     float *__restrict__ dist, uint32_t *__restrict__ wpk, const Geom g, const BrickGrid bg, const Mat44 ip, const Mat33 k, const uint32_t width,
     const uint32_t height, const uint16_t *__restrict__ depth, const uint16_t *__restrict__ depth_pad, unsigned long long *__restrict__ counter, const OccGrid occ,
-    const uint32_t *__restrict__ list, const uint4 *__restrict__ boxes, const uint32_t *__restrict__ count,
+    const uint32_t *__restrict__ list, const uint4 *__restrict__ boxes, const uint2 *__restrict__ coords, const uint32_t *__restrict__ count,
     const float4 *__restrict__ plane_const, uint8_t *__restrict__ touched) {
     constexpr int kPlanesPerWord = 32 / WBITS, kWords = kBatchZ / kPlanesPerWord;
     static_assert(kBatchZ == 4 && (WBITS == 8 || WBITS == 16), "a batch is two pairs of planes");
@@ -103,8 +103,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TSDF_PACKED
         const uint32_t i = blockIdx.x;
         const uint32_t b = list[i];
         const uint4 box = boxes[i];
+        const uint2 co = coords[i];   // the brick's coordinates as the cull kernel had them (three divisions by run-time extents otherwise)
         if (i >= n_active) return;
-        const uint32_t bx = b % bg.nx, by = (b / bg.nx) % bg.ny, bz = b / (bg.nx * bg.ny);
+#ifdef TSDF_DIAGNOSTICS
+        const uint32_t bx = b % bg.nx, by = (b / bg.nx) % bg.ny, bz = b / (bg.nx * bg.ny);   // (the diagnostics may have re-sorted list and boxes on the host)
+        (void)co;
+#else
+        const uint32_t bx = co.x & 0xffffu, by = co.x >> 16, bz = co.y;
+#endif
         if (tid == 0) touched[b] = 1;   // for the next occupancy rebuild: this brick's distances may change (volume.hip)
         const uint32_t vx = bx * kTileX + threadIdx.x;
         const uint32_t vy = by * kTileY + threadIdx.y;
@@ -355,11 +361,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TSDF_PACKED
 // Launched by launch_integrate (integrate.hip) in place of integrate_kernel<false, *, true> when the volume's weights are packed.
 int launch_integrate_packed_kernel(tsdf_volume *v, dim3 grid, const BrickGrid &bg, const Mat44 &ip, const Mat33 &mk, uint32_t width,
                                    uint32_t height, const uint16_t *d_depth, unsigned long long *counter_arg, const uint4 *boxes,
-                                   const uint32_t *count, const float4 *plane_const) {
+                                   const uint2 *coords, const uint32_t *count, const float4 *plane_const) {
     const dim3 block(kTileX, kTileY, 1);
 #define LAUNCH(CNT, BITS)                                                                                                       \
     TSDF_LAUNCH_TIMED(v, 0, (integrate_packed_kernel<CNT, BITS>), grid, block, v->dist, v->wpacked, v->g, bg, ip, mk, width, height, d_depth, v->depth_pad, \
-                      counter_arg, v->occ, v->brick_list, boxes, count, plane_const, v->touched)
+                      counter_arg, v->occ, v->brick_list, boxes, coords, count, plane_const, v->touched)
     if (v->wmode == 8) {
         if (v->counting) LAUNCH(true, 8); else LAUNCH(false, 8);
     } else if (v->wmode == 16) {
