@@ -44,6 +44,10 @@ $(LIBDIR)/libtsdf_host.so: $(HOST_OBJS) $(LIBDIR)/libtsdf_hip.so
 
 hip: $(LIBDIR)/libtsdf_hip.so
 
+# integrate_packed_kernel is bound by its vector instruction stream: the scheduler's max-ILP strategy is worth 1-1.5 % there
+# (0.0804 against 0.0816 ms; it costs the latency-bound ray kernels 13 % and the bilateral filter 11 %: those keep the default)
+$(CSRC)/integrate_packed.o: HIPFLAGS += -mllvm -amdgpu-sched-strategy=max-ilp
+
 $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.hpp $(CSRC)/integrate_grid.hpp include/tsdf_amd.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
