@@ -1,9 +1,10 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r04final
-timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > gpurun_out/r04final/pytest_gpu.log
-cat gpurun_out/r04final/pytest_gpu.log
-timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee gpurun_out/r04final/smoke.log
-bash tools/profile_round.sh r04zz 20 5 2>&1 | tail -2
-bash tools/profile_round.sh r04zz_config4 20 5 "--workload config4" 1024 2>&1 | tail -2
-bash tools/profile_round.sh r04zz_grid256 20 5 "--grid 256" 256 2>&1 | tail -2
-cp profiles/traffic_r04zz*.json gpurun_out/r04final/ 2>/dev/null
+for r in 1 2; do for n in base prologue noblend nomark nofallback; do
+echo $n $(TSDF_HIP_LIB=$GRAFT_REPO_ROOT/build/variants/d_$n/libtsdf_hip.so python tools/dbg_integrate_only.py 2>&1 | tail -1)
+done; done
+for n in base prologue noblend nomark nofallback; do
+export TSDF_HIP_LIB=$GRAFT_REPO_ROOT/build/variants/d_$n/libtsdf_hip.so
+echo "#### $n"
+bash tools/pmc_cmd.sh d_$n "python $GRAFT_REPO_ROOT/tools/dbg_integrate_only.py" "integrate_packed" "insts:SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAVES"
+cd $GRAFT_REPO_ROOT
+done
