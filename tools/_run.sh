@@ -1,10 +1,10 @@
 cd $GRAFT_REPO_ROOT
-for r in 1 2; do for n in base prologue noblend nomark nofallback; do
-echo $n $(TSDF_HIP_LIB=$GRAFT_REPO_ROOT/build/variants/d_$n/libtsdf_hip.so python tools/dbg_integrate_only.py 2>&1 | tail -1)
+for r in 1 2; do for s in 0 1 2; do
+TSDF_EVENT_SCOPE=$s python bench.py --no-cpu-baseline --steps 20 --warmup 5 --repeats 3 > gpurun_out/ev_s${s}_$r.json 2>gpurun_out/ev_err.txt || tail -3 gpurun_out/ev_err.txt
+python - <<PY
+import json
+d=json.loads(open("gpurun_out/ev_s${s}_$r.json").read().strip().splitlines()[-1])
+print("scope $s run $r ms_per_step", d["ms_per_step"], d.get("ms_per_step_runs"), "parity", d.get("parity",{}).get("status") if isinstance(d.get("parity"),dict) else d.get("parity"), "bits", d.get("last_frame_vertex_bits"))
+PY
 done; done
-for n in base prologue noblend nomark nofallback; do
-export TSDF_HIP_LIB=$GRAFT_REPO_ROOT/build/variants/d_$n/libtsdf_hip.so
-echo "#### $n"
-bash tools/pmc_cmd.sh d_$n "python $GRAFT_REPO_ROOT/tools/dbg_integrate_only.py" "integrate_packed" "insts:SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAVES"
-cd $GRAFT_REPO_ROOT
-done
+for s in 0 1 2; do echo scope $s $(TSDF_EVENT_SCOPE=$s python tools/dbg_tracking.py 2>&1 | tail -1); done

@@ -309,10 +309,10 @@ int tsdf_pipeline_create(tsdf_volume *volume, const tsdf_bilateral *filter, uint
     for (int b = 0; b < 2 && e == hipSuccess; b++) {
         e = hipMalloc((void **)&p->filtered[b], n * sizeof(uint16_t));
         if (e == hipSuccess) e = hipMalloc((void **)&p->tile_max[b], tiles * sizeof(uint16_t));
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->done[b], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ready[b], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->done[b], stream_order_event_flags());
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ready[b], stream_order_event_flags());
     }
-    if (e == hipSuccess && overlap) e = hipEventCreateWithFlags(&p->bulk, hipEventDisableTiming);
+    if (e == hipSuccess && overlap) e = hipEventCreateWithFlags(&p->bulk, stream_order_event_flags());
     if (e == hipSuccess && p->xstream) e = hipEventCreateWithFlags(&p->cast, hipEventDisableTiming);
     if (e == hipSuccess && p->xstream) e = hipEventCreateWithFlags(&p->merged, hipEventDisableTiming);
     if (e == hipSuccess && exchange) {
@@ -515,9 +515,9 @@ int tsdf_tracker_create(tsdf_volume *volume, const tsdf_bilateral *filter, tsdf_
     for (int b = 0; b < 2 && e == hipSuccess; b++) {
         e = hipMalloc((void **)&t->filtered[b], n * sizeof(uint16_t));
         if (e == hipSuccess) e = hipMalloc((void **)&t->tile_max[b], tiles * sizeof(uint16_t));
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&t->integrated[b], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&t->integrated[b], stream_order_event_flags());
     }
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&t->ready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&t->ready, stream_order_event_flags());
     if (e == hipSuccess) e = hipMalloc((void **)&t->model, n * sizeof(uint16_t));
     if (e != hipSuccess) {
         const int rc = hip_fail(e, "tsdf_tracker_create");

@@ -51,6 +51,7 @@ const Tuning &tuning() {
         if (u.weight_pack != 0 && u.weight_pack != 16) u.weight_pack = 8;
         u.pipe_release = clamp(num("TSDF_PIPE_RELEASE", 0), 0, 2);
         u.pipe_host_wait = num("TSDF_PIPE_HOST_WAIT", 0) != 0;
+        u.event_scope = clamp(num("TSDF_EVENT_SCOPE", 0), 0, 2);
         u.timing_bracket = num("TSDF_TIMING_BRACKET", 0) != 0;
         u.verbose = getenv("TSDF_VERBOSE") != nullptr;
         u.debug_waves = getenv("TSDF_DEBUG_WAVES") != nullptr;
@@ -520,7 +521,7 @@ int occupancy_rebuild(tsdf_volume *v) {
 // loose -- then the ray cast itself must rebuild first -- or when nothing is due.
 int occupancy_tighten_on(tsdf_volume *v, hipStream_t stream) {
     if (!v->occ_tighten_due || v->occ_dirty || v->occ_tighten_pending) return TSDF_OK;
-    if (!v->occ_tightened) TSDF_HIP(hipEventCreateWithFlags(&v->occ_tightened, hipEventDisableTiming), "occupancy event");
+    if (!v->occ_tightened) TSDF_HIP(hipEventCreateWithFlags(&v->occ_tightened, stream_order_event_flags()), "occupancy event");
     int rc = occupancy_rebuild_on(v, stream);
     if (rc != TSDF_OK) return rc;
     TSDF_HIP(hipEventRecord(v->occ_tightened, stream), "occupancy event");
