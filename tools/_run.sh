@@ -1,10 +1,14 @@
 cd $GRAFT_REPO_ROOT
-for r in 1 2; do for s in 0 1 2; do
-TSDF_EVENT_SCOPE=$s python bench.py --no-cpu-baseline --steps 20 --warmup 5 --repeats 3 > gpurun_out/ev_s${s}_$r.json 2>gpurun_out/ev_err.txt || tail -3 gpurun_out/ev_err.txt
-python - <<PY
+mkdir -p gpurun_out/final
+( time python -m pytest tests -m gpu -x -q ) > gpurun_out/final/pytest_gpu.txt 2>&1; tail -3 gpurun_out/final/pytest_gpu.txt
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/final/smoke.txt 2>&1; tail -2 gpurun_out/final/smoke.txt
+for s in 0 2 0 2; do echo scope $s $(TSDF_EVENT_SCOPE=$s python tools/dbg_tracking.py 2>&1 | grep -i "per frame" | tail -1); done > gpurun_out/final/tracking_scope.txt 2>&1; cat gpurun_out/final/tracking_scope.txt
+bash tools/profile_round.sh r04zz 20 5 > gpurun_out/final/pr1.log 2>&1
+bash tools/profile_round.sh r04zz_config4 20 5 "--workload config4" 1024 > gpurun_out/final/pr2.log 2>&1
+bash tools/profile_round.sh r04zz_grid256 20 5 "--grid 256" 256 > gpurun_out/final/pr3.log 2>&1
+for t in r04zz r04zz_config4 r04zz_grid256; do python - <<PY
 import json
-d=json.loads(open("gpurun_out/ev_s${s}_$r.json").read().strip().splitlines()[-1])
-print("scope $s run $r ms_per_step", d["ms_per_step"], d.get("ms_per_step_runs"), "parity", d.get("parity",{}).get("status") if isinstance(d.get("parity"),dict) else d.get("parity"), "bits", d.get("last_frame_vertex_bits"))
+d=json.loads(open("gpurun_out/profiles_$t/${t}_bench.json").read().strip().splitlines()[-1])
+print("$t", d["ms_per_step"], d.get("ms_per_step_runs"), d["value"], d["roofline"]["achieved"], d["roofline"]["frac"], d["roofline"]["traffic"], d.get("tracking",{}))
 PY
-done; done
-for s in 0 1 2; do echo scope $s $(TSDF_EVENT_SCOPE=$s python tools/dbg_tracking.py 2>&1 | tail -1); done
+done

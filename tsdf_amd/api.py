@@ -45,7 +45,7 @@ class TSDFVolume:
             check(lib.tsdf_volume_create_slab(sx, sy, sz, px, py, pz, int(slab[0]), int(slab[1]), C.byref(self._h)))
 
     def close(self):
-        if getattr(self, "_h", None) is not None and self._h.value:
+        if lib is not None and getattr(self, "_h", None) is not None and self._h.value:   # (lib is None during interpreter shutdown)
             for ref in getattr(self, "_dependents", ()):      # pipelines built on this volume hold its stream: they go first
                 dep = ref()
                 if dep is not None:
@@ -351,7 +351,7 @@ class BilateralFilter:
         check(lib.tsdf_bilateral_create(float(sigma_colour), float(sigma_space), C.byref(self._h)))
 
     def close(self):
-        if getattr(self, "_h", None) is not None and self._h.value:
+        if lib is not None and getattr(self, "_h", None) is not None and self._h.value:   # (lib is None during interpreter shutdown)
             lib.tsdf_bilateral_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -431,7 +431,7 @@ class ICPOdometry:
         self.last_error, self.last_inliers = 0.0, float(width * height)
 
     def close(self):
-        if getattr(self, "_h", None) is not None and self._h.value:
+        if lib is not None and getattr(self, "_h", None) is not None and self._h.value:   # (lib is None during interpreter shutdown)
             lib.tsdf_icp_destroy(self._h)
             self._h = C.c_void_p()
 

@@ -59,15 +59,18 @@ struct Tuning {
     int pipe_release;        // TSDF_PIPE_RELEASE       when tsdf_pipeline_step lets the next frame's filter + culling start on the side stream: 0 after
                              //                          this frame's integrate (beside the bulk ray kernel), 1 after the bulk ray kernel (beside the tail kernel), 2 the filter already after the previous step (beside integrate); both measured slower
     int pipe_host_wait;      // TSDF_PIPE_HOST_WAIT     1: tsdf_pipeline_step waits on the HOST for the frame filtered ahead instead of putting a wait packet into the step's stream
-    int event_scope;         // TSDF_EVENT_SCOPE        release scope of the events that order the library's own streams: 0 system (HIP's default: a cache write-back
-                             //                          and invalidate for the host's and other devices' sake), 1 device (hipEventReleaseToDevice), 2 no system fence
+    int event_scope;         // TSDF_EVENT_SCOPE        the events that order the library's own streams: 0 HIP's default (a system-scope fence when the event completes: cache
+                             //                          write-back + invalidate for the host's and other devices' sake), 1 hipEventReleaseToDevice, 2 (default) hipEventDisableSystemFence
     int timing_bracket;      // TSDF_TIMING_BRACKET     1: tsdf_volume_set_timing brackets launches with hipEventRecord
     int verbose;             // TSDF_VERBOSE            the reference's chatter
     int debug_waves;         // TSDF_DEBUG_WAVES        per-wave clocks of the two ray kernels (synchronises)
     int debug_rays;          // TSDF_DEBUG_RAYS         how many pieces went through the tail queue (synchronises)
 };
 const Tuning &tuning();
-// flags of an event that only orders streams of this device against each other (nothing the host or another device reads hangs on it)
+// Flags of an event that only orders streams of THIS device against each other: nothing the host or another device reads hangs on
+// it (the kernels either side of it release / acquire at device scope at their own boundaries, as consecutive kernels of one stream
+// do), so the system-scope fence HIP attaches to an event by default is dropped: 4-6 us of every 270 us step (profiles/r04zz_event_scope_ab.txt).
+// The events of the multi-GPU exchange (pipeline.hip: cast, merged) keep HIP's default.
 inline unsigned stream_order_event_flags() {
     const int scope = tuning().event_scope;
     return hipEventDisableTiming | (scope == 1 ? hipEventReleaseToDevice : scope == 2 ? hipEventDisableSystemFence : 0u);

@@ -71,7 +71,7 @@ class FusionPipeline:
         check(lib.tsdf_pipeline_synchronize(self._h))
 
     def close(self):
-        if getattr(self, "_h", None) is not None and self._h.value:
+        if lib is not None and getattr(self, "_h", None) is not None and self._h.value:   # (lib is None during interpreter shutdown)
             lib.tsdf_pipeline_destroy(self._h)
             self._h = C.c_void_p()
 

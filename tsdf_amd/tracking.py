@@ -47,7 +47,7 @@ class FrameToModelTracker:
         self.last_T = None          # the last incremental transformation (4x4, metres) as ICPOdometry returned it
 
     def close(self):
-        if getattr(self, "_h", None) is not None and self._h.value:
+        if lib is not None and getattr(self, "_h", None) is not None and self._h.value:   # (lib is None during interpreter shutdown)
             lib.tsdf_tracker_destroy(self._h)
             self._h = C.c_void_p()
 
