@@ -34,6 +34,8 @@ struct tsdf_icp {
     double *state;                           // device, 2 x kIcpStateDoubles: [0..15] T (column-major), [16..17] residual,
                                              //         inliers, [18..53] A (float values), [54..59] b
     int side;                                // which copy of state / partial holds the latest step
+    double *host_io;                         // pinned host memory the device reads and writes in place: [0..15] the pose an alignment starts from,
+    double *host_io_dev;                     // [16..33] its result (pose, residual, inliers) -- no copy launches either side of the chain (4-5 us each)
     unsigned long long *arrivals;            // icp_persistent_kernel's grid barrier: a counter that only grows ...
     unsigned long long arrivals_base;        // ... and the value it will have when the next launch starts
     unsigned long long published_base;       // (leader variant: [1] = last published step, [2..] the published poses)
@@ -268,10 +270,18 @@ __global__ __launch_bounds__(kIcpThreads) void icp_reduce_kernel(const double *_
 }
 
 // Finishes the last step of a sequence (nothing follows whose prologue would): one workgroup.
+// `mirror` (pinned host memory, or null): pose, residual and inliers also go there, for the host to read after the stream's end.
 __global__ __launch_bounds__(kIcpThreads) void icp_finish_kernel(const double *__restrict__ state_in, double *__restrict__ state_out,
-                                                                const float *__restrict__ partial_prev, int n_blocks, int update) {
+                                                                const float *__restrict__ partial_prev, int n_blocks, int update,
+                                                                double *__restrict__ mirror) {
     __shared__ double pose[16];
     icp_finish_step(partial_prev, n_blocks, state_in, update, pose, state_out);
+    if (mirror && threadIdx.x == 0) {   // (thread 0 solved the step: what it has just written)
+#pragma unroll
+        for (int i = 0; i < 16; i++) mirror[i] = pose[i];
+        mirror[16] = state_out[16];
+        mirror[17] = state_out[17];
+    }
 }
 
 // x = A^-1 b, 6x6 symmetric positive (semi-)definite, LDL^T with diagonal pivoting in double -- the job of
@@ -611,6 +621,7 @@ static void free_icp(tsdf_icp *f) {
     if (f->partial) (void)hipFree(f->partial);
     if (f->state) (void)hipFree(f->state);
     if (f->arrivals) (void)hipFree(f->arrivals);
+    if (f->host_io) (void)hipHostFree(f->host_io);
     delete f;
 }
 
@@ -641,10 +652,11 @@ static int build_maps(tsdf_icp *f, const uint16_t *depth0, float **vmaps, float 
 }
 
 // Launches the sums of one step at `level`, taken at the pose the pending step (if any) leads to.
-static void launch_step(tsdf_icp *f, int level, int pending) {
+// `start` (pending == 0 only): where the pose to start from lies, if not in the device state (the host's pinned copy).
+static void launch_step(tsdf_icp *f, int level, int pending, const double *start = nullptr) {
     const int rows = f->height >> level, cols = f->width >> level, div = 1 << level;
     const int in = f->side, out = 1 - f->side;
-    hipLaunchKernelGGL(icp_reduce_kernel, dim3(kIcpBlocks), dim3(kIcpThreads), 0, f->stream, f->state + in * kIcpStateDoubles,
+    hipLaunchKernelGGL(icp_reduce_kernel, dim3(kIcpBlocks), dim3(kIcpThreads), 0, f->stream, start ? start : f->state + in * kIcpStateDoubles,
                        f->state + out * kIcpStateDoubles, f->partial + (size_t)in * kIcpBlocks * 32, pending, f->vmap_curr[level],
                        f->nmap_curr[level], f->vmap_prev[level], f->nmap_prev[level], rows, cols, f->fx / div, f->fy / div,
                        f->cx / div, f->cy / div, f->dist_thresh, f->angle_thresh, f->partial + (size_t)out * kIcpBlocks * 32);
@@ -652,10 +664,10 @@ static void launch_step(tsdf_icp *f, int level, int pending) {
 }
 
 // Finishes the step whose sums the last launch_step left (with or without the pose update).
-static void launch_finish(tsdf_icp *f, int update) {
+static void launch_finish(tsdf_icp *f, int update, double *mirror = nullptr) {
     const int in = f->side, out = 1 - f->side;
     hipLaunchKernelGGL(icp_finish_kernel, dim3(1), dim3(kIcpThreads), 0, f->stream, f->state + in * kIcpStateDoubles,
-                       f->state + out * kIcpStateDoubles, f->partial + (size_t)in * kIcpBlocks * 32, kIcpBlocks, update);
+                       f->state + out * kIcpStateDoubles, f->partial + (size_t)in * kIcpBlocks * 32, kIcpBlocks, update, mirror);
     f->side = out;
 }
 
@@ -692,6 +704,9 @@ int tsdf_icp_create(int width, int height, float cx, float cy, float fx, float f
     if (e == hipSuccess) e = hipMemset(f->state, 0, 2 * kIcpStateDoubles * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&f->arrivals, (2 + 32) * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(f->arrivals, 0, (2 + 32) * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&f->host_io, (16 + 18) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);   // (fine-grained: the device reads and writes it past its caches)
+    if (e == hipSuccess) std::memset(f->host_io, 0, (16 + 18) * sizeof(double));
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&f->host_io_dev, f->host_io, 0);
     if (e != hipSuccess) {
         free_icp(f);
         return hip_fail(e, "ICP alloc failed");
@@ -774,10 +789,17 @@ int tsdf_icp_estimate_step(tsdf_icp *f, int level, const float R[9], const float
 
 int tsdf_icp_get_incremental_transformation(tsdf_icp *f, double T_prev_curr[16], float *last_error, float *last_inliers) {
     TSDF_REQUIRE(f && T_prev_curr, "tsdf_icp_get_incremental_transformation: null argument");
-    TSDF_HIP(hipMemcpyAsync(f->state + f->side * kIcpStateDoubles, T_prev_curr, 16 * sizeof(double), hipMemcpyHostToDevice, f->stream),
-             "ICP pose upload");
     const int iterations[kIcpLevels] = {10, 5, 4};  // ICPOdometry.cpp:99-101
-    if (tuning().icp_persistent) {
+    const bool persistent = tuning().icp_persistent != 0;
+    // The pose goes to the device and the result comes back through pinned host memory that the first and the last launch of the chain
+    // address directly (every call ends with the stream idle, so the host may write it here): the two 128-byte copies were launches of
+    // their own on the stream, 4-5 us each plus their boundaries, on the path every tracked frame waits for.
+    if (persistent)
+        TSDF_HIP(hipMemcpyAsync(f->state + f->side * kIcpStateDoubles, T_prev_curr, 16 * sizeof(double), hipMemcpyHostToDevice, f->stream),
+                 "ICP pose upload");
+    else
+        std::memcpy(f->host_io, T_prev_curr, 16 * sizeof(double));
+    if (persistent) {
         // one launch: the workgroups stay through all 19 iterations and meet in a grid barrier (icp_persistent_kernel)
         IcpRun run;
         for (int i = 0; i < kIcpLevels; i++) {
@@ -805,15 +827,16 @@ int tsdf_icp_get_incremental_transformation(tsdf_icp *f, double T_prev_curr[16],
         int pending = 0;   // every launch finishes the step before it, the last step gets a launch of its own
         for (int i = kIcpLevels - 1; i >= 0; i--)
             for (int j = 0; j < iterations[i]; j++) {
-                launch_step(f, i, pending);
+                launch_step(f, i, pending, pending ? nullptr : f->host_io_dev);
                 pending = 1;
             }
-        launch_finish(f, 1);
+        launch_finish(f, 1, f->host_io_dev + 16);
     }
     TSDF_HIP(hipGetLastError(), "ICP kernels failed");
     double out[18];
-    TSDF_HIP(hipMemcpyAsync(out, f->state + f->side * kIcpStateDoubles, sizeof(out), hipMemcpyDeviceToHost, f->stream), "ICP pose download");
-    TSDF_HIP(hipStreamSynchronize(f->stream), "ICP");
+    if (persistent) TSDF_HIP(hipMemcpyAsync(out, f->state + f->side * kIcpStateDoubles, sizeof(out), hipMemcpyDeviceToHost, f->stream), "ICP pose download");
+    TSDF_HIP(hipStreamSynchronize(f->stream), "ICP");   // (polling a ticket in the pinned block instead: 0.5-1 %, not kept)
+    if (!persistent) std::memcpy(out, f->host_io + 16, sizeof(out));
     std::memcpy(T_prev_curr, out, 16 * sizeof(double));
     // lastError = sqrt(residual) / inliers, lastInliers = inliers of the last iteration (ICPOdometry.cpp:127-128)
     if (last_error) *last_error = sqrtf((float)out[16]) / (float)out[17];
