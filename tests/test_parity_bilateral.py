@@ -54,6 +54,21 @@ def test_u16_full_range_values(oracle):
     assert np.array_equal(got, oracle.bilateral_u16(img, 53, 37, 2000.0, 3.0))
 
 
+@pytest.mark.parametrize("sigma_colour", [30.0, 27.0, 5.0])
+def test_u16_full_range_values_through_the_15x15_kernel(oracle, sigma_colour):
+    # radius 7 = the staged kernel of the pipeline's filter.  Full-range values: nearly every tap's difference lies beyond the head of
+    # the similarity table held in LDS (its look-up goes past the table and is replaced by the entry from memory).  sigma_colour 30:
+    # the smallest weight is 1.9e-34 and the kernel carries 4 * sum; 27 and 5: the table reaches denormals / zero, the smallest
+    # weight is below 2^-120 and the plain loops run instead (tsdf_bilateral::scale_exact) -- all three must equal the oracle.
+    rng = np.random.RandomState(int(sigma_colour))
+    img = rng.randint(0, 65536, (48, 64)).astype(np.uint16)
+    img[10:20, 10:30] = 0                       # a hole: centre pixels of value 0 whose whole sum comes from far values
+    img[30:40, 5:25] = rng.randint(900, 1100, (10, 20)).astype(np.uint16)   # and a smooth patch (differences inside the head)
+    got = img.copy()
+    tsdf_amd.BilateralFilter(sigma_colour, 4.5).filter(got, 64, 48)
+    assert np.array_equal(got, oracle.bilateral_u16(img, 64, 48, sigma_colour, 4.5))
+
+
 def test_device_variant_matches_host_variant():
     import torch
     d, _ = synth.depth_frame(1, 10, seed=5)

@@ -2,13 +2,7 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/final
 ( time python -m pytest tests -m gpu -x -q ) > gpurun_out/final/pytest_gpu.txt 2>&1; tail -3 gpurun_out/final/pytest_gpu.txt
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/final/smoke.txt 2>&1; tail -1 gpurun_out/final/smoke.txt
-dir=/tmp/tsdf_tum_trk
-python - <<PY
-import sys; sys.path.insert(0, "$GRAFT_REPO_ROOT")
-from tsdf_amd import synth
-synth.write_tum_directory("$dir", 25, seed=0x5EED0003, stream_frames=200)
-PY
-for r in 1 2 3; do build/kinfu_stream -d $dir --track -k 24; python tools/dbg_tracking.py 2>&1 | grep "per frame"; done > gpurun_out/final/tracked_loop.txt 2>&1; cat gpurun_out/final/tracked_loop.txt | cut -c100-220
+python tools/bench_bilateral.py 200 2>&1 | tail -1
 bash tools/profile_round.sh r04zz 20 5 > gpurun_out/final/pr1.log 2>&1
 bash tools/profile_round.sh r04zz_config4 20 5 "--workload config4" 1024 > gpurun_out/final/pr2.log 2>&1
 bash tools/profile_round.sh r04zz_grid256 20 5 "--grid 256" 256 > gpurun_out/final/pr3.log 2>&1

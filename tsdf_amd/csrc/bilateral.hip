@@ -170,10 +170,12 @@ __global__ __launch_bounds__(256) void bilateral_kernel(const PIX *__restrict__ 
             }
 #pragma unroll
             for (int j = 0; j < CNT; j++)
-                w[j] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(sim_lds) + (delta4[j] & (kStagedBytes - 1u)));
+                w[j] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(sim_lds) + delta4[j]);   // (no mask: see below)
             if (sizeof(PIX) != 1) {
                 // differences beyond the staged head (kSimLds mm and more): one test per half column; the entries come through
-                // a load the compiler cannot fold with the LDS read into a generic-address load
+                // a load the compiler cannot fold with the LDS read into a generic-address load.  (The LDS read above is not
+                // masked into the head: an offset past it lands in the tile behind the table or past the workgroup's allocation,
+                // where the hardware returns 0 for a read -- either way a value this test replaces.)
                 unsigned big = delta4[0];
 #pragma unroll
                 for (int j = 1; j < CNT; j++) big = max(big, delta4[j]);
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(256) void bilateral_kernel(const PIX *__restrict__ 
             constexpr int CNT = decltype(count)::value;
             (void)i;
 #pragma unroll
-            for (int j = 0; j < CNT; j++) bilateral_tap(w[j], (double)(v4[j] >> 2), sum, total_weight);
+            for (int j = 0; j < CNT; j++) bilateral_tap(w[j], (double)v4[j], sum, total_weight);   // (4 * intensity: `sum` runs as 4 * the reference's, see below)
         };
         using Lo = std::integral_constant<int, 0>;
         using Hi = std::integral_constant<int, NA>;
@@ -231,6 +233,11 @@ __global__ __launch_bounds__(256) void bilateral_kernel(const PIX *__restrict__ 
             __builtin_amdgcn_s_setprio(3);                 // the few rim waves do more per tap: let them run ahead of their SIMD's other waves
             run(std::true_type{});
         }
+        // The chain above fed the tile's words, 4 * intensity, into the products (a shift per tap less): every partial sum was 4 times
+        // the reference's, exactly -- scaling by a power of two commutes with both roundings of a tap as long as no partial sum is a
+        // denormal float, and a nonzero partial sum is at least the smallest nonzero weight (terms are >= 0, intensities integers),
+        // which launch_bilateral has checked to be >= 2^-120 before it picked this kernel (tsdf_bilateral::scale_exact).
+        sum *= 0.25f;
     } else {
 #pragma unroll 1
         for (int i = 0; i < n; i++) {                      // conv_x: outer loop of the reference
@@ -263,7 +270,9 @@ static int launch_bilateral(const tsdf_bilateral *f, const PIX *in, PIX *out, in
                             uint16_t *tile_max = nullptr) {
     dim3 grid((width + kBTile - 1) / kBTile, (height + kBTile - 1) / kBTile);
     const int span = kBTile + 2 * f->radius, n = 2 * f->radius + 1;
-    const bool staged = f->radius == 7;      // the depth filter of the pipeline: sigma_space 4.5 -> 15 x 15 taps (other radii: the plain loops)
+    // the depth filter of the pipeline: sigma_space 4.5 -> 15 x 15 taps (other radii, or weights so small that the staged kernel's
+    // scaled sum could meet denormals: the plain loops)
+    const bool staged = f->radius == 7 && f->scale_exact;
     size_t smem = (size_t)span * span * ((staged ? 0 : sizeof(double)) + sizeof(uint32_t)) + (size_t)n * n * sizeof(float) +
                   (staged ? kSimLds * sizeof(float) : 0);
     if (staged)
@@ -336,6 +345,13 @@ int tsdf_bilateral_create(float sigma_colour, float sigma_space, tsdf_bilateral 
     f->sigma_colour = sigma_colour;
     f->sigma_space = sigma_space;
     f->radius = kernel_radius;
+    {
+        // smallest nonzero weight a tap can have: the float product of the smallest nonzero entries of the two tables
+        float min_k = 0.0f, min_s = 0.0f;
+        for (float k : kernel) if (k > 0.0f && (min_k == 0.0f || k < min_k)) min_k = k;
+        for (float x : similarity) if (x > 0.0f && (min_s == 0.0f || x < min_s)) min_s = x;
+        f->scale_exact = (min_k * min_s >= 0x1p-120f) ? 1 : 0;
+    }
     hipError_t e = hipGetDevice(&f->device);
     if (e == hipSuccess) e = hipMalloc((void **)&f->kernel_dev, kernel.size() * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&f->similarity_dev, similarity.size() * sizeof(float));

@@ -346,6 +346,7 @@ struct tsdf_bilateral {
     float sigma_colour, sigma_space;
     int radius;
     int device;
+    int scale_exact;         // every nonzero tap weight is >= 2^-120: the staged kernel may carry 4 * sum (bilateral.hip)
     float *kernel_dev;       // (2r+1)^2
     float *similarity_dev;   // 65536 entries (first 256 = the reference's table)
     void *img_in;            // cached device images for the host variants
