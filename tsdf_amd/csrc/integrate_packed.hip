@@ -98,13 +98,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TSDF_PACKED
     // over bricks: what the prologue needs of the kernel's arguments is dead once the planes are walked, which the scalar register
     // file needs (with a loop around it the compiler kept it all live and spilled scalars into vector lanes: a v_readlane per use).
     {
-        // (the list's entry and its box are requested together with the list's length -- both arrays hold an entry for every brick of the
-        // grid, so reading past the length is harmless -- instead of one round trip after it)
+        // The list's length first (the same word for every workgroup: a scalar-cache hit; the many workgroups beyond the list -- nine in ten
+        // at 1024^3 -- leave here without touching memory), then the list entry, its box and the brick's coordinates in ONE scalar round
+        // trip: all three are needed here, in scalar registers -- left alone the compiler spreads them over three dependent trips to L2
+        // (the coordinates, the entry inside the `touched` store's branch, the box) in front of the tile's pixels.
         const uint32_t i = blockIdx.x;
+        if (i >= n_active) return;
         const uint32_t b = list[i];
         const uint4 box = boxes[i];
         const uint2 co = coords[i];   // the brick's coordinates as the cull kernel had them (three divisions by run-time extents otherwise)
-        if (i >= n_active) return;
+        asm volatile("" :: "s"(b), "s"(box.x), "s"(box.y), "s"(box.z), "s"(box.w), "s"(co.x), "s"(co.y));
 #ifdef TSDF_DIAGNOSTICS
         const uint32_t bx = b % bg.nx, by = (b / bg.nx) % bg.ny, bz = b / (bg.nx * bg.ny);   // (the diagnostics may have re-sorted list and boxes on the host)
         (void)co;
