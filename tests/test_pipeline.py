@@ -251,3 +251,46 @@ def test_a_volume_takes_one_pipeline_or_tracker_at_a_time():
     b.synchronize()
     b.close()
     vol.close()
+
+
+KNOB_SCRIPT = r"""
+import sys, hashlib, numpy as np, torch
+sys.path.insert(0, %r)
+import tsdf_amd
+from tsdf_amd import synth
+from tsdf_amd.pipeline import FusionPipeline
+W, H, n = 640, 480, 96
+frames = [synth.depth_frame(i * 3, 200, seed=0x5EED0003) for i in range(20)]   # (past the 16th integration: one flag rebuild beside a ray cast)
+vol = tsdf_amd.TSDFVolume((n, n, n), (3000.0,) * 3)
+pipe = FusionPipeline(vol, tsdf_amd.BilateralFilter(30.0, 4.5), tsdf_amd.GPURaycaster(W, H), W, H, overlap=True)
+depth = torch.from_numpy(np.stack([d for d, _ in frames]).view(np.int16)).cuda()
+vert = torch.empty((H * W, 3), dtype=torch.float32, device="cuda")
+norm = torch.empty_like(vert)
+h = hashlib.sha256()
+for i, (_, cam) in enumerate(frames):   # (no host round trip between the steps, as bench.py drives it)
+    nxt = depth[i + 1].data_ptr() if i + 1 < len(frames) else None
+    pipe.step(depth[i].data_ptr(), cam, vert.data_ptr(), norm.data_ptr(), nxt, frames[i + 1][1] if nxt is not None else None)
+    if i %% 5 == 4:
+        pipe.synchronize()
+        h.update(vert.cpu().numpy().tobytes()); h.update(norm.cpu().numpy().tobytes())
+pipe.synchronize()
+h.update(vol.get_distance_data().tobytes()); h.update(vol.get_weight_data().tobytes())
+print(h.hexdigest())
+"""
+
+
+def test_the_schedule_knobs_of_the_pipeline_change_no_bit():
+    """Where the side stream is released, how the step waits for it and what fence its events carry are scheduling: the same volume and
+    the same pictures under every setting (each in a process of its own: the knobs are read once)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seen = {}
+    for name, env in (("default", {}), ("event scope 0", {"TSDF_EVENT_SCOPE": "0"}), ("event scope 1", {"TSDF_EVENT_SCOPE": "1"}),
+                      ("release 1", {"TSDF_PIPE_RELEASE": "1"}), ("release 2", {"TSDF_PIPE_RELEASE": "2"}),
+                      ("host wait", {"TSDF_PIPE_HOST_WAIT": "1"})):
+        out = subprocess.run([sys.executable, "-c", KNOB_SCRIPT % root], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, (name, out.stderr[-2000:])
+        seen[name] = out.stdout.split()[-1]
+    assert len(set(seen.values())) == 1, seen
