@@ -49,8 +49,9 @@ struct Tuning {
     int ray_tile_map;        // TSDF_RAY_TILE_MAP       which tiles an XCD gets: 0 every eighth, 1 a contiguous eighth, 2 one block per block row (default)
     int ray_learned_order;   // TSDF_RAY_LEARNED_ORDER  0: launch order, one workgroup per (range, tile) (default 1: the order learnt from the previous cast)
     int ray_heavy_passes;    // TSDF_RAY_HEAVY_PASSES   passes from which a wave counts as long for that order (0: three quarters of the budget)
+    int ray_fused;           // TSDF_RAY_FUSED          1: the march and its queue of unfinished stretches in ONE launch (process_ray_fused_kernel; measured slower, LABNOTES round 5); default 0: two launches
     int ray_entry_bound;     // TSDF_RAY_ENTRY_BOUND    0: no per-tile entry bound (default 1: rays start at the nearest flagged block their 16 x 16 tile can see)
-    int icp_persistent;      // TSDF_ICP_PERSISTENT     0: one launch per ICP iteration (the chain of rounds 1-3); default 1: all 19 in one launch with a grid barrier
+    int icp_persistent;      // TSDF_ICP_PERSISTENT     default 0: one launch per ICP iteration (the chain); 1 / 2: all 19 in one launch with a grid barrier (slower, kept for study)
     int occ_rebuild_period;  // TSDF_OCC_REBUILD_PERIOD integrations between tightenings of the ray caster's flags (16; 0: never)
     int occ_scan_all;        // TSDF_OCC_SCAN_ALL       1: every tightening reads the whole distance array
     int reach_lds;           // TSDF_REACH_LDS          1: the workgroup variant of the reach summary on every grid

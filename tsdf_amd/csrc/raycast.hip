@@ -387,6 +387,19 @@ __device__ inline int lipschitz_lookahead(float val, float c000, float c100, flo
     return (int)fminf(x, (float)limit);
 }
 
+// Diagnostics build (-DTSDF_DIAG_RAY_MIX, tools/dbg_ray_mix.py): what the passes of the two march kernels are spent on.
+// [0..7] bulk kernel, per lane and pass: 0 block jump (reach), 1 cell-brick jump, 2 another slab's cell, 3 cell of positive voxels,
+// 4 evaluated: hit, 5 evaluated: look-ahead to the cell's exit, 6 evaluated: look-ahead short of it, 7 the reference's full path;
+// [8..15] the same for the tail kernel's lanes, [16..23] for lane 0 of its groups; [24..27] bulk passes by lanes active (1-4, 5-16,
+// 17-32, 33-64), [28..31] the same counting only the waves' passes 12 and later.
+#ifdef TSDF_DIAG_RAY_MIX
+__device__ unsigned long long g_ray_mix[64];
+#define RAY_MIX(slot) atomicAdd(&g_ray_mix[(slot)], 1ull)
+#else
+#define RAY_MIX(slot) ((void)0)
+#endif
+struct MixSlot { int base; };
+
 // ---- one sample of one ray ------------------------------------------------------------------------------------
 struct RayState {
     float dx, dy, dz;  // direction (not normalised: Q6)
@@ -461,6 +474,7 @@ __device__ inline float process_sample(float t, int k, const RayState &r, const 
             bc.k_brick_end = k + n;
             if (empty) {
                 if (STATS) work.hops++;
+                RAY_MIX(0);
                 jump = n;
                 return 1.0f;
             }
@@ -488,6 +502,7 @@ __device__ inline float process_sample(float t, int k, const RayState &r, const 
                 bc.cellbrick_clear = occ.cell[(__umul24((uint32_t)qz, occ.nby) + (uint32_t)qy) * occ.nbx + (uint32_t)qx] == 0;
             }
             if (bc.cellbrick_clear && k < bc.k_cellbrick_end) {
+                RAY_MIX(1);
                 jump = bc.k_cellbrick_end - k;
                 return 1.0f;
             }
@@ -496,6 +511,7 @@ __device__ inline float process_sample(float t, int k, const RayState &r, const 
             const int n_cell = samples_until<false>(__builtin_fmaf(cell_hi - cell_lo, sc.posx, cell_lo) - rx, __builtin_fmaf(cell_hi - cell_lo, sc.posy, cell_lo) - ry,
                                                     __builtin_fmaf(cell_hi - cell_lo, sc.posz, cell_lo) - rz, sc);
             if (SLAB && !((uint32_t)lz >= rp.own_lo && (uint32_t)lz < rp.own_hi)) {
+                RAY_MIX(2);
                 jump = n_cell;  // not this rank's samples (and possibly not its planes): passed unevaluated
                 return 1.0f;
             }
@@ -508,6 +524,7 @@ __device__ inline float process_sample(float t, int k, const RayState &r, const 
             // non-zero, so with a NaN corner every sample of the cell is NaN, which the reference steps over as well)
             const bool positive = fminf(fminf(fminf(c000, c100), fminf(c010, c110)), fminf(fminf(c001, c101), fminf(c011, c111))) > kCellPositive;
             if (positive) {
+                RAY_MIX(3);
                 jump = n_cell;
                 return 1.0f;
             }
@@ -531,14 +548,42 @@ __device__ inline float process_sample(float t, int k, const RayState &r, const 
                               c110 * u * v * (1 - w) +
                               c111 * u * v * w;
             ahead = lipschitz_lookahead(val, c000, c100, c010, c110, c001, c101, c011, c111, sc, n_cell - 1);
+            RAY_MIX(val <= 0 ? 4 : (ahead == n_cell - 1 ? 5 : 6));
             return val;
         }
     }
+    RAY_MIX(7);
     bool owned;
     const float tsdf = trilinear<SLAB, STATS, FASTDIV>(px, py, pz, dist, g, tc, rp, owned, touched);
     if (STATS && owned) work.samples++;
     return tsdf;
 }
+
+// Samples from the one at parameter t until the ray leaves that sample's dual cell shrunk by eps (>= 1): n_cell of process_sample, from
+// the position alone -- no look-up.  The tail kernel spaces the lanes of a group by it (march_tail).
+__device__ inline int cell_steps(float t, const RayState &r, const SkipCtx &sc) {
+    const float cell_lo = sc.eps, cell_hi = 1.0f - sc.eps;
+    const float cx = ((t * r.dx) + r.sx) * sc.inv_vx - 0.5f, cy = ((t * r.dy) + r.sy) * sc.inv_vy - 0.5f, cz = ((t * r.dz) + r.sz) * sc.inv_vz - 0.5f;
+    const float rx = cx - floorf(cx), ry = cy - floorf(cy), rz = cz - floorf(cz);
+    return samples_until<false>(__builtin_fmaf(cell_hi - cell_lo, sc.posx, cell_lo) - rx, __builtin_fmaf(cell_hi - cell_lo, sc.posy, cell_lo) - ry,
+                                __builtin_fmaf(cell_hi - cell_lo, sc.posz, cell_lo) - rz, sc);
+}
+// The value lane q of this lane's group of `lanes` lanes holds (groups of 4: one DPP move)
+template <int LANES>
+__device__ inline int group_lane(int x, int q, uint32_t lanes) {
+    if (LANES == 4) {
+        switch (q) {
+        case 0: return __builtin_amdgcn_mov_dpp(x, 0x00, 0xf, 0xf, true);   // quad_perm [0,0,0,0]
+        case 1: return __builtin_amdgcn_mov_dpp(x, 0x55, 0xf, 0xf, true);   // [1,1,1,1]
+        case 2: return __builtin_amdgcn_mov_dpp(x, 0xaa, 0xf, 0xf, true);   // [2,2,2,2]
+        default: return __builtin_amdgcn_mov_dpp(x, 0xff, 0xf, 0xf, true);  // [3,3,3,3]
+        }
+    }
+    return __shfl(x, (int)((threadIdx.x & 63u & ~(lanes - 1u)) + (uint32_t)q));
+}
+#ifndef TSDF_RAY_TAIL_CHAIN
+#define TSDF_RAY_TAIL_CHAIN 0   // (measured slower, LABNOTES round 5: where the look-ahead is short the spaced lanes leave gaps)
+#endif
 
 // process_sample for the tail kernel: the same decisions in the same order, but without the per-brick memory (a lane
 // takes a different ray's sample every time) and with every load issued before the first decision -- the brick's reach,
@@ -547,7 +592,7 @@ __device__ inline float process_sample(float t, int k, const RayState &r, const 
 // cost bandwidth in the bulk kernel.)
 template <bool SLAB, bool FASTDIV>
 __device__ inline float process_sample_eager(float t, const RayState &r, const SkipCtx &sc, const float *__restrict__ dist,
-                                             const Geom &g, const TriConst &tc, const RayParams &rp, const OccGrid &occ, int &jump, int &ahead) {
+                                             const Geom &g, const TriConst &tc, const RayParams &rp, const OccGrid &occ, int &jump, int &ahead, bool mix0 = false) {
     const float px = (t * r.dx) + r.sx, py = (t * r.dy) + r.sy, pz = (t * r.dz) + r.sz;
     const float cell_lo = sc.eps, cell_hi = 1.0f - sc.eps, cell_half = 0.5f - sc.eps;
     jump = 0;
@@ -582,11 +627,13 @@ __device__ inline float process_sample_eager(float t, const RayState &r, const S
             }
         }
         if (empty) {
+            RAY_MIX(8); if (mix0) RAY_MIX(16);
             jump = n_brick;
             return 1.0f;
         }
         if (safe) {
             if (cell_flag == 0) {
+                RAY_MIX(9); if (mix0) RAY_MIX(17);
                 jump = n_cb;
                 return 1.0f;
             }
@@ -594,6 +641,7 @@ __device__ inline float process_sample_eager(float t, const RayState &r, const S
             // non-zero, so with a NaN corner every sample of the cell is NaN, which the reference steps over as well)
             const bool positive = fminf(fminf(fminf(c000, c100), fminf(c010, c110)), fminf(fminf(c001, c101), fminf(c011, c111))) > kCellPositive;
             if (!owned || positive) {
+                RAY_MIX(owned ? 11 : 10); if (mix0) RAY_MIX(owned ? 19 : 18);
                 jump = n_cell;
                 return 1.0f;
             }
@@ -614,9 +662,11 @@ __device__ inline float process_sample_eager(float t, const RayState &r, const S
                               c110 * u * v * (1 - w) +
                               c111 * u * v * w;
             ahead = lipschitz_lookahead(val, c000, c100, c010, c110, c001, c101, c011, c111, sc, n_cell - 1);
+            RAY_MIX(val <= 0 ? 12 : (ahead == n_cell - 1 ? 13 : 14)); if (mix0) RAY_MIX(val <= 0 ? 20 : (ahead == n_cell - 1 ? 21 : 22));
             return val;
         }
     }
+    RAY_MIX(15); if (mix0) RAY_MIX(23);
     bool owned;
     return trilinear<SLAB, false, FASTDIV>(px, py, pz, dist, g, tc, rp, owned, nullptr);
 }
@@ -731,7 +781,22 @@ struct TailQueue {
                            // same again for waves that took heavy_passes passes or more
     uint32_t heavy_passes;
     unsigned long long *wave_log;   // diagnostics (TSDF_DEBUG_WAVES): per wave of the tail kernel {batches << 32 | rounds, start, end}
+    // One launch for both kernels (process_ray_fused_kernel, round 5): count[1] = waves of the marching workgroups that have left,
+    // `producers` = how many there are; count[2] != 0 = a queue worker gave up waiting (the sweep launch behind takes what is left);
+    // count[kTailSignals + i], i < n_signals: written by the LAST producer, the final number of entries + 1 -- one word per waiting
+    // workgroup, so that nobody polls an address the producers' atomics need (6 000 waves polling count[0] made the launch 0.6 ms).
+    // Entries then live by their first word: kInvalidEntry = not written yet / taken.
+    uint32_t producers, n_signals;   // (producers: marching WORKGROUPS of the launch)
+    uint32_t consume;      // (classic tail kernel as the fused launch's sweep: entries are taken by overwriting their first word)
 };
+constexpr uint32_t kInvalidEntry = 0xffffffffu;
+constexpr uint32_t kTailSignals = 4;   // TailQueue::count: [0] appended, [1] sub-counters complete, [2] gave up, [3] -, then the signal words, then the sub-counters
+// A marching workgroup counts itself out in one of kSubCounters words (64 words apart, by its index), the workgroup that completes a
+// word in count[1]: an atomic on ONE address from every wave of the launch serialises at 10-14 ns each -- 28 800 waves made the
+// launch 0.4 ms long (profiles/r05c_*).
+constexpr uint32_t kSubCounters = 64, kSubCounterStride = 64;
+__host__ __device__ inline uint32_t tail_counter_words(uint32_t n_signals) { return kTailSignals + n_signals + kSubCounters * kSubCounterStride; }
+constexpr uint32_t kTailSpinLimit = 1u << 15;   // polls (of ~ 1 us) before a queue worker of the fused launch gives up
 constexpr uint32_t kNoHit = 0xffffffffu;
 constexpr uint32_t kNoSlot = 0xffffffffu;   // TailQueue::order: a slot of the launch with nothing to do
 // the sample range the z-th slab of workgroups marches (rp.range_order: 0 near to far, 1 far to near, 2 last, first, then far to near)
@@ -767,13 +832,35 @@ __device__ inline void lower_best(uint64_t *p, int k, float tsdf) { atomicMin(re
 //   SEG: nothing is written but best[]; otherwise out = packed float3 vertices (diagnostic variants).
 //   STATS: counters[1] += samples evaluated, counters[2] += hits, touched bitmap marked per tap.  With
 //          SKIP=false the counts are those of the reference's march.
-template <bool SLAB, bool STATS, bool SKIP, bool FASTDIV, bool SEG, bool TAIL>
-__global__ __launch_bounds__(256) void process_ray_kernel(const float *__restrict__ dist, const Geom g,
-                                                          const RayParams rp, float *__restrict__ out,
-                                                          unsigned long long *__restrict__ counters,
-                                                          unsigned int *__restrict__ touched,
-                                                          const OccGrid occ, const float *__restrict__ t_table,
-                                                          const TailQueue tail) {
+// A marching workgroup of the fused launch has appended what it had (every reservation in count[0] came back before this): it counts
+// itself out; the last one to do so publishes the final number of entries to every waiting workgroup.  (Called by a whole wave.)
+__device__ inline void producer_workgroup_leaves(const TailQueue &tail, uint32_t wg) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t c = wg % kSubCounters, quota = tail.producers / kSubCounters + (c < tail.producers % kSubCounters ? 1u : 0u);
+    const uint32_t words = min(tail.producers, kSubCounters);   // sub-counters in use
+    uint32_t last = 0;
+    if (lane == 0) {
+        uint32_t *sub = tail.count + kTailSignals + tail.n_signals + c * kSubCounterStride;
+        if (__hip_atomic_fetch_add(sub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == quota)
+            last = __hip_atomic_fetch_add(&tail.count[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == words ? 1u : 0u;
+    }
+    if (__shfl(last, 0)) {
+        const uint32_t n = __hip_atomic_load(&tail.count[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (uint32_t i = lane; i < tail.n_signals; i += 64) __hip_atomic_store(&tail.count[kTailSignals + i], n + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// ... a wave of it: the workgroup's last wave speaks for the workgroup (wg_waves_left: a word in LDS set to 4 before the table's barrier)
+__device__ inline void producer_wave_leaves(const TailQueue &tail, uint32_t wg, uint32_t *wg_waves_left) {
+    uint32_t left = 0;
+    if ((threadIdx.x & 63u) == 0) left = atomicSub(wg_waves_left, 1u);
+    if (__shfl(left, 0) == 1u) producer_workgroup_leaves(tail, wg);
+}
+
+template <bool SLAB, bool STATS, bool SKIP, bool FASTDIV, bool SEG, bool TAIL, bool FUSED>
+__device__ inline void march_bulk(const float *__restrict__ dist, const Geom &g, const RayParams &rp, float *__restrict__ out,
+                                  unsigned long long *__restrict__ counters, unsigned int *__restrict__ touched, const OccGrid &occ,
+                                  const float *__restrict__ t_table, const TailQueue &tail, float *Ts, const uint32_t nz) {
+    // (nz: slabs of marching workgroups in the launch -- gridDim.z, or less when queue workers follow them: process_ray_fused_kernel)
     // Whole volume: range z of the workgroup grid is the fixed sample interval [z * seg_len, (z+1) * seg_len).
     // Slab (rp.slab_ranges > 0): a slab owns only a short stretch of every ray, a different one per ray, so the ranges
     // are cut per ray out of ITS stretch (below); any sample index may be needed and the whole table is staged.
@@ -787,7 +874,7 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
     // dispatched last and is done at 56 us when dispatched first; ranges 4 and 3 have 424 and 329 such waves, range 0 (10.5
     // passes through the entry rim, none over 23 us) ends last at 89 us.  Any order gives the same picture: the ranges meet in
     // an atomicMin, and the early exit below only ever drops work.
-    const uint32_t nz = gridDim.z, bz_ = blockIdx.z;
+    const uint32_t bz_ = blockIdx.z;
     // Which (sample range, tile) this workgroup takes: its own in launch order, or -- tail.order, scheduling only -- what the order
     // learnt from the previous cast gives its slot: the pairs in which a wave used its whole pass budget first.  The launch is as long
     // as its long waves (40-60 us each on the bench scene, 1 400 of 24 000) started late: the chip holds a quarter of the launch,
@@ -801,7 +888,10 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
     uint32_t range = ray_range_of_slot(bz_, nz, rp.range_order), range_hi = range + 1u;
     if (TAIL && tail.order) {
         const uint32_t e = tail.order[bz_ * (gridDim.x * gridDim.y) + lin];
-        if (e == kNoSlot) return;
+        if (e == kNoSlot) {
+            if (FUSED && threadIdx.x < 64u) producer_workgroup_leaves(tail, bz_ * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x);
+            return;
+        }
         lin = e & 0xffffu;
         range = (e >> 16) & 0xffu;
         range_hi = e >> 24;
@@ -812,9 +902,9 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
     // T[0], T[1] (the step) and the part of the table this range reads, T[k_lo .. k_hi], at Ts[2 ..]: 3.5 KB of LDS for a fifth of
     // the table (dynamic allocation, ray_table_lds_bytes) instead of 17.6 KB for all of it.  (Workgroup residency is not what
     // limits this kernel: 9 -> 16 workgroups per compute unit by LDS left the launch at 0.091 ms.)
-    extern __shared__ float Ts[];
     for (int i = (int)threadIdx.x; i <= k_hi - k_lo; i += 256) Ts[2 + i] = t_table[k_lo + i];
     if (threadIdx.x < 2) Ts[threadIdx.x] = t_table[threadIdx.x];
+    if (FUSED && threadIdx.x == 2) *reinterpret_cast<uint32_t *>(Ts + kTableLen + 1) = 4u;   // waves of this workgroup still marching (producer_wave_leaves)
     __syncthreads();
     const int t_off = 2 - k_lo;
     auto T = [&](int k_) { return Ts[k_ + t_off]; };
@@ -941,6 +1031,15 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
         if (TAIL && trip >= tail.trip_budget) break;
         dbg_trips = trip + 1;
         if (STATS) work.trips++;
+#ifdef TSDF_DIAG_RAY_MIX
+        {
+            const int act = __popcll(__ballot(k != kDone)), bucket = act <= 4 ? 0 : act <= 16 ? 1 : act <= 32 ? 2 : 3;
+            if ((threadIdx.x & 63u) == 0) {
+                RAY_MIX(24 + bucket);
+                if (trip >= 12) RAY_MIX(28 + bucket);
+            }
+        }
+#endif
         if (k != kDone) {
             const float t = T(k);
             int jump, ahead;
@@ -965,8 +1064,13 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
         // ([0]: a pass at all -- the range is not free space for this tile; [1]: a long wave.  A merged workgroup speaks for all its ranges)
         if (tail.heavy && dbg_trips >= 1u && lane < range_hi - range) {
             const uint32_t n_tiles = gridDim.x * gridDim.y, at = (range + lane) * n_tiles + lin;
-            tail.heavy[at] = 1;
-            if (dbg_trips >= tail.heavy_passes) tail.heavy[gridDim.z * n_tiles + at] = 1;
+            if (FUSED) {   // (read by the order's builder inside this launch, on another XCD: past the L2)
+                __hip_atomic_store(&tail.heavy[at], (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (dbg_trips >= tail.heavy_passes) __hip_atomic_store(&tail.heavy[nz * n_tiles + at], (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                tail.heavy[at] = 1;
+                if (dbg_trips >= tail.heavy_passes) tail.heavy[nz * n_tiles + at] = 1;
+            }
         }
         // hand over what is left of the unfinished rays, in pieces (one atomic per wave); a ray whose hit is already known
         // to lie at or before its next sample is dropped
@@ -988,9 +1092,16 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
             base = __shfl(base, 0) + incl - n_sub;
             for (uint32_t s_ = 0; s_ < n_sub; s_++) {
                 const int a = k + (int)((uint32_t)len * s_ / n_sub), b = k + (int)((uint32_t)len * (s_ + 1) / n_sub);
-                tail.entries[base + s_] = make_uint2((uint32_t)idx, ((uint32_t)b << 13) | (uint32_t)a);
+                const uint2 entry = make_uint2((uint32_t)idx, ((uint32_t)b << 13) | (uint32_t)a);
+                if (FUSED)   // (taken by a queue worker of this launch, on any XCD: written through, one 64-bit store)
+                    __hip_atomic_store(reinterpret_cast<unsigned long long *>(&tail.entries[base + s_]), ((unsigned long long)entry.y << 32) | entry.x,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else
+                    tail.entries[base + s_] = entry;
             }
         }
+        // this wave has appended what it had (its reservation in count[0] came back before its entries went out)
+        if (FUSED) producer_wave_leaves(tail, bz_ * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x, reinterpret_cast<uint32_t *>(Ts + kTableLen + 1));
     }
     if (TAIL && !STATS && counters && lane == 0) {   // diagnostics: {range, passes of the main loop, start and end of the marching part} per wave
         const size_t w = ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave;
@@ -1024,6 +1135,17 @@ __global__ __launch_bounds__(256) void process_ray_kernel(const float *__restric
     }
 }
 
+template <bool SLAB, bool STATS, bool SKIP, bool FASTDIV, bool SEG, bool TAIL>
+__global__ __launch_bounds__(256) void process_ray_kernel(const float *__restrict__ dist, const Geom g,
+                                                          const RayParams rp, float *__restrict__ out,
+                                                          unsigned long long *__restrict__ counters,
+                                                          unsigned int *__restrict__ touched,
+                                                          const OccGrid occ, const float *__restrict__ t_table,
+                                                          const TailQueue tail) {
+    extern __shared__ float Ts[];
+    march_bulk<SLAB, STATS, SKIP, FASTDIV, SEG, TAIL, false>(dist, g, rp, out, counters, touched, occ, t_table, tail, Ts, gridDim.z);
+}
+
 // The dispatch order of the next cast's first kernel (TailQueue::order), from the marks this cast's waves left: heavy[range][tile
 // slot] = some wave made a pass there, and behind those n_ranges * n_tiles bytes the same for long waves.  Workgroup i of a launch
 // runs on XCD i % 8, so each XCD orders its own tile slots (8 j + xcd) and they stay on it.  Per tile the ranges become entries: one
@@ -1037,6 +1159,8 @@ struct OrderJob {
 };
 constexpr uint32_t kOrderWorkgroups = 2;   // workgroups of 4 waves appended to the tail kernel's launch for the 8 XCDs
 constexpr uint32_t kOrderMaxRanges = 16;   // (a range index in 8 bits of an entry, a mask of ranges in 32 bits: more ranges, no learnt order)
+// COHERENT: the marks were written by waves of THIS launch on other XCDs (process_ray_fused_kernel): read past the L2.
+template <bool COHERENT>
 __device__ inline void order_ray_tiles(uint32_t xcd, const OrderJob &job) {
     if (xcd >= 8u || job.n_ranges == 0u) return;
     const uint32_t lane = threadIdx.x & 63u, n_tiles = job.n_tiles, n = job.n_ranges, per_xcd = n_tiles / 8;
@@ -1050,8 +1174,10 @@ __device__ inline void order_ray_tiles(uint32_t xcd, const OrderJob &job) {
             uint32_t any_m = 0, long_m = 0;
             if (j < per_xcd)
                 for (uint32_t r = 0; r < n; r++) {
-                    any_m |= (any_[(size_t)r * n_tiles + tile] ? 1u : 0u) << r;
-                    long_m |= (long_[(size_t)r * n_tiles + tile] ? 1u : 0u) << r;
+                    const uint8_t a_ = COHERENT ? __hip_atomic_load(&any_[(size_t)r * n_tiles + tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : any_[(size_t)r * n_tiles + tile];
+                    const uint8_t l_ = COHERENT ? __hip_atomic_load(&long_[(size_t)r * n_tiles + tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : long_[(size_t)r * n_tiles + tile];
+                    any_m |= (a_ ? 1u : 0u) << r;
+                    long_m |= (l_ ? 1u : 0u) << r;
                 }
             // this tile's entries of the class, in dispatch order: twice the same walk, first to count, then to write
             auto walk = [&](uint32_t at, bool write) {
@@ -1106,19 +1232,20 @@ __device__ inline void order_ray_tiles(uint32_t xcd, const OrderJob &job) {
 // expressions whichever lane does it, so the result does not depend on the schedule.  Groups take queue entries round
 // robin until none is left (persistent workgroups); every pass of the loop is uniform across the wave.
 //   LANES: lanes per queue entry fixed at compile time (the group reductions become DPP operations), 0 = tail.lanes.
-template <bool SLAB, bool FASTDIV, int LANES>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void process_ray_tail_kernel(const float *__restrict__ dist, const Geom g, const RayParams rp,
-                                                               const OccGrid occ, const float *__restrict__ t_table,
-                                                               const TailQueue tail, const OrderJob order_job) {
-    __shared__ float T[kTableLen];
-    if (blockIdx.x < kOrderWorkgroups) {   // the first workgroups: the next cast's dispatch order, one wave per XCD (beside the march, from its start)
-        if (order_job.n_ranges) order_ray_tiles(blockIdx.x * 4u + (threadIdx.x >> 6), order_job);
-        return;
-    }
-    const uint32_t block = blockIdx.x - kOrderWorkgroups;
-    const uint32_t n_entries = tail.count[0];
+//   POLL (process_ray_fused_kernel): the queue is still being filled, by the marching workgroups of the same launch.  A wave waits for
+//   its batch -- until the batch is reserved as a whole and its entries have arrived, or until every producer has left and the count
+//   is final -- instead of reading a finished queue; entries are taken by overwriting their first word, so that the sweep launch
+//   behind (the classic kernel, consume = 1) only finds what a worker that gave up waiting has left, and the next cast an empty queue.
+template <bool SLAB, bool FASTDIV, int LANES, bool POLL>
+__device__ inline void march_tail(const float *__restrict__ dist, const Geom &g, const RayParams &rp, const OccGrid &occ,
+                                  const float *__restrict__ t_table, const TailQueue &tail, float *T, const uint32_t block,
+                                  const uint32_t n_blocks) {
     const uint32_t lanes_per_ray = LANES ? (uint32_t)LANES : tail.lanes;
-    if ((size_t)block * 4u * (64u / lanes_per_ray) >= n_entries) return;   // nothing for this workgroup: skip the staging too
+    uint32_t n_entries = 0;
+    if (!POLL) {
+        n_entries = tail.count[0];
+        if ((size_t)block * 4u * (64u / lanes_per_ray) >= n_entries) return;   // nothing for this workgroup: skip the staging too
+    }
     for (int i = (int)threadIdx.x; i < kTableLen; i += 256) T[i] = t_table[i];
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
@@ -1129,29 +1256,73 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     // A wave takes as many consecutive queue entries as it has groups (pieces of one ray, or of rays of one tile and one
     // sample range: alike in length), works on them until all are finished, then takes the next batch: waves round robin.
     const uint32_t groups_per_wave = 64 / lanes_per_ray;
-    const uint32_t n_waves = (gridDim.x - kOrderWorkgroups) * 4, wave_id = block * 4 + (threadIdx.x >> 6);
+    const uint32_t n_waves = n_blocks * 4, wave_id = block * 4 + (threadIdx.x >> 6);
     const unsigned long long dbg_t0 = tail.wave_log ? wall_clock64() : 0ull;
     uint32_t dbg_batches = 0, dbg_rounds = 0;
-    for (uint32_t batch = wave_id * groups_per_wave; batch < n_entries; batch += n_waves * groups_per_wave) {
+    for (uint32_t batch = wave_id * groups_per_wave;; batch += n_waves * groups_per_wave) {
+        uint2 q = make_uint2(kInvalidEntry, 0u);
+        const uint32_t e = batch + (lane / lanes_per_ray);
+        if (POLL) {
+            // Wait for this batch: its entries are polled themselves (one line per wave) and the workgroup's own signal word -- nothing
+            // the producers' atomics need.  All of its entries there: go.  The signal there: the count is final -- the batch does not
+            // exist, or it is the last, partial one (whose entries are then on their way).
+            unsigned long long *slot = reinterpret_cast<unsigned long long *>(&tail.entries[e]);
+            bool exists = false, gave_up = true;
+            for (uint32_t spin = 0; spin < kTailSpinLimit; spin++) {
+                const unsigned long long w = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t fin = __hip_atomic_load(&tail.count[kTailSignals + block], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                q = make_uint2((uint32_t)w, (uint32_t)(w >> 32));
+                const bool here = q.x != kInvalidEntry;
+                if (__ballot(!here) == 0ull) { exists = true; gave_up = false; n_entries = batch + groups_per_wave; break; }
+                if (fin != 0u) {
+                    n_entries = fin - 1u;
+                    if (n_entries <= batch) { gave_up = false; break; }                                      // no such batch
+                    if (__ballot(!here && e < n_entries) == 0ull) { exists = true; gave_up = false; break; }   // the last one, partial
+                }
+                __builtin_amdgcn_s_sleep(32);
+            }
+            if (gave_up && lane == 0) __hip_atomic_store(&tail.count[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!exists) break;
+            if (e < n_entries && q.x != kInvalidEntry && j == 0)
+                __hip_atomic_store(reinterpret_cast<uint32_t *>(slot), kInvalidEntry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // taken
+            if (e >= n_entries) q.x = kInvalidEntry;
+        } else if (batch >= n_entries) {
+            break;
+        }
         dbg_batches++;
         RayState ray = {0, 0, 0, 0, 0, 0};
         int k = kDone, k_end = 0;   // the group's stretch (all its lanes hold the same values); kDone: none
         uint64_t *best = tail.best;
-        const uint32_t e = batch + (lane / lanes_per_ray);
         if (e < n_entries) {
-            const uint2 q = tail.entries[e];
-            float max_t;
-            (void)ray_geometry((int)(q.x % rp.width), (int)(q.x / rp.width), true, rp, ray, max_t);
-            set_ray<true>(sc, ray, step_size, g);
-            k = (int)(q.y & 0x1fffu);
-            k_end = (int)((q.y >> 13) & 0x1fffu);
-            best += q.x;
+            if (!POLL) {
+                q = tail.entries[e];
+                if (tail.consume && q.x != kInvalidEntry && j == 0) tail.entries[e].x = kInvalidEntry;   // (taken; an entry a worker of the fused launch took is skipped)
+            }
+            if (q.x != kInvalidEntry) {
+                float max_t;
+                (void)ray_geometry((int)(q.x % rp.width), (int)(q.x / rp.width), true, rp, ray, max_t);
+                set_ray<true>(sc, ray, step_size, g);
+                k = (int)(q.y & 0x1fffu);
+                k_end = (int)((q.y >> 13) & 0x1fffu);
+                best += q.x;
+            }
         }
         while (true) {
             if (__ballot(k != kDone) == 0ull) break;
             dbg_rounds++;
-            const int kk = k + j;
-            int adv = 0;
+            // Which sample a lane takes.  A ray's passes are the CELLS it crosses (the look-ahead of an evaluated sample nearly always
+            // reaches its cell's exit, profiles/r05b_*): consecutive samples k .. k+3 lie in one cell 9 times in 10 and the group's four
+            // gathers fetched the same 8 voxels.  So lane j starts where the ray enters its j-th cell from here -- cell_steps, from the
+            // position alone -- and a round deals with up to `lanes` cells instead of one.  Any spacing gives the same picture: the fold
+            // below only joins what is contiguous.
+            int kk = k;
+            if (TSDF_RAY_TAIL_CHAIN && sc.skip_ok) {
+                for (int i = 0; i < j; i++)
+                    if (k != kDone && kk < k_end) kk += cell_steps(T[min(kk, kTableLen - 1)], ray, sc);
+            } else {
+                kk = k + j;
+            }
+            int end_ = kk;   // samples in [kk, end_) are dealt with by this lane (a hit: sample kk itself)
             bool hit = false;
             float hit_value = 0.0f;
             uint32_t known = kNoHit;
@@ -1161,30 +1332,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             if (k != kDone && kk < k_end) {
                 const float t = T[kk];
                 int jump, ahead;
-                const float tsdf = process_sample_eager<SLAB, FASTDIV>(t, ray, sc, dist, g, tc, rp, occ, jump, ahead);
+                const float tsdf = process_sample_eager<SLAB, FASTDIV>(t, ray, sc, dist, g, tc, rp, occ, jump, ahead, j == 0);
                 if (jump > 0) {
-                    adv = j + jump;
+                    end_ = kk + jump;
                 } else if (tsdf <= 0) {
                     hit = true;
                     hit_value = tsdf;
                 } else {
-                    adv = j + 1 + (tsdf > 0 ? ahead : 0);
+                    end_ = kk + 1 + (tsdf > 0 ? ahead : 0);
                 }
             }
-            // over the group: the furthest sample (relative to k) it has dealt with, its first lane with a hit, and the
-            // leader's view of best[] (the other lanes hold kNoHit, the largest value)
-            int first = hit ? j : (int)lanes_per_ray;
-            for (int o = 1; o < (int)lanes_per_ray; o <<= 1) {
-                adv = max(adv, __shfl_xor(adv, o));
-                first = min(first, __shfl_xor(first, o));
-                known = min(known, (uint32_t)__shfl_xor((int)known, o));
+            // over the group, in lane order: `cover` = every sample before it is dealt with.  A lane joins while its start is not
+            // beyond the cover; the first one that joins with a hit has the stretch's first sample <= 0.
+            int cover = k, hit_lane = -1;
+            bool open = true;
+            for (int q = 0; q < (int)lanes_per_ray; q++) {
+                const int kq = group_lane<LANES>(kk, q, lanes_per_ray), eq = group_lane<LANES>(end_, q, lanes_per_ray);
+                const bool hq = group_lane<LANES>((int)hit, q, lanes_per_ray) != 0;
+                open = open && kq <= cover && kq < k_end;
+                if (open) {
+                    if (hq) {
+                        hit_lane = q;
+                        open = false;
+                    } else {
+                        cover = max(cover, eq);
+                    }
+                }
             }
+            for (int o = 1; o < (int)lanes_per_ray; o <<= 1) known = min(known, (uint32_t)__shfl_xor((int)known, o));
             if (k != kDone) {
-                if (first < (int)lanes_per_ray) {
-                    if (j == first) lower_best(best, kk, hit_value);
+                if (hit_lane >= 0) {
+                    if (j == hit_lane) lower_best(best, kk, hit_value);
                     k = kDone;
                 } else {
-                    k += adv;
+                    k = cover;
                     if (k >= k_end || known <= (uint32_t)k) k = kDone;
                 }
             }
@@ -1194,6 +1375,54 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         tail.wave_log[3 * wave_id + 0] = ((unsigned long long)dbg_batches << 32) | dbg_rounds;
         tail.wave_log[3 * wave_id + 1] = dbg_t0;
         tail.wave_log[3 * wave_id + 2] = wall_clock64();
+    }
+}
+
+template <bool SLAB, bool FASTDIV, int LANES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void process_ray_tail_kernel(const float *__restrict__ dist, const Geom g, const RayParams rp,
+                                                               const OccGrid occ, const float *__restrict__ t_table,
+                                                               const TailQueue tail, const OrderJob order_job) {
+    __shared__ float T[kTableLen];
+    if (tail.consume && tail.count[2] == 0u) return;   // the sweep behind a fused launch whose workers took everything: nothing to do
+    if (blockIdx.x < kOrderWorkgroups) {   // the first workgroups: the next cast's dispatch order, one wave per XCD (beside the march, from its start)
+        if (order_job.n_ranges) order_ray_tiles<false>(blockIdx.x * 4u + (threadIdx.x >> 6), order_job);
+        return;
+    }
+    march_tail<SLAB, FASTDIV, LANES, false>(dist, g, rp, occ, t_table, tail, T, blockIdx.x - kOrderWorkgroups, gridDim.x - kOrderWorkgroups);
+}
+
+// Both kernels in ONE launch (round 5).  The two launches each end in a long ramp-down -- the chip holds 6 144 waves, the bulk
+// kernel's packed wave time is 34 us of its 62, the tail kernel's 29 of its 54 (per-wave clocks, profiles/r05a_*) -- and the tail's
+// work only exists once the bulk kernel's longest waves have used their whole pass budget.  Here the marching workgroups come first
+// in the grid and the queue workers behind them (slabs z >= nz_bulk of the same grid): workgroups are dispatched in index order, so
+// the workers move into the slots the marching waves free, every producer is resident or done by then (nothing a worker waits for
+// can be waiting for a slot), and they take batches of queue entries as the marching waves append them (march_tail<POLL>).  With
+// the chip kept busy by the workers the pass budget of a marching wave can be short -- the long stretches start early -- instead of
+// long enough to fill the launch.  The last kOrderWorkgroups workgroups build the next cast's dispatch order once every marching wave
+// has left its marks.  Scheduling only: a sample is computed by the same expressions whoever computes it, the pixel's word is an
+// atomicMin.  A worker that has waited kTailSpinLimit polls (a dispatcher that does not keep the order) raises count[2] and leaves;
+// the classic tail kernel launched behind as a sweep (consume = 1) then finishes what is left -- it returns at once otherwise.
+template <bool SLAB, bool FASTDIV>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void process_ray_fused_kernel(const float *__restrict__ dist, const Geom g, const RayParams rp,
+                                                               unsigned long long *__restrict__ counters, const OccGrid occ, const float *__restrict__ t_table,
+                                                               const TailQueue tail, const OrderJob order_job, const uint32_t nz_bulk,
+                                                               const uint32_t n_workers) {
+    extern __shared__ float Ts[];   // the whole table (a worker's T; a marching workgroup stages its ranges' part at Ts + 2)
+    if (blockIdx.z < nz_bulk) {
+        march_bulk<SLAB, false, true, FASTDIV, true, true, true>(dist, g, rp, nullptr, counters, nullptr, occ, t_table, tail, Ts, nz_bulk);
+        return;
+    }
+    const uint32_t w = ((blockIdx.z - nz_bulk) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (w < n_workers) {
+        march_tail<SLAB, FASTDIV, kTailLanesDefault, true>(dist, g, rp, occ, t_table, tail, Ts, w, n_workers);
+    } else if (w < n_workers + kOrderWorkgroups && order_job.n_ranges) {
+        // the next cast's dispatch order, one wave per XCD, once every marching wave has left (its marks are written through)
+        bool done = false;
+        for (uint32_t spin = 0; spin < kTailSpinLimit && !done; spin++) {
+            done = __hip_atomic_load(&tail.count[kTailSignals + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+            if (!done) __builtin_amdgcn_s_sleep(64);
+        }
+        if (done) order_ray_tiles<true>((w - n_workers) * 4u + (threadIdx.x >> 6), order_job);
     }
 }
 
@@ -1234,9 +1463,10 @@ template <bool SLAB>
 __global__ __launch_bounds__(256) void resolve_hits_kernel(const Geom g, const RayParams rp,
                                                            const float *__restrict__ t_table, const uint64_t *__restrict__ best,
                                                            uint64_t *__restrict__ best_next, float *__restrict__ out,
-                                                           uint32_t *__restrict__ reset, const Mat44 ip, uint16_t *__restrict__ depth) {
+                                                           uint32_t *__restrict__ reset, const uint32_t n_signals, const Mat44 ip, uint16_t *__restrict__ depth) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) *reset = 0;
+    if (i < kTailSignals + n_signals) reset[i] = 0;   // entries appended, producers gone, the give-up flag; the fused launch's signal words (TailQueue)
+    if (n_signals && i < kSubCounters) reset[kTailSignals + n_signals + i * kSubCounterStride] = 0;   // ... and its sub-counters
     if (i >= rp.width * rp.height) return;
     best_next[i] = kNoHitWord;
     float ix, iy, iz, th;
@@ -1260,12 +1490,16 @@ constexpr int kResolveThreads = 320;
 __global__ __launch_bounds__(kResolveThreads) void resolve_normals_kernel(const Geom g, const RayParams rp,
                                                                           const float *__restrict__ t_table, const uint64_t *__restrict__ best,
                                                                           uint64_t *__restrict__ best_next, float *__restrict__ V,
-                                                                          float *__restrict__ N, uint32_t *__restrict__ reset) {
+                                                                          float *__restrict__ N, uint32_t *__restrict__ reset, const uint32_t n_signals) {
     constexpr int kT = 16, kS = kT + 1;
 
     static_assert(kS * kS <= kResolveThreads, "one thread per pixel of the tile and its halo");
     __shared__ float vx[kS * kS], vy[kS * kS], vz[kS * kS];
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *reset = 0;
+    {   // entries appended, producers gone, the give-up flag; the fused launch's signal words and sub-counters (TailQueue)
+        const uint32_t t_ = (blockIdx.y * gridDim.x + blockIdx.x) * kResolveThreads + threadIdx.x;
+        if (t_ < kTailSignals + n_signals) reset[t_] = 0;
+        if (n_signals && t_ < kSubCounters) reset[kTailSignals + n_signals + t_ * kSubCounterStride] = 0;
+    }
     const uint32_t x0 = blockIdx.x * kT, y0 = blockIdx.y * kT;
     // own pixels first (threads 0..255, row-major in the tile), then the halo column and row
     const uint32_t s_ = threadIdx.x;
@@ -1456,7 +1690,7 @@ __global__ __launch_bounds__(256) void popcount_kernel(const unsigned int *__res
 // are cut per ray: slabs, seg_len == 0)
 static size_t ray_table_lds_bytes(const RayParams &rp, bool per_ray_ranges) {
     const size_t entries = (rp.seg_len && !per_ray_ranges) ? std::min<size_t>(kMaxSamples, rp.seg_len) + 1 : (size_t)kMaxSamples + 1;
-    return (entries + 2) * sizeof(float);
+    return (entries + 2 + 2) * sizeof(float);   // (+ the word at Ts[kTableLen + 1]: the fused launch's waves-left counter, whole table only)
 }
 
 static RayParams make_params(const tsdf_volume *v, uint32_t width, uint32_t height, const float pose[16],
@@ -1579,7 +1813,9 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
     // ceil(kMaxSamples / n_segments) samples, whole volume or slab)
     const int max_len = (kMaxSamples + n_segments - 1) / n_segments;
     const int max_pieces = std::min(kTailPieces, (max_len + tail_piece_min() - 1) / tail_piece_min());
-    const size_t n_entries = n_pix * n_segments * (size_t)std::max(max_pieces, 1);
+    // (+ a batch per wave of the fused launch's workers: a worker polls the slots of the batch it waits for, which may lie past the last entry)
+    const size_t n_signal_words = (size_t)tail_grid() + kOrderWorkgroups;
+    const size_t n_entries = n_pix * n_segments * (size_t)std::max(max_pieces, 1) + (size_t)tail_grid() * 4 * 64;
     if (v->ray_best_cap < n_pix) {
         if (v->ray_best) (void)hipFree(v->ray_best);
         v->ray_best = nullptr;
@@ -1593,10 +1829,11 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
         v->tail_entries = nullptr;
         v->tail_cap = 0;
         TSDF_HIP(hipMalloc(&v->tail_entries, n_entries * sizeof(uint2)), "ray tail queue alloc");
+        TSDF_HIP(hipMemsetAsync(v->tail_entries, 0xff, n_entries * sizeof(uint2), v->stream), "ray tail queue reset");   // (kInvalidEntry: the fused launch's workers take entries by their first word)
         v->tail_cap = n_entries;
     }
     if (!v->tail_count) {
-        TSDF_HIP(hipMalloc((void **)&v->tail_count, 2 * sizeof(uint32_t)), "ray tail counter alloc");
+        TSDF_HIP(hipMalloc((void **)&v->tail_count, tail_counter_words((uint32_t)n_signal_words) * sizeof(uint32_t)), "ray tail counter alloc");
         v->ray_best_dirty = 1;
     }
     if (v->ray_best_pixels != n_pix) {   // the copy this march's resolve does not read was reset for another image size
@@ -1605,10 +1842,13 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
     }
     if (v->ray_best_dirty) {   // otherwise the previous march's resolve kernel left both reset
         TSDF_HIP(hipMemsetAsync(v->ray_best, 0xff, 2 * v->ray_best_cap * sizeof(uint64_t), v->stream), "ray result reset");
-        TSDF_HIP(hipMemsetAsync(v->tail_count, 0, 2 * sizeof(uint32_t), v->stream), "ray tail counter reset");
+        TSDF_HIP(hipMemsetAsync(v->tail_count, 0, tail_counter_words((uint32_t)n_signal_words) * sizeof(uint32_t), v->stream), "ray tail counter reset");
+        if (tuning().ray_fused) TSDF_HIP(hipMemsetAsync(v->tail_entries, 0xff, v->tail_cap * sizeof(uint2), v->stream), "ray tail queue reset");   // (a march without its resolve may have left entries)
     }
     v->ray_best_dirty = 1;
     TailQueue tail = {reinterpret_cast<uint2 *>(v->tail_entries), v->tail_count, (uint32_t)trip_budget(), (uint32_t)tail_lanes(), v->ray_best + (size_t)v->ray_best_side * v->ray_best_cap, tail_piece_min(), nullptr};
+    // one launch for the march and its queue (process_ray_fused_kernel) unless switched off or the group width is not the compiled one
+    const bool fused = tuning().ray_fused != 0 && tail_lanes() == kTailLanesDefault;
     uint64_t *best_next = v->ray_best + (size_t)(1 - v->ray_best_side) * v->ray_best_cap;
     // the dispatch order learnt from the previous cast (TSDF_RAY_LEARNED_ORDER=0: launch order, tuning aid)
     const bool learn_order = tuning().ray_learned_order != 0;
@@ -1647,8 +1887,29 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
         (void)hipMalloc((void **)&wave_log, 3 * n_waves_log * sizeof(unsigned long long));
         (void)hipMemset(wave_log, 0, 3 * n_waves_log * sizeof(unsigned long long));
     }
-    const size_t table_lds = ray_table_lds_bytes(rp, (SLAB && rp.slab_ranges > 0) || tail.order != nullptr);   // (a merged workgroup may read any part of the table)
-    if (v->fast_div)
+    unsigned long long *tail_log = nullptr;
+    const size_t n_tail_waves = (size_t)tail_grid() * 4;
+    if (debug_waves) {
+        (void)hipMalloc((void **)&tail_log, 3 * n_tail_waves * sizeof(unsigned long long));
+        (void)hipMemset(tail_log, 0, 3 * n_tail_waves * sizeof(unsigned long long));
+        if (fused) tail.wave_log = tail_log;
+    }
+    const size_t table_lds = ray_table_lds_bytes(rp, fused || (SLAB && rp.slab_ranges > 0) || tail.order != nullptr);   // (a merged workgroup may read any part of the table, a queue worker all of it)
+    const dim3 grid_bulk = grid;
+    if (fused) {
+        // the queue workers and the order's builders behind the marching workgroups, in whole slabs of the grid
+        const uint32_t per_slab = grid.x * grid.y, n_workers = (uint32_t)tail_grid();
+        grid.z += (n_workers + kOrderWorkgroups + per_slab - 1) / per_slab;
+        tail.producers = per_slab * (uint32_t)n_segments;
+        tail.n_signals = n_workers + kOrderWorkgroups;
+        order_job.range_order = rp.range_order;
+        if (v->fast_div)
+            TSDF_LAUNCH_TIMED_LDS(v, 1, (process_ray_fused_kernel<SLAB, true>), grid, dim3(256), table_lds, v->dist, v->g, rp, wave_log, v->occ, v->t_table, tail,
+                                  order_job, (uint32_t)n_segments, n_workers);
+        else
+            TSDF_LAUNCH_TIMED_LDS(v, 1, (process_ray_fused_kernel<SLAB, false>), grid, dim3(256), table_lds, v->dist, v->g, rp, wave_log, v->occ, v->t_table, tail,
+                                  order_job, (uint32_t)n_segments, n_workers);
+    } else if (v->fast_div)
         TSDF_LAUNCH_TIMED_LDS(v, 1, (process_ray_kernel<SLAB, false, true, true, true, true>), grid, dim3(256), table_lds, v->dist, v->g, rp,
                               (float *)nullptr, wave_log, (unsigned int *)nullptr, v->occ, v->t_table, tail);
     else
@@ -1665,7 +1926,7 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
         for (size_t w = 0; w < n_waves_log; w++) if (log[3 * w + 1]) { t0 = std::min(t0, log[3 * w + 1]); t1 = std::max(t1, log[3 * w + 2]); }
         fprintf(stderr, "tsdf: bulk ray kernel, marching part %.1f us (100 MHz clock); per range: waves, mean passes, waves with all %u passes, mean / max wave time us, last end us\n",
                 (t1 - t0) / 100.0, (unsigned)trip_budget());
-        for (uint32_t r = 0; r < grid.z; r++) {
+        for (uint32_t r = 0; r < grid_bulk.z; r++) {
             size_t n = 0, full = 0; double passes = 0, dur = 0, dmax = 0, last = 0, t_setup = 0, t_lead = 0;
             for (size_t w = 0; w < n_waves_log; w++) {
                 if (!log[3 * w + 1] || (log[3 * w] >> 56) != r) continue;
@@ -1681,7 +1942,7 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
             unsigned long long e0 = ~0ull;
             for (size_t w = 0; w < n_waves_log; w++) if (log[3 * w + 1]) e0 = std::min(e0, log[3 * w + 1] - ((log[3 * w] >> 40) & 0xffffu) - ((log[3 * w] >> 24) & 0xffffu));
             const double span = (double)(t1 - e0);
-            for (int r = -1; r < (int)grid.z; r++) {
+            for (int r = -1; r < (int)grid_bulk.z; r++) {
                 size_t alive[16] = {};
                 for (size_t w = 0; w < n_waves_log; w++) {
                     if (!log[3 * w + 1] || (r >= 0 && (int)(log[3 * w] >> 56) != r)) continue;
@@ -1694,18 +1955,20 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
             }
         }
     }
-    unsigned long long *tail_log = nullptr;
-    const size_t n_tail_waves = (size_t)tail_grid() * 4;
-    if (debug_waves) {
-        (void)hipMalloc((void **)&tail_log, 3 * n_tail_waves * sizeof(unsigned long long));
-        (void)hipMemset(tail_log, 0, 3 * n_tail_waves * sizeof(unsigned long long));
-        tail.wave_log = tail_log;
-    }
     // persistent workgroups: groups of 16 lanes, fetching queue entries until none is left
     // (the default group width is compiled in; another one, a tuning aid, takes the variant that reads it at run time)
     const bool fixed_lanes = tail_lanes() == kTailLanesDefault;
     order_job.range_order = rp.range_order;
-    const dim3 tgrid_(tail_grid() + kOrderWorkgroups);
+    dim3 tgrid_(tail_grid() + kOrderWorkgroups);
+    if (!fused) tail.wave_log = tail_log;
+    const bool order_built = order_job.n_ranges != 0;
+    if (fused) {
+        // the sweep: returns at once unless a queue worker gave up waiting (count[2]); then it finishes the entries still in the queue
+        tail.consume = 1;
+        tgrid_ = dim3(512 + kOrderWorkgroups);
+        order_job = {nullptr, nullptr, 0, 0, 0};
+        tail.wave_log = nullptr;
+    }
     if (v->fast_div && fixed_lanes)
         TSDF_LAUNCH_TIMED(v, 2, (process_ray_tail_kernel<SLAB, true, kTailLanesDefault>), tgrid_, dim3(256), v->dist, v->g, rp, v->occ, v->t_table, tail, order_job);
     else if (v->fast_div)
@@ -1744,15 +2007,15 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
     const dim3 rgrid((unsigned)((n_pix + 255) / 256)), tgrid((rp.width + 15) / 16, (rp.height + 15) / 16);
     if (!SLAB && normals) {
         hipLaunchKernelGGL(resolve_normals_kernel, tgrid, dim3(kResolveThreads), 0, v->stream, v->g, rp, v->t_table, tail.best, best_next, out, normals,
-                           v->tail_count);
+                           v->tail_count, tail.n_signals);
     } else {
         Mat44 ip;
         memset(&ip, 0, sizeof(ip));
         if (depth_inv_pose) memcpy(&ip, depth_inv_pose, sizeof(ip));
-        hipLaunchKernelGGL((resolve_hits_kernel<SLAB>), rgrid, dim3(256), 0, v->stream, v->g, rp, v->t_table, tail.best, best_next, out, v->tail_count, ip,
+        hipLaunchKernelGGL((resolve_hits_kernel<SLAB>), rgrid, dim3(256), 0, v->stream, v->g, rp, v->t_table, tail.best, best_next, out, v->tail_count, tail.n_signals, ip,
                            SLAB ? (uint16_t *)nullptr : depth_out);
     }
-    if (order_job.n_ranges) v->ray_order_valid = 1;
+    if (order_built) v->ray_order_valid = 1;
     TSDF_HIP(hipGetLastError(), "resolve ray hits failed");
     v->ray_best_side = 1 - v->ray_best_side;
     v->ray_best_dirty = 0;
@@ -1764,6 +2027,17 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
 using namespace tsdf;
 
 extern "C" {
+
+#ifdef TSDF_DIAG_RAY_MIX
+// diagnostics build only: read (and reset) the pass-type counters
+int tsdf_debug_ray_mix(unsigned long long out[64]) {
+    (void)hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ray_mix), 64 * sizeof(unsigned long long)) != hipSuccess) return TSDF_ERR_INVALID;
+    unsigned long long zero[64] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ray_mix), zero, sizeof(zero));
+    return TSDF_OK;
+}
+#endif
 
 int tsdf_raycast_device(const tsdf_volume *v, uint32_t width, uint32_t height, const float pose[16],
                         const float kinv[9], float *device_vertices, float *device_normals) {

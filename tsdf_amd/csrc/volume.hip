@@ -32,6 +32,7 @@ const Tuning &tuning() {
         Tuning u;
         u.ray_segments = clamp(num("TSDF_RAY_SEGMENTS", 6), 1, 64);
         u.ray_slab_ranges = clamp(num("TSDF_RAY_SLAB_RANGES", 0), 0, 64);
+        u.ray_fused = num("TSDF_RAY_FUSED", 0) != 0;
         u.ray_trip_budget = std::max(num("TSDF_RAY_TRIP_BUDGET", 22), 1);
         u.ray_tail_lanes = num("TSDF_RAY_TAIL_LANES", 4);
         if (!(u.ray_tail_lanes >= 1 && u.ray_tail_lanes <= 64 && (u.ray_tail_lanes & (u.ray_tail_lanes - 1)) == 0)) u.ray_tail_lanes = 4;
