@@ -424,6 +424,45 @@ def main():
         torch.cuda.synchronize()
         U_frames.append(vol.last_updated_voxels())
     vol.set_counting(False)
+    # ---- the same K frames once more with ONE event behind every step (pipelined as in the timed regions; an event costs a few us of
+    # stream time, so these are not `value`): what the worst step of the stream costs beside the median -- the periodic rebuild of the
+    # ray caster's flags, a widening of the weight storage
+    vol.clear()
+    for i in range(Wu):
+        step(i, False)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
+    torch.cuda.synchronize()
+    marks[0].record(stream)
+    for i in range(Wu, Wu + K):
+        step(i, False)
+        marks[i - Wu + 1].record(stream)
+    torch.cuda.synchronize()
+    per_step = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(K)], np.float64)
+    step_spread = {"median": round(float(np.median(per_step)), 4), "p95": round(float(np.percentile(per_step, 95)), 4),
+                   "max": round(float(per_step.max()), 4), "max_over_median": round(float(per_step.max() / np.median(per_step)), 3),
+                   "steps": K, "how": "an event behind every pipelined step of one more run of the same frames"}
+    # ---- integrate under each way the weights can be stored (weights.hip): 8-bit counts (what the timed frames run on), 16-bit counts
+    # (a voxel updated more than 255 times), the reference's fp32 array (after weight_data() / beyond 65535): same frames, same bits
+    int_by_storage = {}
+    if not sharded:
+        for bits in (8, 16, 32):
+            vol.clear()
+            if vol.weight_storage()[0] <= bits:
+                vol.set_weight_storage(bits)
+            for i in range(Wu):
+                step(i, False)
+            torch.cuda.synchronize()
+            vol.set_timing(1)
+            for i in range(Wu, Wu + K):
+                bil.filter_device(depth_dev[i].data_ptr(), filt_dev.data_ptr(), W, H, bits=16, stream=stream.cuda_stream, tile_max_ptr=tiles_of(0))
+                vol.integrate_device(filt_dev.data_ptr(), W, H, cams[i], tile_max_ptr=tiles_of(0))
+            torch.cuda.synchronize()
+            int_by_storage[str(vol.weight_storage()[0])] = round(vol.kernel_time("integrate")[1], 4)
+            vol.set_timing(False)
+        vol.clear()   # (back to the starting storage for the legs below)
+        for i in range(Wu + K):
+            step(i, False)
+        torch.cuda.synchronize()
     ms_per_step = elapsed * 1e3 / K
     value = N_vox * K / elapsed / 1e6
 
@@ -441,6 +480,8 @@ def main():
         "ms_per_step": round(ms_per_step, 4),
         "ms_per_step_is": "median of %d timed regions of %d steps, each on a freshly cleared volume fed the same %d warm-up + %d timed frames" % (R, K, Wu, K),
         "ms_per_step_runs": [round(r_ * 1e3 / K, 4) for r_ in runs],
+        "ms_per_step_max": step_spread["max"], "ms_per_step_p95": step_spread["p95"], "step_ms_spread": step_spread,
+        "integrate_ms_by_weight_storage": int_by_storage or None,
         "picture_bits_equal_across_runs": bool(all(b_ == run_bits[0] for b_ in run_bits)),
         "higher_is_better": True,
         "scaling": "strong",
@@ -521,7 +562,8 @@ def main():
             r_["measured_copy_gbs"] = round(copy_gbs, 1)
             r_["frac_of_measured_copy"] = round(r_["achieved"] / copy_gbs, 5)
         roof_int["measured_inplace_update_gbs"] = round(update_gbs, 1)
-        roof_int["frac_of_inplace_update"] = round(roof_int["achieved"] / update_gbs, 5)
+        # (the walk moves what it touches: it is compared with the bytes the kernel MOVES, not with SURVEY 8d's 16 B per voxel)
+        roof_int["moved_frac_of_inplace_update"] = round(roof_int["moved_gbs"] / update_gbs, 5)
     if rank == 0 and not sharded:
         out["roofline"] = roof_ray if dominant == "raycast" else roof_int
         out["roofline_other"] = roof_int if dominant == "raycast" else roof_ray
@@ -785,9 +827,11 @@ def parity_gate(tsdf_amd, frames, cams, n, physical, Wu, K):
             res["normal_max_abs_err"] = max(res["normal_max_abs_err"], float(np.abs(Nn[okn] - No[okn]).max()))
     res["seconds"] = round(time.perf_counter() - t0, 2)
     res["oracle_threads"] = threads
-    res["pass"] = bool(res["weight_mismatch"] == 0 and res["dist_max_rel_err"] <= 1e-4 and res["nan_mask_mismatch"] == 0
-                       and res["vertex_max_rel_err"] <= 1e-4 and res["normal_max_abs_err"] <= 1e-4
-                       and res["bilateral_mismatch"] == 0)
+    res["pass_within_1e-4"] = bool(res["weight_mismatch"] == 0 and res["dist_max_rel_err"] <= 1e-4 and res["nan_mask_mismatch"] == 0
+                                   and res["vertex_max_rel_err"] <= 1e-4 and res["normal_max_abs_err"] <= 1e-4
+                                   and res["bilateral_mismatch"] == 0)
+    # the gate is bit for bit: north_star's 1e-4 alone would let a regression of the exact arithmetic through
+    res["pass"] = bool(res["pass_within_1e-4"] and res["dist_bit_mismatch"] == 0 and res["vertex_bit_mismatch"] == 0)
     gv.close()
     return res
 

@@ -138,6 +138,10 @@ int tsdf_volume_weights(const tsdf_volume *volume, float **device_ptr);
 /* How the weights are stored now: 8 or 16 (bits per voxel, counts) or 32 (fp32); *pinned (may be NULL) = 1 once tsdf_volume_weights
  * has handed the fp32 pointer out.  Integration computes the same bits in every storage ((float)count is exact). */
 int tsdf_volume_weight_storage(const tsdf_volume *volume, int *bits_per_weight, int *pinned);
+/* Widen the storage now -- 8 -> 16 -> 32 bits per weight, values unchanged -- instead of when a count is about to overflow in the middle
+ * of a stream (the conversion allocates and synchronises: a caller that knows a session will revisit one region for hundreds of
+ * frames pays it up front).  Narrowing is refused; clear() returns an unpinned volume to the starting mode. */
+int tsdf_volume_set_weight_storage(tsdf_volume *volume, int bits_per_weight);
 /* Self-test of the kernel arithmetic behind packed weights: integrate divides by (count + 1) with a short exact sequence instead of
  * the division instruction sequence (integrate_packed.hip: div_by_count, with the proof); this compares the two bit for bit for every
  * mantissa of the dividend (both signs, three exponents) and every divisor in [b_begin, b_end), 1 <= b_begin < b_end <= 2^17 + 1, and

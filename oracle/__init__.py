@@ -11,11 +11,13 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libtsdf_oracle.so")
-_REF = os.path.join(_HERE, "_ref", "libref_bilateral.so")
+# the reference's own BilateralFilter.cpp compiled natively: built OUTSIDE the tree (it must not travel to the GPU box)
+REF_BUILD = os.environ.get("TSDF_REF_BUILD") or "/tmp/tsdf_ref_build"
+_REF = os.path.join(REF_BUILD, "libref_bilateral.so")
 
 
 def build(force=False):
-    """(Re)build the oracle .so (and oracle/_ref when /root/reference is mounted)."""
+    """(Re)build the oracle .so (and, when /root/reference is mounted, the reference build under REF_BUILD)."""
     if force or not os.path.exists(_LIB) or not os.path.exists(_FMAD) or \
             os.path.getmtime(_LIB) < max(os.path.getmtime(os.path.join(_HERE, f))
                                          for f in ("tsdf_oracle.c", "icp_oracle.c", "mc_oracle.c", "tsdf_oracle.h")):
@@ -352,7 +354,7 @@ def have_ref():
 
 
 def ref_bilateral_u8(image, width, height, sigma_colour, sigma_space):
-    """The reference's own BilateralFilter (oracle/_ref, built from /root/reference/src/BilateralFilter.cpp)."""
+    """The reference's own BilateralFilter (REF_BUILD/libref_bilateral.so, built from /root/reference/src/BilateralFilter.cpp)."""
     L = C.CDLL(_REF, mode=getattr(os, "RTLD_LOCAL", 0) | getattr(os, "RTLD_DEEPBIND", 0))
     L.ref_bilateral_u8.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_float, C.c_float]
     img = np.ascontiguousarray(image, np.uint8).reshape(-1).copy()

@@ -3,8 +3,9 @@ TUMDataLoader / extract_surface ...) on the GPU.
 
   * build/test_surface (tests/cpp/test_surface.cpp) drives the classes the way the reference's kinfu.cpp does and
     dumps raw results; they must be bit-identical to what the oracle computes from the same inputs.
-  * when build/linkcheck/bin/kinfu exists (the REFERENCE's unchanged src/Tools/kinfu.cpp compiled against this repo's
-    headers by tools/linkcheck.sh), it is run end to end on a synthetic TUM-layout directory.
+  * where $TSDF_REF_BUILD/linkcheck/bin/kinfu exists (the REFERENCE's unchanged src/Tools/kinfu.cpp compiled against this
+    repo's headers by tools/linkcheck.sh -- outside the tree, so only on a machine that has both the reference and a GPU), it is
+    run end to end on a synthetic TUM-layout directory.
 """
 import os
 import subprocess
@@ -17,7 +18,8 @@ from tsdf_amd import synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "build", "test_surface")
-KINFU = os.path.join(ROOT, "build", "linkcheck", "bin", "kinfu")
+REF_BUILD = os.environ.get("TSDF_REF_BUILD") or "/tmp/tsdf_ref_build"
+KINFU = os.path.join(REF_BUILD, "linkcheck", "bin", "kinfu")
 
 
 def test_headers_of_the_class_surface_compile_standalone():
@@ -144,7 +146,7 @@ def test_cpp_surface_matches_the_oracle(tmp_path, oracle):
 @pytest.mark.gpu
 def test_reference_kinfu_runs_end_to_end_against_this_library(tmp_path):
     if not os.path.exists(KINFU):
-        pytest.skip("build/linkcheck/bin/kinfu not built (needs the reference tree at build time)")
+        pytest.skip("linkcheck/bin/kinfu not present (compiled reference code stays in the build container)")
     d = tmp_path / "tum"
     synth.write_tum_directory(str(d), 3, seed=0x5EED0002)
     r = subprocess.run([KINFU, "-m", "3", "-d", str(d)], capture_output=True, text=True, timeout=300)
@@ -162,9 +164,9 @@ def test_reference_kinfu_runs_end_to_end_against_this_library(tmp_path):
 def test_reference_tsdf_icp_runs_against_this_library(tmp_path):
     """src/Tools/tsdf_icp.cpp of the reference, compiled unchanged (tools/linkcheck.sh): loads a .tsdf volume and a depth
     PNG, renders the volume from the pose stored in it and runs ICPOdometry between the two images."""
-    tool = os.path.join(ROOT, "build", "linkcheck", "bin", "tsdf_icp")
+    tool = os.path.join(REF_BUILD, "linkcheck", "bin", "tsdf_icp")
     if not os.path.exists(tool) or not os.path.exists(BIN):
-        pytest.skip("build/linkcheck/bin/tsdf_icp not built (needs the reference tree at build time)")
+        pytest.skip("linkcheck/bin/tsdf_icp not present (compiled reference code stays in the build container)")
     # a volume file written by the class surface (test_surface saves <out>/volume.tsdf) ...
     depth, cam = synth.depth_frame(2, 30, seed=0x5EED0001)
     depth.tofile(str(tmp_path / "depth.u16"))

@@ -1,7 +1,7 @@
 """Pins the CPU oracle before anything trusts it (no GPU needed).
 
 Sources of truth, in decreasing strength:
-  * the reference's own BilateralFilter compiled natively into oracle/_ref (bit-exact), and the
+  * the reference's own BilateralFilter compiled natively (outside the tree, $TSDF_REF_BUILD: this container only; bit-exact), and the
     committed fixtures generated from it (tests/golden/bilateral_ref_*.npz);
   * figures recorded in SURVEY.md 8c / BASELINE.md 2 from a run of the reference's device source in the
     survey container (updated-voxel counts, sign change at the wall, centre vertex, mean hit depth);
@@ -215,7 +215,7 @@ def _test_images():
 @pytest.mark.parametrize("sigmas", [(3.0, 2.0), (30.0, 4.5), (12.5, 0.7)])
 def test_bilateral_u8_oracle_equals_the_reference_build(oracle, sigmas):
     if not oracle.have_ref():
-        pytest.skip("oracle/_ref not built (reference tree not mounted)")
+        pytest.skip("reference build not present (it stays in the build container)")
     for name, img in _test_images().items():
         h, w = img.shape
         ref = oracle.ref_bilateral_u8(img, w, h, *sigmas)

@@ -1,5 +1,5 @@
 """GPU parity: BilateralFilter (HIP, through the C ABI) against the reference's own outputs (committed
-fixtures from oracle/_ref), the CPU oracle and -- when present -- the reference build itself.  Byte/integer
+fixtures made from the reference build), the CPU oracle and -- when present -- the reference build itself.  Byte/integer
 work: bit-exact."""
 import os
 

@@ -137,6 +137,10 @@ class TSDFVolume:
         check(lib.tsdf_volume_weight_storage(self._h, C.byref(bits), C.byref(pinned)))
         return bits.value, bool(pinned.value)
 
+    def set_weight_storage(self, bits):
+        """Widen the weight storage now (8 -> 16 -> 32 bits, values unchanged) instead of when a count is about to overflow."""
+        check(lib.tsdf_volume_set_weight_storage(self._h, int(bits)))
+
     def deformation(self):
         p = C.c_void_p()
         check(lib.tsdf_volume_deformation(self._h, C.byref(p)))

@@ -968,7 +968,9 @@ __device__ inline void march_bulk(const float *__restrict__ dist, const Geom &g,
         const float t_safe = (__uint_as_float(rp.ztile[tile_y * rp.ztile_pitch + tile_x]) - near_t) * 0.9999f;   // (the tile's word: uniform)
         // the last sample of [k, k_end) with T[ks] < t_safe: T[k] is k * step up to the rounding of its k additions (under a sample
         // over the whole table), so the walk down from the estimate is a few entries
-        int ks = min(f2i_sat(t_safe * sc.inv_step) + 2, k_end - 1);
+        // (clamped BEFORE the + 2: a tile that sees no flagged unit has the word kEntryFar, the estimate saturates at INT_MAX, and
+        // INT_MAX + 2 wrapped negative -- the tiles with nothing in view, of all, kept hopping through the whole volume)
+        int ks = min(f2i_sat(t_safe * sc.inv_step), k_end - 3) + 2;
         while (ks >= k && !(T(ks) < t_safe)) ks--;
         if (ks >= k) k = ks + 1 >= k_end ? kDone : ks + 1;
     }

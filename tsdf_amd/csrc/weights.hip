@@ -124,6 +124,32 @@ static int expand_into(const tsdf_volume *v, float *dst) {
     return TSDF_OK;
 }
 
+// get / set_weight_data in a packed mode go through a BOUNDED staging buffer, a few planes at a time (a multiple of 4: whole dwords of
+// either packed mode) -- not through an fp32 copy of the whole array (4 GiB at 1024^3), which the reference's plain memcpy never needed.
+constexpr size_t kWeightStageBytes = (size_t)64 << 20;
+static uint32_t stage_planes(const tsdf_volume *v) {
+    const size_t xy = (size_t)v->g.X * v->g.Y, planes = v->g.z_store_end - v->g.z_store_begin;
+    size_t n = std::max<size_t>(4, (kWeightStageBytes / (xy * sizeof(float))) & ~(size_t)3);
+    return (uint32_t)std::min(n, (planes + 3) & ~(size_t)3);
+}
+// planes [z0, z0 + nz) of the packed array `wp` (mode `bits`) <-> `stage` (nz * xy floats), on the volume's stream
+static int stage_expand(const tsdf_volume *v, const uint32_t *wp, int bits, uint32_t z0, uint32_t nz, float *stage) {
+    const size_t xy = (size_t)v->g.X * v->g.Y, per = 32 / bits, words = xy * ((nz + per - 1) / per);
+    const dim3 grid((unsigned)std::min<size_t>((words + 255) / 256, 4096));
+    if (bits == 8) hipLaunchKernelGGL(weights_expand_kernel<8>, grid, dim3(256), 0, v->stream, wp + (z0 / per) * xy, stage, xy, nz, words);
+    else hipLaunchKernelGGL(weights_expand_kernel<16>, grid, dim3(256), 0, v->stream, wp + (z0 / per) * xy, stage, xy, nz, words);
+    TSDF_HIP(hipGetLastError(), "Couldn't expand the weights");
+    return TSDF_OK;
+}
+static int stage_pack(const tsdf_volume *v, uint32_t *wp, int bits, uint32_t z0, uint32_t nz, const float *stage) {
+    const size_t xy = (size_t)v->g.X * v->g.Y, per = 32 / bits, words = xy * ((nz + per - 1) / per);
+    const dim3 grid((unsigned)std::min<size_t>((words + 255) / 256, 4096));
+    if (bits == 8) hipLaunchKernelGGL(weights_pack_kernel<8>, grid, dim3(256), 0, v->stream, stage, wp + (z0 / per) * xy, xy, nz, words);
+    else hipLaunchKernelGGL(weights_pack_kernel<16>, grid, dim3(256), 0, v->stream, stage, wp + (z0 / per) * xy, xy, nz, words);
+    TSDF_HIP(hipGetLastError(), "Couldn't pack the weights");
+    return TSDF_OK;
+}
+
 // The reference's layout from here on (until clear(), unless pinned).
 int weights_require_f32(tsdf_volume *v) {
     if (v->wmode == 0) return TSDF_OK;
@@ -171,24 +197,41 @@ static int refresh_bound(tsdf_volume *v) {
 }
 
 // Before an integration in a packed mode: no count may pass what the mode holds.
+// 8-bit counts -> 16-bit counts (the new array is allocated before the old one goes)
+static int widen_to_16(tsdf_volume *v) {
+    uint32_t *w16 = nullptr;
+    int rc = alloc_packed(v, 16, &w16);
+    if (rc != TSDF_OK) return rc;
+    const size_t xy = (size_t)v->g.X * v->g.Y, n8 = packed_words(v, 8), n16 = packed_words(v, 16);
+    hipLaunchKernelGGL(weights_widen_kernel, dim3((unsigned)std::min<size_t>((n8 + 255) / 256, 4096)), dim3(256), 0, v->stream, v->wpacked, w16, xy, n8, n16);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(v->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(w16);
+        return hip_fail(e, "Couldn't widen the weights");
+    }
+    (void)hipFree(v->wpacked);
+    v->wpacked = w16;
+    v->wmode = 16;
+    return TSDF_OK;
+}
+
+// The look at the counts (a scan of the packed array and a host round trip inside integrate) must not come back every few frames: a
+// region seen 250 times that then leaves the view would leave the bound at 250 and the scan due every 5th frame for the rest of the
+// session.  So the mode is widened already when the largest count is in the top quarter of what it holds, and a scan that keeps the
+// mode buys at least 64 (16 384) integrations without another.
 int weights_make_room(tsdf_volume *v) {
+    bool widen = false;
     if ((v->wmode == 8 && v->weight_bound >= 255u) || (v->wmode == 16 && v->weight_bound >= 65535u)) {
         const int rc = refresh_bound(v);
         if (rc != TSDF_OK) return rc;
+        widen = v->wmode == 8 ? v->weight_bound >= 192u : v->weight_bound >= 49152u;
     }
-    if (v->wmode == 8 && v->weight_bound >= 255u) {
-        uint32_t *w16 = nullptr;
-        int rc = alloc_packed(v, 16, &w16);
+    if (v->wmode == 8 && widen) {
+        const int rc = widen_to_16(v);
         if (rc != TSDF_OK) return rc;
-        const size_t xy = (size_t)v->g.X * v->g.Y, n8 = packed_words(v, 8), n16 = packed_words(v, 16);
-        hipLaunchKernelGGL(weights_widen_kernel, dim3((unsigned)std::min<size_t>((n8 + 255) / 256, 4096)), dim3(256), 0, v->stream, v->wpacked, w16, xy, n8, n16);
-        TSDF_HIP(hipGetLastError(), "Couldn't widen the weights");
-        TSDF_HIP(hipStreamSynchronize(v->stream), "Couldn't widen the weights");
-        (void)hipFree(v->wpacked);
-        v->wpacked = w16;
-        v->wmode = 16;
     }
-    if (v->wmode == 16 && v->weight_bound >= 65535u) return weights_require_f32(v);
+    if (v->wmode == 16 && (v->weight_bound >= 65535u || (widen && v->weight_bound >= 49152u))) return weights_require_f32(v);
     return TSDF_OK;
 }
 
@@ -211,82 +254,113 @@ int weights_clear(tsdf_volume *v) {
     return TSDF_OK;
 }
 
-// set_weight_data(): counts are packed (into the narrowest mode from the starting one that holds them), anything else is kept as fp32
+// set_weight_data(): counts are packed (into the narrowest mode from the starting one that holds them), anything else is kept as fp32.
+// The host array is surveyed first, staged a few planes at a time (are these counts? the largest?), and only then is anything of the
+// volume's replaced: a failed allocation leaves the volume as it was.
 int weights_upload(tsdf_volume *v, const float *host) {
-    const size_t n = v->resident_voxels();
-    float *w = nullptr;
+    const size_t n = v->resident_voxels(), xy = (size_t)v->g.X * v->g.Y;
+    const uint32_t planes = v->g.z_store_end - v->g.z_store_begin;
     TSDF_HIP(hipStreamSynchronize(v->stream), "Couldn't set weight data");
-    if (v->wmode == 0) w = v->weight;
-    else TSDF_HIP(hipMalloc((void **)&w, n * sizeof(float)), "Couldn't allocate space for TSDF weights");
-    hipError_t e = hipMemcpyAsync(w, host, n * sizeof(float), hipMemcpyHostToDevice, v->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(v->stream);
-    if (e != hipSuccess) {
-        if (w != v->weight) (void)hipFree(w);
-        return hip_fail(e, "Couldn't set weight data");
+    const bool keep_f32 = v->weight_pinned || weight_pack_start() == 0;
+    if (v->wmode == 0 && keep_f32) {
+        TSDF_HIP(hipMemcpyAsync(v->weight, host, n * sizeof(float), hipMemcpyHostToDevice, v->stream), "Couldn't set weight data");
+        TSDF_HIP(hipStreamSynchronize(v->stream), "Couldn't set weight data");
+        return TSDF_OK;
     }
-    if (v->wmode == 0 && (v->weight_pinned || weight_pack_start() == 0)) return TSDF_OK;
-    // are they counts?
+    const uint32_t chunk = stage_planes(v);
+    float *stage = nullptr;
+    TSDF_HIP(hipMalloc((void **)&stage, (size_t)chunk * xy * sizeof(float)), "Couldn't allocate space for TSDF weights");
     uint32_t stats[2] = {0, 0};
-    e = hipMemsetAsync(v->counter_dev + 3, 0, sizeof(stats), v->stream);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(weights_survey_kernel, dim3(2048), dim3(256), 0, v->stream, w, n, reinterpret_cast<uint32_t *>(v->counter_dev + 3));
-        e = hipMemcpyAsync(stats, v->counter_dev + 3, sizeof(stats), hipMemcpyDeviceToHost, v->stream);
+    uint32_t *slot = reinterpret_cast<uint32_t *>(v->counter_dev + 3);   // (scratch slot shared with verify_fast_division)
+    hipError_t e = hipMemsetAsync(slot, 0, sizeof(stats), v->stream);
+    for (uint32_t z0 = 0; z0 < planes && e == hipSuccess; z0 += chunk) {
+        const uint32_t nz = std::min(chunk, planes - z0);
+        e = hipMemcpyAsync(stage, host + (size_t)z0 * xy, (size_t)nz * xy * sizeof(float), hipMemcpyHostToDevice, v->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(weights_survey_kernel, dim3(2048), dim3(256), 0, v->stream, stage, (size_t)nz * xy, slot);
+            e = hipStreamSynchronize(v->stream);   // (the staging buffer is reused)
+        }
     }
+    if (e == hipSuccess) e = hipMemcpyAsync(stats, slot, sizeof(stats), hipMemcpyDeviceToHost, v->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(v->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(v->counter_dev + 3, 0, sizeof(stats), v->stream);   // (scratch slot shared with verify_fast_division)
+    if (e == hipSuccess) e = hipMemsetAsync(slot, 0, sizeof(stats), v->stream);
     if (e != hipSuccess) {
-        if (w != v->weight) (void)hipFree(w);
+        (void)hipFree(stage);
         return hip_fail(e, "Couldn't set weight data");
     }
-    const int want = stats[0] ? 0 : (stats[1] <= 255u && weight_pack_start() == 8 ? 8 : 16);
+    const int want = (stats[0] || keep_f32) ? 0 : (stats[1] <= 255u && weight_pack_start() == 8 ? 8 : 16);
+    // the array of the mode the weights will live in: the present one, or a new one allocated BEFORE the old one goes
+    float *new_f32 = nullptr;
+    uint32_t *new_packed = nullptr;
+    if (want == 0 && v->wmode != 0) e = hipMalloc((void **)&new_f32, n * sizeof(float));
+    if (want != 0 && v->wmode != want) {
+        if (alloc_packed(v, want, &new_packed) != TSDF_OK) e = hipErrorOutOfMemory;
+    }
+    if (e != hipSuccess) {
+        (void)hipFree(stage);
+        return hip_fail(e, "Couldn't allocate space for TSDF weights");
+    }
     if (want == 0) {   // not counts: the reference's layout
-        if (v->wmode != 0) {
+        float *dst = new_f32 ? new_f32 : v->weight;
+        e = hipMemcpyAsync(dst, host, n * sizeof(float), hipMemcpyHostToDevice, v->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(v->stream);
+        (void)hipFree(stage);
+        if (e != hipSuccess) {
+            if (new_f32) (void)hipFree(new_f32);
+            return hip_fail(e, "Couldn't set weight data");
+        }
+        if (new_f32) {
             (void)hipFree(v->wpacked);
             v->wpacked = nullptr;
-            v->weight = w;
+            v->weight = new_f32;
             v->wmode = 0;
         }
         return TSDF_OK;
     }
-    if (v->wmode != want) {
-        if (v->wpacked) (void)hipFree(v->wpacked);
-        v->wpacked = nullptr;
-        const int rc = alloc_packed(v, want, &v->wpacked);
-        if (rc != TSDF_OK) {
-            if (w != v->weight) (void)hipFree(w);
-            return rc;
-        }
+    uint32_t *dst = new_packed ? new_packed : v->wpacked;
+    int rc = TSDF_OK;
+    for (uint32_t z0 = 0; z0 < planes && e == hipSuccess && rc == TSDF_OK; z0 += chunk) {
+        const uint32_t nz = std::min(chunk, planes - z0);
+        e = hipMemcpyAsync(stage, host + (size_t)z0 * xy, (size_t)nz * xy * sizeof(float), hipMemcpyHostToDevice, v->stream);
+        if (e == hipSuccess) rc = stage_pack(v, dst, want, z0, nz, stage);
+        if (e == hipSuccess && rc == TSDF_OK) e = hipStreamSynchronize(v->stream);
     }
-    const size_t xy = (size_t)v->g.X * v->g.Y, words = packed_words(v, want);
-    const uint32_t planes = v->g.z_store_end - v->g.z_store_begin;
-    const dim3 grid((unsigned)std::min<size_t>((words + 255) / 256, 4096));
-    if (want == 8) hipLaunchKernelGGL(weights_pack_kernel<8>, grid, dim3(256), 0, v->stream, w, v->wpacked, xy, planes, words);
-    else hipLaunchKernelGGL(weights_pack_kernel<16>, grid, dim3(256), 0, v->stream, w, v->wpacked, xy, planes, words);
-    e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(v->stream);
-    (void)hipFree(w);
-    if (w == v->weight) v->weight = nullptr;
-    v->wmode = want;
+    (void)hipFree(stage);
+    if (e != hipSuccess || rc != TSDF_OK) {   // (the volume keeps what it had; its weights may be partly overwritten when the mode did not change)
+        if (new_packed) (void)hipFree(new_packed);
+        return e != hipSuccess ? hip_fail(e, "Couldn't set weight data") : rc;
+    }
+    if (new_packed) {
+        if (v->wpacked) (void)hipFree(v->wpacked);
+        if (v->weight) (void)hipFree(v->weight);
+        v->weight = nullptr;
+        v->wpacked = new_packed;
+        v->wmode = want;
+    }
     v->weight_bound = stats[1];
-    if (e != hipSuccess) return hip_fail(e, "Couldn't set weight data");
     return TSDF_OK;
 }
 
 // get_weight_data(): fp32 on the host whatever the mode
 int weights_download(const tsdf_volume *v, float *host) {
-    const size_t n = v->resident_voxels();
+    const size_t n = v->resident_voxels(), xy = (size_t)v->g.X * v->g.Y;
     if (v->wmode == 0) {
         TSDF_HIP(hipMemcpyAsync(host, v->weight, n * sizeof(float), hipMemcpyDeviceToHost, v->stream), "Couldn't read weight data");
         TSDF_HIP(hipStreamSynchronize(v->stream), "Couldn't read weight data");
         return TSDF_OK;
     }
-    float *w = nullptr;
-    TSDF_HIP(hipMalloc((void **)&w, n * sizeof(float)), "Couldn't read weight data");
-    int rc = expand_into(v, w);
+    const uint32_t planes = v->g.z_store_end - v->g.z_store_begin, chunk = stage_planes(v);
+    float *stage = nullptr;
+    TSDF_HIP(hipMalloc((void **)&stage, (size_t)chunk * xy * sizeof(float)), "Couldn't read weight data");
+    int rc = TSDF_OK;
     hipError_t e = hipSuccess;
-    if (rc == TSDF_OK) e = hipMemcpyAsync(host, w, n * sizeof(float), hipMemcpyDeviceToHost, v->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(v->stream);
-    (void)hipFree(w);
+    for (uint32_t z0 = 0; z0 < planes && rc == TSDF_OK && e == hipSuccess; z0 += chunk) {
+        const uint32_t nz = std::min(chunk, planes - z0);
+        rc = stage_expand(v, v->wpacked, v->wmode, z0, nz, stage);
+        if (rc == TSDF_OK) e = hipMemcpyAsync(host + (size_t)z0 * xy, stage, (size_t)nz * xy * sizeof(float), hipMemcpyDeviceToHost, v->stream);
+        if (rc == TSDF_OK && e == hipSuccess) e = hipStreamSynchronize(v->stream);   // (the staging buffer is reused)
+    }
+    (void)hipFree(stage);
     if (rc != TSDF_OK) return rc;
     if (e != hipSuccess) return hip_fail(e, "Couldn't read weight data");
     return TSDF_OK;
@@ -297,6 +371,17 @@ int weights_download(const tsdf_volume *v, float *host) {
 using namespace tsdf;
 
 extern "C" {
+
+int tsdf_volume_set_weight_storage(tsdf_volume *v, int bits_per_weight) {
+    TSDF_REQUIRE(v, "null argument");
+    TSDF_REQUIRE(bits_per_weight == 8 || bits_per_weight == 16 || bits_per_weight == 32, "tsdf_volume_set_weight_storage: 8, 16 or 32 bits");
+    const int now = v->wmode == 0 ? 32 : v->wmode;
+    TSDF_REQUIRE(bits_per_weight >= now, "tsdf_volume_set_weight_storage: the storage can only be widened (clear() returns to the starting mode)");
+    int rc = TSDF_OK;
+    if (now == 8 && bits_per_weight >= 16) rc = widen_to_16(v);
+    if (rc == TSDF_OK && bits_per_weight == 32) rc = weights_require_f32(v);
+    return rc;
+}
 
 int tsdf_volume_weight_storage(const tsdf_volume *v, int *bits_per_weight, int *pinned) {
     TSDF_REQUIRE(v && bits_per_weight, "null argument");
