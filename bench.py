@@ -54,6 +54,9 @@ def parse():
                     help="N > 1: Z-slab boundaries re-cut from the ranks' measured times on the first frames (default), from a "
                          "work estimate of a small planner volume, or equal plane counts")
     ap.add_argument("--plan-rounds", type=int, default=3, help="--slab-plan measured: rebalancing rounds (each costs a few frames)")
+    ap.add_argument("--validate-merge", action="store_true",
+                    help="N > 1: SURVEY.md 8e mode B after the measurements -- every rank all-gathers the distance slabs, casts the whole "
+                         "volume the single-volume way and compares its bits with the merged picture (tsdf_slab_validate_merge)")
     ap.add_argument("--one-rank-slab-path", action="store_true",
                     help="--gpus 1 only: run the N > 1 code path (slab volume, slab ray cast, all-gather of the hit records over the "
                          "nccl = RCCL backend, merge) with a world of one rank -- the collective degenerates but RCCL initialises, "
@@ -614,6 +617,21 @@ def main():
                                  "hits": int((~torch.isnan(ref_v[:, 0])).sum().item()), "pass": same}
                 whole.close()
 
+    if sharded:
+        # what the communicator itself says (ncclCommCount), so that a run of one rank is not read as a scaling point
+        coll = {"ranks_seen": exch.ranks_seen(), "world": world, "how": exch_note}
+        if args.validate_merge:
+            # mode B: the merged picture of the last pipelined step (volume = cleared + the warm-up and timed frames) against the
+            # ordinary cast of the all-gathered distance slabs, on every rank
+            torch.cuda.synchronize()
+            barrier()
+            n_diff = exch.validate_merge(vol, W, H, cams[Wu + K - 1], vert_dev, norm_dev)
+            t = torch.tensor([n_diff], dtype=torch.int64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            coll["validate_merge"] = {"mode": "B: all-gather of the distance slabs + the whole volume's ordinary cast on every rank",
+                                      "differing_words_max_over_ranks": int(t.item()), "pass": int(t.item()) == 0}
+        if rank == 0:
+            out["collective"] = coll
     trace("parity replay done")
     if rank == 0:
         def finite(o):      # strict JSON: a non-finite number (an unsampled average, an empty ratio) becomes null

@@ -304,6 +304,18 @@ typedef int (*tsdf_exchange_fn)(void *user, const tsdf_hit_record *device_mine, 
                                 void *hip_stream);
 int tsdf_slab_exchange_create_callback(int rank, int world, tsdf_exchange_fn all_gather, void *user, tsdf_slab_exchange **out);
 int tsdf_slab_exchange_world(const tsdf_slab_exchange *exchange, int *rank, int *world);
+/* How many ranks the communicator itself reports (ncclCommCount; the world handed in at creation for a caller's own collective):
+ * what a driver prints beside its timings, so that nobody takes a run of one rank for a scaling point. */
+int tsdf_slab_exchange_ranks_seen(const tsdf_slab_exchange *exchange, int *ranks);
+/* SURVEY.md 8e, mode B -- the cross-rank validator of the merge path (no reference counterpart: the reference has one GPU).  Every
+ * rank gathers every rank's DISTANCE slab through the exchange, assembles the whole volume, casts it the ordinary single-volume way
+ * and counts the words in which that picture differs from the merged one (device_merged_*: what tsdf_pipeline_step or
+ * tsdf_merge_hits_normals_device left; normals may be NULL); NaN equals NaN.  0 differing words on every rank = the 8-byte {k, t}
+ * records + min-k merge reproduce the whole volume's cast bit for bit.  Collective (every rank calls it, on its slab's stream),
+ * blocking, and expensive by design: 4 N bytes per rank through the collective and a whole volume resident on every rank. */
+int tsdf_slab_validate_merge(tsdf_volume *slab_volume, tsdf_slab_exchange *exchange, uint32_t width, uint32_t height,
+                             const float pose[16], const float kinv[9], const float *device_merged_vertices,
+                             const float *device_merged_normals, uint64_t *differing_words);
 /* device_all: world x n_pixels records, rank r's at [r * n_pixels, (r + 1) * n_pixels).  Asynchronous on hip_stream. */
 int tsdf_slab_exchange_all_gather(tsdf_slab_exchange *exchange, const tsdf_hit_record *device_mine, tsdf_hit_record *device_all,
                                   uint32_t n_pixels, void *hip_stream);

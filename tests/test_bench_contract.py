@@ -92,8 +92,12 @@ def test_one_rank_walks_the_sharded_path_over_rccl():
     """What a one-GPU box can check of the multi-GPU path on the real backend: a world of ONE rank initialises nccl (= RCCL),
     builds a communicator on the box's GPU and pushes the hit records through all_gather_into_tensor on device memory, between the
     slab ray cast and the merge kernel of every step; the merged picture must equal a single-volume replay."""
-    d = run_bench("--gpus", "1", "--one-rank-slab-path", "--steps", "6", "--warmup", "2", "--plan-rounds", "1", "--no-cpu-baseline")
+    d = run_bench("--gpus", "1", "--one-rank-slab-path", "--steps", "6", "--warmup", "2", "--plan-rounds", "1", "--no-cpu-baseline", "--validate-merge")
     assert d["config"]["collective_backend"] == "nccl" and d["config"]["ranks"] == 1 and d["config"]["parallelism"] == "zslab1"
+    # the line says how many ranks the communicator itself holds (ncclCommCount), and mode B -- the all-gathered distance slab cast
+    # the single-volume way -- gives the merged picture bit for bit
+    assert d["collective"]["ranks_seen"] == 1 and d["collective"]["world"] == 1
+    assert d["collective"]["validate_merge"]["pass"] is True and d["collective"]["validate_merge"]["differing_words_max_over_ranks"] == 0
     assert d["parity"]["pass"] is True and d["parity"]["merged_picture_equals_single_volume_replay"] is True
     assert d["slabs"] == [[0, 512]]
     assert d["per_rank_ms"]["exchange"][0] > 0 and d["value"] > 0

@@ -179,3 +179,25 @@ def test_kinfu_stream_ranks_gives_the_single_volume_picture(tmp_path, ranks):
     for r in range(ranks):
         z0, z1 = n * r // ranks, n * (r + 1) // ranks
         assert_same_floats(np.fromfile(str(many / ("distances.rank%d.f32" % r)), np.float32), whole[z0:z1], "slab %d distances" % r)
+
+
+@pytest.mark.gpu
+def test_kinfu_stream_eight_ranks_over_1024_planes_validate_their_merge(tmp_path):
+    """The shape of BASELINE configs[3] -- 1024 planes in eight Z-slabs -- on a grid small enough for eight processes to share one GPU
+    (48 x 48 x 1024 voxels over the 3 m cube): every rank's slab integrate + slab cast, the all-gather of the 8-byte records, the min-k
+    merge, and then SURVEY.md 8e's mode B as the validator (--validate-merge): every rank all-gathers the DISTANCE slabs, casts the whole
+    volume the ordinary way and must find the merged picture's bits.  The single-volume run of the same command is the second witness."""
+    n, planes, F, Wu, K = 48, 1024, 4, 1, 3
+    d = tmp_path / "tum"
+    synth.write_tum_directory(str(d), F, seed=0x5EED0004, stream_frames=40)
+    base = [BIN, "-d", str(d), "-n", str(n), "--planes", str(planes), "-k", str(K), "-w", str(Wu)]
+    r1 = subprocess.run(base, capture_output=True, text=True, timeout=300)
+    assert r1.returncode == 0, r1.stdout + r1.stderr
+    r8 = subprocess.run(base + ["--ranks", "8", "--validate-merge"], capture_output=True, text=True, timeout=900)
+    assert r8.returncode == 0, r8.stdout + r8.stderr
+    a = json.loads(r1.stdout.strip().splitlines()[-1])
+    b = json.loads([l for l in r8.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert b["ranks"] == 8 and b["ranks_seen"] == 8 and b["slab_planes"] == 128 and b["planes"] == planes
+    assert b["merge_validated_mode_b"] is True and b["mode_b_differing_words"] == 0 and b["ranks_hold_the_same_picture"] is True
+    assert b["last_frame_vertex_bits"] == a["last_frame_vertex_bits"] and b["last_frame_normal_bits"] == a["last_frame_normal_bits"]
+    assert b["last_frame_hits"] == a["last_frame_hits"] > 1000

@@ -169,3 +169,63 @@ def test_slab_meshes_gathered_over_gloo_are_the_whole_mesh_in_cube_order(tmp_pat
     mp.spawn(_mesh_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     n_got, n_whole, same_xy = np.load(os.path.join(str(tmp_path), "mesh.npy"))
     assert n_got == n_whole and n_whole > 100 and same_xy == 1
+
+
+@pytest.mark.gpu
+def test_mode_b_validator_counts_the_words_that_differ(oracle):
+    """tsdf_slab_validate_merge (SURVEY.md 8e mode B) in one process: a slab that is the whole grid, an exchange of one rank over a
+    caller's collective.  The merged picture of the slab path passes with 0 differing words; the same picture with three words
+    changed is counted as 3; a NaN (no hit) only equals a NaN."""
+    import ctypes as C
+    import tsdf_amd
+    from tsdf_amd import _capi, synth
+    from tsdf_amd.multi import device_words
+    from tests.helpers import H, W
+    lib, check = _capi.lib, _capi.check
+    n = 64
+    vol = tsdf_amd.TSDFVolume((n, n, n), (3000.0,) * 3, slab=(0, n))
+    bil = tsdf_amd.BilateralFilter(30.0, 4.5)
+    cam = None
+    for i in range(3):
+        depth, cam = synth.depth_frame(i, 30, seed=0x5EED0004)
+        f = depth.copy()
+        bil.filter(f, W, H)
+        vol.integrate(f, W, H, cam)
+
+    def gather(user, mine, allr, n_pixels, stream):     # world of one: rank 0's records are everybody's
+        device_words(allr, 2 * n_pixels).copy_(device_words(mine, 2 * n_pixels))
+        torch.cuda.synchronize()
+        return 0
+    cb = _capi.EXCHANGE_FN(gather)
+    h = C.c_void_p()
+    check(lib.tsdf_slab_exchange_create_callback(0, 1, cb, None, C.byref(h)))
+    seen = C.c_int()
+    check(lib.tsdf_slab_exchange_ranks_seen(h, C.byref(seen)))
+    assert seen.value == 1
+    rc = tsdf_amd.GPURaycaster(W, H)
+    hits = torch.empty((H * W, 2), dtype=torch.int32, device="cuda")
+    V = torch.empty((H * W, 3), dtype=torch.float32, device="cuda")
+    N = torch.empty_like(V)
+    rc.raycast_slab_device(vol, cam, hits.data_ptr())
+    tsdf_amd.merge_hits_normals_device(vol, hits.data_ptr(), 1, W, H, cam, V.data_ptr(), N.data_ptr(), 0)
+    torch.cuda.synchronize()
+    assert int((~torch.isnan(V[:, 0])).sum().item()) > 1000 and int(torch.isnan(V[:, 0]).sum().item()) > 0
+
+    def differing(v, nrm):
+        fp = C.POINTER(C.c_float)
+        out = C.c_uint64()
+        pose, kinv = np.ascontiguousarray(cam.pose(), np.float32), np.ascontiguousarray(cam.kinv(), np.float32)
+        check(lib.tsdf_slab_validate_merge(vol._h, h, W, H, pose.ctypes.data_as(fp), kinv.ctypes.data_as(fp), C.c_void_p(v.data_ptr()),
+                                           C.c_void_p(nrm.data_ptr()) if nrm is not None else None, C.byref(out)))
+        return int(out.value)
+    assert differing(V, N) == 0
+    assert differing(V, None) == 0
+    bad = V.clone()
+    hit = int(torch.nonzero(~torch.isnan(V[:, 0]))[0].item()); miss = int(torch.nonzero(torch.isnan(V[:, 0]))[0].item())
+    bad[hit, 0] += 1.0                       # a vertex off by a millimetre
+    bad[hit + 1, 2] = float("nan")           # a hit turned into a miss (or a miss stays one)
+    bad[miss, 1] = 0.0                       # a miss turned into a number
+    expected = 2 + (0 if bool(torch.isnan(V[hit + 1, 2]).item()) else 1)
+    assert differing(bad, N) == expected
+    lib.tsdf_slab_exchange_destroy(h)
+    vol.close()

@@ -8,7 +8,10 @@
 // the same entry points from Python: same checksum, same ms per step (tools/compare_drivers.sh).
 //
 //   kinfu_stream -d <tum dir> [-n grid=512] [-p physical_mm=3000] [-k steps=20] [-w warmup=5] [--no-overlap]
-//                [--no-cull-ahead] [--dump <dir>] [--track] [--ranks P] [--share-gpu]
+//                [--no-cull-ahead] [--dump <dir>] [--track] [--ranks P] [--share-gpu] [--planes Z] [--validate-merge]
+//   --planes Z: a grid of n x n x Z voxels over the same physical cube (flat voxels along z): many planes to shard at a small cost
+//   --validate-merge (with --ranks): SURVEY.md 8e mode B after the timed steps -- every rank all-gathers the distance slabs, casts the
+//           whole volume the single-volume way and compares its bits with the merged picture (tsdf_slab_validate_merge)
 //   --ranks P: the volume in P Z-slabs, one PROCESS per slab (fork, before anything touches the GPU), each on its own GPU: slab
 //           integrate + slab ray cast, the frame's all-gather of 8-byte hit records (tsdf_slab_exchange_*: RCCL on the step's
 //           stream, the 128-byte id from rank 0 through shared memory) and the min-k merge on every rank, all through
@@ -77,6 +80,7 @@ struct Shared {
     uint8_t id[TSDF_EXCHANGE_ID_BYTES];
     double elapsed[kMaxRanks];
     long long bits_v[kMaxRanks], bits_n[kMaxRanks];
+    unsigned long long merge_diff[kMaxRanks];
     int use_rccl;
 };
 struct ShmGather {   // user data of the host-staged all-gather (one GPU shared by every rank)
@@ -102,7 +106,8 @@ int main(int argc, char **argv) {
     unsigned n = 512;
     float physical = 3000.0f;
     int K = 20, Wu = 5;
-    bool overlap = true, cull_ahead = true, track = false;
+    bool overlap = true, cull_ahead = true, track = false, validate_merge = false;
+    unsigned planes = 0;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto value = [&]() -> const char * {
@@ -123,12 +128,15 @@ int main(int argc, char **argv) {
         else if (a == "--track") track = true;
         else if (a == "--ranks") ranks = std::atoi(value());
         else if (a == "--share-gpu") share_gpu = true;
+        else if (a == "--planes") planes = (unsigned)std::atoi(value());
+        else if (a == "--validate-merge") validate_merge = true;
         else {
-            std::fprintf(stderr, "usage: kinfu_stream -d <tum dir> [-n grid] [-p physical_mm] [-k steps] [-w warmup] [--no-overlap] [--no-cull-ahead] [--dump dir] [--track] [--ranks P] [--share-gpu]\n");
+            std::fprintf(stderr, "usage: kinfu_stream -d <tum dir> [-n grid] [-p physical_mm] [-k steps] [-w warmup] [--no-overlap] [--no-cull-ahead] [--dump dir] [--track] [--ranks P] [--share-gpu] [--planes Z] [--validate-merge]\n");
             return 2;
         }
     }
-    if (dir.empty() || K < 1 || Wu < 0 || n < 1 || ranks < 1 || ranks > kMaxRanks || (unsigned)ranks > n || (track && ranks > 1)) {
+    if (planes == 0) planes = n;
+    if (dir.empty() || K < 1 || Wu < 0 || n < 1 || ranks < 1 || ranks > kMaxRanks || (unsigned)ranks > planes || (track && ranks > 1)) {
         std::fprintf(stderr, "kinfu_stream: -d <tum dir>, -k >= 1, -w >= 0, -n >= 1, 1 <= --ranks <= min(%d, grid), --track is single-volume\n", kMaxRanks);
         return 2;
     }
@@ -231,11 +239,11 @@ int main(int argc, char **argv) {
     tsdf_pipeline *pipe = nullptr;
     tsdf_slab_exchange *exch = nullptr;
     ShmGather shm_gather = {shared, shared_records, rank, ranks};
-    const uint32_t z_begin = (uint32_t)((uint64_t)n * rank / ranks), z_end = (uint32_t)((uint64_t)n * (rank + 1) / ranks);   // equal plane counts
+    const uint32_t z_begin = (uint32_t)((uint64_t)planes * rank / ranks), z_end = (uint32_t)((uint64_t)planes * (rank + 1) / ranks);   // equal plane counts
     if (ranks == 1) {
-        ok(tsdf_volume_create(n, n, n, physical, physical, physical, &vol), "volume");
+        ok(tsdf_volume_create(n, n, planes, physical, physical, physical, &vol), "volume");
     } else {
-        ok(tsdf_volume_create_slab(n, n, n, physical, physical, physical, z_begin, z_end, &vol), "slab volume");
+        ok(tsdf_volume_create_slab(n, n, planes, physical, physical, physical, z_begin, z_end, &vol), "slab volume");
         if (use_rccl) {
             if (rank == 0) ok(tsdf_slab_exchange_unique_id(shared->id, nullptr), "RCCL unique id");
             pthread_barrier_wait(&shared->barrier);
@@ -296,7 +304,7 @@ int main(int argc, char **argv) {
                     inliers, error);
         if (!dump_dir.empty()) {
             dump(dump_dir + "/poses.f32", tracked.data(), tracked.size() * sizeof(float));
-            std::vector<float> a((size_t)n * n * n);
+            std::vector<float> a((size_t)n * n * planes);
             ok(tsdf_volume_get_distance_data(vol, a.data()), "distances");
             dump(dump_dir + "/distances.f32", a.data(), a.size() * sizeof(float));
         }
@@ -349,19 +357,35 @@ int main(int argc, char **argv) {
             ranks_agree = ranks_agree && shared->bits_v[r] == bits_v && shared->bits_n[r] == bits_n;
         }
     }
-    const double ms = elapsed * 1e3 / K, voxels = (double)n * n * n;
+    // mode B: the merged picture against the ordinary cast of the all-gathered distance slabs, on every rank (collective)
+    unsigned long long merge_diff = 0;
+    int ranks_seen = ranks;
+    if (shared) {
+        ok(tsdf_slab_exchange_ranks_seen(exch, &ranks_seen), "ranks seen");
+        if (validate_merge) {
+            const tsdf_camera_matrices &last = cams[(size_t)(Wu + K - 1) % F];
+            uint64_t d = 0;
+            ok(tsdf_slab_validate_merge(vol, exch, W, H, last.pose, last.kinv, vert_dev, norm_dev, &d), "validate merge (mode B)");
+            shared->merge_diff[rank] = d;
+            pthread_barrier_wait(&shared->barrier);
+            for (int r = 0; r < ranks; r++) merge_diff = std::max(merge_diff, shared->merge_diff[r]);
+            ranks_agree = ranks_agree && merge_diff == 0;
+        }
+    }
+    const double ms = elapsed * 1e3 / K, voxels = (double)n * n * planes;
     if (rank == 0) {
         if (ranks > 1)
             std::printf("{\"driver\": \"tools/kinfu_stream.cpp --ranks (C++, one process per Z-slab, tsdf_pipeline_step + tsdf_slab_exchange)\", \"ranks\": %d, "
-                        "\"exchange\": \"%s\", \"slab_planes\": %u, \"ranks_hold_the_same_picture\": %s, ",
+                        "\"exchange\": \"%s\", \"ranks_seen\": %d, \"slab_planes\": %u, \"ranks_hold_the_same_picture\": %s, \"merge_validated_mode_b\": %s, "
+                        "\"mode_b_differing_words\": %llu, ",
                         ranks, use_rccl ? "ncclAllGather on the step's stream (librccl, id through shared memory)" : "host shared memory, every rank on GPU 0 (timings meaningless)",
-                        z_end - z_begin, ranks_agree ? "true" : "false");
+                        ranks_seen, z_end - z_begin, ranks_agree ? "true" : "false", validate_merge ? (merge_diff == 0 ? "true" : "false") : "null", merge_diff);
         else
             std::printf("{\"driver\": \"tools/kinfu_stream.cpp (C++, tsdf_pipeline_step)\", ");
-        std::printf("\"grid\": %u, \"image\": [%u, %u], \"frames_in_directory\": %zu, "
+        std::printf("\"grid\": %u, \"planes\": %u, \"image\": [%u, %u], \"frames_in_directory\": %zu, "
                     "\"steps\": %d, \"warmup\": %d, \"overlap\": %s, \"cull_ahead\": %s, \"ms_per_step\": %.4f, \"value\": %.3f, \"unit\": \"Mvoxels/s\", "
                     "\"last_frame_vertex_bits\": %lld, \"last_frame_normal_bits\": %lld, \"last_frame_hits\": %lld}\n",
-                    n, W, H, F, K, Wu, overlap ? "true" : "false", cull_ahead ? "true" : "false", ms, voxels * K / elapsed / 1e6, bits_v, bits_n, hits);
+                    n, planes, W, H, F, K, Wu, overlap ? "true" : "false", cull_ahead ? "true" : "false", ms, voxels * K / elapsed / 1e6, bits_v, bits_n, hits);
     }
 
     if (!dump_dir.empty() && ranks > 1) {   // the merged picture (rank 0) and every rank's slab of the volume (its own planes, without the halo)
@@ -377,7 +401,7 @@ int main(int argc, char **argv) {
     } else if (!dump_dir.empty()) {
         dump(dump_dir + "/vertices.f32", V.data(), V.size() * sizeof(float));
         dump(dump_dir + "/normals.f32", N.data(), N.size() * sizeof(float));
-        std::vector<float> a((size_t)n * n * n);
+        std::vector<float> a((size_t)n * n * planes);
         ok(tsdf_volume_get_distance_data(vol, a.data()), "distances");
         dump(dump_dir + "/distances.f32", a.data(), a.size() * sizeof(float));
         ok(tsdf_volume_get_weight_data(vol, a.data()), "weights");

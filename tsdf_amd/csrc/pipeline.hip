@@ -26,6 +26,9 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <algorithm>
+#include <vector>
+
 #include "common.hpp"
 
 // ---- RCCL, by hand: only the five entry points used, resolved with dlsym (rccl.h: NCCL_UNIQUE_ID_BYTES = 128, ncclUint8 = 1)
@@ -38,6 +41,7 @@ typedef int (*nccl_comm_init_rank_fn)(void **comm, int nranks, NcclUniqueId id, 
 typedef int (*nccl_all_gather_fn)(const void *send, void *recv, size_t count, int dtype, void *comm, hipStream_t stream);
 typedef int (*nccl_comm_destroy_fn)(void *comm);
 typedef const char *(*nccl_get_error_string_fn)(int);
+typedef int (*nccl_comm_count_fn)(const void *comm, int *count);
 constexpr int kNcclUint8 = 1;
 
 struct Rccl {
@@ -47,6 +51,7 @@ struct Rccl {
     nccl_all_gather_fn all_gather = nullptr;
     nccl_comm_destroy_fn comm_destroy = nullptr;
     nccl_get_error_string_fn error_string = nullptr;
+    nccl_comm_count_fn comm_count = nullptr;   // (optional: what the communicator itself says its size is)
 };
 
 // library == nullptr: the librccl this process holds already if any, else the one of the ROCm installation
@@ -69,6 +74,7 @@ int open_rccl(const char *library, Rccl &r) {
     r.all_gather = (nccl_all_gather_fn)dlsym(r.dl, "ncclAllGather");
     r.comm_destroy = (nccl_comm_destroy_fn)dlsym(r.dl, "ncclCommDestroy");
     r.error_string = (nccl_get_error_string_fn)dlsym(r.dl, "ncclGetErrorString");
+    r.comm_count = (nccl_comm_count_fn)dlsym(r.dl, "ncclCommCount");
     if (!r.get_unique_id || !r.comm_init_rank || !r.all_gather || !r.comm_destroy || !r.error_string) {
         tsdf::set_error("slab exchange: librccl lacks a symbol (ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy / ncclGetErrorString)");
         dlclose(r.dl);
@@ -214,6 +220,130 @@ int tsdf_slab_exchange_world(const tsdf_slab_exchange *x, int *rank, int *world)
     TSDF_REQUIRE(x, "null exchange");
     if (rank) *rank = x->rank;
     if (world) *world = x->world;
+    return TSDF_OK;
+}
+
+int tsdf_slab_exchange_ranks_seen(const tsdf_slab_exchange *x, int *ranks) {
+    TSDF_REQUIRE(x && ranks, "null argument");
+    *ranks = x->world;
+    if (!x->callback && x->comm && x->rccl.comm_count) {
+        int n = 0;
+        const int e = x->rccl.comm_count(x->comm, &n);
+        if (e != 0) return rccl_fail(x->rccl, e, "ncclCommCount");
+        *ranks = n;
+    }
+    return TSDF_OK;
+}
+
+namespace {
+// words of a and b that differ (a NaN equals a NaN)
+__global__ __launch_bounds__(256) void count_differing_words_kernel(const float *__restrict__ a, const float *__restrict__ b, size_t n,
+                                                                    unsigned long long *__restrict__ count) {
+    unsigned long long c = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float x = a[i], y = b[i];
+        c += (__float_as_uint(x) != __float_as_uint(y) && !(x != x && y != y)) ? 1ull : 0ull;
+    }
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & 63u) == 0 && c) atomicAdd(count, c);
+}
+}  // namespace
+
+// SURVEY.md 8e, mode B: the cross-rank validator of the merge path.  Every rank gathers every rank's distance slab (its own planes,
+// padded to the longest slab; the same collective as the frame's, by the byte), assembles the whole volume, casts it the ordinary
+// single-volume way and counts the words in which that picture differs from the merged one it was handed.  Collective: every rank of
+// the exchange calls it with its own slab.  Expensive by design (4 N bytes per rank at the node's link rate, a whole volume resident per
+// rank): for validation, never inside a timed step.
+int tsdf_slab_validate_merge(tsdf_volume *slab, tsdf_slab_exchange *x, uint32_t width, uint32_t height, const float pose[16],
+                             const float kinv[9], const float *device_merged_vertices, const float *device_merged_normals,
+                             uint64_t *differing_words) {
+    TSDF_REQUIRE(slab && x && pose && kinv && device_merged_vertices && differing_words, "tsdf_slab_validate_merge: null argument");
+    *differing_words = ~0ull;
+    const Geom &g = slab->g;
+    const size_t xy = (size_t)g.X * g.Y;
+    hipStream_t s = slab->stream;
+    int rc = occupancy_join(slab);
+    if (rc != TSDF_OK) return rc;
+    // (1) everybody's plane range
+    tsdf_hit_record *ranges_dev = nullptr;
+    std::vector<tsdf_hit_record> ranges((size_t)x->world);
+    TSDF_HIP(hipMalloc((void **)&ranges_dev, ((size_t)x->world + 1) * sizeof(tsdf_hit_record)), "validate merge: alloc");
+    const uint32_t mine[2] = {slab->z_begin, slab->z_end};
+    static_assert(sizeof(tsdf_hit_record) == 8, "a record is two words");
+    hipError_t e = hipMemcpyAsync(ranges_dev + x->world, mine, sizeof(mine), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) rc = tsdf_slab_exchange_all_gather(x, ranges_dev + x->world, ranges_dev, 1, s);
+    if (e == hipSuccess && rc == TSDF_OK) e = hipMemcpyAsync(ranges.data(), ranges_dev, ranges.size() * sizeof(tsdf_hit_record), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && rc == TSDF_OK) e = hipStreamSynchronize(s);
+    (void)hipFree(ranges_dev);
+    if (rc != TSDF_OK) return rc;
+    if (e != hipSuccess) return hip_fail(e, "validate merge: plane ranges");
+    uint32_t longest = 0, covered = 0;
+    for (int r = 0; r < x->world; r++) {
+        uint32_t zb, ze;
+        memcpy(&zb, reinterpret_cast<const char *>(&ranges[r]), 4);
+        memcpy(&ze, reinterpret_cast<const char *>(&ranges[r]) + 4, 4);
+        TSDF_REQUIRE(zb == covered && ze > zb && ze <= g.Z, "tsdf_slab_validate_merge: the ranks' slabs are not consecutive plane ranges of the grid");
+        covered = ze;
+        longest = std::max(longest, ze - zb);
+    }
+    TSDF_REQUIRE(covered == g.Z, "tsdf_slab_validate_merge: the ranks' slabs do not cover the grid");
+    // (2) the slabs themselves, by the byte: records of 8 bytes, rank r's at r * per_rank
+    const size_t per_rank = ((size_t)longest * xy + 1) / 2;   // records per rank
+    TSDF_REQUIRE(per_rank <= 0xffffffffull, "tsdf_slab_validate_merge: slab too long for one collective");
+    tsdf_hit_record *send = nullptr, *recv = nullptr;
+    tsdf_volume *whole = nullptr;
+    float *V = nullptr, *N = nullptr;
+    unsigned long long *count_dev = nullptr;
+    auto cleanup = [&]() {
+        if (send) (void)hipFree(send);
+        if (recv) (void)hipFree(recv);
+        if (V) (void)hipFree(V);
+        if (N) (void)hipFree(N);
+        if (count_dev) (void)hipFree(count_dev);
+        if (whole) (void)tsdf_volume_destroy(whole);
+    };
+    e = hipMalloc((void **)&send, per_rank * sizeof(tsdf_hit_record));
+    if (e == hipSuccess) e = hipMalloc((void **)&recv, per_rank * (size_t)x->world * sizeof(tsdf_hit_record));
+    if (e == hipSuccess) e = hipMemsetAsync(send, 0, per_rank * sizeof(tsdf_hit_record), s);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(send, slab->dist + (size_t)(slab->z_begin - g.z_store_begin) * xy, (size_t)(slab->z_end - slab->z_begin) * xy * sizeof(float),
+                           hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) { cleanup(); return hip_fail(e, "validate merge: staging"); }
+    rc = tsdf_slab_exchange_all_gather(x, send, recv, (uint32_t)per_rank, s);
+    if (rc != TSDF_OK) { cleanup(); return rc; }
+    // (3) the whole volume with this slab's header, and its ordinary cast
+    rc = tsdf_volume_create(g.X, g.Y, g.Z, g.phys.x, g.phys.y, g.phys.z, &whole);
+    if (rc == TSDF_OK) {
+        const float off[3] = {g.offset.x, g.offset.y, g.offset.z};
+        rc = tsdf_volume_set_header(whole, off, g.trunc, slab->max_weight, slab->global_translation, slab->global_rotation);
+    }
+    if (rc == TSDF_OK) rc = tsdf_volume_set_stream(whole, s);
+    if (rc != TSDF_OK) { cleanup(); return rc; }
+    for (int r = 0; r < x->world && e == hipSuccess; r++) {
+        uint32_t zb, ze;
+        memcpy(&zb, reinterpret_cast<const char *>(&ranges[r]), 4);
+        memcpy(&ze, reinterpret_cast<const char *>(&ranges[r]) + 4, 4);
+        e = hipMemcpyAsync(whole->dist + (size_t)zb * xy, reinterpret_cast<const float *>(recv + (size_t)r * per_rank), (size_t)(ze - zb) * xy * sizeof(float),
+                           hipMemcpyDeviceToDevice, s);
+    }
+    const size_t words = (size_t)width * height * 3;
+    if (e == hipSuccess) e = hipMalloc((void **)&V, words * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&N, words * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&count_dev, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemsetAsync(count_dev, 0, sizeof(unsigned long long), s);
+    if (e != hipSuccess) { cleanup(); return hip_fail(e, "validate merge: assembling the volume"); }
+    rc = tsdf_volume_mark_dirty(whole);   // (the distances were written through the pointer)
+    if (rc == TSDF_OK) rc = tsdf_raycast_device(whole, width, height, pose, kinv, V, device_merged_normals ? N : nullptr);
+    if (rc != TSDF_OK) { cleanup(); return rc; }
+    hipLaunchKernelGGL(count_differing_words_kernel, dim3(256), dim3(256), 0, s, V, device_merged_vertices, words, count_dev);
+    if (device_merged_normals) hipLaunchKernelGGL(count_differing_words_kernel, dim3(256), dim3(256), 0, s, N, device_merged_normals, words, count_dev);
+    unsigned long long n_diff = 0;
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&n_diff, count_dev, sizeof(n_diff), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    cleanup();
+    if (e != hipSuccess) return hip_fail(e, "validate merge: comparing the pictures");
+    *differing_words = n_diff;
     return TSDF_OK;
 }
 

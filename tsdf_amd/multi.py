@@ -256,6 +256,26 @@ class SlabExchange:
         self._check(self._lib.tsdf_slab_exchange_all_gather(self._h, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()), nbytes // 8,
                                                             C.c_void_p(int(stream))))
 
+    def ranks_seen(self):
+        """How many ranks the communicator itself reports (ncclCommCount; the world of a caller's own collective)."""
+        n = self._C.c_int()
+        self._check(self._lib.tsdf_slab_exchange_ranks_seen(self._h, self._C.byref(n)))
+        return n.value
+
+    def validate_merge(self, slab_volume, width, height, cam, merged_vertices, merged_normals=None):
+        """SURVEY.md 8e mode B (tsdf_slab_validate_merge): all-gather of the ranks' distance slabs, the whole volume's ordinary ray cast
+        on every rank, and the number of words in which it differs from the merged picture (CUDA tensors).  Collective; 0 = equal."""
+        import numpy as np
+        C = self._C
+        pose = np.ascontiguousarray(cam.pose(), np.float32).reshape(-1)
+        kinv = np.ascontiguousarray(cam.kinv(), np.float32).reshape(-1)
+        fp = C.POINTER(C.c_float)
+        n = C.c_uint64()
+        self._check(self._lib.tsdf_slab_validate_merge(slab_volume._h, self._h, width, height, pose.ctypes.data_as(fp), kinv.ctypes.data_as(fp),
+                                                       C.c_void_p(merged_vertices.data_ptr()),
+                                                       C.c_void_p(merged_normals.data_ptr()) if merged_normals is not None else None, C.byref(n)))
+        return int(n.value)
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             self._lib.tsdf_slab_exchange_destroy(self._h)
