@@ -48,7 +48,7 @@ hip: $(LIBDIR)/libtsdf_hip.so
 # (0.0804 against 0.0816 ms; it costs the latency-bound ray kernels 13 % and the bilateral filter 11 %: those keep the default)
 $(CSRC)/integrate_packed.o: HIPFLAGS += -mllvm -amdgpu-sched-strategy=max-ilp
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.hpp $(CSRC)/integrate_grid.hpp include/tsdf_amd.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.hpp) include/tsdf_amd.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIBDIR)/libtsdf_hip.so: $(HIP_OBJS)

@@ -29,3 +29,4 @@ for base, what in ((0, "bulk kernel, lane-passes"), (8, "tail kernel, lane-round
     for i, nm in enumerate(names):
         print("   %-26s %9d  %5.1f %%" % (nm, c[base + i], 100.0 * c[base + i] / tot))
 print("bulk wave-passes by active lanes (1-4, 5-16, 17-32, 33-64):", c[24:28].tolist(), " passes 12+:", c[28:32].tolist())
+print("cell cast: bricks %d, mixed cells %d, (cell, pixel) pairs %d, pairs whose ray crosses the cell %d, ... not behind a known hit %d, candidate samples %d, evaluated from the cell %d, by the full path %d" % tuple(c[32:40].tolist()))

@@ -49,6 +49,10 @@ struct Tuning {
     int ray_tile_map;        // TSDF_RAY_TILE_MAP       which tiles an XCD gets: 0 every eighth, 1 a contiguous eighth, 2 one block per block row (default)
     int ray_learned_order;   // TSDF_RAY_LEARNED_ORDER  0: launch order, one workgroup per (range, tile) (default 1: the order learnt from the previous cast)
     int ray_heavy_passes;    // TSDF_RAY_HEAVY_PASSES   passes from which a wave counts as long for that order (0: three quarters of the budget)
+    int ray_cells;           // TSDF_RAY_CELLS          the cell-parallel cast (raycast_cells.hpp): 0 never, 1 (default) unless the previous cast listed more than
+                             //                          TSDF_RAY_CELLS_LIMIT flagged bricks, 2 whenever the view has a projection
+    int ray_cells_limit;     // TSDF_RAY_CELLS_LIMIT    (131072)
+    int ray_cells_grid;      // TSDF_RAY_CELLS_GRID     workgroups of cast_cells_kernel (2048)
     int ray_fused;           // TSDF_RAY_FUSED          1: the march and its queue of unfinished stretches in ONE launch (process_ray_fused_kernel; measured slower, LABNOTES round 5); default 0: two launches
     int ray_entry_bound;     // TSDF_RAY_ENTRY_BOUND    0: no per-tile entry bound (default 1: rays start at the nearest flagged block their 16 x 16 tile can see)
     int icp_persistent;      // TSDF_ICP_PERSISTENT     default 0: one launch per ICP iteration (the chain); 1 / 2: all 19 in one launch with a grid barrier (slower, kept for study)
@@ -83,6 +87,7 @@ struct EntryParams;
 // volume.hip: bring fine + reach up to date; with `entry` (a whole-volume ray cast whose camera allows it) the same launch also leaves
 // the per-tile entry bound of that view (EntryParams)
 int occupancy_refresh(struct ::tsdf_volume *v, const EntryParams *entry = nullptr);
+int occupancy_flags_refresh(struct ::tsdf_volume *v);   // volume.hip: the flags only (fine, cell), not the reach summary: what the cell-parallel cast reads
 int build_t_table(struct ::tsdf_volume *v);      // volume.hip
 // timing helpers (volume.hip).  When timing is on, a launch of kernel `which` carries a start and a stop event that take the
 // dispatch's own begin / end timestamps (hipExtLaunchKernel: what rocprofv3's kernel trace reads), TSDF_LAUNCH_TIMED below.
@@ -276,6 +281,13 @@ struct tsdf_volume {
     void *tail_entries;
     uint32_t *tail_count;
     size_t tail_cap;
+    // the cell-parallel cast (raycast_cells.hpp): one 32-byte record per pixel, the list of flagged bricks (counter in front), and the
+    // list's length of the previous cast in pinned host memory (which kernels the next cast takes)
+    void *cell_rays;
+    size_t cell_rays_cap;
+    uint32_t *cell_bricks;
+    size_t cell_bricks_cap;
+    uint32_t *cell_cast_host;
     // Dispatch order of the first ray-cast kernel, learnt from the previous cast (scheduling only): ray_heavy[range][workgroup] = 1
     // when a wave of that (sample range, tile) used its whole pass budget, ray_order[z][i] = range << 16 | tile slot that the i-th
     // workgroup of the z-th slab of the launch takes -- the heavy pairs of its XCD first (raycast.hip: order_ray_tiles).

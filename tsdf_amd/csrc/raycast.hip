@@ -361,8 +361,12 @@ __device__ inline int wave_min(int v) {
 // to 1 % (the approximate reciprocals; T[k+1] - T[k] is the step to 5e-4).  So while  val - margin - n * drop > 0 (drop: the bound with that 1 % applied term by term, below)
 // sample k+n cannot be <= 0.  Returns that n, at most `limit` (the samples known to stay inside the cell); 0 when anything is NaN
 // or infinite.
-__device__ inline int lipschitz_lookahead(float val, float c000, float c100, float c010, float c110, float c001, float c101, float c011,
-                                          float c111, const SkipCtx &sc, int limit) {
+struct CellBound {   // what the look-ahead needs of a cell and a ray: the same for every sample evaluated inside the cell
+    float margin, inv_drop;
+    bool finite;
+};
+__device__ inline CellBound cell_bound(float c000, float c100, float c010, float c110, float c001, float c101, float c011, float c111,
+                                       const SkipCtx &sc) {
     const float x0 = c100 - c000, x1 = c110 - c010, x2 = c101 - c001, x3 = c111 - c011;
     const float y0 = c010 - c000, y1 = c110 - c100, y2 = c011 - c001, y3 = c111 - c101;
     const float z0 = c001 - c000, z1 = c101 - c100, z2 = c011 - c010, z3 = c111 - c110;
@@ -370,7 +374,8 @@ __device__ inline int lipschitz_lookahead(float val, float c000, float c100, flo
     const float ry = fmaxf(fmaxf(fabsf(y0), fabsf(y1)), fmaxf(fabsf(y2), fabsf(y3)));
     const float rz = fmaxf(fmaxf(fabsf(z0), fabsf(z1)), fmaxf(fabsf(z2), fabsf(z3)));
     const float rsum = (rx + ry) + rz;
-    const float margin = 4.0f * sc.eps * rsum + 2.0e-5f * (fabsf(c000) + rsum);   // |corner| <= |c000| + rsum
+    CellBound cb;
+    cb.margin = 4.0f * sc.eps * rsum + 2.0e-5f * (fabsf(c000) + rsum);   // |corner| <= |c000| + rsum
     // the ray's movement per sample in cell units, signed (posx = 1 when it moves towards +x)
     const float du = sc.posx != 0.0f ? sc.su : -sc.su, dv = sc.posy != 0.0f ? sc.sv : -sc.sv, dw = sc.posz != 0.0f ? sc.sw : -sc.sw;
     const float lx = fminf(fminf(du * x0, du * x1), fminf(du * x2, du * x3));
@@ -381,10 +386,19 @@ __device__ inline int lipschitz_lookahead(float val, float c000, float c100, flo
     // 1.01 (-(N + P)) + 0.02 P so that rising terms cannot cancel more of the fall than they are sure to
     const float rising = (fmaxf(lx, 0.0f) + fmaxf(ly, 0.0f)) + fmaxf(lz, 0.0f);
     const float drop = fmaxf(__builtin_fmaf(1.01f, -((lx + ly) + lz), 0.02f * rising), 0.0f);
-    const float x = 0.99f * (val - margin) * __builtin_amdgcn_rcpf(drop);        // (inf when f cannot fall: limit applies)
-    // (a NaN corner makes val, hence x, NaN -- fmaxf / fminf would drop it from the slopes; an infinite one makes rsum infinite)
-    if (!(rsum < INFINITY) || !(x > 0.0f)) return 0;
+    cb.inv_drop = __builtin_amdgcn_rcpf(drop);   // (inf when f cannot fall: the limit applies)
+    cb.finite = rsum < INFINITY;                 // (an infinite corner makes rsum infinite or NaN)
+    return cb;
+}
+__device__ inline int lookahead_in_cell(float val, const CellBound &cb, int limit) {
+    const float x = 0.99f * (val - cb.margin) * cb.inv_drop;
+    // (a NaN corner makes val, hence x, NaN -- fmaxf / fminf would drop it from the slopes)
+    if (!cb.finite || !(x > 0.0f)) return 0;
     return (int)fminf(x, (float)limit);
+}
+__device__ inline int lipschitz_lookahead(float val, float c000, float c100, float c010, float c110, float c001, float c101, float c011,
+                                          float c111, const SkipCtx &sc, int limit) {
+    return lookahead_in_cell(val, cell_bound(c000, c100, c010, c110, c001, c101, c011, c111, sc), limit);
 }
 
 // Diagnostics build (-DTSDF_DIAG_RAY_MIX, tools/dbg_ray_mix.py): what the passes of the two march kernels are spent on.
@@ -790,7 +804,7 @@ struct TailQueue {
     uint32_t consume;      // (classic tail kernel as the fused launch's sweep: entries are taken by overwriting their first word)
 };
 constexpr uint32_t kInvalidEntry = 0xffffffffu;
-constexpr uint32_t kTailSignals = 4;   // TailQueue::count: [0] appended, [1] sub-counters complete, [2] gave up, [3] -, then the signal words, then the sub-counters
+constexpr uint32_t kTailSignals = 4;   // TailQueue::count: [0] appended, [1] sub-counters complete, [2] gave up, [3] the cell-parallel cast's listed bricks, then the signal words, then the sub-counters
 // A marching workgroup counts itself out in one of kSubCounters words (64 words apart, by its index), the workgroup that completes a
 // word in count[1]: an atomic on ONE address from every wave of the launch serialises at 10-14 ns each -- 28 800 waves made the
 // launch 0.4 ms long (profiles/r05c_*).
@@ -1736,9 +1750,10 @@ static int check_ray_args(const tsdf_volume *v, uint32_t width, uint32_t height,
 // The entry bound of a whole-volume ray cast (EntryParams, common.hpp): usable when the camera depth of a sample is near + t --
 // K^-1 with last row (0, 0, 1) -- and the pose's 3 x 3 block has an inverse.  Fills `ep` and rp's fields and returns true, or leaves
 // rp.ztile null.  The launch that fills the words is the reach summary's (occupancy_refresh(v, &ep)).
-static bool prepare_entry_bound(tsdf_volume *v, RayParams &rp, EntryParams &ep, int &rc) {
-    rc = TSDF_OK;
-    if (!tuning().ray_entry_bound) return false;
+// The view's projection (world -> pixel) from the pose and K^-1 a cast is given: exists when the camera depth of a sample is its ray
+// parameter (K^-1 with last row (0, 0, 1)) and both 3 x 3 blocks have inverses.  Used only to BOUND what can be seen where (the entry
+// bound's tiles, the cell-parallel cast's pixel boxes): no result is computed with it.
+static bool view_projection(const tsdf_volume *v, const RayParams &rp, EntryParams &ep) {
     const Geom &g = v->g;
     const Mat33 &ki = rp.kinv;
     if (ki.m31 != 0.0f || ki.m32 != 0.0f || ki.m33 != 1.0f) return false;   // the ray's camera z must be 1 per unit of t
@@ -1774,6 +1789,12 @@ static bool prepare_entry_bound(tsdf_volume *v, RayParams &rp, EntryParams &ep, 
     ep.tiles_x = (rp.width + kEntryTile - 1) / kEntryTile; ep.tiles_y = (rp.height + kEntryTile - 1) / kEntryTile;
     ep.slack_z = 2.0f * std::max(g.vs.x, std::max(g.vs.y, g.vs.z));
     ep.units_x = (v->occ.nbx + 3) / 4; ep.units_y = (v->occ.nby + 3) / 4; ep.units_z = (v->occ.nbz + 3) / 4;
+    return true;
+}
+static bool prepare_entry_bound(tsdf_volume *v, RayParams &rp, EntryParams &ep, int &rc) {
+    rc = TSDF_OK;
+    if (!tuning().ray_entry_bound) return false;
+    if (!view_projection(v, rp, ep)) return false;
     const size_t n_words = (size_t)ep.tiles_x * ep.tiles_y + 1;
     if (v->ztile_words != n_words) {   // (first use, or another image size: both copies start reset)
         if (v->ztile) (void)hipFree(v->ztile);
@@ -1804,11 +1825,24 @@ static int refresh_for_cast(tsdf_volume *v, RayParams &rp) {
     return occupancy_refresh(v, bound ? &ep : nullptr);
 }
 
+#include "raycast_cells.hpp"
+
+// Which kernels a cast takes (scheduling only: the same bits either way).  The cell-parallel cast needs the view's projection; it is
+// left to the march kernels when the previous cast listed so many flagged bricks that marching is cheaper (arbitrary fields in which
+// every cell is mixed; TSDF_RAY_CELLS = 0 never / 1 by that count (default) / 2 whenever the view allows).
+static bool choose_cell_cast(const tsdf_volume *v, const RayParams &rp, EntryParams &ep) {
+    const int mode = tuning().ray_cells;
+    if (mode == 0 || v->occ.fine_count() >= ((size_t)1 << 30) || !view_projection(v, rp, ep)) return false;   // (a list entry: 30 bits of brick index)
+    if (mode == 2) return true;
+    const uint32_t listed = v->cell_cast_host ? *v->cell_cast_host : 0u;
+    return listed <= (uint32_t)tuning().ray_cells_limit;
+}
+
 // The production march: process_ray_kernel over the sample ranges of every ray with a pass budget, process_ray_tail_kernel
 // for the stretches it handed over, resolve_hits_kernel for the vertices (packed float3, or {k, t} records for a slab).
 template <bool SLAB>
 static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *normals = nullptr, const float *depth_inv_pose = nullptr,
-                             uint16_t *depth_out = nullptr) {
+                             uint16_t *depth_out = nullptr, const EntryParams *cells = nullptr) {
     const size_t n_pix = (size_t)rp.width * rp.height;
     const int n_segments = SLAB ? slab_ray_ranges(v) : ray_segments();
     // queue capacity: every range unfinished and cut into all the pieces its length allows (a range holds at most
@@ -1825,6 +1859,27 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
         TSDF_HIP(hipMalloc((void **)&v->ray_best, 2 * n_pix * sizeof(uint64_t)), "ray result alloc");   // (double buffered)
         v->ray_best_cap = n_pix;
         v->ray_best_dirty = 1;
+    }
+    if (cells) {
+        const size_t n_bricks_max = v->occ.fine_count();
+        if (v->cell_rays_cap < n_pix) {
+            if (v->cell_rays) (void)hipFree(v->cell_rays);
+            v->cell_rays = nullptr;
+            v->cell_rays_cap = 0;
+            TSDF_HIP(hipMalloc(&v->cell_rays, n_pix * sizeof(RayRecord)), "ray record alloc");
+            v->cell_rays_cap = n_pix;
+        }
+        if (v->cell_bricks_cap < n_bricks_max) {
+            if (v->cell_bricks) (void)hipFree(v->cell_bricks);
+            v->cell_bricks = nullptr;
+            v->cell_bricks_cap = 0;
+            TSDF_HIP(hipMalloc((void **)&v->cell_bricks, (n_bricks_max + 1) * sizeof(uint32_t)), "brick list alloc");   // (+ the counter)
+            v->cell_bricks_cap = n_bricks_max;
+        }
+        if (!v->cell_cast_host) {
+            TSDF_HIP(hipHostMalloc((void **)&v->cell_cast_host, sizeof(uint32_t), hipHostMallocDefault), "brick count mirror alloc");
+            *v->cell_cast_host = 0;
+        }
     }
     if (v->tail_cap < n_entries) {
         if (v->tail_entries) (void)hipFree(v->tail_entries);
@@ -1877,6 +1932,29 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
         tail.order = v->ray_order_valid ? v->ray_order : nullptr;
         order_job = {v->ray_heavy, v->ray_order, n_tiles, (uint32_t)n_segments, 0};
     }
+    bool order_built = false;
+    if (cells) {
+        // ---- the cell-parallel cast (raycast_cells.hpp): the rays' records, the flagged bricks, one wave per brick ----
+        CellCast cc = {reinterpret_cast<RayRecord *>(v->cell_rays), v->cell_bricks, v->tail_count + 3, v->cell_cast_host};
+        const size_t table_lds = ((size_t)kMaxSamples + 1) * sizeof(float);
+        const uint32_t n_ray_blocks = (uint32_t)((n_pix + 255) / 256);
+        const uint32_t n_list_blocks = (uint32_t)std::min<size_t>((v->occ.fine_count() / 4 + 255) / 256 + 1, 2048);
+        hipLaunchKernelGGL((cell_cast_prepare_kernel<SLAB>), dim3(n_ray_blocks + n_list_blocks), dim3(256), (uint32_t)table_lds, v->stream, v->g, rp, v->t_table,
+                           v->occ, cc, n_ray_blocks);
+        const dim3 cgrid((unsigned)tuning().ray_cells_grid);
+        if (v->fast_div)
+            TSDF_LAUNCH_TIMED(v, 1, (cast_cells_kernel<SLAB, true>), cgrid, dim3(256), v->dist, v->g, rp, *cells, v->occ, v->t_table, cc, tail.best);
+        else
+            TSDF_LAUNCH_TIMED(v, 1, (cast_cells_kernel<SLAB, false>), cgrid, dim3(256), v->dist, v->g, rp, *cells, v->occ, v->t_table, cc, tail.best);
+        if (getenv("TSDF_DEBUG_CELLS_TWICE")) {   // (diagnostics: the same launch again, every pixel's word final: what perfect culling of hidden cells would cost)
+            if (v->fast_div)
+                TSDF_LAUNCH_TIMED(v, 2, (cast_cells_kernel<SLAB, true>), cgrid, dim3(256), v->dist, v->g, rp, *cells, v->occ, v->t_table, cc, tail.best);
+            else
+                TSDF_LAUNCH_TIMED(v, 2, (cast_cells_kernel<SLAB, false>), cgrid, dim3(256), v->dist, v->g, rp, *cells, v->occ, v->t_table, cc, tail.best);
+        }
+        TSDF_HIP(hipGetLastError(), "cell-parallel cast failed");
+        if (v->after_bulk) TSDF_HIP(hipEventRecord(v->after_bulk, v->stream), "process_ray: bulk kernel event");
+    } else {
     rp.seg_len = (kMaxSamples + n_segments - 1) / n_segments;
     rp.slab_ranges = SLAB ? (uint32_t)n_segments : 0u;
     rp.tile_map = (uint32_t)tuning().ray_tile_map;
@@ -1963,7 +2041,7 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
     order_job.range_order = rp.range_order;
     dim3 tgrid_(tail_grid() + kOrderWorkgroups);
     if (!fused) tail.wave_log = tail_log;
-    const bool order_built = order_job.n_ranges != 0;
+    order_built = order_job.n_ranges != 0;
     if (fused) {
         // the sweep: returns at once unless a queue worker gave up waiting (count[2]); then it finishes the entries still in the queue
         tail.consume = 1;
@@ -2005,6 +2083,7 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
         uint32_t n_tail = 0;
         (void)hipMemcpy(&n_tail, v->tail_count, sizeof(n_tail), hipMemcpyDeviceToHost);
         fprintf(stderr, "tsdf: %u pieces of the %zu (ray, range) pairs finished by the tail kernel\n", n_tail, n_pix * n_segments);
+    }
     }
     const dim3 rgrid((unsigned)((n_pix + 255) / 256)), tgrid((rp.width + 15) / 16, (rp.height + 15) / 16);
     if (!SLAB && normals) {
@@ -2048,6 +2127,12 @@ int tsdf_raycast_device(const tsdf_volume *v, uint32_t width, uint32_t height, c
     TSDF_REQUIRE(device_vertices, "tsdf_raycast: null vertex buffer");
     TSDF_REQUIRE(v->z_begin == 0 && v->z_end == v->g.Z, "tsdf_raycast on a slab: use tsdf_raycast_slab_device");
     RayParams rp = make_params(v, width, height, pose, kinv);
+    EntryParams view;
+    if (choose_cell_cast(v, rp, view)) {
+        rc = occupancy_flags_refresh(const_cast<tsdf_volume *>(v));
+        if (rc != TSDF_OK) return rc;
+        return march_and_resolve<false>(const_cast<tsdf_volume *>(v), rp, device_vertices, device_normals, nullptr, nullptr, &view);
+    }
     rc = refresh_for_cast(const_cast<tsdf_volume *>(v), rp);
     if (rc != TSDF_OK) return rc;
     return march_and_resolve<false>(const_cast<tsdf_volume *>(v), rp, device_vertices, device_normals);
@@ -2085,6 +2170,12 @@ int tsdf_raycast_depth_device(const tsdf_volume *v, uint32_t width, uint32_t hei
     TSDF_REQUIRE(device_depth && inv_pose, "tsdf_raycast_depth: null argument");
     TSDF_REQUIRE(v->z_begin == 0 && v->z_end == v->g.Z, "tsdf_raycast_depth needs a whole volume");
     RayParams rp = make_params(v, width, height, pose, kinv);
+    EntryParams view;
+    if (choose_cell_cast(v, rp, view)) {
+        rc = occupancy_flags_refresh(const_cast<tsdf_volume *>(v));
+        if (rc != TSDF_OK) return rc;
+        return march_and_resolve<false>(const_cast<tsdf_volume *>(v), rp, device_vertices, nullptr, inv_pose, device_depth, &view);
+    }
     rc = refresh_for_cast(const_cast<tsdf_volume *>(v), rp);
     if (rc != TSDF_OK) return rc;
     return march_and_resolve<false>(const_cast<tsdf_volume *>(v), rp, device_vertices, nullptr, inv_pose, device_depth);
@@ -2181,9 +2272,15 @@ int tsdf_raycast_slab_device(const tsdf_volume *v, uint32_t width, uint32_t heig
     int rc = check_ray_args(v, width, height, pose, kinv);
     if (rc != TSDF_OK) return rc;
     TSDF_REQUIRE(device_hits, "tsdf_raycast_slab: null hit buffer");
+    RayParams rp = make_params(v, width, height, pose, kinv);
+    EntryParams view;
+    if (choose_cell_cast(v, rp, view)) {
+        rc = occupancy_flags_refresh(const_cast<tsdf_volume *>(v));
+        if (rc != TSDF_OK) return rc;
+        return march_and_resolve<true>(const_cast<tsdf_volume *>(v), rp, reinterpret_cast<float *>(device_hits), nullptr, nullptr, nullptr, &view);
+    }
     rc = occupancy_refresh(const_cast<tsdf_volume *>(v));
     if (rc != TSDF_OK) return rc;
-    RayParams rp = make_params(v, width, height, pose, kinv);
     // as on a single GPU the march is split into sample ranges; one {k, t} record per pixel leaves this rank
     return march_and_resolve<true>(const_cast<tsdf_volume *>(v), rp, reinterpret_cast<float *>(device_hits));
 }

@@ -1,0 +1,417 @@
+// The cell-parallel cast (round 5): the reference's first sample <= 0 of every ray WITHOUT marching the rays.
+// (Included by raycast.hip inside namespace tsdf, behind the helpers it uses: ray_geometry / setup_ray, trilinear, the evaluation
+// expressions of process_sample, lipschitz_lookahead, hit_word / lower_best.)
+//
+// process_ray (src/RayCaster/GPURaycaster.cu:265-377) stops at the first sample whose interpolated value is <= 0.  The march kernels
+// above find it ray by ray, each ray a chain of dependent look-ups whose length is the number of cells it crosses near surfaces; a wave
+// is as slow as its slowest lane and the launches as their slowest waves (22 passes of 2.5 us, then the queue: 0.12 ms for 1.07 M
+// evaluated samples).  But WHICH samples can be <= 0 is a property of the volume, not of the ray:
+//   * a sample strictly inside the lattice of voxel centres interpolates the 8 voxels of its dual cell with weights in [0, 1]: it can
+//     only be <= 0 when one of the 8 is not safely positive (kCellPositive, process_sample) -- a MIXED cell.  Mixed cells lie in
+//     bricks whose `cell` flag is set (OccGrid: a superset at all times), and those in bricks whose `fine` flag is set too;
+//   * a sample in the outer half-voxel shell of the grid (where the reference extrapolates, Q10) or off the grid by rounding can only
+//     be <= 0 when the boundary brick of its voxel is flagged (`fine`: otherwise every voxel in reach is flat, OccGrid).
+// So the work is turned round: one wave per flagged brick.  It loads the brick's 5^3 voxels once, finds its mixed cells, projects each
+// (grown by the guard band eps) into the image -- the view's projection is only used to bound the PIXELS worth looking at -- and for
+// every such pixel intersects that pixel's ray (the same start point and direction as ever: ray_records_kernel runs setup_ray) with
+// the cell, walks the few samples inside -- the reference's expressions for the value, the look-ahead of process_sample to pass the
+// ones proven positive -- and lowers the pixel's word to the first one <= 0.  A sample within eps of a cell face, where the cheap
+// arithmetic and the reference's may disagree about the cell, takes the reference's full trilinearly_interpolate, which picks its own
+// cell: it is evaluated by the task of every mixed cell it could belong to, and two tasks that evaluate the same sample compute the
+// same value.  The minimum over all tasks (atomicMin on {k, value}) is the sample the reference's loop stops at: every sample <= 0 is
+// found by some task, and every sample evaluated is one the reference would evaluate with the same result.  resolve_*_kernel is unchanged.
+// No ray is marched through free space, no wave waits for a long ray: the cast is the number of (mixed cell, pixel) pairs, a few per ray.
+// Needs a view whose projection exists (camera depth == ray parameter: view_projection); a mixed cell that straddles the camera plane
+// is offered to every pixel.  Volumes whose flagged bricks are so many that marching is cheaper (arbitrary fields: every cell mixed)
+// keep the march kernels: the count of the previous cast decides (scheduling only -- both give the same bits).
+
+struct RayRecord {      // 32 bytes per pixel: what setup_ray leaves
+    float dx, dy, dz;   // direction (not normalised: Q6)
+    uint32_t k_range;   // first sample | one past the last << 16 (k_end <= 4402)
+    float sx, sy, sz;   // start point in grid coordinates
+    float pad;
+};
+static_assert(sizeof(RayRecord) == 32, "two 16-byte loads");
+
+struct CellCast {
+    RayRecord *rays;        // width * height
+    uint32_t *bricks;       // flagged bricks: index | kCellTasks | kShellTasks
+    uint32_t *n_bricks;     // entries appended: TailQueue::count[3], reset by the resolve kernel of the previous cast
+    uint32_t *n_bricks_host;  // pinned mirror of the count (the next cast's choice of kernels), may be null
+};
+constexpr uint32_t kCellTasks = 1u << 31, kShellTasks = 1u << 30, kBrickIndexMask = (1u << 30) - 1u;
+
+// One launch in front of the cast, two kinds of workgroup.
+// The first n_ray_blocks: per pixel the direction, start point and sample range of its ray, exactly as the march kernels set a ray up
+// (setup_ray with the whole table: samples [k_first, k_end) are the ones the reference evaluates unless it stops earlier; a slab's range
+// is clipped to a superset of its own stretch).
+// The others: the bricks the cast has to look at -- `cell` and `fine` set (mixed cells), or a brick touching the grid boundary with
+// `fine` set (shell samples); a slab lists the bricks that hold a cell whose lower plane it owns.  Four bricks a thread (one word of
+// each flag array), the brick's coordinates only for a flagged one, and ONE atomic per workgroup of 1 024 bricks: returning atomics
+// on one address serialise at ~10 ns each, and one per wave and word made this 37 us for 20 000 listed bricks.  The counter
+// (TailQueue::count[3]) is reset by the resolve kernel of the previous cast.
+template <bool SLAB>
+__global__ __launch_bounds__(256) void cell_cast_prepare_kernel(const Geom g, const RayParams rp, const float *__restrict__ t_table, const OccGrid occ,
+                                                                const CellCast cc, const uint32_t n_ray_blocks) {
+    extern __shared__ float Ts[];   // T[0 .. kMaxSamples] (ray workgroups); the list workgroups use its first words
+    if (blockIdx.x < n_ray_blocks) {
+        for (int i = (int)threadIdx.x; i <= kMaxSamples; i += 256) Ts[i] = t_table[i];
+        __syncthreads();
+        const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+        if (i >= rp.width * rp.height) return;
+        RayState ray;
+        int k_first, k_end;
+        setup_ray<SLAB>((int)(i % rp.width), (int)(i / rp.width), true, 0, kMaxSamples, Ts, 0, rp, g, Ts[1], ray, k_first, k_end);
+        if (k_end <= k_first) k_first = k_end = 0;
+        float4 *dst = reinterpret_cast<float4 *>(cc.rays + i);
+        dst[0] = make_float4(ray.dx, ray.dy, ray.dz, __uint_as_float((uint32_t)k_first | ((uint32_t)k_end << 16)));
+        dst[1] = make_float4(ray.sx, ray.sy, ray.sz, 0.0f);
+        return;
+    }
+    uint32_t *wave_count = reinterpret_cast<uint32_t *>(Ts);   // [0..3] the waves' entries, [4] the workgroup's base in the list
+    const uint32_t n = (uint32_t)occ.fine_count(), n_words = (n + 3u) / 4u, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t *fine4 = reinterpret_cast<const uint32_t *>(occ.fine), *cell4 = reinterpret_cast<const uint32_t *>(occ.cell);
+    const uint32_t n_list_blocks = gridDim.x - n_ray_blocks;
+    for (uint32_t w0 = (blockIdx.x - n_ray_blocks) * 256u; w0 < n_words; w0 += n_list_blocks * 256u) {   // (uniform over the workgroup)
+        const uint32_t w = w0 + threadIdx.x;
+        uint32_t f = 0, c = 0;
+        if (w < n_words) {
+            if (4u * w + 3u < n) {
+                f = fine4[w];
+                if (f) c = cell4[w];
+            } else {   // (the array's last, partial word)
+                for (uint32_t j = 0; 4u * w + j < n; j++) {
+                    f |= (occ.fine[4u * w + j] ? 1u : 0u) << (8u * j);
+                    c |= (occ.cell[4u * w + j] ? 1u : 0u) << (8u * j);
+                }
+            }
+        }
+        if (__syncthreads_or(f != 0u) == 0) continue;
+        uint32_t entry[4], mine_n = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; j++) {
+            entry[j] = 0;
+            if ((f >> (8u * j)) & 0xffu) {
+                const uint32_t b = 4u * w + j;
+                const uint32_t bz = b / (occ.nbx * occ.nby), r = b - bz * (occ.nbx * occ.nby), by = r / occ.nbx, bx = r - by * occ.nbx;
+                bool mine = true;
+                if (SLAB) mine = (bz + 1u) * kBrick > rp.own_lo && bz * kBrick < rp.own_hi + 1u;   // (a cell's lower plane, or a shell sample's lower tap, in [own_lo, own_hi))
+                if (mine) {
+                    if ((c >> (8u * j)) & 0xffu) entry[j] |= kCellTasks;
+                    if (bx == 0 || by == 0 || bz == 0 || bx + 1 == occ.nbx || by + 1 == occ.nby || bz + 1 == occ.nbz) entry[j] |= kShellTasks;
+                    if (entry[j]) entry[j] |= b;
+                }
+            }
+            mine_n += entry[j] ? 1u : 0u;
+        }
+        uint32_t incl = mine_n;   // inclusive prefix over the wave
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o);
+            if ((int)lane >= o) incl += up;
+        }
+        if (lane == 63u) wave_count[wave] = incl;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t total = wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+            wave_count[4] = total ? atomicAdd(cc.n_bricks, total) : 0u;
+        }
+        __syncthreads();
+        uint32_t at = wave_count[4] + incl - mine_n;
+        for (uint32_t q = 0; q < wave; q++) at += wave_count[q];
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; j++)
+            if (entry[j]) cc.bricks[at++] = entry[j];
+        __syncthreads();   // (wave_count is written again in the next turn)
+    }
+}
+
+// pixel box of the axis-aligned box [lo, hi] (grid millimetres) under the view's projection: false = no pixel can see it
+struct PixelBox {
+    int u0, v0, w, h;
+};
+__device__ inline bool project_box(const EntryParams &ep, float lox, float loy, float loz, float hix, float hiy, float hiz, PixelBox &pb) {
+    float zmin = INFINITY, zmax = -INFINITY, umin = INFINITY, umax = -INFINITY, vmin = INFINITY, vmax = -INFINITY;
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const float wx = ((c & 1) ? hix : lox) + ep.offset.x, wy = ((c & 2) ? hiy : loy) + ep.offset.y, wz = ((c & 4) ? hiz : loz) + ep.offset.z;
+        const float cx = ep.r[0][0] * wx + ep.r[0][1] * wy + ep.r[0][2] * wz + ep.r[0][3];
+        const float cy = ep.r[1][0] * wx + ep.r[1][1] * wy + ep.r[1][2] * wz + ep.r[1][3];
+        const float cz = ep.r[2][0] * wx + ep.r[2][1] * wy + ep.r[2][2] * wz + ep.r[2][3];
+        bad = bad || !(cz == cz);
+        zmin = fminf(zmin, cz);
+        zmax = fmaxf(zmax, cz);
+        const float rz = __builtin_amdgcn_rcpf(cz);   // (a bound, not a result: the margin below covers the last bits)
+        const float u = (ep.k[0][0] * cx + ep.k[0][1] * cy + ep.k[0][2] * cz) * rz, w = (ep.k[1][0] * cx + ep.k[1][1] * cy + ep.k[1][2] * cz) * rz;
+        umin = fminf(umin, u); umax = fmaxf(umax, u);
+        vmin = fminf(vmin, w); vmax = fmaxf(vmax, w);
+    }
+    // a sample's camera depth is its ray parameter (>= 0, up to rounding): a box wholly behind the camera, with room to spare, holds none
+    const float guard = ep.slack_z;   // (two voxels)
+    if (!bad && zmax < -guard) return false;
+    int u0 = 0, v0 = 0, u1 = (int)ep.width - 1, v1 = (int)ep.height - 1;
+    if (!bad && zmin > guard && umin <= umax && vmin <= vmax) {
+        // The hull of the corners bounds the projection; a ray exists per INTEGER pixel, so the pixels worth asking are the integers inside
+        // the hull's box.  Margin: the projection is the double-precision inverse of the matrices the rays are formed with, evaluated
+        // in fp32 on coordinates below 2^16 -- 1e-2 pixel at the very most; the box is that of the cell already grown by eps.
+        const float kMargin = 0.05f;
+        const float a0 = ceilf(umin - kMargin), a1 = floorf(umax + kMargin), b0 = ceilf(vmin - kMargin), b1 = floorf(vmax + kMargin);
+        if (a1 < a0 || b1 < b0 || a1 < 0.0f || b1 < 0.0f || a0 > (float)u1 || b0 > (float)v1) return false;
+        u0 = (int)fmaxf(a0, 0.0f); u1 = (int)fminf(a1, (float)u1);
+        v0 = (int)fmaxf(b0, 0.0f); v1 = (int)fminf(b1, (float)v1);
+    }   // (else: straddles the camera plane, or something not finite: every pixel is asked)
+    pb.u0 = u0; pb.v0 = v0; pb.w = u1 - u0 + 1; pb.h = v1 - v0 + 1;
+    return true;
+}
+
+// Samples of the ray (s, d) whose positions can lie in the box [lo, hi] (grid millimetres): [k_lo, k_hi], clipped to [k_first, k_end).
+// Approximate on purpose -- the caller tests every candidate's own position -- and generous by two samples either side (T[k] is k * step
+// up to the rounding of its k additions, under a sample over the whole table).
+__device__ inline bool sample_interval(const RayState &r, float lox, float loy, float loz, float hix, float hiy, float hiz, float inv_step, float step,
+                                       const float *T, int k_first, int k_end, int &k_lo, int &k_hi) {
+    float tin = 0.0f, tout = INFINITY;
+    bool miss = false;
+    auto axis = [&](float s, float d, float lo, float hi) {
+        if (d != 0.0f) {
+            const float rd = __builtin_amdgcn_rcpf(d);
+            const float t0 = (lo - s) * rd, t1 = (hi - s) * rd;
+            tin = fmaxf(tin, fminf(t0, t1));
+            tout = fminf(tout, fmaxf(t0, t1));
+        } else if (s < lo || s > hi) {
+            miss = true;
+        }
+    };
+    axis(r.sx, r.dx, lox, hix);
+    axis(r.sy, r.dy, loy, hiy);
+    axis(r.sz, r.dz, loz, hiz);
+    // (relative slack on the parameters: the reciprocal and the products are good to a few ulps, the table to a sample -- covered below)
+    if (miss || !(tin <= tout * 1.00001f + 1.0e-3f)) return false;
+    // T[k] = k * step + drift(k), the drift -- the rounding of k additions -- under a sample over the whole table and all but constant
+    // over a cell's few samples: read where the ray enters, then one sample of room either side
+    const float kc = fminf(fmaxf(rintf(tin * inv_step), 0.0f), (float)kMaxSamples);
+    const float drift = T[(int)kc] - kc * step;
+    const float a = floorf((tin - drift) * inv_step) - 1.0f, b = ceilf((tout - drift) * inv_step) + 1.0f;
+    k_lo = max(k_first, a > 0.0f ? (a < 8192.0f ? (int)a : 8192) : 0);
+    k_hi = min(k_end - 1, b < 8192.0f ? (b > 0.0f ? (int)b : 0) : 8192);
+    return k_lo <= k_hi;
+}
+
+// One wave per flagged brick; the four waves of a workgroup share the table and nothing else.
+template <bool SLAB, bool FASTDIV>
+__global__ __launch_bounds__(256) void cast_cells_kernel(const float *__restrict__ dist, const Geom g, const RayParams rp, const EntryParams ep,
+                                                         const OccGrid occ, const float *__restrict__ t_table, const CellCast cc,
+                                                         uint64_t *__restrict__ best) {
+    __shared__ float T[kTableLen];
+    __shared__ float corner[4][128];       // the brick's 5^3 voxels, x fastest
+    __shared__ int box_of[4][64][4];       // per cell lane: its pixel box
+    __shared__ int prefix[4][64];          // pairs of the cells before this one
+    for (int i = (int)threadIdx.x; i < kTableLen; i += 256) T[i] = t_table[i];
+    const uint32_t n_bricks = *cc.n_bricks;
+    if (cc.n_bricks_host && blockIdx.x == 0 && threadIdx.x == 0) *cc.n_bricks_host = n_bricks;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const float step_size = t_table[1], previous_unused = 0.0f;
+    (void)previous_unused;
+    const TriConst &tc = rp.tc;
+    SkipCtx sc = make_skip_ctx(g, step_size);
+    const float e = sc.eps;
+    const size_t plane = (size_t)g.X * g.Y;
+    __syncthreads();   // (the table; from here on the four waves go their own ways: every other array is a wave's own)
+    // LDS traffic inside one wave is in program order; the fence keeps the compiler from moving a lane's read above another lane's write
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // a brick's 5^3 voxels, lane i voxels i and i + 64: requested a turn ahead, while the brick before is worked on
+    auto brick_voxels = [&](uint32_t entry_, float &va, float &vb) {
+        va = vb = 0.0f;
+        if (!(entry_ & kCellTasks)) return;
+        const uint32_t b_ = entry_ & kBrickIndexMask;
+        const uint32_t bz_ = b_ / (occ.nbx * occ.nby), r_ = b_ - bz_ * (occ.nbx * occ.nby), by_ = r_ / occ.nbx, bx_ = r_ - by_ * occ.nbx;
+        auto voxel = [&](uint32_t i) {
+            const uint32_t cx = i % 5u, cy = (i / 5u) % 5u, cz = i / 25u;
+            const uint32_t vx = min(bx_ * kBrick + cx, g.X - 1u), vy = min(by_ * kBrick + cy, g.Y - 1u);
+            const uint32_t vz = min(max(bz_ * kBrick + cz, g.z_store_begin), g.z_store_end - 1u);   // (a cell that needs a plane this object does not hold is not valid below)
+            return dist[plane * (vz - g.z_store_begin) + (size_t)g.X * vy + vx];
+        };
+        va = voxel(lane);
+        if (lane + 64u < 125u) vb = voxel(lane + 64u);
+    };
+    const uint32_t n_waves = gridDim.x * 4u;
+    uint32_t ei = blockIdx.x * 4u + wave;
+    uint32_t entry_next = ei < n_bricks ? cc.bricks[ei] : 0u;
+    float va_next, vb_next;
+    brick_voxels(entry_next, va_next, vb_next);
+    for (; ei < n_bricks; ei += n_waves) {
+        const uint32_t entry = entry_next;
+        const float va = va_next, vb = vb_next;
+        entry_next = ei + n_waves < n_bricks ? cc.bricks[ei + n_waves] : 0u;
+        brick_voxels(entry_next, va_next, vb_next);
+        const uint32_t b = entry & kBrickIndexMask;
+        const uint32_t bz = b / (occ.nbx * occ.nby), r_xy = b - bz * (occ.nbx * occ.nby), by = r_xy / occ.nbx, bx = r_xy - by * occ.nbx;
+        const uint32_t x0 = bx * kBrick, y0 = by * kBrick, z0 = bz * kBrick;
+        wave_sync();   // (the previous turn's readers of corner / box_of / prefix)
+        corner[wave][lane] = va;
+        corner[wave][lane + 64u] = vb;
+        wave_sync();
+        // ---- the brick's mixed cells, one per lane ----
+        const uint32_t cx = lane & 3u, cy = (lane >> 2) & 3u, cz = lane >> 4;
+        const uint32_t lx = x0 + cx, ly = y0 + cy, lz = z0 + cz;
+        bool mixed = false;
+        float c000 = 0, c100 = 0, c010 = 0, c110 = 0, c001 = 0, c101 = 0, c011 = 0, c111 = 0;
+        if (entry & kCellTasks) {
+            bool valid = lx + 1u < g.X && ly + 1u < g.Y && lz + 1u < g.Z && lz >= g.z_store_begin && lz + 1u < g.z_store_end;
+            if (SLAB) valid = valid && lz >= rp.own_lo && lz < rp.own_hi;
+            const float *c = &corner[wave][cx + 5u * cy + 25u * cz];
+            c000 = c[0]; c100 = c[1]; c010 = c[5]; c110 = c[6];
+            c001 = c[25]; c101 = c[26]; c011 = c[30]; c111 = c[31];
+            const bool positive = fminf(fminf(fminf(c000, c100), fminf(c010, c110)), fminf(fminf(c001, c101), fminf(c011, c111))) > kCellPositive;
+            mixed = valid && !positive;
+        }
+        PixelBox pb = {0, 0, 0, 0};
+        // the cell in grid millimetres, grown by eps: voxel centres lx + 1/2 .. lx + 3/2
+        const float clx = ((float)lx + 0.5f - e) * g.vs.x, chx = ((float)lx + 1.5f + e) * g.vs.x;
+        const float cly = ((float)ly + 0.5f - e) * g.vs.y, chy = ((float)ly + 1.5f + e) * g.vs.y;
+        const float clz = ((float)lz + 0.5f - e) * g.vs.z, chz = ((float)lz + 1.5f + e) * g.vs.z;
+        if (mixed) mixed = project_box(ep, clx, cly, clz, chx, chy, chz, pb);
+        if (lane == 0 && ei < n_bricks) { RAY_MIX(32); }
+        if (mixed) { RAY_MIX(33); }
+        // ---- (cell, pixel) pairs, packed: pair q of the brick belongs to the last cell whose exclusive prefix is <= q ----
+        int n_mine = mixed ? pb.w * pb.h : 0, incl = n_mine;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o);
+            if ((int)lane >= o) incl += up;
+        }
+        const int n_pairs = __shfl(incl, 63);
+        prefix[wave][lane] = incl - n_mine;
+        if (mixed) {
+            box_of[wave][lane][0] = pb.u0; box_of[wave][lane][1] = pb.v0; box_of[wave][lane][2] = pb.w; box_of[wave][lane][3] = pb.h;
+        }
+        wave_sync();
+        for (int q0 = 0; q0 < n_pairs; q0 += 64) {
+            const int q = q0 + (int)lane;
+            if (q >= n_pairs) continue;
+            int cl = 0, hi_ = 63;
+#pragma unroll
+            for (int it = 0; it < 6; it++) {
+                const int mid = (cl + hi_ + 1) >> 1;
+                if (prefix[wave][mid] <= q) cl = mid; else hi_ = mid - 1;
+            }
+            const int pi = q - prefix[wave][cl];
+            const int u0 = box_of[wave][cl][0], v0 = box_of[wave][cl][1], bw = box_of[wave][cl][2];
+            // that cell's corner and voxels
+            const uint32_t qx = (uint32_t)cl & 3u, qy = ((uint32_t)cl >> 2) & 3u, qz = (uint32_t)cl >> 4;
+            const float lfx = (float)(x0 + qx), lfy = (float)(y0 + qy), lfz = (float)(z0 + qz);
+            const float blx = (lfx + 0.5f - e) * g.vs.x, bhx = (lfx + 1.5f + e) * g.vs.x;
+            const float bly = (lfy + 0.5f - e) * g.vs.y, bhy = (lfy + 1.5f + e) * g.vs.y;
+            const float blz = (lfz + 0.5f - e) * g.vs.z, bhz = (lfz + 1.5f + e) * g.vs.z;
+            {
+                RAY_MIX(34);
+                const int py = pi / bw, px = pi - py * bw;
+                const uint32_t idx = (uint32_t)(v0 + py) * rp.width + (uint32_t)(u0 + px);
+                const float4 ra = reinterpret_cast<const float4 *>(cc.rays + idx)[0], rb = reinterpret_cast<const float4 *>(cc.rays + idx)[1];
+                const RayState ray = {ra.x, ra.y, ra.z, rb.x, rb.y, rb.z};
+                const uint32_t kr = __float_as_uint(ra.w);
+                const int k_first = (int)(kr & 0xffffu), k_end = (int)(kr >> 16);
+                int k, k_hi;
+                if (!sample_interval(ray, blx, bly, blz, bhx, bhy, bhz, sc.inv_step, step_size, T, k_first, k_end, k, k_hi)) continue;
+                RAY_MIX(35);
+                if ((uint32_t)(best[idx] >> 32) <= (uint32_t)k) continue;   // (a hit in front of this cell is known already: a stale word only costs the work)
+                RAY_MIX(36);
+                const float *c = &corner[wave][qx + 5u * qy + 25u * qz];
+                const float d000 = c[0], d100 = c[1], d010 = c[5], d110 = c[6], d001 = c[25], d101 = c[26], d011 = c[30], d111 = c[31];
+                // (lower + 0.5f) * vs: the centre of the lower voxel, as process_sample forms it
+                const float lcx = (lfx + 0.5f) * g.vs.x, lcy = (lfy + 0.5f) * g.vs.y, lcz = (lfz + 0.5f) * g.vs.z;
+                SkipCtx rs = sc;
+                set_ray<true>(rs, ray, step_size, g);
+                const CellBound cb = cell_bound(d000, d100, d010, d110, d001, d101, d011, d111, rs);   // (the look-ahead's constants: per cell and ray)
+                while (k <= k_hi) {
+                    RAY_MIX(37);
+                    const float t = T[k];
+                    const float ppx = (t * ray.dx) + ray.sx, ppy = (t * ray.dy) + ray.sy, ppz = (t * ray.dz) + ray.sz;
+                    // position inside the cell, in cell units (approximate)
+                    const float rx = (ppx * rs.inv_vx - 0.5f) - lfx, ry = (ppy * rs.inv_vy - 0.5f) - lfy, rz = (ppz * rs.inv_vz - 0.5f) - lfz;
+                    const float far_ = fmaxf(fmaxf(fabsf(rx - 0.5f), fabsf(ry - 0.5f)), fabsf(rz - 0.5f));
+                    if (!(far_ <= 0.5f + e)) {   // outside the grown cell (or NaN)
+                        k++;
+                        continue;
+                    }
+                    if (far_ < 0.5f - e) {
+                        RAY_MIX(38);
+                        // the sample's dual cell is this one, to the reference's arithmetic too: its value from the 8 voxels at hand
+                        const float u = div_by<FASTDIV>(ppx - lcx, tc.dx);
+                        const float v = div_by<FASTDIV>(ppy - lcy, tc.dy);
+                        const float w = div_by<FASTDIV>(ppz - lcz, tc.dz);
+                        const float val = d000 * (1 - u) * (1 - v) * (1 - w) +
+                                          d001 * (1 - u) * (1 - v) * w +
+                                          d010 * (1 - u) * v * (1 - w) +
+                                          d011 * (1 - u) * v * w +
+                                          d100 * u * (1 - v) * (1 - w) +
+                                          d101 * u * (1 - v) * w +
+                                          d110 * u * v * (1 - w) +
+                                          d111 * u * v * w;
+                        if (val <= 0) {
+                            lower_best(&best[idx], k, val);
+                            break;
+                        }
+                        int ahead = 0;
+                        if (rs.skip_ok && val > 0) {
+                            const float cell_lo = e, cell_hi = 1.0f - e;
+                            const int n_cell = samples_until<false>(__builtin_fmaf(cell_hi - cell_lo, rs.posx, cell_lo) - rx, __builtin_fmaf(cell_hi - cell_lo, rs.posy, cell_lo) - ry,
+                                                                    __builtin_fmaf(cell_hi - cell_lo, rs.posz, cell_lo) - rz, rs);
+                            ahead = lookahead_in_cell(val, cb, n_cell - 1);
+                        }
+                        k += 1 + ahead;
+                    } else {
+                        // within eps of a face of the cell: the reference's own choice of cell and taps
+                        RAY_MIX(39);
+                        bool owned;
+                        const float tsdf = trilinear<SLAB, false, FASTDIV>(ppx, ppy, ppz, dist, g, tc, rp, owned, nullptr);
+                        if (tsdf <= 0) {
+                            lower_best(&best[idx], k, tsdf);
+                            break;
+                        }
+                        k++;
+                    }
+                }
+            }
+        }
+        // ---- shell samples of a flagged boundary brick: every pixel its voxel box can be seen by, 64 a round ----
+        if (entry & kShellTasks) {
+            // the brick's voxels in grid millimetres, grown by eps (and so reaching off the grid where the brick touches it)
+            const float fx0 = (float)x0 - e, fx1 = (float)min(x0 + kBrick, g.X) + e, fy0 = (float)y0 - e, fy1 = (float)min(y0 + kBrick, g.Y) + e;
+            const float fz0 = (float)z0 - e, fz1 = (float)min(z0 + kBrick, g.Z) + e;
+            PixelBox sb;
+            if (project_box(ep, fx0 * g.vs.x, fy0 * g.vs.y, fz0 * g.vs.z, fx1 * g.vs.x, fy1 * g.vs.y, fz1 * g.vs.z, sb)) {
+                const int n_pix = sb.w * sb.h;
+                const float hx = (float)g.X - 1.0f, hy = (float)g.Y - 1.0f, hz = (float)g.Z - 1.0f;
+                for (int pi = (int)lane; pi < n_pix; pi += 64) {
+                    const int py = pi / sb.w, px = pi - py * sb.w;
+                    const uint32_t idx = (uint32_t)(sb.v0 + py) * rp.width + (uint32_t)(sb.u0 + px);
+                    const float4 ra = reinterpret_cast<const float4 *>(cc.rays + idx)[0], rb = reinterpret_cast<const float4 *>(cc.rays + idx)[1];
+                    const RayState ray = {ra.x, ra.y, ra.z, rb.x, rb.y, rb.z};
+                    const uint32_t kr = __float_as_uint(ra.w);
+                    const int k_first = (int)(kr & 0xffffu), k_end = (int)(kr >> 16);
+                    int k, k_hi;
+                    if (!sample_interval(ray, fx0 * g.vs.x, fy0 * g.vs.y, fz0 * g.vs.z, fx1 * g.vs.x, fy1 * g.vs.y, fz1 * g.vs.z, sc.inv_step, step_size, T, k_first, k_end, k, k_hi)) continue;
+                    if ((uint32_t)(best[idx] >> 32) <= (uint32_t)k) continue;
+                    for (; k <= k_hi; k++) {
+                        const float t = T[k];
+                        const float ppx = (t * ray.dx) + ray.sx, ppy = (t * ray.dy) + ray.sy, ppz = (t * ray.dz) + ray.sz;
+                        const float fx = ppx * sc.inv_vx, fy = ppy * sc.inv_vy, fz = ppz * sc.inv_vz;
+                        // in this brick's (grown) voxel box, and its lower tap off the lattice of cells on some axis, or within eps of that
+                        const bool here = fx >= fx0 && fx <= fx1 && fy >= fy0 && fy <= fy1 && fz >= fz0 && fz <= fz1;
+                        const bool shell = fx - 0.5f < e || fy - 0.5f < e || fz - 0.5f < e || fx - 0.5f > hx - e || fy - 0.5f > hy - e || fz - 0.5f > hz - e;
+                        if (!(here && shell)) continue;
+                        bool owned;
+                        const float tsdf = trilinear<SLAB, false, FASTDIV>(ppx, ppy, ppz, dist, g, tc, rp, owned, nullptr);
+                        if (tsdf <= 0) {
+                            lower_best(&best[idx], k, tsdf);
+                            break;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}

@@ -33,6 +33,9 @@ const Tuning &tuning() {
         u.ray_segments = clamp(num("TSDF_RAY_SEGMENTS", 6), 1, 64);
         u.ray_slab_ranges = clamp(num("TSDF_RAY_SLAB_RANGES", 0), 0, 64);
         u.ray_fused = num("TSDF_RAY_FUSED", 0) != 0;
+        u.ray_cells = clamp(num("TSDF_RAY_CELLS", 1), 0, 2);
+        u.ray_cells_limit = std::max(num("TSDF_RAY_CELLS_LIMIT", 131072), 0);
+        u.ray_cells_grid = clamp(num("TSDF_RAY_CELLS_GRID", 2048), 1, 65535);
         u.ray_trip_budget = std::max(num("TSDF_RAY_TRIP_BUDGET", 22), 1);
         u.ray_tail_lanes = num("TSDF_RAY_TAIL_LANES", 4);
         if (!(u.ray_tail_lanes >= 1 && u.ray_tail_lanes <= 64 && (u.ray_tail_lanes & (u.ray_tail_lanes - 1)) == 0)) u.ray_tail_lanes = 4;
@@ -539,6 +542,11 @@ int occupancy_tighten_on(tsdf_volume *v, hipStream_t stream) {
     return TSDF_OK;
 }
 
+int occupancy_flags_refresh(tsdf_volume *v) {
+    if (v->occ_dirty || v->occ_tighten_due) return occupancy_rebuild(v);
+    return TSDF_OK;
+}
+
 int occupancy_refresh(tsdf_volume *v, const EntryParams *entry) {
     if (v->occ_dirty || v->occ_tighten_due) {
         int rc = occupancy_rebuild(v);
@@ -897,6 +905,9 @@ int tsdf_volume_destroy(tsdf_volume *v) {
     if (v->depth_pad) (void)hipFree(v->depth_pad);
     if (v->tail_entries) (void)hipFree(v->tail_entries);
     if (v->tail_count) (void)hipFree(v->tail_count);
+    if (v->cell_rays) (void)hipFree(v->cell_rays);
+    if (v->cell_bricks) (void)hipFree(v->cell_bricks);
+    if (v->cell_cast_host) (void)hipHostFree(v->cell_cast_host);
     if (v->ray_heavy) (void)hipFree(v->ray_heavy);
     if (v->ray_order) (void)hipFree(v->ray_order);
     if (v->ztile) (void)hipFree(v->ztile);
