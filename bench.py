@@ -542,10 +542,16 @@ def main():
         ray_gbs = ray_bytes / (ray_ms * 1e-3) / 1e9
         # dominant = the single kernel with the longest average launch
         dominant = "raycast" if max(ray_main_ms, ray_tail_ms) >= int_ms else "integrate"
-        roof_ray = {"kernel": "process_ray_kernel + process_ray_tail_kernel", "bound": "hbm", "achieved": round(ray_gbs, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(ray_gbs / HBM_PEAK_GBS, 5), "traffic": (traffic.get("process_ray_kernel", 0) + traffic.get("process_ray_tail_kernel", 0)) or None,
+        cells = vol.last_raycast_cell_parallel()     # which kernels the casts took: scheduling only, the same bits either way
+        ray_names = ("cast_cells_kernel", None) if cells else ("process_ray_kernel", "process_ray_tail_kernel")
+        roof_ray = {"kernel": "cast_cells_kernel" if cells else "process_ray_kernel + process_ray_tail_kernel",
+                    "cast": ("cell-parallel: one wave per flagged brick, every (mixed cell, pixel) pair's samples inside the cell; no ray is marched (raycast_cells.hpp)"
+                             if cells else "march: sample ranges with a pass budget + the queue of unfinished stretches"),
+                    "bound": "hbm", "achieved": round(ray_gbs, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(ray_gbs / HBM_PEAK_GBS, 5), "traffic": (traffic.get(ray_names[0], 0) + (traffic.get(ray_names[1], 0) if ray_names[1] else 0)) or None,
                     "algorithmic_bytes": ray_bytes, "avg_launch_ms": round(ray_ms, 4), "launches_timed": kern["raycast"][0],
-                    "avg_launch_ms_by_kernel": {"process_ray_kernel": round(ray_main_ms, 4), "process_ray_tail_kernel": round(ray_tail_ms, 4)},
+                    "avg_launch_ms_by_kernel": ({"cast_cells_kernel": round(ray_main_ms, 4)} if cells else
+                                                {"process_ray_kernel": round(ray_main_ms, 4), "process_ray_tail_kernel": round(ray_tail_ms, 4)}),
                     "T_voxels_touched": st["touched"], "S_samples": st["samples"],
                     "samples_evaluated_after_exact_skipping": st["evaluated"],
                     "msamples_per_s": round(st["samples"] / (ray_ms * 1e-3) / 1e6, 1),

@@ -3,7 +3,7 @@ python tools/dbg_ray_mix.py [frames]"""
 import sys, os, ctypes; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, tsdf_amd, torch
 from tsdf_amd import synth, _capi
-n = 512
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 v = tsdf_amd.TSDFVolume((n, n, n), (3000.,) * 3)
 bil = tsdf_amd.BilateralFilter(30.0, 4.5)
@@ -30,3 +30,5 @@ for base, what in ((0, "bulk kernel, lane-passes"), (8, "tail kernel, lane-round
         print("   %-26s %9d  %5.1f %%" % (nm, c[base + i], 100.0 * c[base + i] / tot))
 print("bulk wave-passes by active lanes (1-4, 5-16, 17-32, 33-64):", c[24:28].tolist(), " passes 12+:", c[28:32].tolist())
 print("cell cast: bricks %d, mixed cells %d, (cell, pixel) pairs %d, pairs whose ray crosses the cell %d, ... not behind a known hit %d, candidate samples %d, evaluated from the cell %d, by the full path %d" % tuple(c[32:40].tolist()))
+print("cell cast hits lowered: by the walk %d, by shell tasks %d" % tuple(c[40:42].tolist()))
+print("cell cast shell tasks: bricks %d, pixels asked %d, candidate samples %d" % tuple(c[42:45].tolist()))

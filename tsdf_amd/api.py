@@ -137,6 +137,12 @@ class TSDFVolume:
         check(lib.tsdf_volume_weight_storage(self._h, C.byref(bits), C.byref(pinned)))
         return bits.value, bool(pinned.value)
 
+    def last_raycast_cell_parallel(self):
+        """True when the volume's last ray cast took the cell-parallel kernels (scheduling only: the same bits as the march)."""
+        k = C.c_int()
+        check(lib.tsdf_volume_last_raycast_kind(self._h, C.byref(k)))
+        return bool(k.value)
+
     def set_weight_storage(self, bits):
         """Widen the weight storage now (8 -> 16 -> 32 bits, values unchanged) instead of when a count is about to overflow."""
         check(lib.tsdf_volume_set_weight_storage(self._h, int(bits)))

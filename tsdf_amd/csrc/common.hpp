@@ -52,7 +52,8 @@ struct Tuning {
     int ray_cells;           // TSDF_RAY_CELLS          the cell-parallel cast (raycast_cells.hpp): 0 never, 1 (default) unless the previous cast listed more than
                              //                          TSDF_RAY_CELLS_LIMIT flagged bricks, 2 whenever the view has a projection
     int ray_cells_limit;     // TSDF_RAY_CELLS_LIMIT    (131072)
-    int ray_cells_grid;      // TSDF_RAY_CELLS_GRID     workgroups of cast_cells_kernel (2048)
+    float ray_cells_footprint;   // TSDF_RAY_CELLS_FOOTPRINT  largest voxel footprint (pixels, at the depth of the volume's centre) the cell-parallel cast is taken for (1.8)
+    int ray_cells_grid;      // TSDF_RAY_CELLS_GRID     workgroups of cast_cells_kernel (8192: a wave per brick for 32 768 bricks, the rest in turns)
     int ray_fused;           // TSDF_RAY_FUSED          1: the march and its queue of unfinished stretches in ONE launch (process_ray_fused_kernel; measured slower, LABNOTES round 5); default 0: two launches
     int ray_entry_bound;     // TSDF_RAY_ENTRY_BOUND    0: no per-tile entry bound (default 1: rays start at the nearest flagged block their 16 x 16 tile can see)
     int icp_persistent;      // TSDF_ICP_PERSISTENT     default 0: one launch per ICP iteration (the chain); 1 / 2: all 19 in one launch with a grid barrier (slower, kept for study)
@@ -288,6 +289,7 @@ struct tsdf_volume {
     uint32_t *cell_bricks;
     size_t cell_bricks_cap;
     uint32_t *cell_cast_host;
+    int last_cast_cells;     // 1 = the last ray cast of this volume took the cell-parallel kernels (tsdf_volume_last_raycast_kind)
     // Dispatch order of the first ray-cast kernel, learnt from the previous cast (scheduling only): ray_heavy[range][workgroup] = 1
     // when a wave of that (sample range, tile) used its whole pass budget, ray_order[z][i] = range << 16 | tile slot that the i-th
     // workgroup of the z-th slab of the launch takes -- the heavy pairs of its XCD first (raycast.hip: order_ray_tiles).

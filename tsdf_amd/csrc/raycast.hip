@@ -687,8 +687,8 @@ __device__ inline float process_sample_eager(float t, const RayState &r, const S
 
 // Ray set-up: direction and start point (ray_geometry), and the range of sample indices [k_first, k_end) of the
 // sample range [k_lo, k_hi] that the reference's loop evaluates unless it hits earlier (setup_ray).  T = the staged table.
-__device__ inline bool ray_geometry(int imx, int imy, bool in_image, const RayParams &rp, RayState &ray, float &max_t, float *near_out = nullptr) {
-    // compute_ray_direction_at_pixel (:24-44); f3_normalise is a no-op (by-value argument): Q6
+// compute_ray_direction_at_pixel (:24-44); f3_normalise is a no-op (by-value argument): Q6
+__device__ inline F3 ray_direction(int imx, int imy, const RayParams &rp) {
     uint16_t pix_x = (uint16_t)imx, pix_y = (uint16_t)imy;
     float rcx = pix_x * rp.kinv.m11 + pix_y * rp.kinv.m12 + rp.kinv.m13;
     float rcy = pix_x * rp.kinv.m21 + pix_y * rp.kinv.m22 + rp.kinv.m23;
@@ -697,15 +697,22 @@ __device__ inline bool ray_geometry(int imx, int imy, bool in_image, const RayPa
     dir.x = rp.rot.m11 * rcx + rp.rot.m12 * rcy + rp.rot.m13 * rcz;
     dir.y = rp.rot.m21 * rcx + rp.rot.m22 * rcy + rp.rot.m23 * rcz;
     dir.z = rp.rot.m31 * rcx + rp.rot.m32 * rcy + rp.rot.m33 * rcz;
+    return dir;
+}
+// the start point in grid coordinates (:306) from the ray's near parameter
+__device__ inline RayState ray_from_near(const F3 &dir, float near_t, const RayParams &rp) {
+    const float sx = ((near_t * dir.x) + rp.origin.x) - rp.space_min.x;
+    const float sy = ((near_t * dir.y) + rp.origin.y) - rp.space_min.y;
+    const float sz = ((near_t * dir.z) + rp.origin.z) - rp.space_min.z;
+    return {dir.x, dir.y, dir.z, sx, sy, sz};
+}
+__device__ inline bool ray_geometry(int imx, int imy, bool in_image, const RayParams &rp, RayState &ray, float &max_t, float *near_out = nullptr) {
+    const F3 dir = ray_direction(imx, imy, rp);
 
     float near_t = 0.f, far_t = 0.f;
     bool intersects = in_image && compute_near_and_far_t(rp.origin, dir, rp.space_min, rp.space_max, near_t, far_t);
 
-    // start point in grid coordinates (:306)
-    const float sx = ((near_t * dir.x) + rp.origin.x) - rp.space_min.x;
-    const float sy = ((near_t * dir.y) + rp.origin.y) - rp.space_min.y;
-    const float sz = ((near_t * dir.z) + rp.origin.z) - rp.space_min.z;
-    ray = {dir.x, dir.y, dir.z, sx, sy, sz};
+    ray = ray_from_near(dir, near_t, rp);
     max_t = far_t - near_t;
     if (near_out) *near_out = near_t;
     return intersects;
@@ -1832,8 +1839,20 @@ static int refresh_for_cast(tsdf_volume *v, RayParams &rp) {
 // every cell is mixed; TSDF_RAY_CELLS = 0 never / 1 by that count (default) / 2 whenever the view allows).
 static bool choose_cell_cast(const tsdf_volume *v, const RayParams &rp, EntryParams &ep) {
     const int mode = tuning().ray_cells;
-    if (mode == 0 || v->occ.fine_count() >= ((size_t)1 << 30) || !view_projection(v, rp, ep)) return false;   // (a list entry: 30 bits of brick index)
+    // (a list entry: 30 bits of brick index, 10 of each brick coordinate; a record of the cast: 13 bits of sample index)
+    if (mode == 0 || v->occ.fine_count() >= ((size_t)1 << 30) || v->occ.nbx > 1024u || v->occ.nby > 1024u || v->occ.nbz > 1024u || !view_projection(v, rp, ep)) return false;
     if (mode == 2) return true;
+    // What the cast costs is the number of (mixed cell, pixel) pairs a brick's wave has to go through one after the other: a voxel that
+    // covers several pixels makes every cell a dozen pairs (256^3 at 2 m: 3 px a voxel, 300 pairs a brick, 0.17 ms against the march's
+    // 0.12; 512^3: 1.5 px, 100 pairs, 0.10 ms).  The voxel's footprint at the depth of the volume's centre decides, and the previous
+    // cell-parallel cast's list length (arbitrary fields: every brick flagged).
+    const Geom &g = v->g;
+    const float cxw = g.offset.x + 0.5f * g.phys.x, cyw = g.offset.y + 0.5f * g.phys.y, czw = g.offset.z + 0.5f * g.phys.z;
+    const float depth = ep.r[2][0] * cxw + ep.r[2][1] * cyw + ep.r[2][2] * czw + ep.r[2][3];
+    const float vs_max = std::max(g.vs.x, std::max(g.vs.y, g.vs.z));
+    const float reach = 0.25f * std::max(g.phys.x, std::max(g.phys.y, g.phys.z));   // (a camera inside the volume: surfaces a quarter of it away)
+    const float footprint = vs_max * std::max(std::fabs(ep.k[0][0]), std::fabs(ep.k[1][1])) / std::max(depth, reach);
+    if (!(footprint <= tuning().ray_cells_footprint)) return false;
     const uint32_t listed = v->cell_cast_host ? *v->cell_cast_host : 0u;
     return listed <= (uint32_t)tuning().ray_cells_limit;
 }
@@ -1873,7 +1892,7 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
             if (v->cell_bricks) (void)hipFree(v->cell_bricks);
             v->cell_bricks = nullptr;
             v->cell_bricks_cap = 0;
-            TSDF_HIP(hipMalloc((void **)&v->cell_bricks, (n_bricks_max + 1) * sizeof(uint32_t)), "brick list alloc");   // (+ the counter)
+            TSDF_HIP(hipMalloc((void **)&v->cell_bricks, n_bricks_max * sizeof(uint2)), "brick list alloc");
             v->cell_bricks_cap = n_bricks_max;
         }
         if (!v->cell_cast_host) {
@@ -1933,9 +1952,10 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
         order_job = {v->ray_heavy, v->ray_order, n_tiles, (uint32_t)n_segments, 0};
     }
     bool order_built = false;
+    v->last_cast_cells = cells ? 1 : 0;
     if (cells) {
         // ---- the cell-parallel cast (raycast_cells.hpp): the rays' records, the flagged bricks, one wave per brick ----
-        CellCast cc = {reinterpret_cast<RayRecord *>(v->cell_rays), v->cell_bricks, v->tail_count + 3, v->cell_cast_host};
+        CellCast cc = {reinterpret_cast<RayRecord *>(v->cell_rays), reinterpret_cast<uint2 *>(v->cell_bricks), v->tail_count + 3, v->cell_cast_host};
         const size_t table_lds = ((size_t)kMaxSamples + 1) * sizeof(float);
         const uint32_t n_ray_blocks = (uint32_t)((n_pix + 255) / 256);
         const uint32_t n_list_blocks = (uint32_t)std::min<size_t>((v->occ.fine_count() / 4 + 255) / 256 + 1, 2048);
@@ -2160,6 +2180,12 @@ int tsdf_raycast(const tsdf_volume *cv, uint32_t width, uint32_t height, const f
     if (host_normals)
         TSDF_HIP(hipMemcpyAsync(host_normals, v->norm_buf, bytes, hipMemcpyDeviceToHost, v->stream), "Normals Memcpy failed");
     TSDF_HIP(hipStreamSynchronize(v->stream), "process_ray failed");
+    return TSDF_OK;
+}
+
+int tsdf_volume_last_raycast_kind(const tsdf_volume *v, int *cell_parallel) {
+    TSDF_REQUIRE(v && cell_parallel, "null argument");
+    *cell_parallel = v->last_cast_cells;
     return TSDF_OK;
 }
 

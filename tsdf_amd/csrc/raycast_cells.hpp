@@ -25,17 +25,16 @@
 // is offered to every pixel.  Volumes whose flagged bricks are so many that marching is cheaper (arbitrary fields: every cell mixed)
 // keep the march kernels: the count of the previous cast decides (scheduling only -- both give the same bits).
 
-struct RayRecord {      // 32 bytes per pixel: what setup_ray leaves
-    float dx, dy, dz;   // direction (not normalised: Q6)
+struct RayRecord {      // 8 bytes per pixel: what of setup_ray's result cannot be formed again in a dozen instructions
+    float near_t;       // the ray's start point is origin + near_t * direction (ray_from_near); the direction follows from the pixel (ray_direction)
     uint32_t k_range;   // first sample | one past the last << 16 (k_end <= 4402)
-    float sx, sy, sz;   // start point in grid coordinates
-    float pad;
 };
-static_assert(sizeof(RayRecord) == 32, "two 16-byte loads");
+static_assert(sizeof(RayRecord) == 8, "one 8-byte load");
+// (32-byte records with direction and start point spelt out were 9.8 MB read in no order at all; the direction is a dozen instructions from the pixel)
 
 struct CellCast {
     RayRecord *rays;        // width * height
-    uint32_t *bricks;       // flagged bricks: index | kCellTasks | kShellTasks
+    uint2 *bricks;          // flagged bricks: {index | kCellTasks | kShellTasks, brick coordinates 3 x 10 bits}
     uint32_t *n_bricks;     // entries appended: TailQueue::count[3], reset by the resolve kernel of the previous cast
     uint32_t *n_bricks_host;  // pinned mirror of the count (the next cast's choice of kernels), may be null
 };
@@ -61,11 +60,10 @@ __global__ __launch_bounds__(256) void cell_cast_prepare_kernel(const Geom g, co
         if (i >= rp.width * rp.height) return;
         RayState ray;
         int k_first, k_end;
-        setup_ray<SLAB>((int)(i % rp.width), (int)(i / rp.width), true, 0, kMaxSamples, Ts, 0, rp, g, Ts[1], ray, k_first, k_end);
+        float near_t = 0.f;
+        setup_ray<SLAB>((int)(i % rp.width), (int)(i / rp.width), true, 0, kMaxSamples, Ts, 0, rp, g, Ts[1], ray, k_first, k_end, &near_t);
         if (k_end <= k_first) k_first = k_end = 0;
-        float4 *dst = reinterpret_cast<float4 *>(cc.rays + i);
-        dst[0] = make_float4(ray.dx, ray.dy, ray.dz, __uint_as_float((uint32_t)k_first | ((uint32_t)k_end << 16)));
-        dst[1] = make_float4(ray.sx, ray.sy, ray.sz, 0.0f);
+        cc.rays[i] = {near_t, (uint32_t)k_first | ((uint32_t)k_end << 16)};
         return;
     }
     uint32_t *wave_count = reinterpret_cast<uint32_t *>(Ts);   // [0..3] the waves' entries, [4] the workgroup's base in the list
@@ -87,10 +85,11 @@ __global__ __launch_bounds__(256) void cell_cast_prepare_kernel(const Geom g, co
             }
         }
         if (__syncthreads_or(f != 0u) == 0) continue;
-        uint32_t entry[4], mine_n = 0;
+        uint32_t entry[4], coords[4], mine_n = 0;
 #pragma unroll
         for (uint32_t j = 0; j < 4u; j++) {
             entry[j] = 0;
+            coords[j] = 0;
             if ((f >> (8u * j)) & 0xffu) {
                 const uint32_t b = 4u * w + j;
                 const uint32_t bz = b / (occ.nbx * occ.nby), r = b - bz * (occ.nbx * occ.nby), by = r / occ.nbx, bx = r - by * occ.nbx;
@@ -100,6 +99,7 @@ __global__ __launch_bounds__(256) void cell_cast_prepare_kernel(const Geom g, co
                     if ((c >> (8u * j)) & 0xffu) entry[j] |= kCellTasks;
                     if (bx == 0 || by == 0 || bz == 0 || bx + 1 == occ.nbx || by + 1 == occ.nby || bz + 1 == occ.nbz) entry[j] |= kShellTasks;
                     if (entry[j]) entry[j] |= b;
+                    coords[j] = bx | (by << 10) | (bz << 20);
                 }
             }
             mine_n += entry[j] ? 1u : 0u;
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void cell_cast_prepare_kernel(const Geom g, co
         for (uint32_t q = 0; q < wave; q++) at += wave_count[q];
 #pragma unroll
         for (uint32_t j = 0; j < 4u; j++)
-            if (entry[j]) cc.bricks[at++] = entry[j];
+            if (entry[j]) cc.bricks[at++] = make_uint2(entry[j], coords[j]);
         __syncthreads();   // (wave_count is written again in the next turn)
     }
 }
@@ -197,7 +197,16 @@ __device__ inline bool sample_interval(const RayState &r, float lox, float loy, 
 }
 
 // One wave per flagged brick; the four waves of a workgroup share the table and nothing else.
+// (Measured and dropped, profiles/r05m_*: the walk of a pair's samples deferred to a ring of the wave in LDS and done 64 records at a
+// time, all lanes busy -- three lanes in four idle through the walk otherwise -- was no faster: the deferred walks find their hits
+// later, so twice as many pairs survive the test against the pixel's word, and a record has to fetch its cell's voxels again.)
+#ifndef TSDF_CELLS_WAVES
+#define TSDF_CELLS_WAVES 4
+#endif
 template <bool SLAB, bool FASTDIV>
+#if TSDF_CELLS_WAVES
+__attribute__((amdgpu_waves_per_eu(TSDF_CELLS_WAVES, TSDF_CELLS_WAVES)))
+#endif
 __global__ __launch_bounds__(256) void cast_cells_kernel(const float *__restrict__ dist, const Geom g, const RayParams rp, const EntryParams ep,
                                                          const OccGrid occ, const float *__restrict__ t_table, const CellCast cc,
                                                          uint64_t *__restrict__ best) {
@@ -209,25 +218,47 @@ __global__ __launch_bounds__(256) void cast_cells_kernel(const float *__restrict
     const uint32_t n_bricks = *cc.n_bricks;
     if (cc.n_bricks_host && blockIdx.x == 0 && threadIdx.x == 0) *cc.n_bricks_host = n_bricks;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const float step_size = t_table[1], previous_unused = 0.0f;
-    (void)previous_unused;
+    const float step_size = t_table[1];
     const TriConst &tc = rp.tc;
-    SkipCtx sc = make_skip_ctx(g, step_size);
+    const SkipCtx sc = make_skip_ctx(g, step_size);
     const float e = sc.eps;
     const size_t plane = (size_t)g.X * g.Y;
+    // The pixel box of a cell without projecting its 8 corners.  u = N(P) / D(P), N and D affine in P, D the camera depth: for P in the
+    // (grown) cell |u(P) - u(centre)| = |N(P) - u_c D(P)| / D(P) <= S / D_min, S = half the sum over the axes of |the coefficient of
+    // N - u_c D along the cell's edge| -- the edges are the same for every cell: uniform registers.
+    const float ex = (1.0f + 2.0f * e) * g.vs.x, ey = (1.0f + 2.0f * e) * g.vs.y, ez = (1.0f + 2.0f * e) * g.vs.z;
+    float nu_[3], nv_[3], nz_[3];
+#pragma unroll
+    for (int a_ = 0; a_ < 3; a_++) {
+        const float ext = a_ == 0 ? ex : a_ == 1 ? ey : ez;
+        const float cxa = ep.r[0][a_] * ext, cya = ep.r[1][a_] * ext, cza = ep.r[2][a_] * ext;
+        nu_[a_] = ep.k[0][0] * cxa + ep.k[0][1] * cya + ep.k[0][2] * cza;
+        nv_[a_] = ep.k[1][0] * cxa + ep.k[1][1] * cya + ep.k[1][2] * cza;
+        nz_[a_] = cza;
+    }
+    const float half_dz = 0.5f * ((fabsf(nz_[0]) + fabsf(nz_[1])) + fabsf(nz_[2]));
     __syncthreads();   // (the table; from here on the four waves go their own ways: every other array is a wave's own)
     // LDS traffic inside one wave is in program order; the fence keeps the compiler from moving a lane's read above another lane's write
     auto wave_sync = [] {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's LDS traffic so far is done
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
     // a brick's 5^3 voxels, lane i voxels i and i + 64: requested a turn ahead, while the brick before is worked on
-    auto brick_voxels = [&](uint32_t entry_, float &va, float &vb) {
+    // (lane i's two voxels sit at the same offsets from the brick's first voxel in every brick that lies inside the resident planes)
+    auto offset_of = [&](uint32_t i) { return (size_t)(i / 25u) * plane + (size_t)((i / 5u) % 5u) * g.X + (i % 5u); };
+    const size_t off_a = offset_of(lane), off_b = offset_of(min(lane + 64u, 124u));
+    auto brick_voxels = [&](uint2 entry_, float &va, float &vb) {
         va = vb = 0.0f;
-        if (!(entry_ & kCellTasks)) return;
-        const uint32_t b_ = entry_ & kBrickIndexMask;
-        const uint32_t bz_ = b_ / (occ.nbx * occ.nby), r_ = b_ - bz_ * (occ.nbx * occ.nby), by_ = r_ / occ.nbx, bx_ = r_ - by_ * occ.nbx;
+        if (!(entry_.x & kCellTasks)) return;
+        const uint32_t bx_ = entry_.y & 1023u, by_ = (entry_.y >> 10) & 1023u, bz_ = entry_.y >> 20;
+        if (bx_ * kBrick + kBrick < g.X && by_ * kBrick + kBrick < g.Y && bz_ * kBrick >= g.z_store_begin && bz_ * kBrick + kBrick < g.z_store_end) {   // (uniform)
+            const float *first = dist + (plane * (bz_ * kBrick - g.z_store_begin) + (size_t)g.X * (by_ * kBrick) + bx_ * kBrick);
+            va = first[off_a];
+            vb = first[off_b];
+            return;
+        }
         auto voxel = [&](uint32_t i) {
             const uint32_t cx = i % 5u, cy = (i / 5u) % 5u, cz = i / 25u;
             const uint32_t vx = min(bx_ * kBrick + cx, g.X - 1u), vy = min(by_ * kBrick + cy, g.Y - 1u);
@@ -239,16 +270,16 @@ __global__ __launch_bounds__(256) void cast_cells_kernel(const float *__restrict
     };
     const uint32_t n_waves = gridDim.x * 4u;
     uint32_t ei = blockIdx.x * 4u + wave;
-    uint32_t entry_next = ei < n_bricks ? cc.bricks[ei] : 0u;
+    uint2 entry_next = ei < n_bricks ? cc.bricks[ei] : make_uint2(0u, 0u);
     float va_next, vb_next;
     brick_voxels(entry_next, va_next, vb_next);
     for (; ei < n_bricks; ei += n_waves) {
-        const uint32_t entry = entry_next;
+        const uint2 entry2 = entry_next;
+        const uint32_t entry = entry2.x;
         const float va = va_next, vb = vb_next;
-        entry_next = ei + n_waves < n_bricks ? cc.bricks[ei + n_waves] : 0u;
+        entry_next = ei + n_waves < n_bricks ? cc.bricks[ei + n_waves] : make_uint2(0u, 0u);
         brick_voxels(entry_next, va_next, vb_next);
-        const uint32_t b = entry & kBrickIndexMask;
-        const uint32_t bz = b / (occ.nbx * occ.nby), r_xy = b - bz * (occ.nbx * occ.nby), by = r_xy / occ.nbx, bx = r_xy - by * occ.nbx;
+        const uint32_t bx = entry2.y & 1023u, by = (entry2.y >> 10) & 1023u, bz = entry2.y >> 20;
         const uint32_t x0 = bx * kBrick, y0 = by * kBrick, z0 = bz * kBrick;
         wave_sync();   // (the previous turn's readers of corner / box_of / prefix)
         corner[wave][lane] = va;
@@ -258,23 +289,41 @@ __global__ __launch_bounds__(256) void cast_cells_kernel(const float *__restrict
         const uint32_t cx = lane & 3u, cy = (lane >> 2) & 3u, cz = lane >> 4;
         const uint32_t lx = x0 + cx, ly = y0 + cy, lz = z0 + cz;
         bool mixed = false;
-        float c000 = 0, c100 = 0, c010 = 0, c110 = 0, c001 = 0, c101 = 0, c011 = 0, c111 = 0;
         if (entry & kCellTasks) {
             bool valid = lx + 1u < g.X && ly + 1u < g.Y && lz + 1u < g.Z && lz >= g.z_store_begin && lz + 1u < g.z_store_end;
             if (SLAB) valid = valid && lz >= rp.own_lo && lz < rp.own_hi;
             const float *c = &corner[wave][cx + 5u * cy + 25u * cz];
-            c000 = c[0]; c100 = c[1]; c010 = c[5]; c110 = c[6];
-            c001 = c[25]; c101 = c[26]; c011 = c[30]; c111 = c[31];
-            const bool positive = fminf(fminf(fminf(c000, c100), fminf(c010, c110)), fminf(fminf(c001, c101), fminf(c011, c111))) > kCellPositive;
+            const bool positive = fminf(fminf(fminf(c[0], c[1]), fminf(c[5], c[6])), fminf(fminf(c[25], c[26]), fminf(c[30], c[31]))) > kCellPositive;
             mixed = valid && !positive;
         }
         PixelBox pb = {0, 0, 0, 0};
-        // the cell in grid millimetres, grown by eps: voxel centres lx + 1/2 .. lx + 3/2
-        const float clx = ((float)lx + 0.5f - e) * g.vs.x, chx = ((float)lx + 1.5f + e) * g.vs.x;
-        const float cly = ((float)ly + 0.5f - e) * g.vs.y, chy = ((float)ly + 1.5f + e) * g.vs.y;
-        const float clz = ((float)lz + 0.5f - e) * g.vs.z, chz = ((float)lz + 1.5f + e) * g.vs.z;
-        if (mixed) mixed = project_box(ep, clx, cly, clz, chx, chy, chz, pb);
-        if (lane == 0 && ei < n_bricks) { RAY_MIX(32); }
+        if (mixed) {
+            // the cell's centre (voxel centres lx + 1/2 .. lx + 3/2) in the camera's frame
+            const float wx = ((float)lx + 1.0f) * g.vs.x + ep.offset.x, wy = ((float)ly + 1.0f) * g.vs.y + ep.offset.y, wz = ((float)lz + 1.0f) * g.vs.z + ep.offset.z;
+            const float ccx = ep.r[0][0] * wx + ep.r[0][1] * wy + ep.r[0][2] * wz + ep.r[0][3];
+            const float ccy = ep.r[1][0] * wx + ep.r[1][1] * wy + ep.r[1][2] * wz + ep.r[1][3];
+            const float ccz = ep.r[2][0] * wx + ep.r[2][1] * wy + ep.r[2][2] * wz + ep.r[2][3];
+            const float zmin = ccz - half_dz;
+            if (zmin > ep.slack_z) {
+                const float rz = __builtin_amdgcn_rcpf(ccz), rm = __builtin_amdgcn_rcpf(zmin);
+                const float uc = (ep.k[0][0] * ccx + ep.k[0][1] * ccy + ep.k[0][2] * ccz) * rz, vc = (ep.k[1][0] * ccx + ep.k[1][1] * ccy + ep.k[1][2] * ccz) * rz;
+                const float su = 0.5f * ((fabsf(nu_[0] - uc * nz_[0]) + fabsf(nu_[1] - uc * nz_[1])) + fabsf(nu_[2] - uc * nz_[2]));
+                const float sv = 0.5f * ((fabsf(nv_[0] - vc * nz_[0]) + fabsf(nv_[1] - vc * nz_[1])) + fabsf(nv_[2] - vc * nz_[2]));
+                // (a ray exists per INTEGER pixel; 0.05 px over the fp32 evaluation: coordinates < 2^16, reciprocals to an ulp)
+                const float hu = su * rm * 1.0001f + 0.05f, hv = sv * rm * 1.0001f + 0.05f;
+                const float a0 = fmaxf(ceilf(uc - hu), 0.0f), a1 = fminf(floorf(uc + hu), (float)(ep.width - 1u));
+                const float b0 = fmaxf(ceilf(vc - hv), 0.0f), b1 = fminf(floorf(vc + hv), (float)(ep.height - 1u));
+                mixed = a0 <= a1 && b0 <= b1;   // (false also for anything not a number)
+                if (mixed) { pb.u0 = (int)a0; pb.v0 = (int)b0; pb.w = (int)a1 - (int)a0 + 1; pb.h = (int)b1 - (int)b0 + 1; }
+            } else {
+                // near or behind the camera plane: the 8 corners, every pixel when the cell straddles the plane
+                const float clx = ((float)lx + 0.5f - e) * g.vs.x, chx = ((float)lx + 1.5f + e) * g.vs.x;
+                const float cly = ((float)ly + 0.5f - e) * g.vs.y, chy = ((float)ly + 1.5f + e) * g.vs.y;
+                const float clz = ((float)lz + 0.5f - e) * g.vs.z, chz = ((float)lz + 1.5f + e) * g.vs.z;
+                mixed = project_box(ep, clx, cly, clz, chx, chy, chz, pb);
+            }
+        }
+        if (lane == 0) { RAY_MIX(32); }
         if (mixed) { RAY_MIX(33); }
         // ---- (cell, pixel) pairs, packed: pair q of the brick belongs to the last cell whose exclusive prefix is <= q ----
         int n_mine = mixed ? pb.w * pb.h : 0, incl = n_mine;
@@ -299,80 +348,83 @@ __global__ __launch_bounds__(256) void cast_cells_kernel(const float *__restrict
             }
             const int pi = q - prefix[wave][cl];
             const int u0 = box_of[wave][cl][0], v0 = box_of[wave][cl][1], bw = box_of[wave][cl][2];
-            // that cell's corner and voxels
             const uint32_t qx = (uint32_t)cl & 3u, qy = ((uint32_t)cl >> 2) & 3u, qz = (uint32_t)cl >> 4;
             const float lfx = (float)(x0 + qx), lfy = (float)(y0 + qy), lfz = (float)(z0 + qz);
-            const float blx = (lfx + 0.5f - e) * g.vs.x, bhx = (lfx + 1.5f + e) * g.vs.x;
-            const float bly = (lfy + 0.5f - e) * g.vs.y, bhy = (lfy + 1.5f + e) * g.vs.y;
-            const float blz = (lfz + 0.5f - e) * g.vs.z, bhz = (lfz + 1.5f + e) * g.vs.z;
-            {
-                RAY_MIX(34);
-                const int py = pi / bw, px = pi - py * bw;
-                const uint32_t idx = (uint32_t)(v0 + py) * rp.width + (uint32_t)(u0 + px);
-                const float4 ra = reinterpret_cast<const float4 *>(cc.rays + idx)[0], rb = reinterpret_cast<const float4 *>(cc.rays + idx)[1];
-                const RayState ray = {ra.x, ra.y, ra.z, rb.x, rb.y, rb.z};
-                const uint32_t kr = __float_as_uint(ra.w);
-                const int k_first = (int)(kr & 0xffffu), k_end = (int)(kr >> 16);
-                int k, k_hi;
-                if (!sample_interval(ray, blx, bly, blz, bhx, bhy, bhz, sc.inv_step, step_size, T, k_first, k_end, k, k_hi)) continue;
-                RAY_MIX(35);
-                if ((uint32_t)(best[idx] >> 32) <= (uint32_t)k) continue;   // (a hit in front of this cell is known already: a stale word only costs the work)
-                RAY_MIX(36);
-                const float *c = &corner[wave][qx + 5u * qy + 25u * qz];
-                const float d000 = c[0], d100 = c[1], d010 = c[5], d110 = c[6], d001 = c[25], d101 = c[26], d011 = c[30], d111 = c[31];
-                // (lower + 0.5f) * vs: the centre of the lower voxel, as process_sample forms it
-                const float lcx = (lfx + 0.5f) * g.vs.x, lcy = (lfy + 0.5f) * g.vs.y, lcz = (lfz + 0.5f) * g.vs.z;
-                SkipCtx rs = sc;
-                set_ray<true>(rs, ray, step_size, g);
-                const CellBound cb = cell_bound(d000, d100, d010, d110, d001, d101, d011, d111, rs);   // (the look-ahead's constants: per cell and ray)
-                while (k <= k_hi) {
-                    RAY_MIX(37);
-                    const float t = T[k];
-                    const float ppx = (t * ray.dx) + ray.sx, ppy = (t * ray.dy) + ray.sy, ppz = (t * ray.dz) + ray.sz;
-                    // position inside the cell, in cell units (approximate)
-                    const float rx = (ppx * rs.inv_vx - 0.5f) - lfx, ry = (ppy * rs.inv_vy - 0.5f) - lfy, rz = (ppz * rs.inv_vz - 0.5f) - lfz;
-                    const float far_ = fmaxf(fmaxf(fabsf(rx - 0.5f), fabsf(ry - 0.5f)), fabsf(rz - 0.5f));
-                    if (!(far_ <= 0.5f + e)) {   // outside the grown cell (or NaN)
-                        k++;
-                        continue;
+            RAY_MIX(34);
+            // (pi / bw in floats: exact below 2^22, with the half that keeps the quotient off the integers)
+            const int py = pi < (1 << 22) ? (int)(((float)pi + 0.5f) * __builtin_amdgcn_rcpf((float)bw)) : pi / bw, px = pi - py * bw;
+            const int imx = u0 + px, imy = v0 + py;
+            const uint32_t idx = (uint32_t)imy * rp.width + (uint32_t)imx;
+            const RayRecord rec_ = cc.rays[idx];
+            // (requested with the ray's record, not behind it; past the compute unit's own cache, so that what this wave's earlier pairs lowered is seen)
+            const uint32_t known = __hip_atomic_load(reinterpret_cast<const uint32_t *>(best + idx) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const RayState ray = ray_from_near(ray_direction(imx, imy, rp), rec_.near_t, rp);
+            int k, k_hi;
+            if (!sample_interval(ray, (lfx + 0.5f - e) * g.vs.x, (lfy + 0.5f - e) * g.vs.y, (lfz + 0.5f - e) * g.vs.z, (lfx + 1.5f + e) * g.vs.x,
+                                 (lfy + 1.5f + e) * g.vs.y, (lfz + 1.5f + e) * g.vs.z, sc.inv_step, step_size, T, (int)(rec_.k_range & 0xffffu),
+                                 (int)(rec_.k_range >> 16), k, k_hi))
+                continue;
+            RAY_MIX(35);
+            if (known <= (uint32_t)k) continue;   // (a hit in front of this cell is known already: a stale word only costs the work)
+            RAY_MIX(36);
+            const float *c = &corner[wave][qx + 5u * qy + 25u * qz];
+            const float d000 = c[0], d100 = c[1], d010 = c[5], d110 = c[6], d001 = c[25], d101 = c[26], d011 = c[30], d111 = c[31];
+            // (lower + 0.5f) * vs: the centre of the lower voxel, as process_sample forms it
+            const float lcx = (lfx + 0.5f) * g.vs.x, lcy = (lfy + 0.5f) * g.vs.y, lcz = (lfz + 0.5f) * g.vs.z;
+            SkipCtx rs = sc;
+            set_ray<true>(rs, ray, step_size, g);
+            const CellBound cb = cell_bound(d000, d100, d010, d110, d001, d101, d011, d111, rs);   // (the look-ahead's constants: per cell and ray)
+            bool entered = false;
+            while (k <= k_hi) {
+                RAY_MIX(37);
+                const float t = T[k];
+                const float ppx = (t * ray.dx) + ray.sx, ppy = (t * ray.dy) + ray.sy, ppz = (t * ray.dz) + ray.sz;
+                // position inside the cell, in cell units (approximate)
+                const float rx = (ppx * rs.inv_vx - 0.5f) - lfx, ry = (ppy * rs.inv_vy - 0.5f) - lfy, rz = (ppz * rs.inv_vz - 0.5f) - lfz;
+                const float far_ = fmaxf(fmaxf(fabsf(rx - 0.5f), fabsf(ry - 0.5f)), fabsf(rz - 0.5f));
+                if (!(far_ <= 0.5f + e)) {   // outside the grown cell (or NaN): not yet in, or through (a straight line does not come back)
+                    if (entered) break;
+                    k++;
+                    continue;
+                }
+                entered = true;
+                if (far_ < 0.5f - e) {
+                    RAY_MIX(38);
+                    // the sample's dual cell is this one, to the reference's arithmetic too: its value from the cell's 8 voxels
+                    const float u = div_by<FASTDIV>(ppx - lcx, tc.dx);
+                    const float v = div_by<FASTDIV>(ppy - lcy, tc.dy);
+                    const float w = div_by<FASTDIV>(ppz - lcz, tc.dz);
+                    const float val = d000 * (1 - u) * (1 - v) * (1 - w) +
+                                      d001 * (1 - u) * (1 - v) * w +
+                                      d010 * (1 - u) * v * (1 - w) +
+                                      d011 * (1 - u) * v * w +
+                                      d100 * u * (1 - v) * (1 - w) +
+                                      d101 * u * (1 - v) * w +
+                                      d110 * u * v * (1 - w) +
+                                      d111 * u * v * w;
+                    if (val <= 0) {
+                        RAY_MIX(40);
+                        lower_best(&best[idx], k, val);
+                        break;
                     }
-                    if (far_ < 0.5f - e) {
-                        RAY_MIX(38);
-                        // the sample's dual cell is this one, to the reference's arithmetic too: its value from the 8 voxels at hand
-                        const float u = div_by<FASTDIV>(ppx - lcx, tc.dx);
-                        const float v = div_by<FASTDIV>(ppy - lcy, tc.dy);
-                        const float w = div_by<FASTDIV>(ppz - lcz, tc.dz);
-                        const float val = d000 * (1 - u) * (1 - v) * (1 - w) +
-                                          d001 * (1 - u) * (1 - v) * w +
-                                          d010 * (1 - u) * v * (1 - w) +
-                                          d011 * (1 - u) * v * w +
-                                          d100 * u * (1 - v) * (1 - w) +
-                                          d101 * u * (1 - v) * w +
-                                          d110 * u * v * (1 - w) +
-                                          d111 * u * v * w;
-                        if (val <= 0) {
-                            lower_best(&best[idx], k, val);
-                            break;
-                        }
-                        int ahead = 0;
-                        if (rs.skip_ok && val > 0) {
-                            const float cell_lo = e, cell_hi = 1.0f - e;
-                            const int n_cell = samples_until<false>(__builtin_fmaf(cell_hi - cell_lo, rs.posx, cell_lo) - rx, __builtin_fmaf(cell_hi - cell_lo, rs.posy, cell_lo) - ry,
-                                                                    __builtin_fmaf(cell_hi - cell_lo, rs.posz, cell_lo) - rz, rs);
-                            ahead = lookahead_in_cell(val, cb, n_cell - 1);
-                        }
-                        k += 1 + ahead;
-                    } else {
-                        // within eps of a face of the cell: the reference's own choice of cell and taps
-                        RAY_MIX(39);
-                        bool owned;
-                        const float tsdf = trilinear<SLAB, false, FASTDIV>(ppx, ppy, ppz, dist, g, tc, rp, owned, nullptr);
-                        if (tsdf <= 0) {
-                            lower_best(&best[idx], k, tsdf);
-                            break;
-                        }
-                        k++;
+                    int ahead = 0;
+                    if (rs.skip_ok && val > 0) {
+                        const float cell_lo = e, cell_hi = 1.0f - e;
+                        const int n_cell = samples_until<false>(__builtin_fmaf(cell_hi - cell_lo, rs.posx, cell_lo) - rx, __builtin_fmaf(cell_hi - cell_lo, rs.posy, cell_lo) - ry,
+                                                                __builtin_fmaf(cell_hi - cell_lo, rs.posz, cell_lo) - rz, rs);
+                        ahead = lookahead_in_cell(val, cb, n_cell - 1);
                     }
+                    k += 1 + ahead;
+                } else {
+                    // within eps of a face of the cell: the reference's own choice of cell and taps
+                    RAY_MIX(39);
+                    bool owned;
+                    const float tsdf = trilinear<SLAB, false, FASTDIV>(ppx, ppy, ppz, dist, g, tc, rp, owned, nullptr);
+                    if (tsdf <= 0) {
+                        lower_best(&best[idx], k, tsdf);
+                        break;
+                    }
+                    k++;
                 }
             }
         }
@@ -384,18 +436,21 @@ __global__ __launch_bounds__(256) void cast_cells_kernel(const float *__restrict
             PixelBox sb;
             if (project_box(ep, fx0 * g.vs.x, fy0 * g.vs.y, fz0 * g.vs.z, fx1 * g.vs.x, fy1 * g.vs.y, fz1 * g.vs.z, sb)) {
                 const int n_pix = sb.w * sb.h;
+                if (lane == 0) { RAY_MIX(42); }
                 const float hx = (float)g.X - 1.0f, hy = (float)g.Y - 1.0f, hz = (float)g.Z - 1.0f;
                 for (int pi = (int)lane; pi < n_pix; pi += 64) {
                     const int py = pi / sb.w, px = pi - py * sb.w;
+                    RAY_MIX(43);
                     const uint32_t idx = (uint32_t)(sb.v0 + py) * rp.width + (uint32_t)(sb.u0 + px);
-                    const float4 ra = reinterpret_cast<const float4 *>(cc.rays + idx)[0], rb = reinterpret_cast<const float4 *>(cc.rays + idx)[1];
-                    const RayState ray = {ra.x, ra.y, ra.z, rb.x, rb.y, rb.z};
-                    const uint32_t kr = __float_as_uint(ra.w);
+                    const RayRecord rec_ = cc.rays[idx];
+                    const RayState ray = ray_from_near(ray_direction(sb.u0 + px, sb.v0 + py, rp), rec_.near_t, rp);
+                    const uint32_t kr = rec_.k_range;
                     const int k_first = (int)(kr & 0xffffu), k_end = (int)(kr >> 16);
                     int k, k_hi;
                     if (!sample_interval(ray, fx0 * g.vs.x, fy0 * g.vs.y, fz0 * g.vs.z, fx1 * g.vs.x, fy1 * g.vs.y, fz1 * g.vs.z, sc.inv_step, step_size, T, k_first, k_end, k, k_hi)) continue;
                     if ((uint32_t)(best[idx] >> 32) <= (uint32_t)k) continue;
                     for (; k <= k_hi; k++) {
+                        RAY_MIX(44);
                         const float t = T[k];
                         const float ppx = (t * ray.dx) + ray.sx, ppy = (t * ray.dy) + ray.sy, ppz = (t * ray.dz) + ray.sz;
                         const float fx = ppx * sc.inv_vx, fy = ppy * sc.inv_vy, fz = ppz * sc.inv_vz;
@@ -406,6 +461,7 @@ __global__ __launch_bounds__(256) void cast_cells_kernel(const float *__restrict
                         bool owned;
                         const float tsdf = trilinear<SLAB, false, FASTDIV>(ppx, ppy, ppz, dist, g, tc, rp, owned, nullptr);
                         if (tsdf <= 0) {
+                            RAY_MIX(41);
                             lower_best(&best[idx], k, tsdf);
                             break;
                         }
