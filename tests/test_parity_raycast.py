@@ -357,6 +357,10 @@ np.savez(sys.argv[1], V=V, N=N, D=gv.get_distance_data())
     {"TSDF_OCC_REBUILD_PERIOD": "1"},                                                          # flags rebuilt every frame
     {"TSDF_RAY_ENTRY_BOUND": "0"},                                                             # no per-tile entry bound (round 4)
     {"TSDF_RAY_ENTRY_BOUND": "0", "TSDF_RAY_LEARNED_ORDER": "0"},
+    {"TSDF_RAY_CELLS": "0"},                                                                   # the march kernels, whatever the view (round 5)
+    {"TSDF_RAY_CELLS": "2"},                                                                   # the cell-parallel cast wherever the view allows it
+    {"TSDF_RAY_CELLS": "2", "TSDF_RAY_CELLS_GRID": "3"},                                       # ... every wave through many bricks
+    {"TSDF_RAY_FUSED": "1", "TSDF_RAY_CELLS": "0"},                                            # the march and its queue in one launch
 ])
 def test_schedule_knobs_do_not_change_a_bit(oracle, tmp_path, env):
     """How the march is cut into sample ranges, passes and lane groups, and when the occupancy flags are refreshed, is
@@ -525,3 +529,66 @@ def test_entry_bound_a_surface_on_the_entry_face_and_speckles_in_free_space(orac
     for pos, look in (((480, 480, -700), (480, 480, 480)), ((200, 300, -400), (600, 500, 900)), ((480, 480, 300), (480, 480, 900))):
         cam = camera_at(pos, look_at=look)
         _cast_both(oracle, gv, ov, cam, what="hand-made field from %s:" % (pos,))
+
+
+_CELLS_PROBE = r"""
+import sys, json, numpy as np
+import tsdf_amd
+from tsdf_amd import synth
+from tests.helpers import camera_at
+n, views = int(sys.argv[2]), json.loads(sys.argv[3])
+gv = tsdf_amd.TSDFVolume((n, n, n), (3000, 3000, 3000))
+for i in range(4):
+    d, cam = synth.depth_frame(i, 12, seed=0x5EED0002)
+    gv.integrate(d, synth.WIDTH, synth.HEIGHT, cam)
+out = {"D": gv.get_distance_data()}
+for j, v in enumerate(views):
+    cam = camera_at(tuple(v["at"]), look_at=tuple(v["look"]) if v.get("look") else None, yaw_pitch_roll=tuple(v["ypr"]) if v.get("ypr") else None)
+    V, N = gv.raycast(synth.WIDTH, synth.HEIGHT, cam)
+    out["V%d" % j], out["N%d" % j], out["cells%d" % j] = V, N, np.array(gv.last_raycast_cell_parallel())
+np.savez(sys.argv[1], **out)
+"""
+
+
+@pytest.mark.parametrize("n", [64, 100, 160])
+def test_cell_parallel_cast_from_outside_beside_and_inside(oracle, tmp_path, n):
+    """The cell-parallel cast (raycast_cells.hpp, forced on with TSDF_RAY_CELLS=2 in a process of its own): no ray is marched, every
+    flagged brick's mixed cells are offered to the pixels they project to.  Views from outside (taken), from a camera whose plane
+    cuts through flagged bricks beside it (taken: the cells that straddle the plane in front of which all samples lie are bounded
+    from their part in front), along a face and from a corner; from inside or within four voxels of the volume (left to the march
+    kernels).  One volume cast from one pose after the other; every picture must be the oracle's, bit for bit."""
+    import json
+    import os
+    import subprocess
+    import sys
+    views = [
+        {"at": (1500, 1300, -600), "look": (1500, 1400, 1900), "cells": True},
+        {"at": (1400, 1300, -900), "ypr": (0.1, -0.05, 0.8), "cells": True},
+        {"at": (1500, 1500, -6000), "cells": True},
+        {"at": (1500, 1400, -250), "look": (3000, 1400, 600), "cells": True},        # the camera plane cuts the volume beside the camera
+        {"at": (-300, 1500, 1500), "look": (1500, 1400, 1900), "cells": True},
+        {"at": (-800, -700, -900), "look": (1500, 1400, 1900), "cells": True},       # from a corner
+        {"at": (1500, 1500, 3600), "look": (1500, 1400, 1800), "cells": True},       # from behind the wall
+        {"at": (1500, 1400, 900), "cells": False},                                   # inside
+        {"at": (1500, 1400, 1460), "cells": False},                                  # inside the sphere's shell
+        {"at": (5, 1500, -300), "cells": True},                                      # along the x = 0 face, outside by 300 mm in z
+        {"at": (1500, 1500, -20), "cells": False},                                   # within four voxels of the entry face
+        {"at": (1500, 1300, -600), "look": (1500, 1400, 1900), "cells": True},
+    ]
+    out = str(tmp_path / "cells.npz")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, TSDF_RAY_CELLS="2")
+    e["PYTHONPATH"] = root + os.pathsep + e.get("PYTHONPATH", "")
+    subprocess.run([sys.executable, "-c", _CELLS_PROBE, out, str(n), json.dumps(views)], check=True, env=e, cwd=root, timeout=900)
+    got = np.load(out)
+    ov = oracle.Volume((n, n, n), (3000, 3000, 3000))
+    ov.set_distance_data(got["D"])
+    hits = 0
+    for j, v in enumerate(views):
+        cam = camera_at(tuple(v["at"]), look_at=v.get("look"), yaw_pitch_roll=v.get("ypr"))
+        Vo, No = ov.raycast(W, H, cam.pose(), cam.kinv(), nthreads=oracle.max_threads())
+        assert_same_floats(got["V%d" % j], Vo, "%d^3, view %d %s: vertices" % (n, j, v["at"]))
+        assert_same_floats(got["N%d" % j], No, "%d^3, view %d %s: normals" % (n, j, v["at"]))
+        assert bool(got["cells%d" % j]) == v["cells"], "%d^3, view %d %s: which kernels ran" % (n, j, v["at"])
+        hits += int((~np.isnan(Vo[:, 0])).sum())
+    assert hits > 300000

@@ -227,6 +227,7 @@ struct EntryParams {
     F3 vs, offset;        // voxel size, grid origin (the ray caster's space_min)
     uint32_t width, height, tiles_x, tiles_y;
     float slack_z;        // subtracted from a unit's nearest corner (two voxels, mm)
+    float z_clip;         // cell-parallel cast: no sample of the view has a camera depth below this (> 0: the camera is outside the volume, choose_cell_cast)
     uint32_t *ztile;      // tiles_x * tiles_y words + the on/off word, all kEntryFar / 1 when the launch starts
     uint32_t *ztile_next; // the copy the NEXT cast uses: this launch resets it
     uint32_t units_x, units_y, units_z;   // units (whole or partial) per axis

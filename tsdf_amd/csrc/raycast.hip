@@ -1841,6 +1841,33 @@ static bool choose_cell_cast(const tsdf_volume *v, const RayParams &rp, EntryPar
     const int mode = tuning().ray_cells;
     // (a list entry: 30 bits of brick index, 10 of each brick coordinate; a record of the cast: 13 bits of sample index)
     if (mode == 0 || v->occ.fine_count() >= ((size_t)1 << 30) || v->occ.nbx > 1024u || v->occ.nby > 1024u || v->occ.nbz > 1024u || !view_projection(v, rp, ep)) return false;
+    // The camera must be OUTSIDE the volume, by a margin: then every sample has a camera depth (= its ray parameter) of at least
+    // z_clip > 0, a cell at or behind the camera plane holds none, and one that straddles the plane z_clip is bounded from its part in
+    // front (project_box).  From inside the volume cells beside the camera would have to be offered to every pixel (15 ms at 1024^3).
+    {
+        const Geom &g_ = v->g;
+        const float o[3] = {rp.origin.x, rp.origin.y, rp.origin.z}, lo[3] = {g_.offset.x, g_.offset.y, g_.offset.z};
+        const float hi[3] = {g_.offset.x + g_.phys.x, g_.offset.y + g_.phys.y, g_.offset.z + g_.phys.z};
+        double d2 = 0.0;
+        for (int a = 0; a < 3; a++) {
+            const double d = std::max(0.0, std::max((double)lo[a] - o[a], (double)o[a] - hi[a]));
+            d2 += d * d;
+        }
+        const float outside = (float)std::sqrt(d2), vs_max_ = std::max(g_.vs.x, std::max(g_.vs.y, g_.vs.z));
+        if (!(outside >= 4.0f * vs_max_)) return false;
+        // the longest direction vector of the image (a ray's parameter to the volume is at least outside / |direction|)
+        double dmax = 0.0;
+        const float px[5] = {0.0f, (float)(rp.width - 1), 0.0f, (float)(rp.width - 1), 0.5f * rp.width}, py[5] = {0.0f, 0.0f, (float)(rp.height - 1), (float)(rp.height - 1), 0.5f * rp.height};
+        for (int c = 0; c < 5; c++) {
+            const double rcx = px[c] * rp.kinv.m11 + py[c] * rp.kinv.m12 + rp.kinv.m13, rcy = px[c] * rp.kinv.m21 + py[c] * rp.kinv.m22 + rp.kinv.m23, rcz = 1.0;
+            const double dx = rp.rot.m11 * rcx + rp.rot.m12 * rcy + rp.rot.m13 * rcz, dy = rp.rot.m21 * rcx + rp.rot.m22 * rcy + rp.rot.m23 * rcz,
+                         dz = rp.rot.m31 * rcx + rp.rot.m32 * rcy + rp.rot.m33 * rcz;
+            dmax = std::max(dmax, std::sqrt(dx * dx + dy * dy + dz * dz));
+        }
+        if (!(dmax > 0.0) || !std::isfinite(dmax)) return false;
+        ep.z_clip = (float)(0.5 * outside / dmax);   // (half of it: room for the fp32 evaluation on either side)
+        if (!(ep.z_clip > 0.0f)) return false;
+    }
     if (mode == 2) return true;
     // What the cast costs is the number of (mixed cell, pixel) pairs a brick's wave has to go through one after the other: a voxel that
     // covers several pixels makes every cell a dozen pairs (256^3 at 2 m: 3 px a voxel, 300 pairs a brick, 0.17 ms against the march's

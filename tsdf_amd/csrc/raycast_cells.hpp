@@ -146,21 +146,42 @@ __device__ inline bool project_box(const EntryParams &ep, float lox, float loy, 
         umin = fminf(umin, u); umax = fmaxf(umax, u);
         vmin = fminf(vmin, w); vmax = fmaxf(vmax, w);
     }
-    // a sample's camera depth is its ray parameter (>= 0, up to rounding): a box wholly behind the camera, with room to spare, holds none
-    const float guard = ep.slack_z;   // (two voxels)
-    if (!bad && zmax < -guard) return false;
-    int u0 = 0, v0 = 0, u1 = (int)ep.width - 1, v1 = (int)ep.height - 1;
-    if (!bad && zmin > guard && umin <= umax && vmin <= vmax) {
-        // The hull of the corners bounds the projection; a ray exists per INTEGER pixel, so the pixels worth asking are the integers inside
-        // the hull's box.  Margin: the projection is the double-precision inverse of the matrices the rays are formed with, evaluated
-        // in fp32 on coordinates below 2^16 -- 1e-2 pixel at the very most; the box is that of the cell already grown by eps.
-        const float kMargin = 0.05f;
-        const float a0 = ceilf(umin - kMargin), a1 = floorf(umax + kMargin), b0 = ceilf(vmin - kMargin), b1 = floorf(vmax + kMargin);
-        if (a1 < a0 || b1 < b0 || a1 < 0.0f || b1 < 0.0f || a0 > (float)u1 || b0 > (float)v1) return false;
-        u0 = (int)fmaxf(a0, 0.0f); u1 = (int)fminf(a1, (float)u1);
-        v0 = (int)fmaxf(b0, 0.0f); v1 = (int)fminf(b1, (float)v1);
-    }   // (else: straddles the camera plane, or something not finite: every pixel is asked)
-    pb.u0 = u0; pb.v0 = v0; pb.w = u1 - u0 + 1; pb.h = v1 - v0 + 1;
+    // A sample's camera depth is its ray parameter, and the view has none below z_clip (the camera is outside the volume, by a margin:
+    // choose_cell_cast): a box wholly in front of that plane is bounded by the hull of its corners; one wholly behind holds no sample.
+    if (bad) {   // (something not finite: every pixel is asked)
+        pb.u0 = 0; pb.v0 = 0; pb.w = (int)ep.width; pb.h = (int)ep.height;
+        return true;
+    }
+    if (zmax < ep.z_clip) return false;
+    float a0, a1, b0, b1;
+    const float kMargin = 0.05f;   // (the projection is the double-precision inverse of the matrices the rays are formed with, evaluated in fp32: 1e-2 px at most)
+    if (zmin >= ep.z_clip) {
+        // a ray exists per INTEGER pixel: the integers inside the hull's box
+        a0 = ceilf(umin - kMargin); a1 = floorf(umax + kMargin); b0 = ceilf(vmin - kMargin); b1 = floorf(vmax + kMargin);
+    } else {
+        // The box straddles the plane: only its part with depth >= z_clip can hold samples.  u = N(P) / D(P), N and D affine, D the
+        // depth: for any u*, |u(P) - u*| = |N(P) - u* D(P)| / D(P) <= (|N - u* D| at the centre + half the sum of its coefficients along
+        // the box's edges) / z_clip.  u* = the image's centre.
+        const float mx = 0.5f * (lox + hix) + ep.offset.x, my = 0.5f * (loy + hiy) + ep.offset.y, mz = 0.5f * (loz + hiz) + ep.offset.z;
+        const float ccx = ep.r[0][0] * mx + ep.r[0][1] * my + ep.r[0][2] * mz + ep.r[0][3];
+        const float ccy = ep.r[1][0] * mx + ep.r[1][1] * my + ep.r[1][2] * mz + ep.r[1][3];
+        const float ccz = ep.r[2][0] * mx + ep.r[2][1] * my + ep.r[2][2] * mz + ep.r[2][3];
+        const float us = 0.5f * (float)ep.width, vs_ = 0.5f * (float)ep.height;
+        float ru = fabsf((ep.k[0][0] * ccx + ep.k[0][1] * ccy + ep.k[0][2] * ccz) - us * ccz), rv = fabsf((ep.k[1][0] * ccx + ep.k[1][1] * ccy + ep.k[1][2] * ccz) - vs_ * ccz);
+        const float ext[3] = {hix - lox, hiy - loy, hiz - loz};
+#pragma unroll
+        for (int a_ = 0; a_ < 3; a_++) {
+            const float ex_ = ep.r[0][a_] * ext[a_], ey_ = ep.r[1][a_] * ext[a_], ez_ = ep.r[2][a_] * ext[a_];
+            ru += 0.5f * fabsf((ep.k[0][0] * ex_ + ep.k[0][1] * ey_ + ep.k[0][2] * ez_) - us * ez_);
+            rv += 0.5f * fabsf((ep.k[1][0] * ex_ + ep.k[1][1] * ey_ + ep.k[1][2] * ez_) - vs_ * ez_);
+        }
+        const float rz = 1.0001f / ep.z_clip;
+        a0 = ceilf(us - ru * rz - kMargin); a1 = floorf(us + ru * rz + kMargin); b0 = ceilf(vs_ - rv * rz - kMargin); b1 = floorf(vs_ + rv * rz + kMargin);
+    }
+    const float wmax = (float)(ep.width - 1u), hmax = (float)(ep.height - 1u);
+    if (!(a0 <= a1 && b0 <= b1) || a1 < 0.0f || b1 < 0.0f || a0 > wmax || b0 > hmax) return false;
+    pb.u0 = (int)fmaxf(a0, 0.0f); pb.v0 = (int)fmaxf(b0, 0.0f);
+    pb.w = (int)fminf(a1, wmax) - pb.u0 + 1; pb.h = (int)fminf(b1, hmax) - pb.v0 + 1;
     return true;
 }
 
@@ -304,7 +325,7 @@ __global__ __launch_bounds__(256) void cast_cells_kernel(const float *__restrict
             const float ccy = ep.r[1][0] * wx + ep.r[1][1] * wy + ep.r[1][2] * wz + ep.r[1][3];
             const float ccz = ep.r[2][0] * wx + ep.r[2][1] * wy + ep.r[2][2] * wz + ep.r[2][3];
             const float zmin = ccz - half_dz;
-            if (zmin > ep.slack_z) {
+            if (zmin > ep.z_clip) {
                 const float rz = __builtin_amdgcn_rcpf(ccz), rm = __builtin_amdgcn_rcpf(zmin);
                 const float uc = (ep.k[0][0] * ccx + ep.k[0][1] * ccy + ep.k[0][2] * ccz) * rz, vc = (ep.k[1][0] * ccx + ep.k[1][1] * ccy + ep.k[1][2] * ccz) * rz;
                 const float su = 0.5f * ((fabsf(nu_[0] - uc * nz_[0]) + fabsf(nu_[1] - uc * nz_[1])) + fabsf(nu_[2] - uc * nz_[2]));
@@ -316,7 +337,7 @@ __global__ __launch_bounds__(256) void cast_cells_kernel(const float *__restrict
                 mixed = a0 <= a1 && b0 <= b1;   // (false also for anything not a number)
                 if (mixed) { pb.u0 = (int)a0; pb.v0 = (int)b0; pb.w = (int)a1 - (int)a0 + 1; pb.h = (int)b1 - (int)b0 + 1; }
             } else {
-                // near or behind the camera plane: the 8 corners, every pixel when the cell straddles the plane
+                // at or behind the plane in front of which the view's samples lie: the 8 corners, the part in front of the plane
                 const float clx = ((float)lx + 0.5f - e) * g.vs.x, chx = ((float)lx + 1.5f + e) * g.vs.x;
                 const float cly = ((float)ly + 0.5f - e) * g.vs.y, chy = ((float)ly + 1.5f + e) * g.vs.y;
                 const float clz = ((float)lz + 0.5f - e) * g.vs.z, chz = ((float)lz + 1.5f + e) * g.vs.z;
