@@ -1988,7 +1988,7 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
         const uint32_t n_list_blocks = (uint32_t)std::min<size_t>((v->occ.fine_count() / 4 + 255) / 256 + 1, 2048);
         hipLaunchKernelGGL((cell_cast_prepare_kernel<SLAB>), dim3(n_ray_blocks + n_list_blocks), dim3(256), (uint32_t)table_lds, v->stream, v->g, rp, v->t_table,
                            v->occ, cc, n_ray_blocks);
-        const dim3 cgrid((unsigned)tuning().ray_cells_grid);
+        const dim3 cgrid((unsigned)tuning().ray_cells_grid + kShellWorkgroups);   // (the first kShellWorkgroups: the boundary bricks' shell samples)
         if (v->fast_div)
             TSDF_LAUNCH_TIMED(v, 1, (cast_cells_kernel<SLAB, true>), cgrid, dim3(256), v->dist, v->g, rp, *cells, v->occ, v->t_table, cc, tail.best);
         else

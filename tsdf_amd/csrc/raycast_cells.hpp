@@ -10,7 +10,8 @@
 //     only be <= 0 when one of the 8 is not safely positive (kCellPositive, process_sample) -- a MIXED cell.  Mixed cells lie in
 //     bricks whose `cell` flag is set (OccGrid: a superset at all times), and those in bricks whose `fine` flag is set too;
 //   * a sample in the outer half-voxel shell of the grid (where the reference extrapolates, Q10) or off the grid by rounding can only
-//     be <= 0 when the boundary brick of its voxel is flagged (`fine`: otherwise every voxel in reach is flat, OccGrid).
+//     be <= 0 when the boundary brick of its voxel is flagged (`fine`: otherwise every voxel in reach is flat, OccGrid): the
+//     first workgroups of the launch take those bricks (cast_shell_bricks).
 // So the work is turned round: one wave per flagged brick.  It loads the brick's 5^3 voxels once, finds its mixed cells, projects each
 // (grown by the guard band eps) into the image -- the view's projection is only used to bound the PIXELS worth looking at -- and for
 // every such pixel intersects that pixel's ray (the same start point and direction as ever: ray_records_kernel runs setup_ray) with
@@ -217,6 +218,101 @@ __device__ inline bool sample_interval(const RayState &r, float lox, float loy, 
     return k_lo <= k_hi;
 }
 
+// The shell samples of the flagged bricks that touch the grid boundary (kShellTasks): the work of the FIRST kShellWorkgroups workgroups
+// of cast_cells_kernel.  A few hundred bricks at most, every sample the reference's full interpolation -- a chain of round trips per
+// pixel (17 us as a launch of its own, profiles/r05n_*) that costs next to no issue slots: at the head of the cells' launch it runs
+// beside the bricks' waves from their first microsecond to long before their last.  Inside the brick loop it cost every wave of the
+// kernel a fifth of its registers (132 -> 96 a lane without it); per pixel in the resolve kernels, where no list is needed, it was
+// 20 us on top of their 7 (every pixel pays the flag look-ups, tools/experiments/raycast_shell_in_resolve.patch.txt).
+// Each of these workgroups looks at its share of the brick list -- entries blockIdx.x, + kShellWorkgroups, ... -- one entry a thread, at
+// once (such bricks sit next to each other in the list: a stretch per workgroup left a handful with all of them), and then takes its
+// boundary bricks one after the other: every pixel the brick's voxel box can be seen by, eight threads a pixel -- each every eighth
+// sample of the pixel's stretch through a slab; the samples are independent, the pixel's word takes the minimum -- and per pixel only
+// the samples in the half-voxel slabs along the grid faces the brick touches (a tenth of the samples that cross the brick).
+constexpr uint32_t kShellWorkgroups = 1024;
+template <bool SLAB, bool FASTDIV>
+__device__ inline void cast_shell_bricks(const float *__restrict__ dist, const Geom &g, const RayParams &rp, const EntryParams &ep, const float *T,
+                                         const CellCast &cc, uint64_t *__restrict__ best, uint32_t n_bricks, uint2 *mine, uint32_t *n_mine) {
+    const TriConst &tc = rp.tc;
+    const float step_size = T[1];
+    const SkipCtx sc = make_skip_ctx(g, step_size);
+    const float e = sc.eps;
+    const float size_[3] = {(float)g.X, (float)g.Y, (float)g.Z}, vs_[3] = {g.vs.x, g.vs.y, g.vs.z};
+    for (uint32_t j0 = 0; blockIdx.x + (size_t)j0 * kShellWorkgroups < n_bricks; j0 += 256) {   // (uniform; one turn unless the list is longer than 256 x these workgroups)
+        __syncthreads();   // (the turn before has read `mine`)
+        if (threadIdx.x == 0) *n_mine = 0;
+        __syncthreads();
+        const size_t ei = blockIdx.x + (size_t)(j0 + threadIdx.x) * kShellWorkgroups;
+        if (ei < n_bricks) {
+            const uint2 en = cc.bricks[ei];
+            if (en.x & kShellTasks) mine[atomicAdd(n_mine, 1u)] = en;   // (at most one a thread: 256)
+        }
+        __syncthreads();
+        const uint32_t n_shell = *n_mine;
+        for (uint32_t si = 0; si < n_shell; si++) {
+            const uint2 entry2 = mine[si];
+            const uint32_t o_[3] = {(entry2.y & 1023u) * kBrick, ((entry2.y >> 10) & 1023u) * kBrick, (entry2.y >> 20) * kBrick};
+            // the brick's voxels in voxel units, grown by eps (and so reaching off the grid where the brick touches it)
+            float lo_[3], hi_[3];
+#pragma unroll
+            for (int a_ = 0; a_ < 3; a_++) {
+                lo_[a_] = (float)o_[a_] - e;
+                hi_[a_] = fminf((float)(o_[a_] + kBrick), size_[a_]) + e;
+            }
+            PixelBox sb;
+            if (!project_box(ep, lo_[0] * vs_[0], lo_[1] * vs_[1], lo_[2] * vs_[2], hi_[0] * vs_[0], hi_[1] * vs_[1], hi_[2] * vs_[2], sb)) continue;
+            const int n_pix = sb.w * sb.h;
+            if (threadIdx.x == 0) { RAY_MIX(42); }
+            const int sub = (int)(threadIdx.x & 7u);
+            for (int pi = (int)(threadIdx.x >> 3); pi < n_pix; pi += 32) {
+                const int py = pi / sb.w, px = pi - py * sb.w;
+                if (sub == 0) { RAY_MIX(43); }
+                const uint32_t idx = (uint32_t)(sb.v0 + py) * rp.width + (uint32_t)(sb.u0 + px);
+                const RayRecord rec_ = cc.rays[idx];
+                const uint32_t known = (uint32_t)(best[idx] >> 32);
+                const RayState ray = ray_from_near(ray_direction(sb.u0 + px, sb.v0 + py, rp), rec_.near_t, rp);
+                const int k_first = (int)(rec_.k_range & 0xffffu), k_end = (int)(rec_.k_range >> 16);
+                // the slabs of the brick in which a sample's lower tap is off the lattice of cells (or within eps of that): the first half
+                // voxel behind a low face of the grid, the last half voxel in front of a high one
+#pragma unroll
+                for (int a_ = 0; a_ < 3; a_++) {
+#pragma unroll
+                    for (int side = 0; side < 2; side++) {
+                        float slo[3] = {lo_[0], lo_[1], lo_[2]}, shi[3] = {hi_[0], hi_[1], hi_[2]};
+                        if (side == 0) {
+                            if (o_[a_] != 0u) continue;
+                            shi[a_] = 0.5f + e;
+                        } else {
+                            if ((float)(o_[a_] + kBrick) < size_[a_]) continue;
+                            slo[a_] = size_[a_] - 0.5f - e;
+                        }
+                        int k, k_hi;
+                        if (!sample_interval(ray, slo[0] * vs_[0], slo[1] * vs_[1], slo[2] * vs_[2], shi[0] * vs_[0], shi[1] * vs_[1], shi[2] * vs_[2], sc.inv_step, step_size, T,
+                                             k_first, k_end, k, k_hi))
+                            continue;
+                        if (known <= (uint32_t)k) continue;
+                        for (k += sub; k <= k_hi; k += 8) {
+                            RAY_MIX(44);
+                            const float t = T[k];
+                            const float ppx = (t * ray.dx) + ray.sx, ppy = (t * ray.dy) + ray.sy, ppz = (t * ray.dz) + ray.sz;
+                            const float f_[3] = {ppx * sc.inv_vx, ppy * sc.inv_vy, ppz * sc.inv_vz};
+                            // in this slab of this brick's (grown) voxel box
+                            if (!(f_[0] >= slo[0] && f_[0] <= shi[0] && f_[1] >= slo[1] && f_[1] <= shi[1] && f_[2] >= slo[2] && f_[2] <= shi[2])) continue;
+                            bool owned;
+                            const float tsdf = trilinear<SLAB, false, FASTDIV>(ppx, ppy, ppz, dist, g, tc, rp, owned, nullptr);
+                            if (tsdf <= 0) {
+                                RAY_MIX(41);
+                                lower_best(&best[idx], k, tsdf);
+                                break;   // (of this thread's samples of the slab nothing behind it counts)
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // One wave per flagged brick; the four waves of a workgroup share the table and nothing else.
 // (Measured and dropped, profiles/r05m_*: the walk of a pair's samples deferred to a ring of the wave in LDS and done 64 records at a
 // time, all lanes busy -- three lanes in four idle through the walk otherwise -- was no faster: the deferred walks find their hits
@@ -238,6 +334,12 @@ __global__ __launch_bounds__(256) void cast_cells_kernel(const float *__restrict
     for (int i = (int)threadIdx.x; i < kTableLen; i += 256) T[i] = t_table[i];
     const uint32_t n_bricks = *cc.n_bricks;
     if (cc.n_bricks_host && blockIdx.x == 0 && threadIdx.x == 0) *cc.n_bricks_host = n_bricks;
+    static_assert(sizeof(box_of) >= 256 * sizeof(uint2), "a shell workgroup's list of bricks");
+    if (blockIdx.x < kShellWorkgroups) {   // the boundary bricks' shell samples, beside the cells' waves from the start
+        __syncthreads();
+        cast_shell_bricks<SLAB, FASTDIV>(dist, g, rp, ep, T, cc, best, n_bricks, reinterpret_cast<uint2 *>(&box_of[0][0][0]), reinterpret_cast<uint32_t *>(&prefix[0][0]));
+        return;
+    }
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const float step_size = t_table[1];
     const TriConst &tc = rp.tc;
@@ -289,8 +391,8 @@ __global__ __launch_bounds__(256) void cast_cells_kernel(const float *__restrict
         va = voxel(lane);
         if (lane + 64u < 125u) vb = voxel(lane + 64u);
     };
-    const uint32_t n_waves = gridDim.x * 4u;
-    uint32_t ei = blockIdx.x * 4u + wave;
+    const uint32_t n_waves = (gridDim.x - kShellWorkgroups) * 4u;
+    uint32_t ei = (blockIdx.x - kShellWorkgroups) * 4u + wave;
     uint2 entry_next = ei < n_bricks ? cc.bricks[ei] : make_uint2(0u, 0u);
     float va_next, vb_next;
     brick_voxels(entry_next, va_next, vb_next);
@@ -446,47 +548,6 @@ __global__ __launch_bounds__(256) void cast_cells_kernel(const float *__restrict
                         break;
                     }
                     k++;
-                }
-            }
-        }
-        // ---- shell samples of a flagged boundary brick: every pixel its voxel box can be seen by, 64 a round ----
-        if (entry & kShellTasks) {
-            // the brick's voxels in grid millimetres, grown by eps (and so reaching off the grid where the brick touches it)
-            const float fx0 = (float)x0 - e, fx1 = (float)min(x0 + kBrick, g.X) + e, fy0 = (float)y0 - e, fy1 = (float)min(y0 + kBrick, g.Y) + e;
-            const float fz0 = (float)z0 - e, fz1 = (float)min(z0 + kBrick, g.Z) + e;
-            PixelBox sb;
-            if (project_box(ep, fx0 * g.vs.x, fy0 * g.vs.y, fz0 * g.vs.z, fx1 * g.vs.x, fy1 * g.vs.y, fz1 * g.vs.z, sb)) {
-                const int n_pix = sb.w * sb.h;
-                if (lane == 0) { RAY_MIX(42); }
-                const float hx = (float)g.X - 1.0f, hy = (float)g.Y - 1.0f, hz = (float)g.Z - 1.0f;
-                for (int pi = (int)lane; pi < n_pix; pi += 64) {
-                    const int py = pi / sb.w, px = pi - py * sb.w;
-                    RAY_MIX(43);
-                    const uint32_t idx = (uint32_t)(sb.v0 + py) * rp.width + (uint32_t)(sb.u0 + px);
-                    const RayRecord rec_ = cc.rays[idx];
-                    const RayState ray = ray_from_near(ray_direction(sb.u0 + px, sb.v0 + py, rp), rec_.near_t, rp);
-                    const uint32_t kr = rec_.k_range;
-                    const int k_first = (int)(kr & 0xffffu), k_end = (int)(kr >> 16);
-                    int k, k_hi;
-                    if (!sample_interval(ray, fx0 * g.vs.x, fy0 * g.vs.y, fz0 * g.vs.z, fx1 * g.vs.x, fy1 * g.vs.y, fz1 * g.vs.z, sc.inv_step, step_size, T, k_first, k_end, k, k_hi)) continue;
-                    if ((uint32_t)(best[idx] >> 32) <= (uint32_t)k) continue;
-                    for (; k <= k_hi; k++) {
-                        RAY_MIX(44);
-                        const float t = T[k];
-                        const float ppx = (t * ray.dx) + ray.sx, ppy = (t * ray.dy) + ray.sy, ppz = (t * ray.dz) + ray.sz;
-                        const float fx = ppx * sc.inv_vx, fy = ppy * sc.inv_vy, fz = ppz * sc.inv_vz;
-                        // in this brick's (grown) voxel box, and its lower tap off the lattice of cells on some axis, or within eps of that
-                        const bool here = fx >= fx0 && fx <= fx1 && fy >= fy0 && fy <= fy1 && fz >= fz0 && fz <= fz1;
-                        const bool shell = fx - 0.5f < e || fy - 0.5f < e || fz - 0.5f < e || fx - 0.5f > hx - e || fy - 0.5f > hy - e || fz - 0.5f > hz - e;
-                        if (!(here && shell)) continue;
-                        bool owned;
-                        const float tsdf = trilinear<SLAB, false, FASTDIV>(ppx, ppy, ppz, dist, g, tc, rp, owned, nullptr);
-                        if (tsdf <= 0) {
-                            RAY_MIX(41);
-                            lower_best(&best[idx], k, tsdf);
-                            break;
-                        }
-                    }
                 }
             }
         }
