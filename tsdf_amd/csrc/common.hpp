@@ -52,7 +52,7 @@ struct Tuning {
     int ray_cells;           // TSDF_RAY_CELLS          the cell-parallel cast (raycast_cells.hpp): 0 never, 1 (default) unless the previous cast listed more than
                              //                          TSDF_RAY_CELLS_LIMIT flagged bricks, 2 whenever the view has a projection
     int ray_cells_limit;     // TSDF_RAY_CELLS_LIMIT    (131072)
-    float ray_cells_footprint;   // TSDF_RAY_CELLS_FOOTPRINT  largest voxel footprint (pixels, at the depth of the volume's centre) the cell-parallel cast is taken for (1.8)
+    float ray_cells_footprint;   // TSDF_RAY_CELLS_FOOTPRINT  largest voxel footprint (pixels, at the depth of the volume's centre) the cell-parallel cast is taken for (5)
     int ray_cells_grid;      // TSDF_RAY_CELLS_GRID     workgroups of cast_cells_kernel (8192: a wave per brick for 32 768 bricks, the rest in turns)
     int ray_fused;           // TSDF_RAY_FUSED          1: the march and its queue of unfinished stretches in ONE launch (process_ray_fused_kernel; measured slower, LABNOTES round 5); default 0: two launches
     int ray_entry_bound;     // TSDF_RAY_ENTRY_BOUND    0: no per-tile entry bound (default 1: rays start at the nearest flagged block their 16 x 16 tile can see)

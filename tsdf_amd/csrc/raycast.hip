@@ -1870,9 +1870,11 @@ static bool choose_cell_cast(const tsdf_volume *v, const RayParams &rp, EntryPar
     }
     if (mode == 2) return true;
     // What the cast costs is the number of (mixed cell, pixel) pairs a brick's wave has to go through one after the other: a voxel that
-    // covers several pixels makes every cell a dozen pairs (256^3 at 2 m: 3 px a voxel, 300 pairs a brick, 0.17 ms against the march's
-    // 0.12; 512^3: 1.5 px, 100 pairs, 0.10 ms).  The voxel's footprint at the depth of the volume's centre decides, and the previous
-    // cell-parallel cast's list length (arbitrary fields: every brick flagged).
+    // covers several pixels makes every cell a dozen pairs or more.  Measured over grid sizes on one scene (640x480, the camera 2 m from
+    // the centre of 2 m of volume, profiles/r05q_cells_footprint_sweep.txt; cast stage, march / cells): 384^3, 2 px a voxel, 0.194 / 0.113
+    // ms; 256^3, 3 px, 0.170 / 0.115; 192^3, 4 px, 0.176 / 0.127; 128^3, 6 px, 0.171 / 0.211; 96^3, 8 px, 0.145 / 0.296.  The voxel's
+    // footprint at the depth of the volume's centre decides (5 px), and the previous cell-parallel cast's list length (arbitrary fields:
+    // every brick flagged).
     const Geom &g = v->g;
     const float cxw = g.offset.x + 0.5f * g.phys.x, cyw = g.offset.y + 0.5f * g.phys.y, czw = g.offset.z + 0.5f * g.phys.z;
     const float depth = ep.r[2][0] * cxw + ep.r[2][1] * cyw + ep.r[2][2] * czw + ep.r[2][3];

@@ -36,7 +36,7 @@ const Tuning &tuning() {
         u.ray_cells = clamp(num("TSDF_RAY_CELLS", 1), 0, 2);
         u.ray_cells_limit = std::max(num("TSDF_RAY_CELLS_LIMIT", 131072), 0);
         u.ray_cells_grid = clamp(num("TSDF_RAY_CELLS_GRID", 8192), 1, 65535);
-        { const char *fp = getenv("TSDF_RAY_CELLS_FOOTPRINT"); u.ray_cells_footprint = fp ? (float)atof(fp) : 1.8f; }
+        { const char *fp = getenv("TSDF_RAY_CELLS_FOOTPRINT"); u.ray_cells_footprint = fp ? (float)atof(fp) : 5.0f; }
         u.ray_trip_budget = std::max(num("TSDF_RAY_TRIP_BUDGET", 22), 1);
         u.ray_tail_lanes = num("TSDF_RAY_TAIL_LANES", 4);
         if (!(u.ray_tail_lanes >= 1 && u.ray_tail_lanes <= 64 && (u.ray_tail_lanes & (u.ray_tail_lanes - 1)) == 0)) u.ray_tail_lanes = 4;
