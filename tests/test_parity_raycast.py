@@ -360,6 +360,8 @@ np.savez(sys.argv[1], V=V, N=N, D=gv.get_distance_data())
     {"TSDF_RAY_CELLS": "0"},                                                                   # the march kernels, whatever the view (round 5)
     {"TSDF_RAY_CELLS": "2"},                                                                   # the cell-parallel cast wherever the view allows it
     {"TSDF_RAY_CELLS": "2", "TSDF_RAY_CELLS_GRID": "3"},                                       # ... every wave through many bricks
+    {"TSDF_RAY_CELLS": "2", "TSDF_RAY_CELLS_LOOK": "1", "TSDF_RAY_CELLS_PAIRS": "64"},         # ... the bricks projected when listed, each in many parts
+    {"TSDF_RAY_CELLS": "2", "TSDF_RAY_CELLS_LOOK": "1", "TSDF_RAY_CELLS_PAIRS": "0"},          # ... projected (unseen ones dropped), never in parts
     {"TSDF_RAY_FUSED": "1", "TSDF_RAY_CELLS": "0"},                                            # the march and its queue in one launch
 ])
 def test_schedule_knobs_do_not_change_a_bit(oracle, tmp_path, env):
@@ -555,8 +557,9 @@ def test_cell_parallel_cast_from_outside_beside_and_inside(oracle, tmp_path, n):
     """The cell-parallel cast (raycast_cells.hpp, forced on with TSDF_RAY_CELLS=2 in a process of its own): no ray is marched, every
     flagged brick's mixed cells are offered to the pixels they project to.  Views from outside (taken), from a camera whose plane
     cuts through flagged bricks beside it (taken: the cells that straddle the plane in front of which all samples lie are bounded
-    from their part in front), along a face and from a corner; from inside or within four voxels of the volume (left to the march
-    kernels).  One volume cast from one pose after the other; every picture must be the oracle's, bit for bit."""
+    from their part in front), along a face and from a corner; from inside the volume, where the samples start at the camera: a
+    box that holds the camera asks every pixel, one that reaches across the camera plane beside it is bounded from its side, and a
+    brick seen from close by is worked on in parts.  One volume cast from one pose after the other; every picture must be the oracle's, bit for bit."""
     import json
     import os
     import subprocess
@@ -569,10 +572,13 @@ def test_cell_parallel_cast_from_outside_beside_and_inside(oracle, tmp_path, n):
         {"at": (-300, 1500, 1500), "look": (1500, 1400, 1900), "cells": True},
         {"at": (-800, -700, -900), "look": (1500, 1400, 1900), "cells": True},       # from a corner
         {"at": (1500, 1500, 3600), "look": (1500, 1400, 1800), "cells": True},       # from behind the wall
-        {"at": (1500, 1400, 900), "cells": False},                                   # inside
-        {"at": (1500, 1400, 1460), "cells": False},                                  # inside the sphere's shell
+        {"at": (1500, 1400, 900), "cells": True},                                    # inside
+        {"at": (1500, 1400, 1460), "cells": True},                                   # inside the sphere's shell
         {"at": (5, 1500, -300), "cells": True},                                      # along the x = 0 face, outside by 300 mm in z
-        {"at": (1500, 1500, -20), "cells": False},                                   # within four voxels of the entry face
+        {"at": (1500, 1500, -20), "cells": True},                                    # within four voxels of the entry face
+        {"at": (900, 1400, 1200), "look": (2900, 1500, 2800), "cells": True},        # inside, towards a far corner: bricks beside and behind the camera
+        {"at": (1500, 1400, 2380), "look": (300, 1400, 2390), "cells": True},        # inside, a hand's width from the wall and along it
+        {"at": (1500, 40, 1500), "look": (1500, 3000, 1600), "cells": True},         # inside, a voxel or two from the y = 0 face
         {"at": (1500, 1300, -600), "look": (1500, 1400, 1900), "cells": True},
     ]
     out = str(tmp_path / "cells.npz")

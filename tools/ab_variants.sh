@@ -19,6 +19,6 @@ else
   cmd=$1; shift
   for name in "$@" "$@"; do
     export TSDF_HIP_LIB=$root/build/variants/$name/libtsdf_hip.so
-    echo "== $name"; bash $root/tools/stats_cmd.sh ab_$name "$cmd" 12 | grep -E "integrate_k|cull|bilateral_k|process_ray|tile_max|reach|resolve"
+    echo "== $name"; bash $root/tools/stats_cmd.sh ab_$name "$cmd" 12 | grep -E "integrate_k|cull|bilateral_k|process_ray|tile_max|reach|resolve|cast_cells|cell_cast"
   done
 fi

@@ -1,16 +1,17 @@
 """What the passes of the two ray-march kernels are spent on (a library built with -DTSDF_DIAG_RAY_MIX, TSDF_HIP_LIB):
-python tools/dbg_ray_mix.py [frames]"""
+python tools/dbg_ray_mix.py [frames] [grid] [inside]"""
 import sys, os, ctypes; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, tsdf_amd, torch
 from tsdf_amd import synth, _capi
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+inside = len(sys.argv) > 3 and sys.argv[3] == 'inside'
 v = tsdf_amd.TSDFVolume((n, n, n), (3000.,) * 3)
 bil = tsdf_amd.BilateralFilter(30.0, 4.5)
 rc = tsdf_amd.GPURaycaster(640, 480)
 vert = torch.empty((640 * 480, 3), dtype=torch.float32, device='cuda')
 for i in range(frames):
-    d, cam = synth.depth_frame(i, 200, seed=0x5EED0003)
+    d, cam = synth.depth_frame(i, 100 if inside else 200, seed=0x5EED0004 if inside else 0x5EED0003, inside=inside)
     f = d.copy(); bil.filter(f, 640, 480)
     v.integrate(f, 640, 480, cam)
 for r in range(3):

@@ -53,6 +53,8 @@ struct Tuning {
                              //                          TSDF_RAY_CELLS_LIMIT flagged bricks, 2 whenever the view has a projection
     int ray_cells_limit;     // TSDF_RAY_CELLS_LIMIT    (131072)
     float ray_cells_footprint;   // TSDF_RAY_CELLS_FOOTPRINT  largest voxel footprint (pixels, at the depth of the volume's centre) the cell-parallel cast is taken for (5)
+    int ray_cells_pairs;     // TSDF_RAY_CELLS_PAIRS    estimated (cell, pixel) pairs of a brick above which it is listed in several parts (1024; 0: never)
+    int ray_cells_look;      // TSDF_RAY_CELLS_LOOK     1: project every flagged brick when the list is built (0: only for views that need it, choose_cell_cast)
     int ray_cells_grid;      // TSDF_RAY_CELLS_GRID     workgroups of cast_cells_kernel (8192: a wave per brick for 32 768 bricks, the rest in turns)
     int ray_fused;           // TSDF_RAY_FUSED          1: the march and its queue of unfinished stretches in ONE launch (process_ray_fused_kernel; measured slower, LABNOTES round 5); default 0: two launches
     int ray_entry_bound;     // TSDF_RAY_ENTRY_BOUND    0: no per-tile entry bound (default 1: rays start at the nearest flagged block their 16 x 16 tile can see)
@@ -227,7 +229,9 @@ struct EntryParams {
     F3 vs, offset;        // voxel size, grid origin (the ray caster's space_min)
     uint32_t width, height, tiles_x, tiles_y;
     float slack_z;        // subtracted from a unit's nearest corner (two voxels, mm)
-    float z_clip;         // cell-parallel cast: no sample of the view has a camera depth below this (> 0: the camera is outside the volume, choose_cell_cast)
+    float z_clip;         // cell-parallel cast: no sample of the view has a camera depth below this (> 0 when the camera is outside the volume, else 0: choose_cell_cast)
+    float z_near;         // ... and the depth in front of which a box is projected corner by corner (max(z_clip, a quarter voxel))
+    uint32_t cell_pairs;  // ... 0, or the pairs of a listed brick's task: the list's builder projects the bricks (cell_cast_prepare_kernel)
     uint32_t *ztile;      // tiles_x * tiles_y words + the on/off word, all kEntryFar / 1 when the launch starts
     uint32_t *ztile_next; // the copy the NEXT cast uses: this launch resets it
     uint32_t units_x, units_y, units_z;   // units (whole or partial) per axis

@@ -1839,11 +1839,12 @@ static int refresh_for_cast(tsdf_volume *v, RayParams &rp) {
 // every cell is mixed; TSDF_RAY_CELLS = 0 never / 1 by that count (default) / 2 whenever the view allows).
 static bool choose_cell_cast(const tsdf_volume *v, const RayParams &rp, EntryParams &ep) {
     const int mode = tuning().ray_cells;
-    // (a list entry: 30 bits of brick index, 10 of each brick coordinate; a record of the cast: 13 bits of sample index)
+    // (a list entry: 10 bits of each brick coordinate; a record of the cast: 13 bits of sample index)
     if (mode == 0 || v->occ.fine_count() >= ((size_t)1 << 30) || v->occ.nbx > 1024u || v->occ.nby > 1024u || v->occ.nbz > 1024u || !view_projection(v, rp, ep)) return false;
-    // The camera must be OUTSIDE the volume, by a margin: then every sample has a camera depth (= its ray parameter) of at least
-    // z_clip > 0, a cell at or behind the camera plane holds none, and one that straddles the plane z_clip is bounded from its part in
-    // front (project_box).  From inside the volume cells beside the camera would have to be offered to every pixel (15 ms at 1024^3).
+    // A camera OUTSIDE the volume: every sample has a camera depth (= its ray parameter) of at least z_clip > 0, a cell at or behind the
+    // camera plane holds none, and one that straddles the plane z_clip is bounded from its part in front.  Inside (or within a voxel of)
+    // the volume z_clip = 0: samples start at the camera, a box that holds it asks every pixel, one beside it that reaches across the
+    // camera plane is bounded from the side it lies on (project_box).
     {
         const Geom &g_ = v->g;
         const float o[3] = {rp.origin.x, rp.origin.y, rp.origin.z}, lo[3] = {g_.offset.x, g_.offset.y, g_.offset.z};
@@ -1853,8 +1854,7 @@ static bool choose_cell_cast(const tsdf_volume *v, const RayParams &rp, EntryPar
             const double d = std::max(0.0, std::max((double)lo[a] - o[a], (double)o[a] - hi[a]));
             d2 += d * d;
         }
-        const float outside = (float)std::sqrt(d2), vs_max_ = std::max(g_.vs.x, std::max(g_.vs.y, g_.vs.z));
-        if (!(outside >= 4.0f * vs_max_)) return false;
+        const float outside = (float)std::sqrt(d2), vs_max_ = std::max(g_.vs.x, std::max(g_.vs.y, g_.vs.z)), vs_min_ = std::min(g_.vs.x, std::min(g_.vs.y, g_.vs.z));
         // the longest direction vector of the image (a ray's parameter to the volume is at least outside / |direction|)
         double dmax = 0.0;
         const float px[5] = {0.0f, (float)(rp.width - 1), 0.0f, (float)(rp.width - 1), 0.5f * rp.width}, py[5] = {0.0f, 0.0f, (float)(rp.height - 1), (float)(rp.height - 1), 0.5f * rp.height};
@@ -1864,23 +1864,32 @@ static bool choose_cell_cast(const tsdf_volume *v, const RayParams &rp, EntryPar
                          dz = rp.rot.m31 * rcx + rp.rot.m32 * rcy + rp.rot.m33 * rcz;
             dmax = std::max(dmax, std::sqrt(dx * dx + dy * dy + dz * dz));
         }
-        if (!(dmax > 0.0) || !std::isfinite(dmax)) return false;
-        ep.z_clip = (float)(0.5 * outside / dmax);   // (half of it: room for the fp32 evaluation on either side)
-        if (!(ep.z_clip > 0.0f)) return false;
+        if (!(dmax > 0.0) || !std::isfinite(dmax) || !std::isfinite(outside)) return false;
+        ep.z_clip = outside >= 4.0f * vs_max_ ? (float)(0.5 * outside / dmax) : 0.0f;   // (half of it: room for the fp32 evaluation on either side)
+        if (!(ep.z_clip >= 0.0f)) return false;
+        ep.z_near = std::max(ep.z_clip, 0.25f * vs_min_);
+        if (!(ep.z_near > 0.0f)) return false;
     }
-    if (mode == 2) return true;
-    // What the cast costs is the number of (mixed cell, pixel) pairs a brick's wave has to go through one after the other: a voxel that
-    // covers several pixels makes every cell a dozen pairs or more.  Measured over grid sizes on one scene (640x480, the camera 2 m from
-    // the centre of 2 m of volume, profiles/r05q_cells_footprint_sweep.txt; cast stage, march / cells): 384^3, 2 px a voxel, 0.194 / 0.113
-    // ms; 256^3, 3 px, 0.170 / 0.115; 192^3, 4 px, 0.176 / 0.127; 128^3, 6 px, 0.171 / 0.211; 96^3, 8 px, 0.145 / 0.296.  The voxel's
-    // footprint at the depth of the volume's centre decides (5 px), and the previous cell-parallel cast's list length (arbitrary fields:
-    // every brick flagged).
     const Geom &g = v->g;
     const float cxw = g.offset.x + 0.5f * g.phys.x, cyw = g.offset.y + 0.5f * g.phys.y, czw = g.offset.z + 0.5f * g.phys.z;
     const float depth = ep.r[2][0] * cxw + ep.r[2][1] * cyw + ep.r[2][2] * czw + ep.r[2][3];
     const float vs_max = std::max(g.vs.x, std::max(g.vs.y, g.vs.z));
     const float reach = 0.25f * std::max(g.phys.x, std::max(g.phys.y, g.phys.z));   // (a camera inside the volume: surfaces a quarter of it away)
     const float footprint = vs_max * std::max(std::fabs(ep.k[0][0]), std::fabs(ep.k[1][1])) / std::max(depth, reach);
+    // The list's builder projects the bricks -- those no pixel sees are dropped, those that are large on the screen listed in parts --
+    // when the bricks can be large: a voxel of two pixels or more, a camera inside or next to the volume.  (2.7 us otherwise spent for
+    // little: a brick outside the view costs its wave a microsecond.)
+    ep.cell_pairs = (tuning().ray_cells_look || ep.z_clip == 0.0f || !(footprint < 2.0f)) ? (uint32_t)tuning().ray_cells_pairs : 0u;
+    if (mode == 2) return true;
+    // What the cast costs is the number of (mixed cell, pixel) pairs: a voxel that covers several pixels makes every cell a dozen pairs
+    // or more.  Measured over grid sizes on one scene (640x480, the camera 2 m from the centre of 3 m of volume,
+    // profiles/r05q_cells_footprint_sweep.txt; cast stage, march / cells): 384^3, 2 px a voxel, 0.194 / 0.113 ms; 256^3, 3 px, 0.170 /
+    // 0.115 (0.108 in parts); 192^3, 4 px, 0.176 / 0.127; 128^3, 6 px, 0.171 / 0.211; 96^3, 8 px, 0.145 / 0.296.  The voxel's footprint at
+    // the depth of the volume's centre decides (5 px), and the previous cell-parallel cast's list length (arbitrary fields: every
+    // brick flagged).  From inside the volume the view holds surface after surface behind the first -- every mixed cell is looked at,
+    // hidden or not: 4.2 M pairs at 1024^3 against 2.0 M for the view from outside, 0.29 ms against the march's 0.215 -- and the march
+    // kernels keep it (TSDF_RAY_CELLS=2 takes the cell-parallel cast there too).
+    if (ep.z_clip == 0.0f) return false;
     if (!(footprint <= tuning().ray_cells_footprint)) return false;
     const uint32_t listed = v->cell_cast_host ? *v->cell_cast_host : 0u;
     return listed <= (uint32_t)tuning().ray_cells_limit;
@@ -1909,7 +1918,7 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
         v->ray_best_dirty = 1;
     }
     if (cells) {
-        const size_t n_bricks_max = v->occ.fine_count();
+        const size_t n_bricks_max = cell_list_capacity(v->occ.fine_count());
         if (v->cell_rays_cap < n_pix) {
             if (v->cell_rays) (void)hipFree(v->cell_rays);
             v->cell_rays = nullptr;
@@ -1984,12 +1993,12 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
     v->last_cast_cells = cells ? 1 : 0;
     if (cells) {
         // ---- the cell-parallel cast (raycast_cells.hpp): the rays' records, the flagged bricks, one wave per brick ----
-        CellCast cc = {reinterpret_cast<RayRecord *>(v->cell_rays), reinterpret_cast<uint2 *>(v->cell_bricks), v->tail_count + 3, v->cell_cast_host};
+        CellCast cc = {reinterpret_cast<RayRecord *>(v->cell_rays), reinterpret_cast<uint2 *>(v->cell_bricks), v->tail_count + 3, v->cell_cast_host, cells->cell_pairs};
         const size_t table_lds = ((size_t)kMaxSamples + 1) * sizeof(float);
         const uint32_t n_ray_blocks = (uint32_t)((n_pix + 255) / 256);
         const uint32_t n_list_blocks = (uint32_t)std::min<size_t>((v->occ.fine_count() / 4 + 255) / 256 + 1, 2048);
-        hipLaunchKernelGGL((cell_cast_prepare_kernel<SLAB>), dim3(n_ray_blocks + n_list_blocks), dim3(256), (uint32_t)table_lds, v->stream, v->g, rp, v->t_table,
-                           v->occ, cc, n_ray_blocks);
+        hipLaunchKernelGGL((cell_cast_prepare_kernel<SLAB>), dim3(n_ray_blocks + n_list_blocks), dim3(256), (uint32_t)table_lds, v->stream, v->g, rp, *cells, v->t_table,
+                           v->occ, cc, n_list_blocks);
         const dim3 cgrid((unsigned)tuning().ray_cells_grid + kShellWorkgroups);   // (the first kShellWorkgroups: the boundary bricks' shell samples)
         if (v->fast_div)
             TSDF_LAUNCH_TIMED(v, 1, (cast_cells_kernel<SLAB, true>), cgrid, dim3(256), v->dist, v->g, rp, *cells, v->occ, v->t_table, cc, tail.best);

@@ -35,29 +35,114 @@ static_assert(sizeof(RayRecord) == 8, "one 8-byte load");
 
 struct CellCast {
     RayRecord *rays;        // width * height
-    uint2 *bricks;          // flagged bricks: {index | kCellTasks | kShellTasks, brick coordinates 3 x 10 bits}
+    uint2 *bricks;          // the cast's tasks: {kCellTasks | kShellTasks | part << 10 | parts - 1, brick coordinates 3 x 10 bits}
     uint32_t *n_bricks;     // entries appended: TailQueue::count[3], reset by the resolve kernel of the previous cast
     uint32_t *n_bricks_host;  // pinned mirror of the count (the next cast's choice of kernels), may be null
+    uint32_t pairs_per_task;  // a brick whose (cell, pixel) pairs are estimated above this is listed in several parts (TSDF_RAY_CELLS_PAIRS)
 };
-constexpr uint32_t kCellTasks = 1u << 31, kShellTasks = 1u << 30, kBrickIndexMask = (1u << 30) - 1u;
+constexpr uint32_t kCellTasks = 1u << 31, kShellTasks = 1u << 30;
+// A brick seen from close by -- a camera inside the volume, a coarse grid -- is thousands of pairs, one wave's work for a long time while
+// the chip idles: it is listed in up to kMaxParts parts, each a wave's task (the wave loads the brick, finds its cells and boxes as
+// ever, and takes its share of the packed pairs).  The list has room for kPartsRoom extra entries per 1 024 bricks scanned (a workgroup's turn); a
+// workgroup whose bricks ask for more scales all of them down.
+constexpr uint32_t kMaxParts = 1024, kPartsRoom = 1024;
+__host__ __device__ inline size_t cell_list_capacity(size_t n_bricks) { return n_bricks + (size_t)kPartsRoom * ((n_bricks + 1023) / 1024); }
+
+// pixel box of the axis-aligned box [lo, hi] (grid millimetres) under the view's projection: false = no pixel can see it.
+// A sample's camera depth is its ray parameter t >= z_clip >= 0 (the last row of kinv is (0, 0, 1): view_projection; z_clip > 0 when
+// the camera is outside the volume, choose_cell_cast): only the part of the box with depth D >= z_clip can hold samples.
+//   * wholly behind that plane: none;
+//   * wholly in front of z_near > 0: the integers inside the hull of its 8 projected corners;
+//   * otherwise (the box straddles the plane, or comes within a quarter voxel of the camera plane): u = N(P) / D(P), N and D affine in
+//     P, so for any u*, u - u* = F(P) / D(P) with F = N - u* D affine too: over the box F lies in [F_c - h, F_c + h] (its value at the
+//     centre -+ half the sum of its coefficients along the box's edges) and D in (max(z_min, z_clip), z_max].  F_c - h > 0: the box is
+//     to the right of u* for every sample in it, by at least (F_c - h) / z_max; F_c + h < 0: to the left; the far side is bounded by
+//     the nearest depth when that is positive, not at all otherwise (a box that holds the camera asks every pixel).  u* = the image's
+//     centre: a box beside or behind the camera that reaches across the camera plane lies far off the image and is dropped here.
+struct PixelBox {
+    int u0, v0, w, h;
+};
+template <bool HULL = true>   // (false: the bound from the centre only -- wider in front of z_near, where the cells' kernel has its own)
+__device__ inline bool project_box(const EntryParams &ep, float lox, float loy, float loz, float hix, float hiy, float hiz, PixelBox &pb) {
+    const float mx = 0.5f * (lox + hix) + ep.offset.x, my = 0.5f * (loy + hiy) + ep.offset.y, mz = 0.5f * (loz + hiz) + ep.offset.z;
+    const float ccx = ep.r[0][0] * mx + ep.r[0][1] * my + ep.r[0][2] * mz + ep.r[0][3];
+    const float ccy = ep.r[1][0] * mx + ep.r[1][1] * my + ep.r[1][2] * mz + ep.r[1][3];
+    const float ccz = ep.r[2][0] * mx + ep.r[2][1] * my + ep.r[2][2] * mz + ep.r[2][3];
+    const float ext[3] = {hix - lox, hiy - loy, hiz - loz};
+    const float hz = 0.5f * ((fabsf(ep.r[2][0] * ext[0]) + fabsf(ep.r[2][1] * ext[1])) + fabsf(ep.r[2][2] * ext[2]));
+    // (the centre's coordinates are good to a few ulps of the largest term: 1e-5 of the camera's distance covers it with room)
+    const float zslack = 1.0e-5f * (((fabsf(ep.r[2][0] * mx) + fabsf(ep.r[2][1] * my)) + fabsf(ep.r[2][2] * mz)) + fabsf(ep.r[2][3])) + 1.0e-5f * hz;
+    const float zmin = ccz - hz - zslack, zmax = ccz + hz + zslack;
+    if (!(ccx == ccx && ccy == ccy && zmin == zmin && zmax == zmax) || fabsf(ccx) == INFINITY || fabsf(ccy) == INFINITY || zmax == INFINITY || zmin == -INFINITY) {
+        pb.u0 = 0; pb.v0 = 0; pb.w = (int)ep.width; pb.h = (int)ep.height;   // (something not finite: every pixel is asked)
+        return true;
+    }
+    if (zmax < ep.z_clip) return false;
+    float a0, a1, b0, b1;
+    const float kMargin = 0.05f;   // (the projection is the double-precision inverse of the matrices the rays are formed with, evaluated in fp32: 1e-2 px at most)
+    if (HULL && zmin > ep.z_near) {
+        float umin = INFINITY, umax = -INFINITY, vmin = INFINITY, vmax = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const float wx = ((c & 1) ? hix : lox) + ep.offset.x, wy = ((c & 2) ? hiy : loy) + ep.offset.y, wz = ((c & 4) ? hiz : loz) + ep.offset.z;
+            const float cx = ep.r[0][0] * wx + ep.r[0][1] * wy + ep.r[0][2] * wz + ep.r[0][3];
+            const float cy = ep.r[1][0] * wx + ep.r[1][1] * wy + ep.r[1][2] * wz + ep.r[1][3];
+            const float cz = fmaxf(ep.r[2][0] * wx + ep.r[2][1] * wy + ep.r[2][2] * wz + ep.r[2][3], 0.5f * ep.z_near);
+            const float rz = __builtin_amdgcn_rcpf(cz);   // (a bound, not a result: the margin below covers the last bits)
+            const float u = (ep.k[0][0] * cx + ep.k[0][1] * cy + ep.k[0][2] * cz) * rz, w = (ep.k[1][0] * cx + ep.k[1][1] * cy + ep.k[1][2] * cz) * rz;
+            umin = fminf(umin, u); umax = fmaxf(umax, u);
+            vmin = fminf(vmin, w); vmax = fmaxf(vmax, w);
+        }
+        // a ray exists per INTEGER pixel: the integers inside the hull's box
+        a0 = ceilf(umin - kMargin); a1 = floorf(umax + kMargin); b0 = ceilf(vmin - kMargin); b1 = floorf(vmax + kMargin);
+    } else {
+        const float us = 0.5f * (float)ep.width, vs_ = 0.5f * (float)ep.height;
+        const float dlo = fmaxf(zmin, ep.z_clip), rhi = 1.0f / (zmax * 1.0001f), rlo = dlo > 0.0f ? 1.0001f / dlo : INFINITY;
+        auto side = [&](const float *kr, float centre, float &lo_, float &hi_) {
+            const float t0 = kr[0] * ccx, t1 = kr[1] * ccy, t2 = kr[2] * ccz, t3 = centre * ccz;
+            const float fc = ((t0 + t1) + t2) - t3;
+            float h = 0.0f;
+#pragma unroll
+            for (int a_ = 0; a_ < 3; a_++) {
+                const float ex_ = ep.r[0][a_] * ext[a_], ey_ = ep.r[1][a_] * ext[a_], ez_ = ep.r[2][a_] * ext[a_];
+                h += 0.5f * fabsf(((kr[0] * ex_ + kr[1] * ey_) + kr[2] * ez_) - centre * ez_);
+            }
+            const float slack = 1.0e-5f * ((((fabsf(t0) + fabsf(t1)) + fabsf(t2)) + fabsf(t3)) + h) + (fabsf(kr[0]) + fabsf(kr[1]) + fabsf(kr[2]) + centre) * zslack;
+            const float fmin_ = fc - h - slack, fmax_ = fc + h + slack;
+            lo_ = fmin_ > 0.0f ? fmin_ * rhi : (dlo > 0.0f ? fmin_ * rlo : -INFINITY);
+            hi_ = fmax_ < 0.0f ? fmax_ * rhi : (dlo > 0.0f ? fmax_ * rlo : INFINITY);
+        };
+        float ul, uh, vl, vh;
+        side(ep.k[0], us, ul, uh);
+        side(ep.k[1], vs_, vl, vh);
+        a0 = ceilf(us + ul - kMargin); a1 = floorf(us + uh + kMargin); b0 = ceilf(vs_ + vl - kMargin); b1 = floorf(vs_ + vh + kMargin);
+    }
+    const float wmax = (float)(ep.width - 1u), hmax = (float)(ep.height - 1u);
+    if (!(a0 <= a1 && b0 <= b1) || a1 < 0.0f || b1 < 0.0f || a0 > wmax || b0 > hmax) return false;
+    pb.u0 = (int)fmaxf(a0, 0.0f); pb.v0 = (int)fmaxf(b0, 0.0f);
+    pb.w = (int)fminf(a1, wmax) - pb.u0 + 1; pb.h = (int)fminf(b1, hmax) - pb.v0 + 1;
+    return true;
+}
 
 // One launch in front of the cast, two kinds of workgroup.
-// The first n_ray_blocks: per pixel the direction, start point and sample range of its ray, exactly as the march kernels set a ray up
+// All but the first n_list_blocks: per pixel the direction, start point and sample range of its ray, exactly as the march kernels set a ray up
 // (setup_ray with the whole table: samples [k_first, k_end) are the ones the reference evaluates unless it stops earlier; a slab's range
 // is clipped to a superset of its own stretch).
-// The others: the bricks the cast has to look at -- `cell` and `fine` set (mixed cells), or a brick touching the grid boundary with
+// The first n_list_blocks (their chain of flag loads, prefix sums and one atomic is the launch's longest: they start first): the bricks the cast has to look at -- `cell` and `fine` set (mixed cells), or a brick touching the grid boundary with
 // `fine` set (shell samples); a slab lists the bricks that hold a cell whose lower plane it owns.  Four bricks a thread (one word of
 // each flag array), the brick's coordinates only for a flagged one, and ONE atomic per workgroup of 1 024 bricks: returning atomics
-// on one address serialise at ~10 ns each, and one per wave and word made this 37 us for 20 000 listed bricks.  The counter
-// (TailQueue::count[3]) is reset by the resolve kernel of the previous cast.
+// on one address are a round trip each, one after the other -- one per wave and word made this 37 us for 20 000 listed bricks, one per
+// 256 bricks (a brick a thread) 17 us against 10.  The counter (TailQueue::count[3]) is reset by the resolve kernel of the previous
+// cast.  With cc.pairs_per_task != 0 (a view whose bricks may be large on the screen, or cut by the camera plane: choose_cell_cast)
+// every flagged brick is projected: one that no pixel sees is dropped, a large one is listed in parts (+ 2.7 us).
 template <bool SLAB>
-__global__ __launch_bounds__(256) void cell_cast_prepare_kernel(const Geom g, const RayParams rp, const float *__restrict__ t_table, const OccGrid occ,
-                                                                const CellCast cc, const uint32_t n_ray_blocks) {
+__global__ __launch_bounds__(256) void cell_cast_prepare_kernel(const Geom g, const RayParams rp, const EntryParams ep, const float *__restrict__ t_table,
+                                                                const OccGrid occ, const CellCast cc, const uint32_t n_list_blocks) {
     extern __shared__ float Ts[];   // T[0 .. kMaxSamples] (ray workgroups); the list workgroups use its first words
-    if (blockIdx.x < n_ray_blocks) {
+    if (blockIdx.x >= n_list_blocks) {
         for (int i = (int)threadIdx.x; i <= kMaxSamples; i += 256) Ts[i] = t_table[i];
         __syncthreads();
-        const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+        const uint32_t i = (blockIdx.x - n_list_blocks) * 256 + threadIdx.x;
         if (i >= rp.width * rp.height) return;
         RayState ray;
         int k_first, k_end;
@@ -67,11 +152,16 @@ __global__ __launch_bounds__(256) void cell_cast_prepare_kernel(const Geom g, co
         cc.rays[i] = {near_t, (uint32_t)k_first | ((uint32_t)k_end << 16)};
         return;
     }
-    uint32_t *wave_count = reinterpret_cast<uint32_t *>(Ts);   // [0..3] the waves' entries, [4] the workgroup's base in the list
+    uint32_t *wave_count = reinterpret_cast<uint32_t *>(Ts);   // [0..3] the waves' entries, [4] the workgroup's base in the list, [8..11] the waves' extra parts
     const uint32_t n = (uint32_t)occ.fine_count(), n_words = (n + 3u) / 4u, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t *fine4 = reinterpret_cast<const uint32_t *>(occ.fine), *cell4 = reinterpret_cast<const uint32_t *>(occ.cell);
-    const uint32_t n_list_blocks = gridDim.x - n_ray_blocks;
-    for (uint32_t w0 = (blockIdx.x - n_ray_blocks) * 256u; w0 < n_words; w0 += n_list_blocks * 256u) {   // (uniform over the workgroup)
+    const bool look = cc.pairs_per_task != 0u;   // (uniform) project the bricks: drop the ones no pixel sees, list the large ones in parts
+    const float eps = make_skip_ctx(g, t_table[1]).eps;
+    const float side_ = (float)kBrick + 1.5f + 2.0f * eps;   // the listed box of a brick, in voxels: its half-diagonal in millimetres
+    const float us = 0.5f * (float)ep.width, vs_ = 0.5f * (float)ep.height;
+    const float gu0 = sqrtf(ep.k[0][0] * ep.k[0][0] + ep.k[0][1] * ep.k[0][1] + (ep.k[0][2] - us) * (ep.k[0][2] - us)), gv0 = sqrtf(ep.k[1][0] * ep.k[1][0] + ep.k[1][1] * ep.k[1][1] + (ep.k[1][2] - vs_) * (ep.k[1][2] - vs_));
+    const float radius = 0.5f * sqrtf((side_ * g.vs.x) * (side_ * g.vs.x) + (side_ * g.vs.y) * (side_ * g.vs.y) + (side_ * g.vs.z) * (side_ * g.vs.z));
+    for (uint32_t w0 = blockIdx.x * 256u; w0 < n_words; w0 += n_list_blocks * 256u) {   // (uniform over the workgroup)
         const uint32_t w = w0 + threadIdx.x;
         uint32_t f = 0, c = 0;
         if (w < n_words) {
@@ -86,11 +176,12 @@ __global__ __launch_bounds__(256) void cell_cast_prepare_kernel(const Geom g, co
             }
         }
         if (__syncthreads_or(f != 0u) == 0) continue;
-        uint32_t entry[4], coords[4], mine_n = 0;
+        uint32_t entry[4], coords[4], parts[4], extra = 0;
 #pragma unroll
         for (uint32_t j = 0; j < 4u; j++) {
             entry[j] = 0;
             coords[j] = 0;
+            parts[j] = 0;
             if ((f >> (8u * j)) & 0xffu) {
                 const uint32_t b = 4u * w + j;
                 const uint32_t bz = b / (occ.nbx * occ.nby), r = b - bz * (occ.nbx * occ.nby), by = r / occ.nbx, bx = r - by * occ.nbx;
@@ -99,12 +190,66 @@ __global__ __launch_bounds__(256) void cell_cast_prepare_kernel(const Geom g, co
                 if (mine) {
                     if ((c >> (8u * j)) & 0xffu) entry[j] |= kCellTasks;
                     if (bx == 0 || by == 0 || bz == 0 || bx + 1 == occ.nbx || by + 1 == occ.nby || bz + 1 == occ.nbz) entry[j] |= kShellTasks;
-                    if (entry[j]) entry[j] |= b;
+                }
+                bool seen = true;
+                float bw = 0.0f, bh = 0.0f;   // the sides of the brick's box in pixels
+                if (look && entry[j]) {
+                    // Can any pixel see it?  Its voxels and its cells (voxel centres x0 + 1/2 .. x0 + kBrick + 3/2), grown by eps -- the union
+                    // of what the cells' and the shell's tasks project -- inside a sphere around its centre: in front of the camera by more
+                    // than its radius R, every point of it projects within |grad F| R / (depth - R) of the centre (F = N - u_c D, zero at
+                    // the centre, D >= depth - R; project_box has the symbols).
+                    const float x0 = (float)(bx * kBrick), y0 = (float)(by * kBrick), z0 = (float)(bz * kBrick), mid = 0.5f * ((float)kBrick + 1.5f);
+                    const float wx = (x0 + mid) * g.vs.x + ep.offset.x, wy = (y0 + mid) * g.vs.y + ep.offset.y, wz = (z0 + mid) * g.vs.z + ep.offset.z;
+                    const float ccx = ep.r[0][0] * wx + ep.r[0][1] * wy + ep.r[0][2] * wz + ep.r[0][3];
+                    const float ccy = ep.r[1][0] * wx + ep.r[1][1] * wy + ep.r[1][2] * wz + ep.r[1][3];
+                    const float ccz = ep.r[2][0] * wx + ep.r[2][1] * wy + ep.r[2][2] * wz + ep.r[2][3];
+                    const float zfront = ccz - radius;
+                    if (zfront > ep.z_near && zfront > 0.01f * radius) {
+                        const float rz = __builtin_amdgcn_rcpf(ccz), rf = radius * __builtin_amdgcn_rcpf(zfront) * 1.001f;
+                        const float uc = (ep.k[0][0] * ccx + ep.k[0][1] * ccy + ep.k[0][2] * ccz) * rz, vc = (ep.k[1][0] * ccx + ep.k[1][1] * ccy + ep.k[1][2] * ccz) * rz;
+                        const float gu = sqrtf(ep.k[0][0] * ep.k[0][0] + ep.k[0][1] * ep.k[0][1] + (ep.k[0][2] - uc) * (ep.k[0][2] - uc)) * rf + 0.5f;
+                        const float gv = sqrtf(ep.k[1][0] * ep.k[1][0] + ep.k[1][1] * ep.k[1][1] + (ep.k[1][2] - vc) * (ep.k[1][2] - vc)) * rf + 0.5f;
+                        // (anything not a number: seen, and as large as the image)
+                        seen = !(uc + gu < 0.0f || vc + gv < 0.0f || uc - gu > (float)(ep.width - 1u) || vc - gv > (float)(ep.height - 1u));
+                        bw = fminf(1.2f * gu, (float)ep.width);    // (the sphere is wider than the box it holds: 2 r / sqrt 3)
+                        bh = fminf(1.2f * gv, (float)ep.height);
+                        if (!(bw == bw && bh == bh)) { bw = (float)ep.width; bh = (float)ep.height; }
+                    } else {
+                        // at the camera plane, or across it: beside the camera it lies off the image, on the side it is on (project_box:
+                        // F over the sphere is F_c -+ |grad F| R, D at most depth + R); otherwise it is as large as the image
+                        const float rhi = 1.0f / ((ccz + radius) * 1.001f);
+                        const float fu = (ep.k[0][0] * ccx + ep.k[0][1] * ccy + ep.k[0][2] * ccz) - us * ccz, fv = (ep.k[1][0] * ccx + ep.k[1][1] * ccy + ep.k[1][2] * ccz) - vs_ * ccz;
+                        const float su = gu0 * radius * 1.001f + 1.0e-4f * (fabsf(fu) + us * fabsf(ccz)), sv = gv0 * radius * 1.001f + 1.0e-4f * (fabsf(fv) + vs_ * fabsf(ccz));
+                        seen = !(ccz + radius < ep.z_clip || (fu - su > 0.0f && (fu - su) * rhi > us) || (fu + su < 0.0f && (fu + su) * rhi < -us - 1.0f) ||
+                                 (fv - sv > 0.0f && (fv - sv) * rhi > vs_) || (fv + sv < 0.0f && (fv + sv) * rhi < -vs_ - 1.0f));
+                        bw = (float)ep.width;
+                        bh = (float)ep.height;
+                    }
+                }
+                if (!seen) entry[j] = 0;   // a brick outside the view is not listed at all
+                if (entry[j]) {
                     coords[j] = bx | (by << 10) | (bz << 20);
+                    parts[j] = 1;
+                    if (look && (entry[j] & kCellTasks)) {
+                        // all 64 cells mixed, each a quarter of the brick's box and a pixel of margin: an estimate from above
+                        const float est = 64.0f * (0.25f * bw + 1.0f) * (0.25f * bh + 1.0f);
+                        parts[j] = (uint32_t)fminf(fmaxf(ceilf(est / (float)cc.pairs_per_task), 1.0f), (float)kMaxParts);
+                    }
+                    extra += parts[j] - 1u;
                 }
             }
-            mine_n += entry[j] ? 1u : 0u;
         }
+        if (look) {   // the workgroup's extra parts against the room it has
+            uint32_t extra_wave = extra;
+            for (int o = 32; o > 0; o >>= 1) extra_wave += __shfl_xor(extra_wave, o);
+            if (lane == 0u) wave_count[8u + wave] = extra_wave;
+            __syncthreads();
+            const uint32_t extra_all = wave_count[8] + wave_count[9] + wave_count[10] + wave_count[11];
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; j++)
+                if (extra_all > kPartsRoom && parts[j] > 1u) parts[j] = 1u + (uint32_t)(((uint64_t)(parts[j] - 1u) * kPartsRoom) / extra_all);
+        }
+        const uint32_t mine_n = (parts[0] + parts[1]) + (parts[2] + parts[3]);
         uint32_t incl = mine_n;   // inclusive prefix over the wave
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t up = __shfl_up(incl, o);
@@ -121,69 +266,10 @@ __global__ __launch_bounds__(256) void cell_cast_prepare_kernel(const Geom g, co
         for (uint32_t q = 0; q < wave; q++) at += wave_count[q];
 #pragma unroll
         for (uint32_t j = 0; j < 4u; j++)
-            if (entry[j]) cc.bricks[at++] = make_uint2(entry[j], coords[j]);
+            for (uint32_t part = 0; part < parts[j]; part++)   // (the shell's task goes with the first part only)
+                cc.bricks[at++] = make_uint2((part ? entry[j] & ~kShellTasks : entry[j]) | (part << 10) | (parts[j] - 1u), coords[j]);
         __syncthreads();   // (wave_count is written again in the next turn)
     }
-}
-
-// pixel box of the axis-aligned box [lo, hi] (grid millimetres) under the view's projection: false = no pixel can see it
-struct PixelBox {
-    int u0, v0, w, h;
-};
-__device__ inline bool project_box(const EntryParams &ep, float lox, float loy, float loz, float hix, float hiy, float hiz, PixelBox &pb) {
-    float zmin = INFINITY, zmax = -INFINITY, umin = INFINITY, umax = -INFINITY, vmin = INFINITY, vmax = -INFINITY;
-    bool bad = false;
-#pragma unroll
-    for (int c = 0; c < 8; c++) {
-        const float wx = ((c & 1) ? hix : lox) + ep.offset.x, wy = ((c & 2) ? hiy : loy) + ep.offset.y, wz = ((c & 4) ? hiz : loz) + ep.offset.z;
-        const float cx = ep.r[0][0] * wx + ep.r[0][1] * wy + ep.r[0][2] * wz + ep.r[0][3];
-        const float cy = ep.r[1][0] * wx + ep.r[1][1] * wy + ep.r[1][2] * wz + ep.r[1][3];
-        const float cz = ep.r[2][0] * wx + ep.r[2][1] * wy + ep.r[2][2] * wz + ep.r[2][3];
-        bad = bad || !(cz == cz);
-        zmin = fminf(zmin, cz);
-        zmax = fmaxf(zmax, cz);
-        const float rz = __builtin_amdgcn_rcpf(cz);   // (a bound, not a result: the margin below covers the last bits)
-        const float u = (ep.k[0][0] * cx + ep.k[0][1] * cy + ep.k[0][2] * cz) * rz, w = (ep.k[1][0] * cx + ep.k[1][1] * cy + ep.k[1][2] * cz) * rz;
-        umin = fminf(umin, u); umax = fmaxf(umax, u);
-        vmin = fminf(vmin, w); vmax = fmaxf(vmax, w);
-    }
-    // A sample's camera depth is its ray parameter, and the view has none below z_clip (the camera is outside the volume, by a margin:
-    // choose_cell_cast): a box wholly in front of that plane is bounded by the hull of its corners; one wholly behind holds no sample.
-    if (bad) {   // (something not finite: every pixel is asked)
-        pb.u0 = 0; pb.v0 = 0; pb.w = (int)ep.width; pb.h = (int)ep.height;
-        return true;
-    }
-    if (zmax < ep.z_clip) return false;
-    float a0, a1, b0, b1;
-    const float kMargin = 0.05f;   // (the projection is the double-precision inverse of the matrices the rays are formed with, evaluated in fp32: 1e-2 px at most)
-    if (zmin >= ep.z_clip) {
-        // a ray exists per INTEGER pixel: the integers inside the hull's box
-        a0 = ceilf(umin - kMargin); a1 = floorf(umax + kMargin); b0 = ceilf(vmin - kMargin); b1 = floorf(vmax + kMargin);
-    } else {
-        // The box straddles the plane: only its part with depth >= z_clip can hold samples.  u = N(P) / D(P), N and D affine, D the
-        // depth: for any u*, |u(P) - u*| = |N(P) - u* D(P)| / D(P) <= (|N - u* D| at the centre + half the sum of its coefficients along
-        // the box's edges) / z_clip.  u* = the image's centre.
-        const float mx = 0.5f * (lox + hix) + ep.offset.x, my = 0.5f * (loy + hiy) + ep.offset.y, mz = 0.5f * (loz + hiz) + ep.offset.z;
-        const float ccx = ep.r[0][0] * mx + ep.r[0][1] * my + ep.r[0][2] * mz + ep.r[0][3];
-        const float ccy = ep.r[1][0] * mx + ep.r[1][1] * my + ep.r[1][2] * mz + ep.r[1][3];
-        const float ccz = ep.r[2][0] * mx + ep.r[2][1] * my + ep.r[2][2] * mz + ep.r[2][3];
-        const float us = 0.5f * (float)ep.width, vs_ = 0.5f * (float)ep.height;
-        float ru = fabsf((ep.k[0][0] * ccx + ep.k[0][1] * ccy + ep.k[0][2] * ccz) - us * ccz), rv = fabsf((ep.k[1][0] * ccx + ep.k[1][1] * ccy + ep.k[1][2] * ccz) - vs_ * ccz);
-        const float ext[3] = {hix - lox, hiy - loy, hiz - loz};
-#pragma unroll
-        for (int a_ = 0; a_ < 3; a_++) {
-            const float ex_ = ep.r[0][a_] * ext[a_], ey_ = ep.r[1][a_] * ext[a_], ez_ = ep.r[2][a_] * ext[a_];
-            ru += 0.5f * fabsf((ep.k[0][0] * ex_ + ep.k[0][1] * ey_ + ep.k[0][2] * ez_) - us * ez_);
-            rv += 0.5f * fabsf((ep.k[1][0] * ex_ + ep.k[1][1] * ey_ + ep.k[1][2] * ez_) - vs_ * ez_);
-        }
-        const float rz = 1.0001f / ep.z_clip;
-        a0 = ceilf(us - ru * rz - kMargin); a1 = floorf(us + ru * rz + kMargin); b0 = ceilf(vs_ - rv * rz - kMargin); b1 = floorf(vs_ + rv * rz + kMargin);
-    }
-    const float wmax = (float)(ep.width - 1u), hmax = (float)(ep.height - 1u);
-    if (!(a0 <= a1 && b0 <= b1) || a1 < 0.0f || b1 < 0.0f || a0 > wmax || b0 > hmax) return false;
-    pb.u0 = (int)fmaxf(a0, 0.0f); pb.v0 = (int)fmaxf(b0, 0.0f);
-    pb.w = (int)fminf(a1, wmax) - pb.u0 + 1; pb.h = (int)fminf(b1, hmax) - pb.v0 + 1;
-    return true;
 }
 
 // Samples of the ray (s, d) whose positions can lie in the box [lo, hi] (grid millimetres): [k_lo, k_hi], clipped to [k_first, k_end).
@@ -427,7 +513,7 @@ __global__ __launch_bounds__(256) void cast_cells_kernel(const float *__restrict
             const float ccy = ep.r[1][0] * wx + ep.r[1][1] * wy + ep.r[1][2] * wz + ep.r[1][3];
             const float ccz = ep.r[2][0] * wx + ep.r[2][1] * wy + ep.r[2][2] * wz + ep.r[2][3];
             const float zmin = ccz - half_dz;
-            if (zmin > ep.z_clip) {
+            if (zmin > ep.z_near) {
                 const float rz = __builtin_amdgcn_rcpf(ccz), rm = __builtin_amdgcn_rcpf(zmin);
                 const float uc = (ep.k[0][0] * ccx + ep.k[0][1] * ccy + ep.k[0][2] * ccz) * rz, vc = (ep.k[1][0] * ccx + ep.k[1][1] * ccy + ep.k[1][2] * ccz) * rz;
                 const float su = 0.5f * ((fabsf(nu_[0] - uc * nz_[0]) + fabsf(nu_[1] - uc * nz_[1])) + fabsf(nu_[2] - uc * nz_[2]));
@@ -443,7 +529,7 @@ __global__ __launch_bounds__(256) void cast_cells_kernel(const float *__restrict
                 const float clx = ((float)lx + 0.5f - e) * g.vs.x, chx = ((float)lx + 1.5f + e) * g.vs.x;
                 const float cly = ((float)ly + 0.5f - e) * g.vs.y, chy = ((float)ly + 1.5f + e) * g.vs.y;
                 const float clz = ((float)lz + 0.5f - e) * g.vs.z, chz = ((float)lz + 1.5f + e) * g.vs.z;
-                mixed = project_box(ep, clx, cly, clz, chx, chy, chz, pb);
+                mixed = project_box<false>(ep, clx, cly, clz, chx, chy, chz, pb);
             }
         }
         if (lane == 0) { RAY_MIX(32); }
@@ -460,9 +546,17 @@ __global__ __launch_bounds__(256) void cast_cells_kernel(const float *__restrict
             box_of[wave][lane][0] = pb.u0; box_of[wave][lane][1] = pb.v0; box_of[wave][lane][2] = pb.w; box_of[wave][lane][3] = pb.h;
         }
         wave_sync();
-        for (int q0 = 0; q0 < n_pairs; q0 += 64) {
+        // this task's share of the brick's pairs (all of them, unless the brick was listed in parts)
+        int q_begin = 0, q_end = n_pairs;
+        if (entry & (kMaxParts - 1u)) {   // (uniform)
+            const uint32_t part = (entry >> 10) & (kMaxParts - 1u), parts = (entry & (kMaxParts - 1u)) + 1u;
+            const uint32_t share = ((uint32_t)n_pairs + parts - 1u) / parts;
+            q_begin = (int)min(part * share, (uint32_t)n_pairs);
+            q_end = (int)min((uint32_t)q_begin + share, (uint32_t)n_pairs);
+        }
+        for (int q0 = q_begin; q0 < q_end; q0 += 64) {
             const int q = q0 + (int)lane;
-            if (q >= n_pairs) continue;
+            if (q >= q_end) continue;
             int cl = 0, hi_ = 63;
 #pragma unroll
             for (int it = 0; it < 6; it++) {
