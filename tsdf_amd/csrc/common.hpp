@@ -52,7 +52,7 @@ struct Tuning {
     int ray_cells;           // TSDF_RAY_CELLS          the cell-parallel cast (raycast_cells.hpp): 0 never, 1 (default) unless the previous cast listed more than
                              //                          TSDF_RAY_CELLS_LIMIT flagged bricks, 2 whenever the view has a projection
     int ray_cells_limit;     // TSDF_RAY_CELLS_LIMIT    (131072)
-    float ray_cells_footprint;   // TSDF_RAY_CELLS_FOOTPRINT  largest voxel footprint (pixels, at the depth of the volume's centre) the cell-parallel cast is taken for (5)
+    float ray_cells_footprint;   // TSDF_RAY_CELLS_FOOTPRINT  largest voxel footprint (pixels, at the depth of the volume's centre) the cell-parallel cast is taken for (10)
     int ray_cells_pairs;     // TSDF_RAY_CELLS_PAIRS    estimated (cell, pixel) pairs of a brick above which it is listed in several parts (1024; 0: never)
     int ray_cells_look;      // TSDF_RAY_CELLS_LOOK     1: project every flagged brick when the list is built (0: only for views that need it, choose_cell_cast)
     int ray_cells_grid;      // TSDF_RAY_CELLS_GRID     workgroups of cast_cells_kernel (8192: a wave per brick for 32 768 bricks, the rest in turns)

@@ -1882,13 +1882,13 @@ static bool choose_cell_cast(const tsdf_volume *v, const RayParams &rp, EntryPar
     ep.cell_pairs = (tuning().ray_cells_look || ep.z_clip == 0.0f || !(footprint < 2.0f)) ? (uint32_t)tuning().ray_cells_pairs : 0u;
     if (mode == 2) return true;
     // What the cast costs is the number of (mixed cell, pixel) pairs: a voxel that covers several pixels makes every cell a dozen pairs
-    // or more.  Measured over grid sizes on one scene (640x480, the camera 2 m from the centre of 3 m of volume,
-    // profiles/r05q_cells_footprint_sweep.txt; cast stage, march / cells): 384^3, 2 px a voxel, 0.194 / 0.113 ms; 256^3, 3 px, 0.170 /
-    // 0.115 (0.108 in parts); 192^3, 4 px, 0.176 / 0.127; 128^3, 6 px, 0.171 / 0.211; 96^3, 8 px, 0.145 / 0.296.  The voxel's footprint at
-    // the depth of the volume's centre decides (5 px), and the previous cell-parallel cast's list length (arbitrary fields: every
-    // brick flagged).  From inside the volume the view holds surface after surface behind the first -- every mixed cell is looked at,
-    // hidden or not: 4.2 M pairs at 1024^3 against 2.0 M for the view from outside, 0.29 ms against the march's 0.215 -- and the march
-    // kernels keep it (TSDF_RAY_CELLS=2 takes the cell-parallel cast there too).
+    // or more.  Measured over grid sizes on one scene (640x480, the camera 2 m from the centre of 3 m of volume; cast stage, march /
+    // cells with the large bricks in parts, profiles/r05s_cells_footprint_sweep_parts.txt; one part a brick: r05q_*): 384^3, 2 px a
+    // voxel, 0.194 / 0.113 ms; 256^3, 3 px, 0.170 / 0.106; 192^3, 4 px, 0.176 / 0.113; 128^3, 6 px, 0.170 / 0.132; 96^3, 8 px, 0.145 /
+    // 0.131; 64^3, 12 px, 0.179 / 0.194.  The voxel's footprint at the depth of the volume's centre decides (10 px), and the previous
+    // cell-parallel cast's list length (arbitrary fields: every brick flagged).  From inside the volume the view holds surface after
+    // surface behind the first -- every mixed cell is looked at, hidden or not: 4.2 M pairs at 1024^3 against 2.0 M for the view from
+    // outside, 0.29 ms against the march's 0.215 -- and the march kernels keep it (TSDF_RAY_CELLS=2 takes the cell-parallel cast there too).
     if (ep.z_clip == 0.0f) return false;
     if (!(footprint <= tuning().ray_cells_footprint)) return false;
     const uint32_t listed = v->cell_cast_host ? *v->cell_cast_host : 0u;
