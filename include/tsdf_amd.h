@@ -239,11 +239,11 @@ int tsdf_vertices_to_depth_device(uint32_t width, uint32_t height, const float *
  * as tsdf_raycast_device fills it).  Asynchronous on the volume's stream. */
 int tsdf_raycast_depth_device(const tsdf_volume *volume, uint32_t width, uint32_t height, const float pose[16],
                               const float inv_pose[16], const float kinv[9], uint16_t *device_depth, float *device_vertices);
-/* Diagnostics for the roofline model: S = trilinear samples evaluated, T = distinct voxels
- * touched by any tap, of one raycast with these arguments (runs an instrumented kernel). */
 /* Which kernels the volume's last ray cast took: 1 = the cell-parallel cast (one wave per flagged brick, no ray is marched), 0 = the
  * march kernels.  Scheduling only -- both produce the same bits -- reported by bench.py beside the kernels' times. */
 int tsdf_volume_last_raycast_kind(const tsdf_volume *volume, int *cell_parallel);
+/* Diagnostics for the roofline model: S = trilinear samples evaluated, T = distinct voxels
+ * touched by any tap, of one raycast with these arguments (runs an instrumented kernel). */
 int tsdf_raycast_stats(const tsdf_volume *volume, uint32_t width, uint32_t height, const float pose[16],
                        const float kinv[9], uint64_t *samples, uint64_t *touched_voxels, uint64_t *hits);
 

@@ -23,13 +23,17 @@ def short(name):
 
 
 def kernel_stats(db):
+    """Per kernel: calls, total, mean, min, max, share -- and the MEDIAN launch: the mean of a bench run also holds the first casts on
+    an empty volume and the launches of the warm-up, several times the steady state's."""
     cur = sqlite3.connect(db).cursor()
     rows = cur.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) "
                        "from kernels group by name order by sum(duration) desc").fetchall()
     total = sum(r[2] for r in rows) or 1
-    out = ["%-70s %6s %14s %12s %12s %12s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "min_ns", "max_ns", "pct")]
+    out = ["%-70s %6s %14s %12s %12s %12s %7s %12s" % ("kernel", "calls", "total_ns", "avg_ns", "min_ns", "max_ns", "pct", "median_ns")]
     for name, calls, tot, avg, mn, mx in rows:
-        out.append("%-70s %6d %14d %12.0f %12d %12d %6.2f%%" % (short(name)[:70], calls, tot, avg, mn, mx, 100.0 * tot / total))
+        durs = sorted(r[0] for r in cur.execute("select duration from kernels where name = ?", (name,)).fetchall())
+        med = durs[len(durs) // 2] if durs else 0
+        out.append("%-70s %6d %14d %12.0f %12d %12d %6.2f%% %12d" % (short(name)[:70], calls, tot, avg, mn, mx, 100.0 * tot / total, med))
     return "\n".join(out)
 
 
