@@ -1839,8 +1839,11 @@ static int refresh_for_cast(tsdf_volume *v, RayParams &rp) {
 // every cell is mixed; TSDF_RAY_CELLS = 0 never / 1 by that count (default) / 2 whenever the view allows).
 static bool choose_cell_cast(const tsdf_volume *v, const RayParams &rp, EntryParams &ep) {
     const int mode = tuning().ray_cells;
-    // (a list entry: 10 bits of each brick coordinate; a record of the cast: 13 bits of sample index)
-    if (mode == 0 || v->occ.fine_count() >= ((size_t)1 << 30) || v->occ.nbx > 1024u || v->occ.nby > 1024u || v->occ.nbz > 1024u || !view_projection(v, rp, ep)) return false;
+    // (a list entry: 10 bits of each brick coordinate; a record of the cast: 13 bits of sample index;
+    // ... and a brick's pairs are counted in 31 bits: 64 cells that each ask every pixel)
+    if (mode == 0 || v->occ.fine_count() >= ((size_t)1 << 30) || v->occ.nbx > 1024u || v->occ.nby > 1024u || v->occ.nbz > 1024u ||
+        (uint64_t)rp.width * rp.height > ((uint64_t)1 << 24) || !view_projection(v, rp, ep))
+        return false;
     // A camera OUTSIDE the volume: every sample has a camera depth (= its ray parameter) of at least z_clip > 0, a cell at or behind the
     // camera plane holds none, and one that straddles the plane z_clip is bounded from its part in front.  Inside (or within a voxel of)
     // the volume z_clip = 0: samples start at the camera, a box that holds it asks every pixel, one beside it that reaches across the
