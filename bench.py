@@ -444,6 +444,19 @@ def main():
     step_spread = {"median": round(float(np.median(per_step)), 4), "p95": round(float(np.percentile(per_step, 95)), 4),
                    "max": round(float(per_step.max()), 4), "max_over_median": round(float(per_step.max() / np.median(per_step)), 3),
                    "steps": K, "how": "an event behind every pipelined step of one more run of the same frames"}
+    # ---- and once more, pipelined, with the dominant kernels' launches carrying their dispatches' own begin / end timestamps: the kernels
+    # as they run in the two-stream step -- the cast beside the next frame's filter and culling: what a rocprofv3 kernel trace of this
+    # command sees (profiles/*_kernel_stats.txt) -- beside `avg_launch_ms`, each kernel with nothing beside it
+    vol.clear()
+    for i in range(Wu):
+        step(i, False)
+    torch.cuda.synchronize()
+    vol.set_timing(1)
+    for i in range(Wu, Wu + K):
+        step(i, False)
+    torch.cuda.synchronize()
+    kern_pipelined = {w: vol.kernel_time(w) for w in ("integrate", "raycast", "raycast_tail")}
+    vol.set_timing(False)
     # ---- integrate under each way the weights can be stored (weights.hip): 8-bit counts (what the timed frames run on), 16-bit counts
     # (a voxel updated more than 255 times), the reference's fp32 array (after weight_data() / beyond 65535): same frames, same bits
     int_by_storage = {}
@@ -527,6 +540,7 @@ def main():
     roof_int = {"kernel": int_kernel, "bound": "hbm", "achieved": round(int_gbs, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(int_gbs / HBM_PEAK_GBS, 5), "traffic": traffic.get(int_kernel),
                 "algorithmic_bytes": int_bytes, "avg_launch_ms": round(int_ms, 4), "launches_timed": kern["integrate"][0],
+                "avg_launch_ms_pipelined": round(kern_pipelined["integrate"][1], 4),
                 "U_voxels_updated": U, "U_min_max": [int(min(U_frames)), int(max(U_frames))], "dense_bytes": 16 * N_vox,
                 "weight_storage_bits": wbits, "bytes_moved_per_updated_voxel": moved_per_voxel,
                 "moved_bytes_model": moved_per_voxel * U + 2 * W * H,
@@ -550,6 +564,8 @@ def main():
                     "bound": "hbm", "achieved": round(ray_gbs, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(ray_gbs / HBM_PEAK_GBS, 5), "traffic": (traffic.get(ray_names[0], 0) + (traffic.get(ray_names[1], 0) if ray_names[1] else 0)) or None,
                     "algorithmic_bytes": ray_bytes, "avg_launch_ms": round(ray_ms, 4), "launches_timed": kern["raycast"][0],
+                    "avg_launch_ms_pipelined": round(kern_pipelined["raycast"][1] + kern_pipelined["raycast_tail"][1], 4),
+                    "avg_launch_ms_is": "the kernel with nothing beside it (replay, one stage after the other); _pipelined: in the two-stream step, beside the next frame's filter and culling -- what a kernel trace of this command shows",
                     "avg_launch_ms_by_kernel": ({"cast_cells_kernel": round(ray_main_ms, 4)} if cells else
                                                 {"process_ray_kernel": round(ray_main_ms, 4), "process_ray_tail_kernel": round(ray_tail_ms, 4)}),
                     "T_voxels_touched": st["touched"], "S_samples": st["samples"],

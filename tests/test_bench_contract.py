@@ -43,6 +43,9 @@ def test_default_shaped_run_prints_the_contract_line():
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert math.isclose(r["frac"], r["achieved"] / r["peak"], rel_tol=1e-3) and 0.05 < r["frac"] < 1.0
     assert r["launches_timed"] >= 1 and r["avg_launch_ms"] > 0 and r["algorithmic_bytes"] > 0
+    # the same kernels as they run in the two-stream step (what a kernel trace of the command shows): never faster than alone by more than noise
+    for rr in (r, d["roofline_other"]):
+        assert rr["avg_launch_ms_pipelined"] > 0.8 * rr["avg_launch_ms"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
     assert d["parity"]["pass"] is True
