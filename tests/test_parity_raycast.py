@@ -598,3 +598,72 @@ def test_cell_parallel_cast_from_outside_beside_and_inside(oracle, tmp_path, n):
         assert bool(got["cells%d" % j]) == v["cells"], "%d^3, view %d %s: which kernels ran" % (n, j, v["at"])
         hits += int((~np.isnan(Vo[:, 0])).sum())
     assert hits > 300000
+
+
+_CELLS_PROBE_K = r"""
+import sys, json, numpy as np
+import tsdf_amd
+from tsdf_amd import synth
+n, views = int(sys.argv[2]), json.loads(sys.argv[3])
+gv = tsdf_amd.TSDFVolume((n, n, n), (3000, 3000, 3000))
+for i in range(4):
+    d, cam = synth.depth_frame(i, 12, seed=0x5EED0002)
+    gv.integrate(d, synth.WIDTH, synth.HEIGHT, cam)
+out = {"D": gv.get_distance_data()}
+for j, v in enumerate(views):
+    cam = tsdf_amd.Camera(*v["K"])
+    cam.move_to(*v["at"]); cam.look_at(*v["look"])
+    V, N = gv.raycast(v["size"][0], v["size"][1], cam)
+    out["V%d" % j], out["N%d" % j], out["cells%d" % j] = V, N, np.array(gv.last_raycast_cell_parallel())
+np.savez(sys.argv[1], **out)
+"""
+
+
+@pytest.mark.parametrize("cells", ["2", "0"])
+def test_cell_parallel_cast_with_unusual_intrinsics(oracle, tmp_path, cells):
+    """(cells = 0: the same views through the march kernels.)  The cell-parallel cast bounds a cell's pixels from the view's projection (pixel = K x camera / depth): principal points far off
+    the image's centre or off the image, mirrored and anisotropic focal lengths, a fisheye-wide and a tele lens, odd image sizes -- from
+    outside and from inside the volume.  Every picture the oracle's, bit for bit; the cast is the cell-parallel one every time."""
+    import json
+    import os
+    import subprocess
+    import sys
+    n = 100
+    views = [
+        {"K": (525.0, 525.0, -150.0, 240.0), "size": (640, 480), "at": (1500, 1300, -700), "look": (2300, 1400, 1900)},   # principal point left of the image
+        {"K": (525.0, 525.0, 900.0, 600.0), "size": (640, 480), "at": (1500, 1300, -700), "look": (600, 700, 1900)},      # ... beyond its lower right corner
+        {"K": (-525.0, 525.0, 320.0, 240.0), "size": (640, 480), "at": (1400, 1300, -900), "look": (1500, 1400, 1900)},    # mirrored
+        {"K": (525.0, -400.0, 300.0, 260.0), "size": (640, 480), "at": (1400, 1300, -900), "look": (1500, 1400, 1900)},
+        {"K": (300.0, 800.0, 320.0, 100.0), "size": (640, 480), "at": (-500, 1500, 900), "look": (1500, 1400, 1900)},      # anisotropic
+        {"K": (120.0, 120.0, 320.0, 240.0), "size": (640, 480), "at": (1500, 1400, -300), "look": (1500, 1400, 1900)},     # very wide: the camera plane's neighbourhood in view
+        {"K": (2500.0, 2500.0, 320.0, 240.0), "size": (640, 480), "at": (1500, 1300, -2500), "look": (1500, 1400, 1900)},  # tele: a voxel covers many pixels
+        {"K": (97.0, 61.0, 48.0, 30.0), "size": (97, 61), "at": (1500, 1300, -800), "look": (1500, 1400, 1900)},           # a small odd image
+        {"K": (525.0, 525.0, -150.0, 240.0), "size": (640, 480), "at": (1500, 1400, 900), "look": (2900, 1500, 2800)},     # off-centre, from inside
+        {"K": (120.0, 140.0, 300.0, 250.0), "size": (640, 480), "at": (900, 1400, 1200), "look": (300, 1400, 2390)},       # very wide, from inside
+        {"K": (-525.0, -525.0, 320.0, 240.0), "size": (333, 477), "at": (1500, 1400, 2380), "look": (300, 1400, 2390)},    # mirrored twice, inside, along the wall
+        # from inside along an axis, the principal point on a pixel: a row / a column of rays has a direction component of exactly 0, for
+        # which the reference's ray_box leaves an exit out of its minimum (NaN compares false): those rays are sampled far beyond the
+        # grid -- to sample 4402 when it is the z component -- and the clamped interpolation out there finds "surfaces"
+        {"K": (525.0, 525.0, 320.0, 240.0), "size": (640, 480), "at": (1500, 1400, 900), "look": (1500, 1400, 2900)},
+        {"K": (200.0, 200.0, 320.0, 240.0), "size": (640, 480), "at": (700, 1400, 1500), "look": (2900, 1400, 1500)},
+        {"K": (200.0, 200.0, 320.0, 240.0), "size": (640, 480), "at": (1500, 2600, 1500), "look": (1500, 100, 1500.001)},
+    ]
+    out = str(tmp_path / "cells_k.npz")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, TSDF_RAY_CELLS=cells)
+    e["PYTHONPATH"] = root + os.pathsep + e.get("PYTHONPATH", "")
+    subprocess.run([sys.executable, "-c", _CELLS_PROBE_K, out, str(n), json.dumps(views)], check=True, env=e, cwd=root, timeout=900)
+    got = np.load(out)
+    ov = oracle.Volume((n, n, n), (3000, 3000, 3000))
+    ov.set_distance_data(got["D"])
+    hits = 0
+    for j, v in enumerate(views):
+        cam = tsdf_amd.Camera(*v["K"])
+        cam.move_to(*v["at"])
+        cam.look_at(*v["look"])
+        Vo, No = ov.raycast(v["size"][0], v["size"][1], cam.pose(), cam.kinv(), nthreads=oracle.max_threads())
+        assert_same_floats(got["V%d" % j], Vo, "view %d %s: vertices" % (j, v))
+        assert_same_floats(got["N%d" % j], No, "view %d %s: normals" % (j, v))
+        assert bool(got["cells%d" % j]) == (cells == "2"), "view %d %s: which kernels ran" % (j, v)
+        hits += int((~np.isnan(Vo[:, 0])).sum())
+    assert hits > 200000

@@ -1763,7 +1763,11 @@ static int check_ray_args(const tsdf_volume *v, uint32_t width, uint32_t height,
 static bool view_projection(const tsdf_volume *v, const RayParams &rp, EntryParams &ep) {
     const Geom &g = v->g;
     const Mat33 &ki = rp.kinv;
-    if (ki.m31 != 0.0f || ki.m32 != 0.0f || ki.m33 != 1.0f) return false;   // the ray's camera z must be 1 per unit of t
+    // The ray's camera z must be 1 per unit of t.  (An inverse formed in fp32 -- the reference's Eigen .inverse(), the host Camera's -- leaves
+    // 0.99999994 there for focal lengths like 525 / 400: a depth off by an ulp is far inside every margin taken below -- two voxels for
+    // the entry bound, 0.05 px and 1e-5 of the depth for the cells' boxes -- and the projection carries the factor exactly.)
+    const double w33 = ki.m33;
+    if (ki.m31 != 0.0f || ki.m32 != 0.0f || !(std::fabs(w33 - 1.0) <= 1.0e-6)) return false;
     // pose = [R t; 0 0 0 1] (rp.rot, rp.origin), kinv = [a s c; e b d; 0 0 1]: the inverses in double
     const double R[3][3] = {{rp.rot.m11, rp.rot.m12, rp.rot.m13}, {rp.rot.m21, rp.rot.m22, rp.rot.m23}, {rp.rot.m31, rp.rot.m32, rp.rot.m33}};
     const double det = R[0][0] * (R[1][1] * R[2][2] - R[1][2] * R[2][1]) - R[0][1] * (R[1][0] * R[2][2] - R[1][2] * R[2][0]) +
@@ -1781,9 +1785,9 @@ static bool view_projection(const tsdf_volume *v, const RayParams &rp, EntryPara
     }
     const double kd = (double)ki.m11 * ki.m22 - (double)ki.m12 * ki.m21;
     if (!(std::fabs(kd) > 1e-12) || !std::isfinite(kd)) return false;
-    // inverse of [a s c; e b d; 0 0 1], rows 1-2
-    ep.k[0][0] = (float)(ki.m22 / kd); ep.k[0][1] = (float)(-ki.m12 / kd); ep.k[0][2] = (float)((ki.m12 * (double)ki.m23 - ki.m22 * (double)ki.m13) / kd);
-    ep.k[1][0] = (float)(-ki.m21 / kd); ep.k[1][1] = (float)(ki.m11 / kd); ep.k[1][2] = (float)((ki.m21 * (double)ki.m13 - ki.m11 * (double)ki.m23) / kd);
+    // inverse of [a s c; e b d; 0 0 1], rows 1-2; a direction's camera z is w33: camera x and y count w33-fold (pixel = k * camera / camera.z)
+    ep.k[0][0] = (float)(ki.m22 / kd * w33); ep.k[0][1] = (float)(-ki.m12 / kd * w33); ep.k[0][2] = (float)((ki.m12 * (double)ki.m23 - ki.m22 * (double)ki.m13) / kd);
+    ep.k[1][0] = (float)(-ki.m21 / kd * w33); ep.k[1][1] = (float)(ki.m11 / kd * w33); ep.k[1][2] = (float)((ki.m21 * (double)ki.m13 - ki.m11 * (double)ki.m23) / kd);
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 4; j++)
             if (!std::isfinite(ep.r[i][j])) return false;
@@ -1868,7 +1872,7 @@ static bool choose_cell_cast(const tsdf_volume *v, const RayParams &rp, EntryPar
             dmax = std::max(dmax, std::sqrt(dx * dx + dy * dy + dz * dz));
         }
         if (!(dmax > 0.0) || !std::isfinite(dmax) || !std::isfinite(outside)) return false;
-        ep.z_clip = outside >= 4.0f * vs_max_ ? (float)(0.5 * outside / dmax) : 0.0f;   // (half of it: room for the fp32 evaluation on either side)
+        ep.z_clip = outside >= 4.0f * vs_max_ ? (float)(0.5 * outside / dmax) : 0.0f;   // (a depth is the parameter to within an ulp: view_projection)   // (half of it: room for the fp32 evaluation on either side)
         if (!(ep.z_clip >= 0.0f)) return false;
         ep.z_near = std::max(ep.z_clip, 0.25f * vs_min_);
         if (!(ep.z_near > 0.0f)) return false;
@@ -1996,7 +2000,7 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
     v->last_cast_cells = cells ? 1 : 0;
     if (cells) {
         // ---- the cell-parallel cast (raycast_cells.hpp): the rays' records, the flagged bricks, one wave per brick ----
-        CellCast cc = {reinterpret_cast<RayRecord *>(v->cell_rays), reinterpret_cast<uint2 *>(v->cell_bricks), v->tail_count + 3, v->cell_cast_host, cells->cell_pairs};
+        CellCast cc = {reinterpret_cast<RayRecord *>(v->cell_rays), reinterpret_cast<uint2 *>(v->cell_bricks), v->tail_count + 3, v->cell_cast_host, cells->cell_pairs, v->dist, tail.best};
         const size_t table_lds = ((size_t)kMaxSamples + 1) * sizeof(float);
         const uint32_t n_ray_blocks = (uint32_t)((n_pix + 255) / 256);
         const uint32_t n_list_blocks = (uint32_t)std::min<size_t>((v->occ.fine_count() / 4 + 255) / 256 + 1, 2048);

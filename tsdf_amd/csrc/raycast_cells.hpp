@@ -39,6 +39,8 @@ struct CellCast {
     uint32_t *n_bricks;     // entries appended: TailQueue::count[3], reset by the resolve kernel of the previous cast
     uint32_t *n_bricks_host;  // pinned mirror of the count (the next cast's choice of kernels), may be null
     uint32_t pairs_per_task;  // a brick whose (cell, pixel) pairs are estimated above this is listed in several parts (TSDF_RAY_CELLS_PAIRS)
+    const float *dist;        // the distances and the pixels' words: for the rays whose samples leave the grid (cell_cast_prepare_kernel)
+    uint64_t *best;
 };
 constexpr uint32_t kCellTasks = 1u << 31, kShellTasks = 1u << 30;
 // A brick seen from close by -- a camera inside the volume, a coarse grid -- is thousands of pairs, one wave's work for a long time while
@@ -150,6 +152,43 @@ __global__ __launch_bounds__(256) void cell_cast_prepare_kernel(const Geom g, co
         setup_ray<SLAB>((int)(i % rp.width), (int)(i / rp.width), true, 0, kMaxSamples, Ts, 0, rp, g, Ts[1], ray, k_first, k_end, &near_t);
         if (k_end <= k_first) k_first = k_end = 0;
         cc.rays[i] = {near_t, (uint32_t)k_first | ((uint32_t)k_end << 16)};
+        // Samples far off the grid.  The cells' and the shell's tasks cover the grid grown by eps; the reference's range can reach beyond
+        // it: for a ray that starts inside the volume ray_box (GPURaycaster.cu:197-251) takes the smallest of three exit parameters with
+        // `<` on values that are NaN for a zero direction component -- d.y == 0 leaves the z exit alone, d.z == 0 leaves NaN and the march
+        // goes on to sample 4402 -- and every sample out there interpolates the clamped boundary voxels with unclamped weights, often to
+        // something <= 0.  Such rays (a row or a column of pixels of a camera that looks along an axis plane) are walked here, sample by
+        // sample from where they really leave the grown grid, with the reference's interpolation; their word takes the minimum like
+        // everyone's.  An ordinary ray's last sample lies in front of that exit and costs one comparison.
+        if (k_end > k_first) {
+            const float e = make_skip_ctx(g, Ts[1]).eps;
+            float tout = INFINITY;
+            bool never = false;
+            auto axis = [&](float s_, float d_, float lo, float hi) {
+                if (d_ != 0.0f) tout = fminf(tout, fmaxf((lo - s_) / d_, (hi - s_) / d_));
+                else if (s_ < lo || s_ > hi) never = true;
+            };
+            axis(ray.sx, ray.dx, -e * g.vs.x, ((float)g.X + e) * g.vs.x);
+            axis(ray.sy, ray.dy, -e * g.vs.y, ((float)g.Y + e) * g.vs.y);
+            axis(ray.sz, ray.dz, -e * g.vs.z, ((float)g.Z + e) * g.vs.z);
+            if (never) tout = -INFINITY;
+            if (!(Ts[k_end - 1] <= tout)) {   // (also for anything not a number)
+                const float step = Ts[1], kf = floorf(tout / step) - 2.0f;
+                int k = kf > (float)k_first ? (kf < 8192.0f ? (int)kf : 8192) : k_first;
+                uint64_t *word = cc.best + i;
+                for (; k < k_end; k++) {
+                    const float t = Ts[k];
+                    const float px = (t * ray.dx) + ray.sx, py = (t * ray.dy) + ray.sy, pz = (t * ray.dz) + ray.sz;
+                    const float fx = px / g.vs.x, fy = py / g.vs.y, fz = pz / g.vs.z;
+                    if (fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx <= (float)g.X && fy <= (float)g.Y && fz <= (float)g.Z) continue;   // on the grid: the cells' / the shell's
+                    bool owned;
+                    const float tsdf = trilinear<SLAB, false, false>(px, py, pz, cc.dist, g, rp.tc, rp, owned, nullptr);
+                    if (tsdf <= 0) {
+                        lower_best(word, k, tsdf);
+                        break;
+                    }
+                }
+            }
+        }
         return;
     }
     uint32_t *wave_count = reinterpret_cast<uint32_t *>(Ts);   // [0..3] the waves' entries, [4] the workgroup's base in the list, [8..11] the waves' extra parts
