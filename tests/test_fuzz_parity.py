@@ -90,6 +90,52 @@ def test_random_scene(oracle, seed):
     _SEEN["hit"] += int((~np.isnan(Vo[:, 0])).any())
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_axis_aligned_cameras_on_integer_principal_points(oracle, seed):
+    """Cameras inside, on a face of and beside the volume that look exactly along an axis, principal point on a pixel: a row and a column
+    of rays have a direction component of exactly 0.  For a ray that starts inside the volume the reference's ray_box then leaves an exit
+    out of its minimum (NaN compares false, GPURaycaster.cu:197-251) and the ray is sampled far off the grid, where the clamped
+    interpolation finds "surfaces"; beside the volume the zero component is a ray that runs along a face.  (Run once more with
+    TSDF_RAY_CELLS=2 by the round's evidence runs: the cell-parallel cast walks such rays where it forms the ray records.)"""
+    rng = np.random.default_rng(0xA815 + seed)
+    dims = tuple(int(v) for v in rng.integers(12, 60, size=3))
+    phys = tuple(float(v) for v in rng.uniform(400, 3000, size=3))
+    width, height = int(rng.integers(8, 160)), int(rng.integers(8, 120))
+    n = dims[0] * dims[1] * dims[2]
+    gv = tsdf_amd.TSDFVolume(dims, phys)
+    ov = oracle.Volume(dims, phys)
+    trunc = gv.truncation_distance()
+    # a smooth field with a few surfaces, some of them through the grid's faces
+    zz, yy, xx = np.meshgrid(np.arange(dims[2]), np.arange(dims[1]), np.arange(dims[0]), indexing="ij")
+    c = rng.uniform(0.2, 0.8, size=3) * np.array(dims)
+    r = np.sqrt((xx - c[0]) ** 2 + (yy - c[1]) ** 2 + (zz - c[2]) ** 2)
+    D = np.clip((r - rng.uniform(0.15, 0.6) * min(dims)) * (phys[0] / dims[0]), -trunc, trunc).astype(np.float32)
+    if rng.random() < 0.5:
+        D = np.minimum(D, np.clip((zz - rng.uniform(0.1, 0.9) * dims[2]) * (phys[2] / dims[2]), -trunc, trunc).astype(np.float32))
+    gv.set_distance_data(D.reshape(-1))
+    ov.set_distance_data(D.reshape(-1))
+    for _ in range(3):
+        axis, sign = int(rng.integers(0, 3)), float(rng.choice([-1.0, 1.0]))
+        where = rng.integers(0, 3)     # inside, on a face, outside
+        pos = rng.uniform(0.1, 0.9, size=3) * np.array(phys)
+        if where == 1:
+            pos[int(rng.integers(0, 3))] = rng.choice([0.0, 1.0]) * phys[0]
+        elif where == 2:
+            pos[axis] = -sign * rng.uniform(0.05, 1.0) * phys[axis] + (phys[axis] if sign < 0 else 0.0)
+        fwd = np.zeros(3); fwd[axis] = sign
+        up = np.zeros(3); up[(axis + 1) % 3] = 1.0
+        right = np.cross(up, fwd)
+        M = np.eye(4)
+        M[:3, 0], M[:3, 1], M[:3, 2], M[:3, 3] = right, up, fwd, pos
+        cam = tsdf_amd.Camera(float(rng.uniform(0.4, 1.5) * width), float(rng.uniform(0.4, 1.5) * width), float(rng.integers(0, width)), float(rng.integers(0, height)))
+        cam.set_pose_rows(M)
+        V, N = gv.raycast(width, height, cam)
+        Vo, No = ov.raycast(width, height, cam.pose(), cam.kinv(), nthreads=oracle.max_threads())
+        what = "seed %d dims %s image %dx%d camera at %s along %s%d" % (seed, dims, width, height, pos, "+" if sign > 0 else "-", axis)
+        assert_same_floats(V, Vo, what + " vertices")
+        assert_same_floats(N, No, what + " normals")
+
+
 def test_the_random_scenes_were_not_vacuous():
     if _SEEN["scenes"] < 20:
         pytest.skip("needs the whole sweep")

@@ -8,7 +8,7 @@ fails = 0
 lo = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 hi = int(sys.argv[2]) if len(sys.argv) > 2 else lo + 80
 for seed in range(lo, hi):
-    for fn in (t.test_random_distance_fields, t.test_smooth_distance_fields, t.test_random_scene):
+    for fn in (t.test_random_distance_fields, t.test_smooth_distance_fields, t.test_random_scene, t.test_axis_aligned_cameras_on_integer_principal_points):
         try:
             fn(orc, seed)
         except AssertionError as e:
