@@ -11,10 +11,12 @@
 //     bricks whose `cell` flag is set (OccGrid: a superset at all times), and those in bricks whose `fine` flag is set too;
 //   * a sample in the outer half-voxel shell of the grid (where the reference extrapolates, Q10) or off the grid by rounding can only
 //     be <= 0 when the boundary brick of its voxel is flagged (`fine`: otherwise every voxel in reach is flat, OccGrid): the
-//     first workgroups of the launch take those bricks (cast_shell_bricks).
+//     first workgroups of the launch take those bricks (cast_shell_bricks);
+//   * a sample FAR off the grid exists only on rays for which the reference's ray_box loses an exit (a direction component of exactly 0,
+//     the camera inside): those rays are walked where the ray records are formed (cell_cast_prepare_kernel).
 // So the work is turned round: one wave per flagged brick.  It loads the brick's 5^3 voxels once, finds its mixed cells, projects each
 // (grown by the guard band eps) into the image -- the view's projection is only used to bound the PIXELS worth looking at -- and for
-// every such pixel intersects that pixel's ray (the same start point and direction as ever: ray_records_kernel runs setup_ray) with
+// every such pixel intersects that pixel's ray (the same start point and direction as ever: cell_cast_prepare_kernel runs setup_ray) with
 // the cell, walks the few samples inside -- the reference's expressions for the value, the look-ahead of process_sample to pass the
 // ones proven positive -- and lowers the pixel's word to the first one <= 0.  A sample within eps of a cell face, where the cheap
 // arithmetic and the reference's may disagree about the cell, takes the reference's full trilinearly_interpolate, which picks its own
@@ -22,9 +24,11 @@
 // same value.  The minimum over all tasks (atomicMin on {k, value}) is the sample the reference's loop stops at: every sample <= 0 is
 // found by some task, and every sample evaluated is one the reference would evaluate with the same result.  resolve_*_kernel is unchanged.
 // No ray is marched through free space, no wave waits for a long ray: the cast is the number of (mixed cell, pixel) pairs, a few per ray.
-// Needs a view whose projection exists (camera depth == ray parameter: view_projection); a mixed cell that straddles the camera plane
-// is offered to every pixel.  Volumes whose flagged bricks are so many that marching is cheaper (arbitrary fields: every cell mixed)
-// keep the march kernels: the count of the previous cast decides (scheduling only -- both give the same bits).
+// Needs a view whose projection exists (camera depth == ray parameter: view_projection); a mixed cell that reaches across the camera
+// plane is bounded from the side it lies on, one that holds the camera is offered to every pixel (project_box).  Volumes whose flagged
+// bricks are so many that marching is cheaper (arbitrary fields: every cell mixed), views from inside the volume (surface behind
+// surface: every mixed cell is looked at, hidden or not) and voxels of more than ten pixels keep the march kernels unless
+// TSDF_RAY_CELLS=2 (choose_cell_cast; scheduling only -- both give the same bits).
 
 struct RayRecord {      // 8 bytes per pixel: what of setup_ray's result cannot be formed again in a dozen instructions
     float near_t;       // the ray's start point is origin + near_t * direction (ray_from_near); the direction follows from the pixel (ray_direction)
