@@ -1,6 +1,8 @@
 """GPU parity: GPURaycaster.raycast (process_ray + compute_normals in HIP, through the C ABI) against the CPU
 oracle.  north_star's tolerance is 1e-4 relative with an identical NaN mask; the assertion here is bit-exact
 vertices and normals (the kernels keep the reference's operation order, fp contraction off)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -667,3 +669,34 @@ def test_cell_parallel_cast_with_unusual_intrinsics(oracle, tmp_path, cells):
         assert bool(got["cells%d" % j]) == (cells == "2"), "view %d %s: which kernels ran" % (j, v)
         hits += int((~np.isnan(Vo[:, 0])).sum())
     assert hits > 200000
+
+
+def test_an_uploaded_field_that_flags_every_brick_keeps_the_march(oracle):
+    """The cell-parallel cast's work is the number of flagged bricks times their cells' pixels; the choice goes by the list the previous
+    cast built.  After a bulk change of the distances that count says nothing: the flags are rebuilt and counted before the first cast
+    (count_after_bulk_change).  A field with sign changes everywhere lists every brick -- 262 144 at 256^3, over the limit of 131 072:
+    the march runs (and gives the oracle's picture); after clear() and a few integrated frames the cell-parallel cast is back."""
+    n = 256
+    rng = np.random.default_rng(11)
+    gv = tsdf_amd.TSDFVolume((n, n, n), (3000, 3000, 3000))
+    trunc = gv.truncation_distance()
+    D = (rng.uniform(-1.0, 1.0, size=n * n * n) * trunc).astype(np.float32)
+    gv.set_distance_data(D)
+    cam = camera_at((1500, 1400, -900), look_at=(1500, 1400, 1900))
+    V, N = gv.raycast(W, H, cam)
+    if os.environ.get("TSDF_RAY_CELLS", "1") == "1":
+        assert not gv.last_raycast_cell_parallel()
+    ov = oracle.Volume((n, n, n), (3000, 3000, 3000))
+    ov.set_distance_data(D)
+    Vo, No = ov.raycast(W, H, cam.pose(), cam.kinv(), nthreads=oracle.max_threads())
+    assert_same_floats(V, Vo, "every brick flagged: vertices")
+    assert_same_floats(N, No, "every brick flagged: normals")
+    gv.clear()
+    for i in range(3):
+        d, c = synth.depth_frame(i, 12, seed=0x5EED0002)
+        gv.integrate(d, synth.WIDTH, synth.HEIGHT, c)
+    gv.raycast(W, H, cam)
+    gv.raycast(W, H, cam)
+    if os.environ.get("TSDF_RAY_CELLS", "1") == "1":
+        assert gv.last_raycast_cell_parallel()
+    gv.close()

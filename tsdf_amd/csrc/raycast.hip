@@ -1841,6 +1841,36 @@ static int refresh_for_cast(tsdf_volume *v, RayParams &rp) {
 // Which kernels a cast takes (scheduling only: the same bits either way).  The cell-parallel cast needs the view's projection; it is
 // left to the march kernels when the previous cast listed so many flagged bricks that marching is cheaper (arbitrary fields in which
 // every cell is mixed; TSDF_RAY_CELLS = 0 never / 1 by that count (default) / 2 whenever the view allows).
+// After a bulk change of the distances (set_distance_data, a loaded file: occ_dirty) the count the choice below goes by -- the bricks
+// the previous cell-parallel cast listed -- says nothing about the new field, and an arbitrary field at 1024^3 can list four million
+// bricks of 64 mixed cells each: minutes of pairs.  The flags are rebuilt at once (the cast would do that anyway), one workgroup counts
+// the bricks with `fine` and `cell` set into the mirror, and the host waits for it: once per bulk change, never in a stream of frames.
+__global__ __launch_bounds__(1024) void count_cell_bricks_kernel(const OccGrid occ, uint32_t *__restrict__ mirror) {
+    __shared__ uint32_t total;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    const size_t n = occ.fine_count();
+    for (size_t b = threadIdx.x; b < n; b += 1024) mine += (occ.fine[b] && occ.cell[b]) ? 1u : 0u;
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    if ((threadIdx.x & 63u) == 0) atomicAdd(&total, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) *mirror = total;
+}
+static int count_after_bulk_change(tsdf_volume *v) {
+    if (tuning().ray_cells == 0 || !v->occ_dirty) return TSDF_OK;
+    int rc = occupancy_flags_refresh(v);
+    if (rc != TSDF_OK) return rc;
+    if (!v->cell_cast_host) {
+        TSDF_HIP(hipHostMalloc((void **)&v->cell_cast_host, sizeof(uint32_t), hipHostMallocDefault), "brick count mirror alloc");
+        *v->cell_cast_host = 0;
+    }
+    hipLaunchKernelGGL(count_cell_bricks_kernel, dim3(1), dim3(1024), 0, v->stream, v->occ, v->cell_cast_host);
+    TSDF_HIP(hipGetLastError(), "brick count failed");
+    TSDF_HIP(hipStreamSynchronize(v->stream), "brick count failed");
+    return TSDF_OK;
+}
+
 static bool choose_cell_cast(const tsdf_volume *v, const RayParams &rp, EntryParams &ep) {
     const int mode = tuning().ray_cells;
     // (a list entry: 10 bits of each brick coordinate; a record of the cast: 13 bits of sample index;
@@ -2193,6 +2223,8 @@ int tsdf_raycast_device(const tsdf_volume *v, uint32_t width, uint32_t height, c
     TSDF_REQUIRE(v->z_begin == 0 && v->z_end == v->g.Z, "tsdf_raycast on a slab: use tsdf_raycast_slab_device");
     RayParams rp = make_params(v, width, height, pose, kinv);
     EntryParams view;
+    rc = count_after_bulk_change(const_cast<tsdf_volume *>(v));
+    if (rc != TSDF_OK) return rc;
     if (choose_cell_cast(v, rp, view)) {
         rc = occupancy_flags_refresh(const_cast<tsdf_volume *>(v));
         if (rc != TSDF_OK) return rc;
@@ -2242,6 +2274,8 @@ int tsdf_raycast_depth_device(const tsdf_volume *v, uint32_t width, uint32_t hei
     TSDF_REQUIRE(v->z_begin == 0 && v->z_end == v->g.Z, "tsdf_raycast_depth needs a whole volume");
     RayParams rp = make_params(v, width, height, pose, kinv);
     EntryParams view;
+    rc = count_after_bulk_change(const_cast<tsdf_volume *>(v));
+    if (rc != TSDF_OK) return rc;
     if (choose_cell_cast(v, rp, view)) {
         rc = occupancy_flags_refresh(const_cast<tsdf_volume *>(v));
         if (rc != TSDF_OK) return rc;
@@ -2345,6 +2379,8 @@ int tsdf_raycast_slab_device(const tsdf_volume *v, uint32_t width, uint32_t heig
     TSDF_REQUIRE(device_hits, "tsdf_raycast_slab: null hit buffer");
     RayParams rp = make_params(v, width, height, pose, kinv);
     EntryParams view;
+    rc = count_after_bulk_change(const_cast<tsdf_volume *>(v));
+    if (rc != TSDF_OK) return rc;
     if (choose_cell_cast(v, rp, view)) {
         rc = occupancy_flags_refresh(const_cast<tsdf_volume *>(v));
         if (rc != TSDF_OK) return rc;

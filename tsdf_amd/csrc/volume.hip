@@ -965,6 +965,7 @@ int tsdf_volume_clear(tsdf_volume *v) {
     v->occ_scan_all = 1;
     v->occ_dirty = 0;
     v->occ_tighten_due = 0;
+    if (v->cell_cast_host) *v->cell_cast_host = 0;   // (the cell-parallel cast's list of an empty volume; a cast in flight may still write the old count: it only costs a march)
     v->prepared_valid = 0;   // (a brick list prepared ahead bakes in the offset at clear time)
     v->integrations_since_rebuild = v->integrations_total = 0;
     // initialise_deformation bakes the CURRENT offset into the node translations (Q1)
