@@ -362,8 +362,8 @@ np.savez(sys.argv[1], V=V, N=N, D=gv.get_distance_data())
     {"TSDF_RAY_CELLS": "0"},                                                                   # the march kernels, whatever the view (round 5)
     {"TSDF_RAY_CELLS": "2"},                                                                   # the cell-parallel cast wherever the view allows it
     {"TSDF_RAY_CELLS": "2", "TSDF_RAY_CELLS_GRID": "3"},                                       # ... every wave through many bricks
-    {"TSDF_RAY_CELLS": "2", "TSDF_RAY_CELLS_LOOK": "1", "TSDF_RAY_CELLS_PAIRS": "64"},         # ... the bricks projected when listed, each in many parts
-    {"TSDF_RAY_CELLS": "2", "TSDF_RAY_CELLS_LOOK": "1", "TSDF_RAY_CELLS_PAIRS": "0"},          # ... projected (unseen ones dropped), never in parts
+    {"TSDF_RAY_CELLS": "2", "TSDF_RAY_CELLS_PAIRS": "64"},                                     # ... each brick in many parts
+    {"TSDF_RAY_CELLS": "2", "TSDF_RAY_CELLS_LOOK": "0"},                                       # ... the bricks not projected when listed (none dropped, never in parts)
     {"TSDF_RAY_FUSED": "1", "TSDF_RAY_CELLS": "0"},                                            # the march and its queue in one launch
 ])
 def test_schedule_knobs_do_not_change_a_bit(oracle, tmp_path, env):

@@ -54,7 +54,7 @@ struct Tuning {
     int ray_cells_limit;     // TSDF_RAY_CELLS_LIMIT    (131072)
     float ray_cells_footprint;   // TSDF_RAY_CELLS_FOOTPRINT  largest voxel footprint (pixels, at the depth of the volume's centre) the cell-parallel cast is taken for (10)
     int ray_cells_pairs;     // TSDF_RAY_CELLS_PAIRS    estimated (cell, pixel) pairs of a brick above which it is listed in several parts (1024; 0: never)
-    int ray_cells_look;      // TSDF_RAY_CELLS_LOOK     1: project every flagged brick when the list is built (0: only for views that need it, choose_cell_cast)
+    int ray_cells_look;      // TSDF_RAY_CELLS_LOOK     1 (default): every flagged brick is projected when the list is built -- unseen ones dropped, large ones listed in parts; 0: never
     int ray_cells_grid;      // TSDF_RAY_CELLS_GRID     workgroups of cast_cells_kernel (8192: a wave per brick for 32 768 bricks, the rest in turns)
     int ray_fused;           // TSDF_RAY_FUSED          1: the march and its queue of unfinished stretches in ONE launch (process_ray_fused_kernel; measured slower, LABNOTES round 5); default 0: two launches
     int ray_entry_bound;     // TSDF_RAY_ENTRY_BOUND    0: no per-tile entry bound (default 1: rays start at the nearest flagged block their 16 x 16 tile can see)

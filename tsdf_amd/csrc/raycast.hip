@@ -1913,10 +1913,11 @@ static bool choose_cell_cast(const tsdf_volume *v, const RayParams &rp, EntryPar
     const float vs_max = std::max(g.vs.x, std::max(g.vs.y, g.vs.z));
     const float reach = 0.25f * std::max(g.phys.x, std::max(g.phys.y, g.phys.z));   // (a camera inside the volume: surfaces a quarter of it away)
     const float footprint = vs_max * std::max(std::fabs(ep.k[0][0]), std::fabs(ep.k[1][1])) / std::max(depth, reach);
-    // The list's builder projects the bricks -- those no pixel sees are dropped, those that are large on the screen listed in parts --
-    // when the bricks can be large: a voxel of two pixels or more, a camera inside or next to the volume.  (2.7 us otherwise spent for
-    // little: a brick outside the view costs its wave a microsecond.)
-    ep.cell_pairs = (tuning().ray_cells_look || ep.z_clip == 0.0f || !(footprint < 2.0f)) ? (uint32_t)tuning().ray_cells_pairs : 0u;
+    // The list's builder projects the bricks -- those no pixel sees are dropped, those that are large on the screen listed in parts.
+    // Always: the footprint above is the volume centre's, and a surface just behind the face the camera looks through is hundreds of
+    // pixels a cell -- one wave's work for milliseconds without the parts.  (Its cost hides behind the ray records since the list's
+    // workgroups start first: 11.0 -> 11.3 us; TSDF_RAY_CELLS_LOOK=0 switches it off for study.)
+    ep.cell_pairs = tuning().ray_cells_look ? (uint32_t)tuning().ray_cells_pairs : 0u;
     if (mode == 2) return true;
     // What the cast costs is the number of (mixed cell, pixel) pairs: a voxel that covers several pixels makes every cell a dozen pairs
     // or more.  Measured over grid sizes on one scene (640x480, the camera 2 m from the centre of 3 m of volume; cast stage, march /

@@ -139,8 +139,8 @@ __device__ inline bool project_box(const EntryParams &ep, float lox, float loy, 
 // each flag array), the brick's coordinates only for a flagged one, and ONE atomic per workgroup of 1 024 bricks: returning atomics
 // on one address are a round trip each, one after the other -- one per wave and word made this 37 us for 20 000 listed bricks, one per
 // 256 bricks (a brick a thread) 17 us against 10.  The counter (TailQueue::count[3]) is reset by the resolve kernel of the previous
-// cast.  With cc.pairs_per_task != 0 (a view whose bricks may be large on the screen, or cut by the camera plane: choose_cell_cast)
-// every flagged brick is projected: one that no pixel sees is dropped, a large one is listed in parts (+ 2.7 us).
+// cast.  With cc.pairs_per_task != 0 (the default) every flagged brick is projected: one that no pixel sees is dropped, a large one is
+// listed in parts (+ 0.3 us: these workgroups start first and end with the ray records').
 template <bool SLAB>
 __global__ __launch_bounds__(256) void cell_cast_prepare_kernel(const Geom g, const RayParams rp, const EntryParams ep, const float *__restrict__ t_table,
                                                                 const OccGrid occ, const CellCast cc, const uint32_t n_list_blocks) {
