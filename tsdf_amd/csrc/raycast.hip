@@ -1929,6 +1929,11 @@ static bool choose_cell_cast(const tsdf_volume *v, const RayParams &rp, EntryPar
     // outside, 0.29 ms against the march's 0.215 -- and the march kernels keep it (TSDF_RAY_CELLS=2 takes the cell-parallel cast there too).
     if (ep.z_clip == 0.0f) return false;
     if (!(footprint <= tuning().ray_cells_footprint)) return false;
+    // ... and a camera that could have a surface right in front of it: a wall six voxels behind the face it looks through, the camera
+    // five voxels outside (cells of 48 pixels), is 2.0 ms against the march's 0.08; twenty voxels outside 0.18 against 0.105
+    // (tools/dbg_near_wall.py, profiles/r05x_near_wall.txt).  The nearest depth a sample of the view can have is 2 z_clip: a voxel there
+    // may cover sixteen pixels (the camera some thirty voxels from the volume).
+    if (!(vs_max * std::max(std::fabs(ep.k[0][0]), std::fabs(ep.k[1][1])) <= 16.0f * (2.0f * ep.z_clip))) return false;
     const uint32_t listed = v->cell_cast_host ? *v->cell_cast_host : 0u;
     return listed <= (uint32_t)tuning().ray_cells_limit;
 }

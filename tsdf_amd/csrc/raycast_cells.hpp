@@ -273,8 +273,9 @@ __global__ __launch_bounds__(256) void cell_cast_prepare_kernel(const Geom g, co
                 if (entry[j]) {
                     coords[j] = bx | (by << 10) | (bz << 20);
                     parts[j] = 1;
-                    if (look && (entry[j] & kCellTasks)) {
-                        // all 64 cells mixed, each a quarter of the brick's box and a pixel of margin: an estimate from above
+                    if (look) {
+                        // all 64 cells mixed, each a quarter of the brick's box and a pixel of margin: an estimate from above (a boundary
+                        // brick's shell samples are shared out by the same parts: every pixel of its box is looked at)
                         const float est = 64.0f * (0.25f * bw + 1.0f) * (0.25f * bh + 1.0f);
                         parts[j] = (uint32_t)fminf(fmaxf(ceilf(est / (float)cc.pairs_per_task), 1.0f), (float)kMaxParts);
                     }
@@ -309,8 +310,8 @@ __global__ __launch_bounds__(256) void cell_cast_prepare_kernel(const Geom g, co
         for (uint32_t q = 0; q < wave; q++) at += wave_count[q];
 #pragma unroll
         for (uint32_t j = 0; j < 4u; j++)
-            for (uint32_t part = 0; part < parts[j]; part++)   // (the shell's task goes with the first part only)
-                cc.bricks[at++] = make_uint2((part ? entry[j] & ~kShellTasks : entry[j]) | (part << 10) | (parts[j] - 1u), coords[j]);
+            for (uint32_t part = 0; part < parts[j]; part++)
+                cc.bricks[at++] = make_uint2(entry[j] | (part << 10) | (parts[j] - 1u), coords[j]);
         __syncthreads();   // (wave_count is written again in the next turn)
     }
 }
@@ -390,10 +391,14 @@ __device__ inline void cast_shell_bricks(const float *__restrict__ dist, const G
             }
             PixelBox sb;
             if (!project_box(ep, lo_[0] * vs_[0], lo_[1] * vs_[1], lo_[2] * vs_[2], hi_[0] * vs_[0], hi_[1] * vs_[1], hi_[2] * vs_[2], sb)) continue;
-            const int n_pix = sb.w * sb.h;
+            // this task's share of the box's pixels (all of them, unless the brick was listed in parts: one seen from close by is
+            // tens of thousands of pixels, 32 a turn)
+            const uint32_t part = (entry2.x >> 10) & (kMaxParts - 1u), parts = (entry2.x & (kMaxParts - 1u)) + 1u;
+            const uint32_t share = ((uint32_t)(sb.w * sb.h) + parts - 1u) / parts;
+            const int pi_begin = (int)min(part * share, (uint32_t)(sb.w * sb.h)), n_pix = (int)min((uint32_t)pi_begin + share, (uint32_t)(sb.w * sb.h));
             if (threadIdx.x == 0) { RAY_MIX(42); }
             const int sub = (int)(threadIdx.x & 7u);
-            for (int pi = (int)(threadIdx.x >> 3); pi < n_pix; pi += 32) {
+            for (int pi = pi_begin + (int)(threadIdx.x >> 3); pi < n_pix; pi += 32) {
                 const int py = pi / sb.w, px = pi - py * sb.w;
                 if (sub == 0) { RAY_MIX(43); }
                 const uint32_t idx = (uint32_t)(sb.v0 + py) * rp.width + (uint32_t)(sb.u0 + px);
