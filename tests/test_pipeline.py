@@ -289,7 +289,9 @@ def test_the_schedule_knobs_of_the_pipeline_change_no_bit():
     seen = {}
     for name, env in (("default", {}), ("event scope 0", {"TSDF_EVENT_SCOPE": "0"}), ("event scope 1", {"TSDF_EVENT_SCOPE": "1"}),
                       ("release 1", {"TSDF_PIPE_RELEASE": "1"}), ("release 2", {"TSDF_PIPE_RELEASE": "2"}),
-                      ("host wait", {"TSDF_PIPE_HOST_WAIT": "1"})):
+                      ("host wait", {"TSDF_PIPE_HOST_WAIT": "1"}),
+                      ("word release", {"TSDF_PIPE_WORD_RELEASE": "1"}), ("word release, cells forced", {"TSDF_PIPE_WORD_RELEASE": "1", "TSDF_RAY_CELLS": "2"}),
+                      ("word release, march", {"TSDF_PIPE_WORD_RELEASE": "1", "TSDF_RAY_CELLS": "0"})):
         out = subprocess.run([sys.executable, "-c", KNOB_SCRIPT % root], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, (name, out.stderr[-2000:])
         seen[name] = out.stdout.split()[-1]

@@ -66,6 +66,7 @@ struct Tuning {
     int weight_pack;         // TSDF_WEIGHT_PACK        how a volume's weights are stored to begin with (weights.hip): 8 (default) / 16-bit counts, 0 = the reference's fp32 array
     int pipe_release;        // TSDF_PIPE_RELEASE       when tsdf_pipeline_step lets the next frame's filter + culling start on the side stream: 0 after
                              //                          this frame's integrate (beside the bulk ray kernel), 1 after the bulk ray kernel (beside the tail kernel), 2 the filter already after the previous step (beside integrate); both measured slower
+    int pipe_word_release;   // TSDF_PIPE_WORD_RELEASE  0 (default): the pipeline's second stream is released by an event; 1: by a word the cast's first kernel stores (no packet in the step's stream, but the runtime's wait is a spinning kernel: 0.2167 -> 0.2149 ms, kept as the measured alternative)
     int pipe_host_wait;      // TSDF_PIPE_HOST_WAIT     1: tsdf_pipeline_step waits on the HOST for the frame filtered ahead instead of putting a wait packet into the step's stream
     int event_scope;         // TSDF_EVENT_SCOPE        the events that order the library's own streams: 0 HIP's default (a system-scope fence when the event completes: cache
                              //                          write-back + invalidate for the host's and other devices' sake), 1 hipEventReleaseToDevice, 2 (default) hipEventDisableSystemFence
@@ -90,6 +91,7 @@ struct EntryParams;
 // volume.hip: bring fine + reach up to date; with `entry` (a whole-volume ray cast whose camera allows it) the same launch also leaves
 // the per-tile entry bound of that view (EntryParams)
 int occupancy_refresh(struct ::tsdf_volume *v, const EntryParams *entry = nullptr);
+bool raycast_takes_cells(const struct ::tsdf_volume *v, uint32_t width, uint32_t height, const float pose[16], const float kinv[9]);   // raycast.hip: would tsdf_raycast_device take the cell-parallel cast now?
 int occupancy_flags_refresh(struct ::tsdf_volume *v);   // volume.hip: the flags only (fine, cell), not the reach summary: what the cell-parallel cast reads
 int build_t_table(struct ::tsdf_volume *v);      // volume.hip
 // timing helpers (volume.hip).  When timing is on, a launch of kernel `which` carries a start and a stop event that take the
@@ -277,6 +279,8 @@ struct tsdf_volume {
     size_t ray_cap;
     // per pixel: {the smallest sample index found <= 0 so far by the ray march, that sample's value} in one 64-bit word (all ones
     // = none); every kernel of the march lowers it with atomicMin, resolve_hits_kernel turns it into the vertex and resets it (raycast.hip)
+    uint32_t *release_word;  // when set: the cell-parallel cast's first kernel stores release_value there as it starts (tsdf_pipeline_step, scheduling)
+    uint32_t release_value;
     hipEvent_t after_bulk;   // when set: recorded on the volume's stream right behind the bulk ray kernel's launch (tsdf_pipeline_step, scheduling)
     uint64_t *ray_best;      // two copies of ray_best_cap words, used alternately (ray_best_side)
     size_t ray_best_cap;

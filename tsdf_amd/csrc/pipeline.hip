@@ -111,6 +111,8 @@ struct tsdf_pipeline {
     // signals now and then: a stall of tens of milliseconds in the middle of a stream)
     hipEvent_t done[2], ready[2];   // [b]: the integrate that read buffer b has finished; buffer b has been filtered (and culled) ahead
     hipEvent_t bulk;                // the bulk ray kernel of this frame's cast has ended (TSDF_PIPE_RELEASE=1)
+    uint32_t *release_word;         // signal memory: the cell-parallel cast's first kernel stores release_seq there (see tsdf_pipeline_step); may be null
+    uint32_t release_seq;
     hipEvent_t cast, merged;        // third-stream exchange: the slab cast has left its records; the merge has consumed them
     bool merged_pending;
     const uint16_t *ahead_depth;    // the frame filtered ahead into buffer ahead_buf (nullptr: none)
@@ -393,6 +395,7 @@ int tsdf_pipeline_destroy(tsdf_pipeline *p) {
     if (p->merged) (void)hipEventDestroy(p->merged);
     if (p->hits_mine) (void)hipFree(p->hits_mine);
     if (p->hits_all) (void)hipFree(p->hits_all);
+    if (p->release_word) (void)hipFree(p->release_word);
     if (p->side) (void)hipStreamDestroy(p->side);
     if (p->xstream) (void)hipStreamDestroy(p->xstream);
     if (p->main) (void)hipStreamDestroy(p->main);
@@ -443,6 +446,16 @@ int tsdf_pipeline_create(tsdf_volume *volume, const tsdf_bilateral *filter, uint
         if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ready[b], stream_order_event_flags());
     }
     if (e == hipSuccess && overlap) e = hipEventCreateWithFlags(&p->bulk, stream_order_event_flags());
+    if (e == hipSuccess && overlap && !exchange && tuning().pipe_word_release) {
+        // (a word the second stream can wait for without an event in the step's stream; where the runtime has no such memory the events do it)
+        if (hipExtMallocWithFlags((void **)&p->release_word, 2 * sizeof(uint32_t), hipMallocSignalMemory) != hipSuccess) {
+            (void)hipGetLastError();
+            p->release_word = nullptr;
+        } else if (hipMemset(p->release_word, 0, 2 * sizeof(uint32_t)) != hipSuccess) {
+            (void)hipFree(p->release_word);
+            p->release_word = nullptr;
+        }
+    }
     if (e == hipSuccess && p->xstream) e = hipEventCreateWithFlags(&p->cast, hipEventDisableTiming);
     if (e == hipSuccess && p->xstream) e = hipEventCreateWithFlags(&p->merged, hipEventDisableTiming);
     if (e == hipSuccess && exchange) {
@@ -514,8 +527,10 @@ int tsdf_pipeline_step(tsdf_pipeline *p, const uint16_t *device_depth, const tsd
     rc = tsdf_integrate_device_tiles(p->volume, p->filtered[b], W, H, cam->pose, cam->inv_pose, cam->k, cam->kinv, p->tile_max[b]);
     if (rc != TSDF_OK) return rc;
     bool late_release = false;
+    bool by_word = false;   // the second stream waits for a word the cast's first kernel stores, not for an event of the step's stream
     auto filter_ahead = [&](hipEvent_t release) -> int {
-        TSDF_HIP(hipStreamWaitEvent(p->side, release, 0), "pipeline: release the next frame's filter");
+        if (by_word) TSDF_HIP(hipStreamWaitValue32(p->side, p->release_word, p->release_seq, hipStreamWaitValueGte, 0xffffffffu), "pipeline: release the next frame's filter");
+        else TSDF_HIP(hipStreamWaitEvent(p->side, release, 0), "pipeline: release the next frame's filter");
         int rc_ = early_filter ? TSDF_OK : run_filter(p, next_device_depth, 1 - b, p->side);
         if (rc_ != TSDF_OK) return rc_;
         if (next_cam) {
@@ -529,7 +544,23 @@ int tsdf_pipeline_step(tsdf_pipeline *p, const uint16_t *device_depth, const tsd
         return TSDF_OK;
     };
     if (p->side) {
-        TSDF_HIP(hipEventRecord(p->done[b], p->main), "pipeline: integrate done");
+        // An event recorded behind integrate costs the step's stream 5-6 us (a packet between two kernels that would otherwise run back
+        // to back; profiles/r05y_sync_ubench.txt).  When the cast that follows is the cell-parallel one its first kernel -- in front of
+        // which on this stream lies exactly what the second stream has to wait for -- stores a sequence number into a word of signal
+        // memory as it starts, and the second stream waits for that value: the wait's cost lands where there is slack.  Measured
+        // (TSDF_PIPE_WORD_RELEASE=1, profiles/r05y_word_release_ab.txt): the gap behind integrate goes (5.6 -> 0 us), but the runtime's
+        // wait is a kernel that spins on the word for the 100-150 us until it comes, and the cast's first kernel beside it takes 14 us
+        // instead of 11.8: 0.2167 -> 0.2149 ms per step over three runs each.  Off by default.
+        const bool tighten_ahead = p->volume->occ_tighten_due && !p->volume->occ_dirty && !(p->flags & TSDF_PIPELINE_NO_TIGHTEN_AHEAD);
+        by_word = p->release_word && next_device_depth && !p->exchange && !tighten_ahead && tuning().pipe_release == 0 &&
+                  raycast_takes_cells(p->volume, W, H, cam->pose, cam->kinv);
+        if (by_word) {
+            p->release_seq++;
+            p->volume->release_word = p->release_word;
+            p->volume->release_value = p->release_seq;
+        } else {
+            TSDF_HIP(hipEventRecord(p->done[b], p->main), "pipeline: integrate done");
+        }
         if (p->volume->occ_tighten_due && !p->volume->occ_dirty && !(p->flags & TSDF_PIPELINE_NO_TIGHTEN_AHEAD)) {
             // the periodic tightening of the ray caster's flags (every 16th frame: a scan of what integrate has written since the last
             // one, 60-125 us) goes beside this frame's ray cast instead of in front of it: the flags as they are still cover the
@@ -552,6 +583,12 @@ int tsdf_pipeline_step(tsdf_pipeline *p, const uint16_t *device_depth, const tsd
         p->volume->after_bulk = late_release ? p->bulk : nullptr;
         rc = tsdf_raycast_device(p->volume, W, H, cam->pose, cam->kinv, device_vertices, device_normals);
         p->volume->after_bulk = nullptr;
+        if (by_word && p->volume->release_word) {
+            // (the cast did not take the kernel that stores the word -- the list's count arrived between the two looks at it, or the
+            // cast failed: the step's stream stores it, behind whatever was launched)
+            p->volume->release_word = nullptr;
+            (void)hipStreamWriteValue32(p->main, p->release_word, p->release_seq, 0);
+        }
         if (rc != TSDF_OK) return rc;
         if (late_release) {
             rc = filter_ahead(p->bulk);

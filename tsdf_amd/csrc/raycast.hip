@@ -2036,7 +2036,8 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
     v->last_cast_cells = cells ? 1 : 0;
     if (cells) {
         // ---- the cell-parallel cast (raycast_cells.hpp): the rays' records, the flagged bricks, one wave per brick ----
-        CellCast cc = {reinterpret_cast<RayRecord *>(v->cell_rays), reinterpret_cast<uint2 *>(v->cell_bricks), v->tail_count + 3, v->cell_cast_host, cells->cell_pairs, v->dist, tail.best};
+        CellCast cc = {reinterpret_cast<RayRecord *>(v->cell_rays), reinterpret_cast<uint2 *>(v->cell_bricks), v->tail_count + 3, v->cell_cast_host, cells->cell_pairs, v->dist, tail.best, v->release_word, v->release_value};
+        v->release_word = nullptr;   // (taken)
         const size_t table_lds = ((size_t)kMaxSamples + 1) * sizeof(float);
         const uint32_t n_ray_blocks = (uint32_t)((n_pix + 255) / 256);
         const uint32_t n_list_blocks = (uint32_t)std::min<size_t>((v->occ.fine_count() / 4 + 255) / 256 + 1, 2048);
@@ -2202,6 +2203,15 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
     v->ray_best_side = 1 - v->ray_best_side;
     v->ray_best_dirty = 0;
     return TSDF_OK;
+}
+
+// Would tsdf_raycast_device take the cell-parallel cast for this view now?  (tsdf_pipeline_step: how to release its second stream.)
+bool raycast_takes_cells(const tsdf_volume *v, uint32_t width, uint32_t height, const float pose[16], const float kinv[9]) {
+    if (!v || v->z_begin != 0 || v->z_end != v->g.Z || check_ray_args(v, width, height, pose, kinv) != TSDF_OK) return false;
+    if (count_after_bulk_change(const_cast<tsdf_volume *>(v)) != TSDF_OK) return false;
+    RayParams rp = make_params(v, width, height, pose, kinv);
+    EntryParams view;
+    return choose_cell_cast(v, rp, view);
 }
 
 }  // namespace tsdf

@@ -45,6 +45,8 @@ struct CellCast {
     uint32_t pairs_per_task;  // a brick whose (cell, pixel) pairs are estimated above this is listed in several parts (TSDF_RAY_CELLS_PAIRS)
     const float *dist;        // the distances and the pixels' words: for the rays whose samples leave the grid (cell_cast_prepare_kernel)
     uint64_t *best;
+    uint32_t *release_word;   // null, or where cell_cast_prepare_kernel stores release_value as it starts: everything in front of it on the
+    uint32_t release_value;   // stream (this frame's integrate) is done -- the pipeline's second stream waits for that word, not for an event
 };
 constexpr uint32_t kCellTasks = 1u << 31, kShellTasks = 1u << 30;
 // A brick seen from close by -- a camera inside the volume, a coarse grid -- is thousands of pairs, one wave's work for a long time while
@@ -145,6 +147,7 @@ template <bool SLAB>
 __global__ __launch_bounds__(256) void cell_cast_prepare_kernel(const Geom g, const RayParams rp, const EntryParams ep, const float *__restrict__ t_table,
                                                                 const OccGrid occ, const CellCast cc, const uint32_t n_list_blocks) {
     extern __shared__ float Ts[];   // T[0 .. kMaxSamples] (ray workgroups); the list workgroups use its first words
+    if (cc.release_word && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(cc.release_word, cc.release_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (blockIdx.x >= n_list_blocks) {
         for (int i = (int)threadIdx.x; i <= kMaxSamples; i += 256) Ts[i] = t_table[i];
         __syncthreads();

@@ -58,6 +58,7 @@ const Tuning &tuning() {
         if (u.weight_pack != 0 && u.weight_pack != 16) u.weight_pack = 8;
         u.pipe_release = clamp(num("TSDF_PIPE_RELEASE", 0), 0, 2);
         u.pipe_host_wait = num("TSDF_PIPE_HOST_WAIT", 0) != 0;
+        u.pipe_word_release = num("TSDF_PIPE_WORD_RELEASE", 0) != 0;
         u.event_scope = clamp(num("TSDF_EVENT_SCOPE", 2), 0, 2);
         u.timing_bracket = num("TSDF_TIMING_BRACKET", 0) != 0;
         u.verbose = getenv("TSDF_VERBOSE") != nullptr;
