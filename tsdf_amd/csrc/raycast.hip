@@ -1932,8 +1932,9 @@ static bool choose_cell_cast(const tsdf_volume *v, const RayParams &rp, EntryPar
     // ... and a camera that could have a surface right in front of it: a wall six voxels behind the face it looks through, the camera
     // five voxels outside (cells of 48 pixels), is 2.0 ms against the march's 0.08; twenty voxels outside 0.18 against 0.105
     // (tools/dbg_near_wall.py, profiles/r05x_near_wall.txt).  The nearest depth a sample of the view can have is 2 z_clip: a voxel there
-    // may cover sixteen pixels (the camera some thirty voxels from the volume).
-    if (!(vs_max * std::max(std::fabs(ep.k[0][0]), std::fabs(ep.k[1][1])) <= 16.0f * (2.0f * ep.z_clip))) return false;
+    // may cover 32 pixels (the camera some sixteen voxels from the volume; at 16 pixels the 256^3 bench stream, whose camera comes
+    // within 35 voxels of the volume, went back to the march: 0.148 -> 0.193 ms per step).
+    if (!(vs_max * std::max(std::fabs(ep.k[0][0]), std::fabs(ep.k[1][1])) <= 32.0f * (2.0f * ep.z_clip))) return false;
     const uint32_t listed = v->cell_cast_host ? *v->cell_cast_host : 0u;
     return listed <= (uint32_t)tuning().ray_cells_limit;
 }
