@@ -32,4 +32,4 @@ for base, what in ((0, "bulk kernel, lane-passes"), (8, "tail kernel, lane-round
 print("bulk wave-passes by active lanes (1-4, 5-16, 17-32, 33-64):", c[24:28].tolist(), " passes 12+:", c[28:32].tolist())
 print("cell cast: bricks %d, mixed cells %d, (cell, pixel) pairs %d, pairs whose ray crosses the cell %d, ... not behind a known hit %d, candidate samples %d, evaluated from the cell %d, by the full path %d" % tuple(c[32:40].tolist()))
 print("cell cast hits lowered: by the walk %d, by shell tasks %d" % tuple(c[40:42].tolist()))
-print("cell cast shell tasks: bricks %d, pixels asked %d, candidate samples %d" % tuple(c[42:45].tolist()))
+print("cell cast shell tasks: bricks %d, pixels asked %d, candidate samples %d; face samples from the staged voxels %d" % tuple(c[42:46].tolist()))

@@ -55,7 +55,7 @@ struct Tuning {
     float ray_cells_footprint;   // TSDF_RAY_CELLS_FOOTPRINT  largest voxel footprint (pixels, at the depth of the volume's centre) the cell-parallel cast is taken for (10)
     int ray_cells_pairs;     // TSDF_RAY_CELLS_PAIRS    estimated (cell, pixel) pairs of a brick above which it is listed in several parts (1024; 0: never)
     int ray_cells_look;      // TSDF_RAY_CELLS_LOOK     1 (default): every flagged brick is projected when the list is built -- unseen ones dropped, large ones listed in parts; 0: never
-    int ray_cells_grid;      // TSDF_RAY_CELLS_GRID     workgroups of cast_cells_kernel (8192: a wave per brick for 32 768 bricks, the rest in turns)
+    int ray_cells_grid;      // TSDF_RAY_CELLS_GRID     workgroups of cast_cells_kernel (2048: two or three bricks a wave at 20 000 listed bricks; see raycast_cells.hpp)
     int ray_fused;           // TSDF_RAY_FUSED          1: the march and its queue of unfinished stretches in ONE launch (process_ray_fused_kernel; measured slower, LABNOTES round 5); default 0: two launches
     int ray_entry_bound;     // TSDF_RAY_ENTRY_BOUND    0: no per-tile entry bound (default 1: rays start at the nearest flagged block their 16 x 16 tile can see)
     int icp_persistent;      // TSDF_ICP_PERSISTENT     default 0: one launch per ICP iteration (the chain); 1 / 2: all 19 in one launch with a grid barrier (slower, kept for study)

@@ -451,6 +451,13 @@ __device__ inline void cast_shell_bricks(const float *__restrict__ dist, const G
 }
 
 // One wave per flagged brick; the four waves of a workgroup share the table and nothing else.
+// How many workgroups (TSDF_RAY_CELLS_GRID; round 6, profiles/r06_cells_*): a wave's preamble -- the table, the view's constants, the
+// scalar registers that do not fit parked in vector lanes -- is 300 vector instructions, a brick's turn 630 and a round of 64 pairs
+// 600; a wave per brick (8 192 workgroups, 36 864 waves for 20 000 bricks: round 5) spent a quarter of the kernel's 37.5 M vector
+// instructions on preambles.  2 048 workgroups (each wave two or three bricks, the next one's voxels requested a turn ahead) is the
+// measured optimum at 512^3 and 256^3: 0.083 -> 0.076 ms; as many waves as the chip holds (1 024) with every n-th entry dealt out in
+// advance ends when its unluckiest wave does (0.080), and the same with the list taken a chunk at a time from eight counters is
+// slower still (0.086; 256^3 0.102: tools/experiments/raycast_cells_dynamic_chunks.patch.txt).
 // (Measured and dropped, profiles/r05m_*: the walk of a pair's samples deferred to a ring of the wave in LDS and done 64 records at a
 // time, all lanes busy -- three lanes in four idle through the walk otherwise -- was no faster: the deferred walks find their hits
 // later, so twice as many pairs survive the test against the pixel's word, and a record has to fetch its cell's voxels again.)
@@ -464,11 +471,12 @@ __attribute__((amdgpu_waves_per_eu(TSDF_CELLS_WAVES, TSDF_CELLS_WAVES)))
 __global__ __launch_bounds__(256) void cast_cells_kernel(const float *__restrict__ dist, const Geom g, const RayParams rp, const EntryParams ep,
                                                          const OccGrid occ, const float *__restrict__ t_table, const CellCast cc,
                                                          uint64_t *__restrict__ best) {
-    __shared__ float T[kTableLen];
+    __shared__ __attribute__((aligned(16))) float T[kTableLen];
     __shared__ float corner[4][128];       // the brick's 5^3 voxels, x fastest
     __shared__ int box_of[4][64][4];       // per cell lane: its pixel box
     __shared__ int prefix[4][64];          // pairs of the cells before this one
-    for (int i = (int)threadIdx.x; i < kTableLen; i += 256) T[i] = t_table[i];
+    static_assert(kTableLen % 4 == 0, "the table in 16-byte pieces");
+    for (int i = (int)threadIdx.x; i < kTableLen / 4; i += 256) reinterpret_cast<float4 *>(T)[i] = reinterpret_cast<const float4 *>(t_table)[i];
     const uint32_t n_bricks = *cc.n_bricks;
     if (cc.n_bricks_host && blockIdx.x == 0 && threadIdx.x == 0) *cc.n_bricks_host = n_bricks;
     static_assert(sizeof(box_of) >= 256 * sizeof(uint2), "a shell workgroup's list of bricks");

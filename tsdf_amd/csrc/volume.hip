@@ -35,7 +35,7 @@ const Tuning &tuning() {
         u.ray_fused = num("TSDF_RAY_FUSED", 0) != 0;
         u.ray_cells = clamp(num("TSDF_RAY_CELLS", 1), 0, 2);
         u.ray_cells_limit = std::max(num("TSDF_RAY_CELLS_LIMIT", 131072), 0);
-        u.ray_cells_grid = clamp(num("TSDF_RAY_CELLS_GRID", 8192), 1, 65535);
+        u.ray_cells_grid = clamp(num("TSDF_RAY_CELLS_GRID", 2048), 1, 65535);
         u.ray_cells_pairs = clamp(num("TSDF_RAY_CELLS_PAIRS", 1024), 0, 1 << 24);
         u.ray_cells_look = clamp(num("TSDF_RAY_CELLS_LOOK", 1), 0, 1);
         { const char *fp = getenv("TSDF_RAY_CELLS_FOOTPRINT"); u.ray_cells_footprint = fp ? (float)atof(fp) : 10.0f; }
