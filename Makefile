@@ -1,7 +1,7 @@
 # Builds everything in-tree (no install step):
 #   tsdf_amd/lib/libtsdf_hip.so   HIP kernels + C ABI (include/tsdf_amd.h), gfx950 only
 #   tsdf_amd/lib/libtsdf_host.so  C++ class surface (TSDFVolume, GPURaycaster, Camera, ...) over the C ABI
-#   oracle/libtsdf_oracle.so      CPU oracle (test infrastructure), the reference build under $$TSDF_REF_BUILD (outside the tree) when the reference is mounted
+#   oracle/libtsdf_oracle.so      CPU oracle (test infrastructure), oracle/_ref/*.so: what of the reference compiles from its own sources here (BilateralFilter.cpp, cuda_coordinate_transforms.cu), when the reference is mounted
 HIPCC    ?= /opt/rocm/bin/hipcc
 ARCH     ?= gfx950
 # -ffp-contract=off: every fp32 op rounds on its own, in the reference's order (parity contract)

@@ -11,9 +11,11 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libtsdf_oracle.so")
-# the reference's own BilateralFilter.cpp compiled natively: built OUTSIDE the tree (it must not travel to the GPU box)
-REF_BUILD = os.environ.get("TSDF_REF_BUILD") or "/tmp/tsdf_ref_build"
+# The pieces of the reference that compile from their own sources here (oracle/Makefile target "ref"): built into oracle/_ref/
+# (git-ignored, not gpurun-ignored: the libraries travel to the GPU box, the reference's sources do not).
+REF_BUILD = os.path.join(_HERE, "_ref")
 _REF = os.path.join(REF_BUILD, "libref_bilateral.so")
+_REF_TRANSFORMS = os.path.join(REF_BUILD, "libref_transforms.so")
 
 
 def build(force=False):
@@ -326,6 +328,34 @@ def world_to_pixel(p, inv_pose, k):
     return int(out[0]), int(out[1])
 
 
+def world_to_pixel_n(points, inv_pose, k):
+    p = _f32(points).reshape(-1, 3)
+    out = np.empty((len(p), 2), np.int32)
+    lib().orc_world_to_pixel_n(C.c_size_t(len(p)), _fp(p), _fp(_f32(inv_pose, 16)), _fp(_f32(k, 9)), out.ctypes.data_as(C.POINTER(C.c_int)))
+    return out
+
+
+def world_to_camera_n(points, inv_pose):
+    p = _f32(points).reshape(-1, 3)
+    out = np.empty((len(p), 3), np.float32)
+    lib().orc_world_to_camera_n(C.c_size_t(len(p)), _fp(p), _fp(_f32(inv_pose, 16)), _fp(out))
+    return out
+
+
+def pixel_to_camera_n(pixels, depth, kinv):
+    px = np.ascontiguousarray(pixels, np.int32).reshape(-1, 2)
+    out = np.empty((len(px), 3), np.float32)
+    lib().orc_pixel_to_camera_n(C.c_size_t(len(px)), px.ctypes.data_as(C.POINTER(C.c_int)), _fp(_f32(depth, len(px))), _fp(_f32(kinv, 9)), _fp(out))
+    return out
+
+
+def ray_direction_n(pixels, rot, kinv):
+    px = np.ascontiguousarray(pixels, np.uint16).reshape(-1, 2)
+    out = np.empty((len(px), 3), np.float32)
+    lib().orc_ray_direction_n(C.c_size_t(len(px)), px.ctypes.data_as(C.POINTER(C.c_uint16)), _fp(_f32(rot, 9)), _fp(_f32(kinv, 9)), _fp(out))
+    return out
+
+
 # ------------------------------------------------------------------------------ bilateral
 
 def bilateral_u8(image, width, height, sigma_colour, sigma_space):
@@ -354,12 +384,78 @@ def have_ref():
 
 
 def ref_bilateral_u8(image, width, height, sigma_colour, sigma_space):
-    """The reference's own BilateralFilter (REF_BUILD/libref_bilateral.so, built from /root/reference/src/BilateralFilter.cpp)."""
+    """The reference's own BilateralFilter (oracle/_ref/libref_bilateral.so, built from /root/reference/src/BilateralFilter.cpp)."""
     L = C.CDLL(_REF, mode=getattr(os, "RTLD_LOCAL", 0) | getattr(os, "RTLD_DEEPBIND", 0))
     L.ref_bilateral_u8.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_float, C.c_float]
     img = np.ascontiguousarray(image, np.uint8).reshape(-1).copy()
     L.ref_bilateral_u8(img.ctypes.data_as(C.POINTER(C.c_uint8)), width, height, sigma_colour, sigma_space)
     return img.reshape(height, width)
+
+
+def have_ref_transforms():
+    return os.path.exists(_REF_TRANSFORMS)
+
+
+_ref_t = None
+
+
+def _ref_transforms():
+    """oracle/_ref/libref_transforms.so: the reference's own src/Utilities/cuda_coordinate_transforms.cu compiled with g++ against the
+    CUDA toolkit headers of this image (oracle/ref_transforms_wrap.cpp has the entry points)."""
+    global _ref_t
+    if _ref_t is None:
+        L = C.CDLL(_REF_TRANSFORMS, mode=getattr(os, "RTLD_LOCAL", 0) | getattr(os, "RTLD_DEEPBIND", 0))
+        fp, ip, up = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint16)
+        L.ref_world_to_pixel.argtypes = [C.c_size_t, fp, fp, fp, ip]
+        L.ref_world_to_camera.argtypes = [C.c_size_t, fp, fp, fp]
+        L.ref_pixel_to_camera.argtypes = [C.c_size_t, ip, fp, fp, fp]
+        L.ref_ray_direction.argtypes = [C.c_size_t, up, fp, fp, fp]
+        L.ref_integrate_composed.restype = C.c_int64
+        L.ref_integrate_composed.argtypes = [fp, fp, C.c_uint32, C.c_uint32, C.c_uint32, fp, fp, fp, C.c_float, fp, fp, fp, up,
+                                             C.c_uint32, C.c_uint32]
+        _ref_t = L
+    return _ref_t
+
+
+def ref_world_to_pixel(points, inv_pose, k):
+    p = _f32(points).reshape(-1, 3)
+    out = np.empty((len(p), 2), np.int32)
+    _ref_transforms().ref_world_to_pixel(len(p), _fp(p), _fp(_f32(inv_pose, 16)), _fp(_f32(k, 9)), out.ctypes.data_as(C.POINTER(C.c_int32)))
+    return out
+
+
+def ref_world_to_camera(points, inv_pose):
+    p = _f32(points).reshape(-1, 3)
+    out = np.empty((len(p), 3), np.float32)
+    _ref_transforms().ref_world_to_camera(len(p), _fp(p), _fp(_f32(inv_pose, 16)), _fp(out))
+    return out
+
+
+def ref_pixel_to_camera(pixels, depth, kinv):
+    px = np.ascontiguousarray(pixels, np.int32).reshape(-1, 2)
+    d = _f32(depth, len(px))
+    out = np.empty((len(px), 3), np.float32)
+    _ref_transforms().ref_pixel_to_camera(len(px), px.ctypes.data_as(C.POINTER(C.c_int32)), _fp(d), _fp(_f32(kinv, 9)), _fp(out))
+    return out
+
+
+def ref_ray_direction(pixels, rot, kinv):
+    px = np.ascontiguousarray(pixels, np.uint16).reshape(-1, 2)
+    out = np.empty((len(px), 3), np.float32)
+    _ref_transforms().ref_ray_direction(len(px), px.ctypes.data_as(C.POINTER(C.c_uint16)), _fp(_f32(rot, 9)), _fp(_f32(kinv, 9)), _fp(out))
+    return out
+
+
+def ref_integrate_composed(dist, weight, size, voxel_size, trunc, inv_pose, k, kinv, depth, width, height,
+                           offset_at_clear=(0.0, 0.0, 0.0), offset_now=(0.0, 0.0, 0.0)):
+    """The loop of integrate_kernel around the reference's own compiled world_to_pixel / pixel_to_camera / world_to_camera
+    (oracle/ref_transforms_wrap.cpp); dist / weight (float32, C order z, y, x) are updated in place.  Returns the voxels updated."""
+    assert dist.dtype == np.float32 and weight.dtype == np.float32 and dist.flags.c_contiguous and weight.flags.c_contiguous
+    d = np.ascontiguousarray(depth, np.uint16).reshape(-1)
+    return int(_ref_transforms().ref_integrate_composed(_fp(dist), _fp(weight), int(size[0]), int(size[1]), int(size[2]), _fp(_f32(voxel_size, 3)),
+                                                        _fp(_f32(offset_at_clear, 3)), _fp(_f32(offset_now, 3)), float(trunc),
+                                                        _fp(_f32(inv_pose, 16)), _fp(_f32(k, 9)), _fp(_f32(kinv, 9)),
+                                                        d.ctypes.data_as(C.POINTER(C.c_uint16)), int(width), int(height)))
 
 
 # ---- ICP tracking (icp_oracle.c) -------------------------------------------------------------------------------

@@ -91,6 +91,40 @@ void orc_world_to_pixel(const float p[3], const float ip[16], const float k[9], 
     pix[1] = f2i_sat(roundf(iy / iz));
 }
 
+/* ref: src/Utilities/cuda_coordinate_transforms.cu:108-121 (the full 4 x 4 product, then the divide by w) */
+void orc_world_to_camera(const float p[3], const float ip[16], float out[3]) {
+    float cx = (M4(ip, 1, 1) * p[0]) + (M4(ip, 1, 2) * p[1]) + (M4(ip, 1, 3) * p[2]) + M4(ip, 1, 4);
+    float cy = (M4(ip, 2, 1) * p[0]) + (M4(ip, 2, 2) * p[1]) + (M4(ip, 2, 3) * p[2]) + M4(ip, 2, 4);
+    float cz = (M4(ip, 3, 1) * p[0]) + (M4(ip, 3, 2) * p[1]) + (M4(ip, 3, 3) * p[2]) + M4(ip, 3, 4);
+    float w = (M4(ip, 4, 1) * p[0]) + (M4(ip, 4, 2) * p[1]) + (M4(ip, 4, 3) * p[2]) + M4(ip, 4, 4);
+    out[0] = cx / w;
+    out[1] = cy / w;
+    out[2] = cz / w;
+}
+
+/* ref: src/Utilities/cuda_coordinate_transforms.cu:132-146 (f3_mul_scalar: vec * scalar, cuda_utilities.hpp:56-58) */
+void orc_pixel_to_camera(const int pix[2], float depth, const float kinv[9], float out[3]) {
+    float ipx = M3(kinv, 1, 1) * pix[0] + M3(kinv, 1, 2) * pix[1] + M3(kinv, 1, 3);
+    float ipy = M3(kinv, 2, 1) * pix[0] + M3(kinv, 2, 2) * pix[1] + M3(kinv, 2, 3);
+    float ipz = M3(kinv, 3, 1) * pix[0] + M3(kinv, 3, 2) * pix[1] + M3(kinv, 3, 3);
+    float scale = depth / ipz;
+    out[0] = ipx * scale;
+    out[1] = ipy * scale;
+    out[2] = ipz * scale;
+}
+
+/* the same, many at a time (tests against oracle/_ref/libref_transforms.so and tests/golden/ref_transforms.npz) */
+void orc_world_to_pixel_n(size_t n, const float *points, const float ip[16], const float k[9], int *pixels) {
+    for (size_t i = 0; i < n; i++) orc_world_to_pixel(points + 3 * i, ip, k, pixels + 2 * i);
+}
+void orc_world_to_camera_n(size_t n, const float *points, const float ip[16], float *out) {
+    for (size_t i = 0; i < n; i++) orc_world_to_camera(points + 3 * i, ip, out + 3 * i);
+}
+void orc_pixel_to_camera_n(size_t n, const int *pixels, const float *depth, const float kinv[9], float *out) {
+    for (size_t i = 0; i < n; i++) orc_pixel_to_camera(pixels + 2 * i, depth[i], kinv, out + 3 * i);
+}
+void orc_ray_direction_n(size_t n, const uint16_t *pixels, const float rot[9], const float kinv[9], float *out);
+
 /* ref: src/TSDF/TSDFVolume.cu:308-392 */
 int64_t orc_integrate(float *dist, float *weight, const orc_geom *g, const float ip[16],
                       const float k[9], const float kinv[9], const uint16_t *depth,
@@ -169,6 +203,10 @@ void orc_ray_direction(uint16_t px, uint16_t py, const float rot[9], const float
 }
 
 /* ref: src/RayCaster/GPURaycaster.cu:138-181 */
+void orc_ray_direction_n(size_t n, const uint16_t *pixels, const float rot[9], const float kinv[9], float *out) {
+    for (size_t i = 0; i < n; i++) orc_ray_direction(pixels[2 * i], pixels[2 * i + 1], rot, kinv, out + 3 * i);
+}
+
 static int can_intersect_in_dimension(float space_min, float space_max, float origin, float direction,
                                       float *near_t, float *far_t) {
     int can_intersect = 1;

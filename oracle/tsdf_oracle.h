@@ -116,6 +116,12 @@ int orc_ray_box(const float origin[3], const float dir[3], const float space_min
 float orc_trilinear(const float point[3], const uint32_t dims[3], const float vs[3], const float *dist);
 void orc_ray_direction(uint16_t px, uint16_t py, const float rot[9], const float kinv[9], float dir[3]);
 void orc_world_to_pixel(const float p[3], const float inv_pose[16], const float k[9], int pix[2]);
+void orc_world_to_camera(const float p[3], const float inv_pose[16], float out[3]);
+void orc_pixel_to_camera(const int pix[2], float depth, const float kinv[9], float out[3]);
+void orc_world_to_pixel_n(size_t n, const float *points, const float inv_pose[16], const float k[9], int *pixels);
+void orc_world_to_camera_n(size_t n, const float *points, const float inv_pose[16], float *out);
+void orc_pixel_to_camera_n(size_t n, const int *pixels, const float *depth, const float kinv[9], float *out);
+void orc_ray_direction_n(size_t n, const uint16_t *pixels, const float rot[9], const float kinv[9], float *out);
 
 /* ---- bilateral filter (src/BilateralFilter.cpp:15-121) -------------------------------- */
 /* In place, like the reference.  The 8-bit path reproduces the reference exactly (incl. the

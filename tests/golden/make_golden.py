@@ -2,7 +2,7 @@
 
     python -m tests.golden.make_golden
 
-  bilateral_ref_u8.npz         inputs + outputs of the REFERENCE's own BilateralFilter ($TSDF_REF_BUILD/libref_bilateral.so, built
+  bilateral_ref_u8.npz         inputs + outputs of the REFERENCE's own BilateralFilter (oracle/_ref/libref_bilateral.so, built
                                from /root/reference/src/BilateralFilter.cpp where it lies).  Data only.
   oracle_integrate_raycast.npz small integrate + raycast cases produced by the CPU oracle (oracle/), so the
                                GPU box can check the HIP path against stored vectors as well as live.

@@ -1,8 +1,9 @@
 """Pins the CPU oracle before anything trusts it (no GPU needed).
 
 Sources of truth, in decreasing strength:
-  * the reference's own BilateralFilter compiled natively (outside the tree, $TSDF_REF_BUILD: this container only; bit-exact), and the
-    committed fixtures generated from it (tests/golden/bilateral_ref_*.npz);
+  * what of the reference's hot path compiles from its own sources here (oracle/_ref, oracle/Makefile "ref": BilateralFilter.cpp with
+    g++ as it is; cuda_coordinate_transforms.cu + cuda_utilities.hpp with g++ against the CUDA toolkit headers the image ships), bit for
+    bit, and the committed fixtures generated from them (tests/golden/bilateral_ref_*.npz, tests/golden/ref_transforms.npz);
   * figures recorded in SURVEY.md 8c / BASELINE.md 2 from a run of the reference's device source in the
     survey container (updated-voxel counts, sign change at the wall, centre vertex, mean hit depth);
   * known answers of the reference's tests: Test_Camera.cpp, Test_TSDFMetrics.cpp and the ray/box and
@@ -215,7 +216,7 @@ def _test_images():
 @pytest.mark.parametrize("sigmas", [(3.0, 2.0), (30.0, 4.5), (12.5, 0.7)])
 def test_bilateral_u8_oracle_equals_the_reference_build(oracle, sigmas):
     if not oracle.have_ref():
-        pytest.skip("reference build not present (it stays in the build container)")
+        pytest.skip("oracle/_ref/libref_bilateral.so not present (built where /root/reference is mounted)")
     for name, img in _test_images().items():
         h, w = img.shape
         ref = oracle.ref_bilateral_u8(img, w, h, *sigmas)
@@ -328,3 +329,79 @@ def test_mc_sphere_like_the_reference_fixture(oracle):
     volume = np.einsum("ij,ij->i", a - c, np.cross(b - c, cc - c)).sum() / 6.0
     assert abs(area - 4 * np.pi * r * r) < 0.01 * 4 * np.pi * r * r
     assert abs(volume - 4.0 / 3.0 * np.pi * r ** 3) < 0.01 * 4.0 / 3.0 * np.pi * r ** 3
+
+
+# ----------------------------------------------------------------- the reference's own coordinate transforms, compiled (round 6)
+# oracle/_ref/libref_transforms.so is /root/reference/src/Utilities/cuda_coordinate_transforms.cu (+ src/include/cuda_utilities.hpp)
+# compiled with g++ against the CUDA toolkit headers this image ships (oracle/Makefile "ref"); tests/golden/ref_transforms.npz holds its
+# outputs (tests/golden/make_ref_transform_vectors.py).  SURVEY 8a rows 8-10, 14, 20 -- and, through ref_integrate_composed, every
+# projection / rounding / gating decision of row 7.
+
+INT_MIN = -2 ** 31
+
+
+def _same_bits(a, b):
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    return bool(np.all((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))))
+
+
+def _check_pixels(got, ref):
+    # float -> int of a quotient that does not fit: the target's conversion (CUDA saturates and maps NaN to 0 -- the oracle's f2i_sat --,
+    # x86 gives INT_MIN for all of them): compared where the reference's x86 build produced a number
+    fits = ref != INT_MIN
+    assert fits.mean() > 0.9
+    assert np.array_equal(got[fits], ref[fits])
+    assert np.all(np.isin(got[~fits], (INT_MIN, 2 ** 31 - 1, 0)))
+
+
+def test_transforms_equal_the_committed_vectors_of_the_reference_build(oracle):
+    f = np.load(os.path.join(GOLD, "ref_transforms.npz"))
+    assert int(f["n_cameras"]) >= 4
+    for c in range(int(f["n_cameras"])):
+        ip, k, kinv, rot = f["cam%d_inv_pose" % c], f["cam%d_k" % c], f["cam%d_kinv" % c], f["cam%d_rot" % c]
+        _check_pixels(oracle.world_to_pixel_n(f["cam%d_points" % c], ip, k), f["cam%d_world_to_pixel" % c])
+        assert _same_bits(oracle.world_to_camera_n(f["cam%d_points" % c], ip), f["cam%d_world_to_camera" % c]), str(f["cam%d_name" % c])
+        assert _same_bits(oracle.pixel_to_camera_n(f["cam%d_pixels" % c], f["cam%d_depth" % c], kinv), f["cam%d_pixel_to_camera" % c])
+        assert _same_bits(oracle.ray_direction_n(f["cam%d_ray_pixels" % c], rot, kinv), f["cam%d_ray_direction" % c])
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_transforms_equal_the_reference_build(oracle, seed):
+    if not oracle.have_ref_transforms():
+        pytest.skip("oracle/_ref/libref_transforms.so not present (built where /root/reference is mounted)")
+    rng = np.random.RandomState(seed)
+    k, kinv = oracle.camera_k(400.0 + 300 * rng.rand(), 400.0 + 300 * rng.rand(), 250 + 100 * rng.rand(), 200 + 80 * rng.rand())
+    pose = oracle.look_at(oracle.identity_pose(tuple(rng.rand(3) * 5000 - 1000)), (1500, 1500, 1500))
+    ip = oracle.mat4_inverse(pose)
+    p = (rng.rand(50000, 3) * 4000 - 500).astype(np.float32)
+    _check_pixels(oracle.world_to_pixel_n(p, ip, k), oracle.ref_world_to_pixel(p, ip, k))
+    assert _same_bits(oracle.world_to_camera_n(p, ip), oracle.ref_world_to_camera(p, ip))
+    pix = np.stack([rng.randint(0, 640, 50000), rng.randint(0, 480, 50000)], 1).astype(np.int32)
+    depth = rng.randint(1, 9000, 50000).astype(np.float32)
+    assert _same_bits(oracle.pixel_to_camera_n(pix, depth, kinv), oracle.ref_pixel_to_camera(pix, depth, kinv))
+    rot = np.asarray(pose, np.float32).reshape(4, 4)[:3, :3].reshape(-1).copy()   # (column-major storage: rows of this view are columns)
+    assert _same_bits(oracle.ray_direction_n(pix.astype(np.uint16), rot, kinv), oracle.ref_ray_direction(pix.astype(np.uint16), rot, kinv))
+
+
+def _replay_integrate_case(f, i, integrate_frame):
+    """Feeds case i of ref_transforms.npz to integrate_frame(depth, inv_pose-or-pose index); returns the stored (dist, weight, updates)."""
+    for d, pi in zip(f["integrate%d_depths" % i], f["integrate%d_pose_index" % i]):
+        integrate_frame(d, int(pi))
+    return f["integrate%d_dist" % i], f["integrate%d_weight" % i], f["integrate%d_updates" % i]
+
+
+def test_integrate_equals_the_loop_around_the_reference_s_compiled_transforms(oracle):
+    f = np.load(os.path.join(GOLD, "ref_transforms.npz"))
+    k, kinv, poses = f["integrate_k"], f["integrate_kinv"], f["integrate_poses"]
+    for i in range(int(f["n_integrate"])):
+        size, phys, (off0, off1) = tuple(int(s) for s in f["integrate%d_size" % i]), tuple(float(p) for p in f["integrate%d_phys" % i]), f["integrate%d_offsets" % i]
+        v = oracle.Volume(size, phys)
+        v.offset(*off0)
+        v.clear()               # initialise_deformation bakes the offset of that moment in (Q1) ...
+        v.offset(*off1)         # ... and the kernel adds the offset of now on top
+        counts = []
+        dist, weight, updates = _replay_integrate_case(f, i, lambda d, pi: counts.append(v.integrate(d, 160, 120, oracle.mat4_inverse(poses[pi]), k, kinv)))
+        assert counts == list(updates), str(f["integrate%d_name" % i])
+        assert np.array_equal(v.dist.view(np.uint32), dist.view(np.uint32)), str(f["integrate%d_name" % i])
+        assert np.array_equal(v.weight.view(np.uint32), weight.view(np.uint32))
+        assert int((weight > 0).sum()) > 1000

@@ -374,3 +374,49 @@ def test_camera_inside_with_a_general_projection(oracle):
     gv, ov, up = run_both(oracle, (192, 64, 96), (3000, 3000, 3000), [(d, cam)])
     check(gv, ov, up, "camera inside, general projection")
     assert up[0][1] > 0
+
+
+class _Matrices:
+    """A camera given by its four matrices (column-major), as the reference's integrate receives them (TSDFVolume.cu:867-877)."""
+
+    def __init__(self, pose, inverse_pose, k, kinv):
+        self._m = [np.ascontiguousarray(m, np.float32).reshape(-1) for m in (pose, inverse_pose, k, kinv)]
+
+    def pose(self): return self._m[0]
+    def inverse_pose(self): return self._m[1]
+    def k(self): return self._m[2]
+    def kinv(self): return self._m[3]
+
+
+def test_integrate_equals_the_loop_around_the_reference_s_compiled_transforms(oracle):
+    """tests/golden/ref_transforms.npz: distances and weights left by the loop of integrate_kernel around the REFERENCE's own compiled
+    world_to_pixel / pixel_to_camera / world_to_camera (oracle/ref_transforms_wrap.cpp, generated in the build container): the HIP
+    kernels' projection, rounding and gating decisions of every voxel against reference code, not against the restatement -- and,
+    where oracle/_ref travelled to this box, against that library run here."""
+    f = np.load(os.path.join(GOLD, "ref_transforms.npz"))
+    k, kinv, poses = f["integrate_k"], f["integrate_kinv"], f["integrate_poses"]
+    for i in range(int(f["n_integrate"])):
+        size, phys = tuple(int(s) for s in f["integrate%d_size" % i]), tuple(float(p) for p in f["integrate%d_phys" % i])
+        off0, off1 = f["integrate%d_offsets" % i]
+        name = str(f["integrate%d_name" % i])
+        for storage in (8, 32):
+            gv = tsdf_amd.TSDFVolume(size, phys)
+            gv.set_weight_storage(storage)
+            gv.offset(*off0); gv.clear(); gv.offset(*off1)      # Q1: the offset of clear() is baked in, the offset of now added on top
+            gv.set_counting(True)
+            live = oracle.have_ref_transforms()
+            if live:
+                vs = (np.array(phys, np.float32) / np.array(size, np.float32)).astype(np.float32)
+                rd = np.full(size[0] * size[1] * size[2], gv.truncation_distance(), np.float32)
+                rw = np.zeros_like(rd)
+            for d, pi, u in zip(f["integrate%d_depths" % i], f["integrate%d_pose_index" % i], f["integrate%d_updates" % i]):
+                cam = _Matrices(poses[pi], oracle.mat4_inverse(poses[pi]), k, kinv)
+                gv.integrate(d, 160, 120, cam)
+                assert gv.last_updated_voxels() == int(u), name
+                if live:
+                    assert oracle.ref_integrate_composed(rd, rw, size, vs, gv.truncation_distance(), cam.inverse_pose(), k, kinv, d, 160, 120, off0, off1) == int(u)
+            assert_same_floats(gv.get_weight_data(), f["integrate%d_weight" % i], name + " weights (storage %d)" % storage)
+            assert_same_floats(gv.get_distance_data(), f["integrate%d_dist" % i], name + " distances (storage %d)" % storage)
+            if live:
+                assert_same_floats(gv.get_distance_data(), rd, name + " distances against the library run here")
+                assert_same_floats(gv.get_weight_data(), rw, name + " weights against the library run here")
