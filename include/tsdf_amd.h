@@ -242,6 +242,9 @@ int tsdf_raycast_depth_device(const tsdf_volume *volume, uint32_t width, uint32_
 /* Which kernels the volume's last ray cast took: 1 = the cell-parallel cast (one wave per flagged brick, no ray is marched), 0 = the
  * march kernels.  Scheduling only -- both produce the same bits -- reported by bench.py beside the kernels' times. */
 int tsdf_volume_last_raycast_kind(const tsdf_volume *volume, int *cell_parallel);
+/* Diagnostics: how many tasks (flagged bricks in view, large ones counted by their parts) the volume's last cell-parallel cast listed.
+ * Waits for the volume's stream.  0 before the first such cast. */
+int tsdf_volume_last_cell_list(const tsdf_volume *volume, uint32_t *listed);
 /* Diagnostics for the roofline model: S = trilinear samples evaluated, T = distinct voxels
  * touched by any tap, of one raycast with these arguments (runs an instrumented kernel). */
 int tsdf_raycast_stats(const tsdf_volume *volume, uint32_t width, uint32_t height, const float pose[16],

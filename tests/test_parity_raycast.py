@@ -671,6 +671,72 @@ def test_cell_parallel_cast_with_unusual_intrinsics(oracle, tmp_path, cells):
     assert hits > 200000
 
 
+_CELLS_PROBE_POSE = r"""
+import sys, json, numpy as np
+import tsdf_amd
+from tsdf_amd import synth
+n, views = int(sys.argv[2]), json.loads(sys.argv[3])
+class M:
+    def __init__(self, pose, kinv): self.p, self.ki = np.array(pose, np.float32), np.array(kinv, np.float32)
+    def pose(self): return self.p
+    def inverse_pose(self): return self.p      # (not used by the cast)
+    def k(self): return self.ki
+    def kinv(self): return self.ki
+gv = tsdf_amd.TSDFVolume((n, n, n), (3000, 3000, 3000))
+for i in range(4):
+    d, cam = synth.depth_frame(i, 12, seed=0x5EED0002)
+    gv.integrate(d, synth.WIDTH, synth.HEIGHT, cam)
+out = {"D": gv.get_distance_data()}
+for j, v in enumerate(views):
+    V, N = gv.raycast(640, 480, M(v["pose"], v["kinv"]))
+    out["V%d" % j], out["N%d" % j], out["cells%d" % j], out["listed%d" % j] = V, N, np.array(gv.last_raycast_cell_parallel()), np.array(gv.last_cell_list())
+np.savez(sys.argv[1], **out)
+"""
+
+
+@pytest.mark.parametrize("cells", ["2", "0"])
+def test_poses_that_are_not_rigid(oracle, tmp_path, cells):
+    """The reference takes whatever 4 x 4 it is given (GPURaycaster.cu:449-455 copies the block; nothing asks for a rotation): blocks that
+    shrink (0.5 R), stretch (2 R, 3 along one axis) and shear.  The cell-parallel cast's list drops the bricks no pixel sees by a sphere
+    whose radius has to be taken in the CAMERA's frame -- up to the 2-norm of the inverse block larger than in the world (EntryParams::
+    r_scale; the advisor's finding of round 5: with 0.5 R visible bricks at the image's edge were dropped).  Both casts, the oracle's bits."""
+    import json
+    import os
+    import subprocess
+    import sys
+    n = 100
+    _, cam = synth.depth_frame(1, 12, seed=0x5EED0002)      # a camera the volume was integrated from: surface out to the image's borders
+    P = np.array(cam.pose(), np.float64).reshape(4, 4).T      # rows
+    kinv = [float(x) for x in cam.kinv()]
+    blocks = [np.eye(3), 0.25 * np.eye(3), 2.0 * np.eye(3), np.diag([1.0, 3.0, 1.0]), np.array([[1.0, 0.4, 0.0], [0.0, 1.0, 0.0], [0.3, 0.0, 1.0]]),
+              np.array([[0.4, 0.0, 0.0], [0.2, 0.6, 0.0], [0.0, 0.0, 1.0]])]
+    views = []
+    for B in blocks:
+        Q = P.copy()
+        Q[:3, :3] = P[:3, :3] @ B       # the camera's axes scaled / sheared: directions R B d
+        views.append({"pose": [float(x) for x in Q.T.reshape(-1)], "kinv": kinv})
+    out = str(tmp_path / "cells_pose.npz")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, TSDF_RAY_CELLS=cells)
+    e["PYTHONPATH"] = root + os.pathsep + e.get("PYTHONPATH", "")
+    subprocess.run([sys.executable, "-c", _CELLS_PROBE_POSE, out, str(n), json.dumps(views)], check=True, env=e, cwd=root, timeout=900)
+    got = np.load(out)
+    ov = oracle.Volume((n, n, n), (3000, 3000, 3000))
+    ov.set_distance_data(got["D"])
+    hits = 0
+    for j, v in enumerate(views):
+        Vo, No = ov.raycast(640, 480, np.array(v["pose"], np.float32), np.array(v["kinv"], np.float32), nthreads=oracle.max_threads())
+        assert_same_floats(got["V%d" % j], Vo, "block %d: vertices" % j)
+        assert_same_floats(got["N%d" % j], No, "block %d: normals" % j)
+        assert bool(got["cells%d" % j]) == (cells == "2")
+        hits += int((~np.isnan(Vo[:, 0])).sum())
+    assert hits > 100000
+    if cells == "2":
+        # a pose scaled as a whole shows the same picture of the grid: the bricks in view -- the list -- are the same ones.  (With the
+        # radius taken as a world distance the block 0.25 R listed 7 % fewer: visible bricks across the image's border dropped.)
+        assert int(got["listed1"]) == int(got["listed0"]) and int(got["listed2"]) == int(got["listed0"]), [int(got["listed%d" % j]) for j in range(3)]
+
+
 def test_an_uploaded_field_that_flags_every_brick_keeps_the_march(oracle):
     """The cell-parallel cast's work is the number of flagged bricks times their cells' pixels; the choice goes by the list the previous
     cast built.  After a bulk change of the distances that count says nothing: the flags are rebuilt and counted before the first cast

@@ -78,6 +78,7 @@ _SIGS = {
     "tsdf_volume_weights": (_i, [_vp, C.POINTER(_vp)]),
     "tsdf_volume_weight_storage": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "tsdf_volume_last_raycast_kind": (_i, [_vp, C.POINTER(_i)]),
+    "tsdf_volume_last_cell_list": (_i, [_vp, C.POINTER(C.c_uint32)]),
     "tsdf_volume_set_weight_storage": (_i, [_vp, _i]),
     "tsdf_selftest_count_division": (_i, [_u32, _u32, C.POINTER(C.c_uint64)]),
     "tsdf_volume_deformation": (_i, [_vp, C.POINTER(_vp)]),

@@ -143,6 +143,12 @@ class TSDFVolume:
         check(lib.tsdf_volume_last_raycast_kind(self._h, C.byref(k)))
         return bool(k.value)
 
+    def last_cell_list(self):
+        """Tasks the last cell-parallel cast listed (diagnostics; waits for the volume's stream)."""
+        n = C.c_uint32()
+        check(lib.tsdf_volume_last_cell_list(self._h, C.byref(n)))
+        return int(n.value)
+
     def set_weight_storage(self, bits):
         """Widen the weight storage now (8 -> 16 -> 32 bits, values unchanged) instead of when a count is about to overflow."""
         check(lib.tsdf_volume_set_weight_storage(self._h, int(bits)))

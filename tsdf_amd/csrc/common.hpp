@@ -227,6 +227,7 @@ constexpr int kEntryTile = 16;                  // pixels per side of a tile (= 
 constexpr uint32_t kEntryFar = 0x7f7f7f7fu;     // "no unit": what a byte-wise fill leaves (3.4e38 as a float)
 struct EntryParams {
     float r[3][4];        // world -> camera, rows 1-3 (the inverse of the pose the ray directions are formed with)
+    float r_scale;        // an upper bound of the 2-norm of r's 3 x 3 block: a world distance d is at most r_scale * d in the camera's frame (1 for a rigid pose)
     float k[2][3];        // pixel = k * camera / camera.z (the inverse of kinv), rows 1-2
     F3 vs, offset;        // voxel size, grid origin (the ray caster's space_min)
     uint32_t width, height, tiles_x, tiles_y;

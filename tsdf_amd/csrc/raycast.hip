@@ -1783,6 +1783,18 @@ static bool view_projection(const tsdf_volume *v, const RayParams &rp, EntryPara
         for (int j = 0; j < 3; j++) ep.r[i][j] = (float)Ri[i][j];
         ep.r[i][3] = (float)-(Ri[i][0] * t[0] + Ri[i][1] * t[1] + Ri[i][2] * t[2]);
     }
+    {   // the largest absolute row sum of Ri' Ri bounds its largest eigenvalue, the square of Ri's 2-norm (exactly 1 for a rotation):
+        // poses need not be rigid -- anything with an invertible block is cast -- and a brick's radius in the world is a distance
+        // in the camera's frame only up to that factor (cell_cast_prepare_kernel)
+        double bound = 0.0;
+        for (int i = 0; i < 3; i++) {
+            double row = 0.0;
+            for (int j = 0; j < 3; j++) row += std::fabs(Ri[0][i] * Ri[0][j] + Ri[1][i] * Ri[1][j] + Ri[2][i] * Ri[2][j]);
+            bound = std::max(bound, row);
+        }
+        ep.r_scale = (float)(std::sqrt(bound) * (1.0 + 1.0e-5));
+        if (!std::isfinite(ep.r_scale)) return false;
+    }
     const double kd = (double)ki.m11 * ki.m22 - (double)ki.m12 * ki.m21;
     if (!(std::fabs(kd) > 1e-12) || !std::isfinite(kd)) return false;
     // inverse of [a s c; e b d; 0 0 1], rows 1-2; a direction's camera z is w33: camera x and y count w33-fold (pixel = k * camera / camera.z)
@@ -2280,6 +2292,13 @@ int tsdf_raycast(const tsdf_volume *cv, uint32_t width, uint32_t height, const f
 int tsdf_volume_last_raycast_kind(const tsdf_volume *v, int *cell_parallel) {
     TSDF_REQUIRE(v && cell_parallel, "null argument");
     *cell_parallel = v->last_cast_cells;
+    return TSDF_OK;
+}
+
+int tsdf_volume_last_cell_list(const tsdf_volume *v, uint32_t *listed) {
+    TSDF_REQUIRE(v && listed, "tsdf_volume_last_cell_list: null argument");
+    TSDF_HIP(hipStreamSynchronize(v->stream), "tsdf_volume_last_cell_list");
+    *listed = v->cell_cast_host ? *v->cell_cast_host : 0u;
     return TSDF_OK;
 }
 

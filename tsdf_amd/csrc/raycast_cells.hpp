@@ -206,7 +206,8 @@ __global__ __launch_bounds__(256) void cell_cast_prepare_kernel(const Geom g, co
     const float side_ = (float)kBrick + 1.5f + 2.0f * eps;   // the listed box of a brick, in voxels: its half-diagonal in millimetres
     const float us = 0.5f * (float)ep.width, vs_ = 0.5f * (float)ep.height;
     const float gu0 = sqrtf(ep.k[0][0] * ep.k[0][0] + ep.k[0][1] * ep.k[0][1] + (ep.k[0][2] - us) * (ep.k[0][2] - us)), gv0 = sqrtf(ep.k[1][0] * ep.k[1][0] + ep.k[1][1] * ep.k[1][1] + (ep.k[1][2] - vs_) * (ep.k[1][2] - vs_));
-    const float radius = 0.5f * sqrtf((side_ * g.vs.x) * (side_ * g.vs.x) + (side_ * g.vs.y) * (side_ * g.vs.y) + (side_ * g.vs.z) * (side_ * g.vs.z));
+    // (in the camera's frame: the world's half-diagonal times the bound of the pose's stretch -- a pose need not be rigid)
+    const float radius = 0.5f * sqrtf((side_ * g.vs.x) * (side_ * g.vs.x) + (side_ * g.vs.y) * (side_ * g.vs.y) + (side_ * g.vs.z) * (side_ * g.vs.z)) * ep.r_scale;
     for (uint32_t w0 = blockIdx.x * 256u; w0 < n_words; w0 += n_list_blocks * 256u) {   // (uniform over the workgroup)
         const uint32_t w = w0 + threadIdx.x;
         uint32_t f = 0, c = 0;
