@@ -135,3 +135,33 @@ def test_second_rebuild_reads_only_what_integrate_touched_and_still_equals_the_d
         ef, ec = definition()
         assert np.array_equal(resident(fine), resident(ef)), "fine flags, rebuild %d" % rnd
         assert np.array_equal(resident(cell), resident(ec)), "cell flags, rebuild %d" % rnd
+
+
+@pytest.mark.parametrize("seed", [3, 4])
+def test_incremental_rebuild_equals_a_full_scan(seed):
+    """The incremental rebuild skips every brick whose own `fine` flag is clear and trusts its summary bits (volume.hip,
+    occupancy_scan_kernel; the invariant is stated beside tsdf_volume::occ_dirty).  Pinned on streams that put surface into the rim zone
+    -- walls that leave the grid through its faces (a wall right behind the entry face, the camera inside the volume) -- over several
+    rounds of integrate + rebuild: the flags after each incremental rebuild equal the definition evaluated on ALL distances, i.e. what a
+    full scan gives (definition == full scan: test_rebuilt_flags_equal_their_definition)."""
+    n = 64
+    v = tsdf_amd.TSDFVolume((n, n, n), (3000.0,) * 3)
+    tau = np.float32(0.01) * np.float32(v.truncation_distance())
+    rng = np.random.RandomState(seed)
+    for rnd in range(5):
+        for i in range(1 + rnd % 3):
+            if rng.rand() < 0.5:
+                d, cam = synth.depth_frame(int(rng.randint(0, 100)), 100, seed=0x5EED0004, inside=True)
+            else:
+                # a slanted wall that crosses the grid's faces: depth grows across the image, near enough to start inside the first voxels
+                cam = tsdf_amd.Camera.default_depth_camera()
+                cam.move_to(float(rng.uniform(200, 2800)), float(rng.uniform(200, 2800)), -60.0 - 40.0 * rnd)
+                cam.look_at(1500.0 + float(rng.uniform(-800, 800)), 1500.0, 1500.0)
+                xs = np.arange(synth.WIDTH, dtype=np.float32)[None, :].repeat(synth.HEIGHT, 0)
+                d = (80.0 + 20.0 * rnd + xs * float(rng.uniform(0.2, 4.0))).astype(np.uint16).reshape(-1)
+            v.integrate(d, synth.WIDTH, synth.HEIGHT, cam)
+        fine, cell, _ = v.occupancy_data(force_rebuild=True)     # (occ_dirty only: the incremental path from the second round on)
+        ef, ec = _expected(v.get_distance_data(), (n, n, n), tau, trunc=v.truncation_distance())
+        assert np.array_equal(fine, ef), "fine flags, round %d" % rnd
+        assert np.array_equal(cell, ec), "cell flags, round %d" % rnd
+        assert fine[0].any() or fine[:, 0].any() or fine[:, :, 0].any() or rnd < 1, "no surface in the rim zone: the test would prove nothing"

@@ -737,6 +737,50 @@ def test_poses_that_are_not_rigid(oracle, tmp_path, cells):
         assert int(got["listed1"]) == int(got["listed0"]) and int(got["listed2"]) == int(got["listed0"]), [int(got["listed%d" % j]) for j in range(3)]
 
 
+_RECOUNT_PROBE = r"""
+import sys, numpy as np
+import tsdf_amd
+from tsdf_amd import synth
+n = 96
+gv = tsdf_amd.TSDFVolume((n, n, n), (3000, 3000, 3000))
+for i in range(3):
+    d, cam = synth.depth_frame(i, 4, seed=0x5EED0002)
+    gv.integrate(d, synth.WIDTH, synth.HEIGHT, cam)
+kinds, listed = [], []
+for j in range(40):
+    V, N = gv.raycast(synth.WIDTH, synth.HEIGHT, cam)
+    kinds.append(gv.last_raycast_cell_parallel()); listed.append(gv.last_cell_list())
+np.savez(sys.argv[1], V=V, N=N, D=gv.get_distance_data(), kinds=np.array(kinds), listed=np.array(listed))
+"""
+
+
+def test_a_list_over_the_limit_is_counted_again_now_and_then(oracle, tmp_path):
+    """The choice of cast goes by the list the last cell-parallel cast built; over the limit the march runs, which builds none.  So that a
+    volume does not keep the march for good, every 16th such cast counts the flagged bricks again (choose_cell_cast; the advisor's
+    finding of round 5).  With a limit of 10 bricks: the first cast is the cell-parallel one, the rest march, the count in the mirror is
+    replaced by the recount at the 17th cast -- and every picture is the oracle's."""
+    import os
+    import subprocess
+    import sys
+    out = str(tmp_path / "recount.npz")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, TSDF_RAY_CELLS="1", TSDF_RAY_CELLS_LIMIT="10")
+    e["PYTHONPATH"] = root + os.pathsep + e.get("PYTHONPATH", "")
+    subprocess.run([sys.executable, "-c", _RECOUNT_PROBE, out], check=True, env=e, cwd=root, timeout=600)
+    got = np.load(out)
+    kinds, listed = got["kinds"].astype(bool), got["listed"]
+    assert kinds[0] and not kinds[1:].any(), kinds
+    assert listed[0] > 10 and np.all(listed[:10] == listed[0])
+    # (the cast lists tasks -- bricks in view, the large ones in parts --, the recount counts flagged bricks: 3 485 against 660 here)
+    assert listed[15] == listed[0] and listed[16] != listed[0] and listed[16] > 10 and np.all(listed[16:] == listed[16]), listed
+    ov = oracle.Volume((96, 96, 96), (3000, 3000, 3000))
+    ov.set_distance_data(got["D"])
+    _, cam = synth.depth_frame(2, 4, seed=0x5EED0002)
+    Vo, No = ov.raycast(W, H, cam.pose(), cam.kinv(), nthreads=oracle.max_threads())
+    assert_same_floats(got["V"], Vo, "vertices")
+    assert_same_floats(got["N"], No, "normals")
+
+
 def test_an_uploaded_field_that_flags_every_brick_keeps_the_march(oracle):
     """The cell-parallel cast's work is the number of flagged bricks times their cells' pixels; the choice goes by the list the previous
     cast built.  After a bulk change of the distances that count says nothing: the flags are rebuilt and counted before the first cast

@@ -297,6 +297,8 @@ struct tsdf_volume {
     void *cell_rays;
     size_t cell_rays_cap;
     uint32_t *cell_bricks;
+    uint32_t *cell_count_scratch;   // two words for count_cell_bricks_kernel (raycast.hip)
+    int cell_recount_wait;          // casts that kept the march because the list was over the limit, since the last recount
     size_t cell_bricks_cap;
     uint32_t *cell_cast_host;
     int last_cast_cells;     // 1 = the last ray cast of this volume took the cell-parallel kernels (tsdf_volume_last_raycast_kind)
@@ -321,6 +323,12 @@ struct tsdf_volume {
     // brick occupancy (see OccGrid)
     tsdf::OccGrid occ;
     int occ_dirty;   // 1 = the flags do not cover the distances (upload, new truncation): rebuild before the next ray cast
+    // THE INVARIANT every writer of distances keeps (the incremental rebuild of volume.hip skips bricks whose `fine` flag is clear and
+    // trusts their summary bits): either it sets fine[b] for every brick b whose grown box holds a voxel it leaves low (or, in the rim
+    // zone, not flat) and marks the integrate bricks it wrote in `touched` -- integrate's mark_low_voxels does -- or it sets occ_scan_all
+    // (with occ_dirty) so that the next rebuild reads everything: set_distance_data, mark_dirty, clear, a new truncation distance do.
+    // A writer that only set occ_dirty would leave stale zero summary bits behind, and both casts would miss hits
+    // (tests/test_occupancy.py::test_incremental_rebuild_equals_a_full_scan pins the two rebuilds against each other).
     // 1 = the periodic tightening is due (integrate.hip).  The flags still cover the distances -- integrate only ever sets them --
     // they are just looser than they could be, so this rebuild may also run BESIDE the ray cast that follows (occupancy_tighten_on:
     // the per-frame pipeline puts it on its second stream; every byte it writes is a true statement about the distances integrate

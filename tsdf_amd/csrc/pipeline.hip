@@ -289,7 +289,7 @@ int tsdf_slab_validate_merge(tsdf_volume *slab, tsdf_slab_exchange *x, uint32_t 
         longest = std::max(longest, ze - zb);
     }
     TSDF_REQUIRE(covered == g.Z, "tsdf_slab_validate_merge: the ranks' slabs do not cover the grid");
-    // (2) the slabs themselves, by the byte: records of 8 bytes, rank r's at r * per_rank
+    // the slabs travel by the byte: records of 8 bytes, rank r's at r * per_rank
     const size_t per_rank = ((size_t)longest * xy + 1) / 2;   // records per rank
     TSDF_REQUIRE(per_rank <= 0xffffffffull, "tsdf_slab_validate_merge: slab too long for one collective");
     tsdf_hit_record *send = nullptr, *recv = nullptr;
@@ -304,22 +304,57 @@ int tsdf_slab_validate_merge(tsdf_volume *slab, tsdf_slab_exchange *x, uint32_t 
         if (count_dev) (void)hipFree(count_dev);
         if (whole) (void)tsdf_volume_destroy(whole);
     };
-    e = hipMalloc((void **)&send, per_rank * sizeof(tsdf_hit_record));
-    if (e == hipSuccess) e = hipMalloc((void **)&recv, per_rank * (size_t)x->world * sizeof(tsdf_hit_record));
-    if (e == hipSuccess) e = hipMemsetAsync(send, 0, per_rank * sizeof(tsdf_hit_record), s);
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(send, slab->dist + (size_t)(slab->z_begin - g.z_store_begin) * xy, (size_t)(slab->z_end - slab->z_begin) * xy * sizeof(float),
-                           hipMemcpyDeviceToDevice, s);
-    if (e != hipSuccess) { cleanup(); return hip_fail(e, "validate merge: staging"); }
-    rc = tsdf_slab_exchange_all_gather(x, send, recv, (uint32_t)per_rank, s);
-    if (rc != TSDF_OK) { cleanup(); return rc; }
-    // (3) the whole volume with this slab's header, and its ordinary cast
-    rc = tsdf_volume_create(g.X, g.Y, g.Z, g.phys.x, g.phys.y, g.phys.z, &whole);
-    if (rc == TSDF_OK) {
+    // Everything that can fail on ONE rank -- the staging buffers, the whole volume, the pictures -- is allocated before the large
+    // collective, and the ranks tell each other how that went (one record a rank): a rank that ran out of memory must not leave the
+    // others waiting in ncclAllGather for a partner that has returned.  (The checks above are on gathered data: every rank takes the
+    // same way out.  What cannot be helped: a rank that fails before the FIRST collective -- 8 (world + 1) bytes of device memory, a
+    // dead stream -- leaves the others in it.)
+    const size_t words = (size_t)width * height * 3;
+    tsdf_hit_record *status_dev = nullptr;
+    std::vector<tsdf_hit_record> status((size_t)x->world);
+    e = hipMalloc((void **)&status_dev, ((size_t)x->world + 1) * sizeof(tsdf_hit_record));
+    if (e != hipSuccess) return hip_fail(e, "validate merge: alloc");   // (see above: nothing to tell the others with)
+    int local_rc = TSDF_OK;
+    hipError_t le = hipMalloc((void **)&send, per_rank * sizeof(tsdf_hit_record));
+    if (le == hipSuccess) le = hipMalloc((void **)&recv, per_rank * (size_t)x->world * sizeof(tsdf_hit_record));
+    if (le == hipSuccess) le = hipMalloc((void **)&V, words * sizeof(float));
+    if (le == hipSuccess) le = hipMalloc((void **)&N, words * sizeof(float));
+    if (le == hipSuccess) le = hipMalloc((void **)&count_dev, sizeof(unsigned long long));
+    if (le == hipSuccess) le = hipMemsetAsync(count_dev, 0, sizeof(unsigned long long), s);
+    if (le == hipSuccess) le = hipMemsetAsync(send, 0, per_rank * sizeof(tsdf_hit_record), s);
+    if (le == hipSuccess)
+        le = hipMemcpyAsync(send, slab->dist + (size_t)(slab->z_begin - g.z_store_begin) * xy, (size_t)(slab->z_end - slab->z_begin) * xy * sizeof(float),
+                            hipMemcpyDeviceToDevice, s);
+    if (le != hipSuccess) local_rc = hip_fail(le, "validate merge: staging");
+    // the whole volume with this slab's header
+    if (local_rc == TSDF_OK) local_rc = tsdf_volume_create(g.X, g.Y, g.Z, g.phys.x, g.phys.y, g.phys.z, &whole);
+    if (local_rc == TSDF_OK) {
         const float off[3] = {g.offset.x, g.offset.y, g.offset.z};
-        rc = tsdf_volume_set_header(whole, off, g.trunc, slab->max_weight, slab->global_translation, slab->global_rotation);
+        local_rc = tsdf_volume_set_header(whole, off, g.trunc, slab->max_weight, slab->global_translation, slab->global_rotation);
     }
-    if (rc == TSDF_OK) rc = tsdf_volume_set_stream(whole, s);
+    if (local_rc == TSDF_OK) local_rc = tsdf_volume_set_stream(whole, s);
+    {
+        const uint32_t word[2] = {local_rc == TSDF_OK ? 0u : 1u, 0u};
+        e = hipMemcpyAsync(status_dev + x->world, word, sizeof(word), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) rc = tsdf_slab_exchange_all_gather(x, status_dev + x->world, status_dev, 1, s);
+        if (e == hipSuccess && rc == TSDF_OK) e = hipMemcpyAsync(status.data(), status_dev, status.size() * sizeof(tsdf_hit_record), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && rc == TSDF_OK) e = hipStreamSynchronize(s);
+        (void)hipFree(status_dev);
+        if (rc != TSDF_OK) { cleanup(); return rc; }
+        if (e != hipSuccess) { cleanup(); return hip_fail(e, "validate merge: status"); }
+        for (int r = 0; r < x->world; r++) {
+            uint32_t failed;
+            memcpy(&failed, reinterpret_cast<const char *>(&status[r]), 4);
+            if (failed) {
+                cleanup();
+                if (local_rc != TSDF_OK) return local_rc;   // (this rank's own error, message set)
+                set_error("tsdf_slab_validate_merge: rank %d could not allocate its buffers; every rank returns", r);
+                return TSDF_ERR_DEVICE;
+            }
+        }
+    }
+    // (2) the slabs themselves, (3) assembled
+    rc = tsdf_slab_exchange_all_gather(x, send, recv, (uint32_t)per_rank, s);
     if (rc != TSDF_OK) { cleanup(); return rc; }
     for (int r = 0; r < x->world && e == hipSuccess; r++) {
         uint32_t zb, ze;
@@ -328,11 +363,6 @@ int tsdf_slab_validate_merge(tsdf_volume *slab, tsdf_slab_exchange *x, uint32_t 
         e = hipMemcpyAsync(whole->dist + (size_t)zb * xy, reinterpret_cast<const float *>(recv + (size_t)r * per_rank), (size_t)(ze - zb) * xy * sizeof(float),
                            hipMemcpyDeviceToDevice, s);
     }
-    const size_t words = (size_t)width * height * 3;
-    if (e == hipSuccess) e = hipMalloc((void **)&V, words * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void **)&N, words * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void **)&count_dev, sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemsetAsync(count_dev, 0, sizeof(unsigned long long), s);
     if (e != hipSuccess) { cleanup(); return hip_fail(e, "validate merge: assembling the volume"); }
     rc = tsdf_volume_mark_dirty(whole);   // (the distances were written through the pointer)
     if (rc == TSDF_OK) rc = tsdf_raycast_device(whole, width, height, pose, kinv, V, device_merged_normals ? N : nullptr);
@@ -528,6 +558,21 @@ int tsdf_pipeline_step(tsdf_pipeline *p, const uint16_t *device_depth, const tsd
     if (rc != TSDF_OK) return rc;
     bool late_release = false;
     bool by_word = false;   // the second stream waits for a word the cast's first kernel stores, not for an event of the step's stream
+    // The word's promise, kept on every way out: once the side stream has been told to wait for this step's sequence number, a step
+    // that returns early -- the filter ahead failed, the cast failed or took the march -- stores the number itself (behind whatever the
+    // step's stream holds) and takes the pointer back from the volume: otherwise the side stream waits for ever (synchronize and
+    // destroy with it) and a later cell-parallel cast would store through a pointer whose memory the pipeline has freed.
+    struct WordGuard {
+        tsdf_pipeline *p = nullptr;
+        ~WordGuard() {
+            if (!p || !p->volume->release_word) return;   // (taken: the cast's first kernel stores it)
+            p->volume->release_word = nullptr;
+            if (hipStreamWriteValue32(p->main, p->release_word, p->release_seq, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                set_error("tsdf_pipeline_step: the release word could not be stored; the side stream is left waiting (destroy the pipeline)");
+            }
+        }
+    } word_guard;
     auto filter_ahead = [&](hipEvent_t release) -> int {
         if (by_word) TSDF_HIP(hipStreamWaitValue32(p->side, p->release_word, p->release_seq, hipStreamWaitValueGte, 0xffffffffu), "pipeline: release the next frame's filter");
         else TSDF_HIP(hipStreamWaitEvent(p->side, release, 0), "pipeline: release the next frame's filter");
@@ -558,6 +603,7 @@ int tsdf_pipeline_step(tsdf_pipeline *p, const uint16_t *device_depth, const tsd
             p->release_seq++;
             p->volume->release_word = p->release_word;
             p->volume->release_value = p->release_seq;
+            word_guard.p = p;   // (from here on every way out of the step leaves the word stored: the side stream waits for it)
         } else {
             TSDF_HIP(hipEventRecord(p->done[b], p->main), "pipeline: integrate done");
         }
@@ -583,12 +629,8 @@ int tsdf_pipeline_step(tsdf_pipeline *p, const uint16_t *device_depth, const tsd
         p->volume->after_bulk = late_release ? p->bulk : nullptr;
         rc = tsdf_raycast_device(p->volume, W, H, cam->pose, cam->kinv, device_vertices, device_normals);
         p->volume->after_bulk = nullptr;
-        if (by_word && p->volume->release_word) {
-            // (the cast did not take the kernel that stores the word -- the list's count arrived between the two looks at it, or the
-            // cast failed: the step's stream stores it, behind whatever was launched)
-            p->volume->release_word = nullptr;
-            (void)hipStreamWriteValue32(p->main, p->release_word, p->release_seq, 0);
-        }
+        // (a cast that did not take the kernel that stores the word -- the list's count arrived between the two looks at it, or the
+        // cast failed: word_guard stores it from the step's stream, behind whatever was launched)
         if (rc != TSDF_OK) return rc;
         if (late_release) {
             rc = filter_ahead(p->bulk);

@@ -1857,28 +1857,47 @@ static int refresh_for_cast(tsdf_volume *v, RayParams &rp) {
 // the previous cell-parallel cast listed -- says nothing about the new field, and an arbitrary field at 1024^3 can list four million
 // bricks of 64 mixed cells each: minutes of pairs.  The flags are rebuilt at once (the cast would do that anyway), one workgroup counts
 // the bricks with `fine` and `cell` set into the mirror, and the host waits for it: once per bulk change, never in a stream of frames.
-__global__ __launch_bounds__(1024) void count_cell_bricks_kernel(const OccGrid occ, uint32_t *__restrict__ mirror) {
+// (scratch: [0] the sum so far, [1] workgroups done; the last one to finish writes the mirror and leaves both words zero again)
+__global__ __launch_bounds__(1024) void count_cell_bricks_kernel(const OccGrid occ, uint32_t *__restrict__ mirror, uint32_t *__restrict__ scratch) {
     __shared__ uint32_t total;
     if (threadIdx.x == 0) total = 0;
     __syncthreads();
     uint32_t mine = 0;
     const size_t n = occ.fine_count();
-    for (size_t b = threadIdx.x; b < n; b += 1024) mine += (occ.fine[b] && occ.cell[b]) ? 1u : 0u;
+    for (size_t b = (size_t)blockIdx.x * 1024 + threadIdx.x; b < n; b += (size_t)gridDim.x * 1024) mine += (occ.fine[b] && occ.cell[b]) ? 1u : 0u;
     for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
     if ((threadIdx.x & 63u) == 0) atomicAdd(&total, mine);
     __syncthreads();
-    if (threadIdx.x == 0) *mirror = total;
+    if (threadIdx.x == 0) {
+        if (total) atomicAdd(&scratch[0], total);
+        __threadfence();
+        if (atomicAdd(&scratch[1], 1u) + 1u == gridDim.x) {
+            __threadfence();
+            *mirror = atomicExch(&scratch[0], 0u);
+            scratch[1] = 0u;
+        }
+    }
+}
+static int launch_brick_count(tsdf_volume *v) {
+    if (!v->cell_cast_host) {
+        TSDF_HIP(hipHostMalloc((void **)&v->cell_cast_host, sizeof(uint32_t), hipHostMallocDefault), "brick count mirror alloc");
+        *v->cell_cast_host = 0;
+    }
+    if (!v->cell_count_scratch) {
+        TSDF_HIP(hipMalloc((void **)&v->cell_count_scratch, 2 * sizeof(uint32_t)), "brick count scratch alloc");
+        TSDF_HIP(hipMemsetAsync(v->cell_count_scratch, 0, 2 * sizeof(uint32_t), v->stream), "brick count scratch reset");
+    }
+    const unsigned blocks = (unsigned)std::min<size_t>((v->occ.fine_count() + 65535) / 65536, 256);   // (64 bricks a thread)
+    hipLaunchKernelGGL(count_cell_bricks_kernel, dim3(std::max(blocks, 1u)), dim3(1024), 0, v->stream, v->occ, v->cell_cast_host, v->cell_count_scratch);
+    TSDF_HIP(hipGetLastError(), "brick count failed");
+    return TSDF_OK;
 }
 static int count_after_bulk_change(tsdf_volume *v) {
     if (tuning().ray_cells == 0 || !v->occ_dirty) return TSDF_OK;
     int rc = occupancy_flags_refresh(v);
     if (rc != TSDF_OK) return rc;
-    if (!v->cell_cast_host) {
-        TSDF_HIP(hipHostMalloc((void **)&v->cell_cast_host, sizeof(uint32_t), hipHostMallocDefault), "brick count mirror alloc");
-        *v->cell_cast_host = 0;
-    }
-    hipLaunchKernelGGL(count_cell_bricks_kernel, dim3(1), dim3(1024), 0, v->stream, v->occ, v->cell_cast_host);
-    TSDF_HIP(hipGetLastError(), "brick count failed");
+    rc = launch_brick_count(v);
+    if (rc != TSDF_OK) return rc;
     TSDF_HIP(hipStreamSynchronize(v->stream), "brick count failed");
     return TSDF_OK;
 }
@@ -1948,7 +1967,16 @@ static bool choose_cell_cast(const tsdf_volume *v, const RayParams &rp, EntryPar
     // within 35 voxels of the volume, went back to the march: 0.148 -> 0.193 ms per step).
     if (!(vs_max * std::max(std::fabs(ep.k[0][0]), std::fabs(ep.k[1][1])) <= 32.0f * (2.0f * ep.z_clip))) return false;
     const uint32_t listed = v->cell_cast_host ? *v->cell_cast_host : 0u;
-    return listed <= (uint32_t)tuning().ray_cells_limit;
+    if (listed <= (uint32_t)tuning().ray_cells_limit) return true;
+    // Over the limit: the march runs, and the march never writes that count -- left alone the volume would keep the march for good,
+    // also after the periodic tightening has cleared most of the flags.  Every 16th such cast the flagged bricks are counted again
+    // (asynchronously: a later cast reads the mirror; nothing waits).
+    tsdf_volume *w = const_cast<tsdf_volume *>(v);
+    if (++w->cell_recount_wait >= 16) {
+        w->cell_recount_wait = 0;
+        (void)launch_brick_count(w);
+    }
+    return false;
 }
 
 // The production march: process_ray_kernel over the sample ranges of every ray with a pass budget, process_ray_tail_kernel

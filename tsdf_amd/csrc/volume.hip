@@ -506,8 +506,16 @@ int occupancy_join(tsdf_volume *v) {
 
 static int occupancy_rebuild_on(tsdf_volume *v, hipStream_t stream) {
     const size_t n = v->occ.fine_count();
-    if (!v->occ_bits) TSDF_HIP(hipMalloc((void **)&v->occ_bits, n * sizeof(uint16_t)), "occupancy scratch alloc");
-    if (!v->occ_rim_bits) TSDF_HIP(hipMalloc((void **)&v->occ_rim_bits, n), "occupancy scratch alloc");
+    // (zeroed where they are allocated: an incremental rebuild reads the summary bits of bricks it does not scan, and "all zero" is what a
+    // brick that was never scanned since clear() must say -- not left to the first rebuild being a full one)
+    if (!v->occ_bits) {
+        TSDF_HIP(hipMalloc((void **)&v->occ_bits, n * sizeof(uint16_t)), "occupancy scratch alloc");
+        TSDF_HIP(hipMemsetAsync(v->occ_bits, 0, n * sizeof(uint16_t), stream), "occupancy scratch reset");
+    }
+    if (!v->occ_rim_bits) {
+        TSDF_HIP(hipMalloc((void **)&v->occ_rim_bits, n), "occupancy scratch alloc");
+        TSDF_HIP(hipMemsetAsync(v->occ_rim_bits, 0, n, stream), "occupancy scratch reset");
+    }
     dim3 grid((v->occ.nbx + 63) / 64, v->occ.nby, v->occ.nbz);
     const bool incremental = !tuning().occ_scan_all && !v->occ_scan_all && v->touched && (v->g.z_store_begin % kBrick) == 0;
     const uint32_t n_touched = v->touched ? v->touched_nx * v->touched_ny * v->touched_nz : 0u;
@@ -911,6 +919,7 @@ int tsdf_volume_destroy(tsdf_volume *v) {
     if (v->tail_count) (void)hipFree(v->tail_count);
     if (v->cell_rays) (void)hipFree(v->cell_rays);
     if (v->cell_bricks) (void)hipFree(v->cell_bricks);
+    if (v->cell_count_scratch) (void)hipFree(v->cell_count_scratch);
     if (v->cell_cast_host) (void)hipHostFree(v->cell_cast_host);
     if (v->ray_heavy) (void)hipFree(v->ray_heavy);
     if (v->ray_order) (void)hipFree(v->ray_order);
