@@ -364,7 +364,6 @@ np.savez(sys.argv[1], V=V, N=N, D=gv.get_distance_data())
     {"TSDF_RAY_CELLS": "2", "TSDF_RAY_CELLS_GRID": "3"},                                       # ... every wave through many bricks
     {"TSDF_RAY_CELLS": "2", "TSDF_RAY_CELLS_PAIRS": "64"},                                     # ... each brick in many parts
     {"TSDF_RAY_CELLS": "2", "TSDF_RAY_CELLS_LOOK": "0"},                                       # ... the bricks not projected when listed (none dropped, never in parts)
-    {"TSDF_RAY_FUSED": "1", "TSDF_RAY_CELLS": "0"},                                            # the march and its queue in one launch
 ])
 def test_schedule_knobs_do_not_change_a_bit(oracle, tmp_path, env):
     """How the march is cut into sample ranges, passes and lane groups, and when the occupancy flags are refreshed, is
@@ -810,3 +809,24 @@ def test_an_uploaded_field_that_flags_every_brick_keeps_the_march(oracle):
     if os.environ.get("TSDF_RAY_CELLS", "1") == "1":
         assert gv.last_raycast_cell_parallel()
     gv.close()
+
+
+def test_the_ray_cast_and_fuzz_suites_again_with_the_cell_parallel_cast_forced():
+    """The default choice of cast (choose_cell_cast) keeps the march for views from inside the volume, coarse grids and close-ups: run
+    that way, most tests of this file and of test_fuzz_parity.py only ever exercise the march.  Here the same tests run once more in a
+    process with TSDF_RAY_CELLS=2 -- the cell-parallel cast wherever the view has a projection (the knob is read once per process) --
+    so that the recorded GPU run covers both casts on every scene.  (Left out: the tests that start processes with a setting of their
+    own, the bilateral / ICP fuzz that casts nothing, and this test.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, TSDF_RAY_CELLS="2")
+    e["PYTHONPATH"] = root + os.pathsep + e.get("PYTHONPATH", "")
+    skip = "not again_with_the_cell and not schedule_knobs and not unusual_intrinsics and not not_rigid and not counted_again and not outside_beside_and_inside and not bilateral and not icp"
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_parity_raycast.py", "tests/test_fuzz_parity.py", "-m", "gpu", "-x", "-q", "-k", skip, "-p", "no:cacheprovider"],
+                       env=e, cwd=root, capture_output=True, text=True, timeout=1500)
+    tail = "\n".join(r.stdout.splitlines()[-15:])
+    assert r.returncode == 0, tail + "\n" + r.stderr[-2000:]
+    import re
+    m = re.search(r"(\d+) passed", tail)
+    assert m and int(m.group(1)) >= 100, tail

@@ -9,7 +9,6 @@ python bench.py > $out/${tag}_bench_default.json 2> /dev/null                   
 python bench.py --workload config4 --steps 20 --warmup 5 > $out/${tag}_config4_n1_bench.json 2> /dev/null
 python tools/dbg_ray_only.py 40 > $out/${tag}_ray_only.txt 2>&1
 python tools/dbg_ray_work.py 40 > $out/${tag}_ray_work.txt 2>&1
-TSDF_DEBUG_WAVES=1 python tools/dbg_ray_only.py 40 2>&1 | grep "tsdf:" | tail -16 > $out/${tag}_ray_waves.txt
 python tools/dbg_pipeline_kernels.py 100 > $out/${tag}_pipeline_kernels.txt 2>&1
 python tools/dbg_slab_scaling.py config3 > $out/${tag}_slab_scaling_config3.txt 2>&1
 python tools/dbg_slab_scaling.py config4 > $out/${tag}_slab_scaling_config4.txt 2>&1

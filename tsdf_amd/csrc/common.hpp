@@ -56,7 +56,6 @@ struct Tuning {
     int ray_cells_pairs;     // TSDF_RAY_CELLS_PAIRS    estimated (cell, pixel) pairs of a brick above which it is listed in several parts (1024; 0: never)
     int ray_cells_look;      // TSDF_RAY_CELLS_LOOK     1 (default): every flagged brick is projected when the list is built -- unseen ones dropped, large ones listed in parts; 0: never
     int ray_cells_grid;      // TSDF_RAY_CELLS_GRID     workgroups of cast_cells_kernel (2048: two or three bricks a wave at 20 000 listed bricks; see raycast_cells.hpp)
-    int ray_fused;           // TSDF_RAY_FUSED          1: the march and its queue of unfinished stretches in ONE launch (process_ray_fused_kernel; measured slower, LABNOTES round 5); default 0: two launches
     int ray_entry_bound;     // TSDF_RAY_ENTRY_BOUND    0: no per-tile entry bound (default 1: rays start at the nearest flagged block their 16 x 16 tile can see)
     int icp_persistent;      // TSDF_ICP_PERSISTENT     default 0: one launch per ICP iteration (the chain); 1 / 2: all 19 in one launch with a grid barrier (slower, kept for study)
     int occ_rebuild_period;  // TSDF_OCC_REBUILD_PERIOD integrations between tightenings of the ray caster's flags (16; 0: never)
@@ -72,7 +71,6 @@ struct Tuning {
                              //                          write-back + invalidate for the host's and other devices' sake), 1 hipEventReleaseToDevice, 2 (default) hipEventDisableSystemFence
     int timing_bracket;      // TSDF_TIMING_BRACKET     1: tsdf_volume_set_timing brackets launches with hipEventRecord
     int verbose;             // TSDF_VERBOSE            the reference's chatter
-    int debug_waves;         // TSDF_DEBUG_WAVES        per-wave clocks of the two ray kernels (synchronises)
     int debug_rays;          // TSDF_DEBUG_RAYS         how many pieces went through the tail queue (synchronises)
 };
 const Tuning &tuning();

@@ -32,7 +32,6 @@ const Tuning &tuning() {
         Tuning u;
         u.ray_segments = clamp(num("TSDF_RAY_SEGMENTS", 6), 1, 64);
         u.ray_slab_ranges = clamp(num("TSDF_RAY_SLAB_RANGES", 0), 0, 64);
-        u.ray_fused = num("TSDF_RAY_FUSED", 0) != 0;
         u.ray_cells = clamp(num("TSDF_RAY_CELLS", 1), 0, 2);
         u.ray_cells_limit = std::max(num("TSDF_RAY_CELLS_LIMIT", 131072), 0);
         u.ray_cells_grid = clamp(num("TSDF_RAY_CELLS_GRID", 2048), 1, 65535);
@@ -62,7 +61,6 @@ const Tuning &tuning() {
         u.event_scope = clamp(num("TSDF_EVENT_SCOPE", 2), 0, 2);
         u.timing_bracket = num("TSDF_TIMING_BRACKET", 0) != 0;
         u.verbose = getenv("TSDF_VERBOSE") != nullptr;
-        u.debug_waves = getenv("TSDF_DEBUG_WAVES") != nullptr;
         u.debug_rays = getenv("TSDF_DEBUG_RAYS") != nullptr;
         return u;
     }();
