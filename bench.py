@@ -77,6 +77,8 @@ def parse():
                          "listed in ms_per_step_runs")
     ap.add_argument("--parity-grid", type=int, default=None,
                     help="grid of the parity gate (default: the benchmarked grid, first and last timed frame against the oracle)")
+    ap.add_argument("--spread-steps", type=int, default=100,
+                    help="steps of the run that times every step on its own (step_ms_spread): at least --steps; 0 = --steps (the profiling passes)")
     ap.add_argument("--path-only", action="store_true",
                     help="only the timed hot path and its roofline (no ICP / tracking / host-buffer legs): what the profiling passes run")
     a = ap.parse_args()
@@ -156,7 +158,8 @@ def main():
     n = args.grid
     N_vox = n * n * n
     K, Wu = args.steps, args.warmup
-    n_frames = K + Wu + 1
+    S_spread = K if args.spread_steps <= 0 else max(K, args.spread_steps)   # steps of the per-step timing run
+    n_frames = max(K, S_spread) + Wu + 1
     inside = args.workload == "config4"
     seed = 0x5EED0004 if inside else SEED
 
@@ -433,17 +436,23 @@ def main():
     vol.clear()
     for i in range(Wu):
         step(i, False)
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(S_spread + 1)]
     torch.cuda.synchronize()
     marks[0].record(stream)
-    for i in range(Wu, Wu + K):
+    for i in range(Wu, Wu + S_spread):
         step(i, False)
         marks[i - Wu + 1].record(stream)
     torch.cuda.synchronize()
-    per_step = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(K)], np.float64)
+    per_step = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(S_spread)], np.float64)
+    worst = np.argsort(per_step)[::-1][:5]
     step_spread = {"median": round(float(np.median(per_step)), 4), "p95": round(float(np.percentile(per_step, 95)), 4),
                    "max": round(float(per_step.max()), 4), "max_over_median": round(float(per_step.max() / np.median(per_step)), 3),
-                   "steps": K, "how": "an event behind every pipelined step of one more run of the same frames"}
+                   "steps": S_spread, "worst_steps": [[int(j), round(float(per_step[j]), 4)] for j in worst],
+                   "how": "an event behind every pipelined step of one more run: the %d timed frames%s" % (K, " and the %d that follow them in the stream" % (S_spread - K) if S_spread > K else "")}
+    if os.environ.get("BENCH_DEBUG_STEPS"):
+        print("per step ms:", [round(float(x), 4) for x in per_step], file=sys.stderr)
+    if S_spread > K:   # (the legs below run on the volume as the K timed frames leave it)
+        vol.clear()
     # ---- and once more, pipelined, with the dominant kernels' launches carrying their dispatches' own begin / end timestamps: the kernels
     # as they run in the two-stream step -- the cast beside the next frame's filter and culling: what a rocprofv3 kernel trace of this
     # command sees (profiles/*_kernel_stats.txt) -- beside `avg_launch_ms`, each kernel with nothing beside it
@@ -531,7 +540,7 @@ def main():
     int_bytes = 16 * U + 2 * W * H                 # 16*U + depth frame
     int_ms = kern["integrate"][1] or stage_ms["integrate"]
     int_gbs = int_bytes / (int_ms * 1e-3) / 1e9
-    traffic, traffic_meta = load_traffic(args)
+    traffic, traffic_meta, activity = load_traffic(args)
     # How the weights are stored decides which kernel ran and what it moves per updated voxel: the algorithmic figure stays SURVEY 8d's
     # (the reference's two fp32 arrays read and written: 16 B); with weights kept as 8- / 16-bit counts the kernel moves 10 / 12 B.
     wbits = vol.weight_storage()[0]
@@ -546,6 +555,7 @@ def main():
                 "moved_bytes_model": moved_per_voxel * U + 2 * W * H,
                 "moved_gbs": round((moved_per_voxel * U + 2 * W * H) / (int_ms * 1e-3) / 1e9, 2)}
     roof_int.update(traffic_meta)
+    roof_int.update(activity_of(activity, int_kernel))
     if not sharded:
         st = rc.stats(vol, cams[last - 1])             # S samples, T distinct voxels touched at the end state
         ray_bytes = 4 * st["touched"] + 12 * W * H     # 4*T + vertex store (normals kernel: +12*W*H)
@@ -554,8 +564,12 @@ def main():
         ray_main_ms, ray_tail_ms = kern["raycast"][1], kern["raycast_tail"][1]
         ray_ms = (ray_main_ms + ray_tail_ms) or stage_ms["raycast"]
         ray_gbs = ray_bytes / (ray_ms * 1e-3) / 1e9
-        # dominant = the single kernel with the longest average launch
-        dominant = "raycast" if max(ray_main_ms, ray_tail_ms) >= int_ms else "integrate"
+        # dominant = the single kernel with the longest average launch IN THE PIPELINED STEP (what the step waits for: the cast runs
+        # beside the next frame's filter and culling there, integrate with nothing beside it); the replay's figures -- each kernel
+        # alone -- are what `achieved` / `frac` are priced on, and both are in both objects
+        pip_ray = max(kern_pipelined["raycast"][1], kern_pipelined["raycast_tail"][1]) or max(ray_main_ms, ray_tail_ms)
+        pip_int = kern_pipelined["integrate"][1] or int_ms
+        dominant = "raycast" if pip_ray >= pip_int else "integrate"
         cells = vol.last_raycast_cell_parallel()     # which kernels the casts took: scheduling only, the same bits either way
         ray_names = ("cast_cells_kernel", None) if cells else ("process_ray_kernel", "process_ray_tail_kernel")
         roof_ray = {"kernel": "cast_cells_kernel" if cells else "process_ray_kernel + process_ray_tail_kernel",
@@ -573,6 +587,7 @@ def main():
                     "msamples_per_s": round(st["samples"] / (ray_ms * 1e-3) / 1e6, 1),
                     "l2_level_gbs": round(32 * st["samples"] / (ray_ms * 1e-3) / 1e9, 1)}
         roof_ray.update(traffic_meta)
+        roof_ray.update(activity_of(activity, ray_names[0]))
     if rank == 0:
         # the fraction against the measured device-to-device copy rate (float4 copy kernel of the library, 1 GiB,
         # best of 5, on the launch stream) as well as the nominal peak
@@ -592,6 +607,8 @@ def main():
     if rank == 0 and not sharded:
         out["roofline"] = roof_ray if dominant == "raycast" else roof_int
         out["roofline_other"] = roof_int if dominant == "raycast" else roof_ray
+        out["roofline"]["dominant_by"] = "the longest average launch in the pipelined step: %s %.4f ms, %s %.4f ms" % (
+            roof_ray["kernel"].split(" ")[0], pip_ray, int_kernel, pip_int)
         if not args.path_only:
             out["host_buffer_api"] = host_api_time(vol, bil, frames, cams, last)
             out["icp"] = icp_tracking(tsdf_amd, synth, depth_dev, frames, stream, not args.no_cpu_baseline)
@@ -793,7 +810,7 @@ def load_traffic(args):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic*.json")))
     if not files:
         meta["traffic_note"] = "no counter profile committed"
-        return {}, meta
+        return {}, meta, {}
     want = {"steps": args.steps, "warmup": args.warmup, "grid": args.grid, "gpus": args.gpus}
     sha, notes = kernel_source_sha(), []
     for p in files:
@@ -810,9 +827,18 @@ def load_traffic(args):
             continue
         meta["traffic_source"] = "profiles/%s (%s: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, mean over the %d timed launches of the same command)" % (
             os.path.basename(p), d.get("tag"), args.steps)
-        return d.get("bytes_per_launch", {}), meta
+        return d.get("bytes_per_launch", {}), meta, d.get("activity", {})
     meta["traffic_note"] = "; ".join(notes) + ": not reported"
-    return {}, meta
+    return {}, meta, {}
+
+
+def activity_of(activity, kernel):
+    """valu_busy / lanes_active / valu_insts of one kernel from the committed counter pass (tools/rocprof_summary.py activity: one
+    rocprofv3 --pmc run of this command on the same kernel sources; null when there is none)."""
+    a = activity.get(kernel) or {}
+    return {"valu_busy": a.get("valu_busy"), "lanes_active": a.get("lanes_active"), "valu_insts_per_launch": a.get("valu_insts"),
+            "counters_are": ("valu_busy = 4 x SQ_ACTIVE_INST_VALU / (launch x 2.4 GHz x 1024 SIMDs), lanes_active = SQ_THREAD_CYCLES_VALU / "
+                             "SQ_INSTS_VALU / 64; same profile as `traffic`") if a else None}
 
 
 def parity_gate(tsdf_amd, frames, cams, n, physical, Wu, K):

@@ -46,6 +46,11 @@ def test_default_shaped_run_prints_the_contract_line():
     # the same kernels as they run in the two-stream step (what a kernel trace of the command shows): never faster than alone by more than noise
     for rr in (r, d["roofline_other"]):
         assert rr["avg_launch_ms_pipelined"] > 0.8 * rr["avg_launch_ms"]
+    # the kernel the line names is the one the pipelined step waits for, both carry the counters' fields, the spread is over >= 100 steps
+    assert "dominant_by" in r and all(k in rr for rr in (r, d["roofline_other"]) for k in ("valu_busy", "lanes_active", "frac", "traffic"))
+    pip = {rr["kernel"]: rr["avg_launch_ms_pipelined"] for rr in (r, d["roofline_other"])}
+    assert pip[r["kernel"]] == max(pip.values())
+    assert d["step_ms_spread"]["steps"] >= 100 and len(d["step_ms_spread"]["worst_steps"]) == 5
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
     assert d["parity"]["pass"] is True
@@ -56,7 +61,7 @@ def test_default_shaped_run_prints_the_contract_line():
 
 
 def test_few_steps_and_no_sampled_events_still_give_strict_json():
-    d = run_bench("--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-parity", "--event-period", "0", "--repeats", "1")
+    d = run_bench("--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-parity", "--event-period", "0", "--repeats", "1", "--spread-steps", "0")
     assert d["steps"] == 3 and d["value"] > 0 and len(d["ms_per_step_runs"]) == 1
 
 
@@ -77,7 +82,7 @@ def test_two_ranks_on_one_gpu_walk_the_sharded_path_and_agree_with_one_volume():
     env = dict(os.environ, TSDF_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("WORLD_SIZE", None)
     # started plainly, the way the driver starts N = 1: bench.py becomes its own torch.distributed.run launcher (round 4)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--plan-rounds", "1", "--repeats", "3"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--plan-rounds", "1", "--repeats", "3", "--spread-steps", "0"]
     p = subprocess.run(cmd, cwd=ROOT, timeout=900, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.strip().splitlines() if l.startswith("{")]
@@ -95,7 +100,7 @@ def test_one_rank_walks_the_sharded_path_over_rccl():
     """What a one-GPU box can check of the multi-GPU path on the real backend: a world of ONE rank initialises nccl (= RCCL),
     builds a communicator on the box's GPU and pushes the hit records through all_gather_into_tensor on device memory, between the
     slab ray cast and the merge kernel of every step; the merged picture must equal a single-volume replay."""
-    d = run_bench("--gpus", "1", "--one-rank-slab-path", "--steps", "6", "--warmup", "2", "--plan-rounds", "1", "--no-cpu-baseline", "--validate-merge")
+    d = run_bench("--gpus", "1", "--one-rank-slab-path", "--steps", "6", "--warmup", "2", "--plan-rounds", "1", "--no-cpu-baseline", "--validate-merge", "--spread-steps", "0")
     assert d["config"]["collective_backend"] == "nccl" and d["config"]["ranks"] == 1 and d["config"]["parallelism"] == "zslab1"
     # the line says how many ranks the communicator itself holds (ncclCommCount), and mode B -- the all-gathered distance slab cast
     # the single-volume way -- gives the merged picture bit for bit
@@ -107,6 +112,6 @@ def test_one_rank_walks_the_sharded_path_over_rccl():
     # the collective was RCCL's, called on the step's own stream (no fallback to torch's)
     assert d["config"]["collective"].startswith("ncclAllGather on the step's stream"), d["config"]["collective"]
     t = run_bench("--gpus", "1", "--one-rank-slab-path", "--torch-collective", "--steps", "6", "--warmup", "2", "--plan-rounds", "0",
-                  "--no-cpu-baseline")
+                  "--no-cpu-baseline", "--spread-steps", "0")
     assert t["config"]["collective"].startswith("torch.distributed") and t["parity"]["pass"] is True
     assert t["last_frame_vertex_checksum"] == d["last_frame_vertex_checksum"]

@@ -155,6 +155,40 @@ def traffic(fetch_db, write_db, skip=0, take=0, meta=None):
     return json.dumps(out, indent=1)
 
 
+def activity(db, skip=0, take=0, clock_ghz=2.4, simds=1024):
+    """Per kernel (most-launched variant, launches [skip, skip + take) as in traffic()): vector instructions per launch, the share of
+    the launch in which the SIMDs issue them, and the lanes active per vector instruction -- from ONE pass with
+    SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES.
+      valu_busy    = 4 * SQ_ACTIVE_INST_VALU / (launch duration * clock * SIMDs): SQ_ACTIVE_INST_VALU counts quad-cycles summed over
+                     the chip's SIMDs (a wave64 vector instruction occupies its SIMD for 4 cycles); 2.4 GHz x 1024 SIMDs (MI355X)
+      lanes_active = SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU / 64 (thread-cycles per vector instruction over the wave's 64 lanes)"""
+    names = ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES")
+    per = {}
+    for c in names:
+        best = {}
+        for k, rows in launches_of(db, c).items():
+            key = short(k).split("<")[0]
+            if key not in best or len(rows) > len(best[key]):
+                best[key] = rows
+        for key, rows in best.items():
+            sel = rows[skip:skip + take] if take else rows
+            sel = sel or rows
+            e = per.setdefault(key, {})
+            e[c] = sum(v for _, v, _ in sel) / len(sel)
+            e["avg_ns"] = sum(d or 0 for _, _, d in sel) / len(sel)
+            e["launches_averaged"] = len(sel)
+    out = {}
+    for key, e in per.items():
+        if not e.get("SQ_INSTS_VALU") or not e.get("avg_ns"):
+            continue
+        out[key] = {"valu_insts": int(e["SQ_INSTS_VALU"]),
+                    "valu_busy": round(4.0 * e.get("SQ_ACTIVE_INST_VALU", 0.0) / (e["avg_ns"] * clock_ghz * simds), 4),
+                    "lanes_active": round(e.get("SQ_THREAD_CYCLES_VALU", 0.0) / e["SQ_INSTS_VALU"] / 64.0, 4),
+                    "waves_resident_mean": round(e.get("SQ_WAVE_CYCLES", 0.0) / (e["avg_ns"] * clock_ghz), 1) if e.get("SQ_WAVE_CYCLES") else None,
+                    "avg_ns_under_counters": int(e["avg_ns"]), "launches_averaged": e["launches_averaged"]}
+    return out
+
+
 if __name__ == "__main__":
     mode = sys.argv[1]
     if mode == "stats":
@@ -177,3 +211,17 @@ if __name__ == "__main__":
             except ValueError:      # (a hex digest that starts with a digit)
                 meta[k] = v
         print(traffic(sys.argv[2], sys.argv[3], skip, take, meta))
+    elif mode == "traffic+activity":
+        # traffic+activity FETCH.db WRITE.db ACTIVITY.db skip take [key=value ...]: traffic()'s JSON with an "activity" object beside it
+        skip, take = int(sys.argv[5]), int(sys.argv[6])
+        meta = {}
+        for kv in sys.argv[7:]:
+            k, v = kv.split("=", 1)
+            try:
+                meta[k] = json.loads(v) if v[:1] in "{[0123456789" else v
+            except ValueError:
+                meta[k] = v
+        d = json.loads(traffic(sys.argv[2], sys.argv[3], skip, take, meta))
+        d["activity"] = activity(sys.argv[4], skip, take)
+        d["activity_note"] = activity.__doc__.strip()
+        print(json.dumps(d, indent=1))

@@ -611,6 +611,9 @@ int tsdf_pipeline_step(tsdf_pipeline *p, const uint16_t *device_depth, const tsd
             // the periodic tightening of the ray caster's flags (every 16th frame: a scan of what integrate has written since the last
             // one, 60-125 us) goes beside this frame's ray cast instead of in front of it: the flags as they are still cover the
             // distances, and the next integrate waits (occupancy_join)
+            // (round 6: the rebuild -- 40 + 15 us alone, 45 + 42 beside the cast -- in front of the filter and the culling makes the side
+            // stream's chain longer than the cast it runs beside: every 16th step is 1.10-1.12 x the median.  On a third stream, beside the
+            // cast AND the filter, it cost the cast more than it saved the chain: 1.17-1.18 x, profiles/r06_step_jitter.txt.)
             TSDF_HIP(hipStreamWaitEvent(p->side, p->done[b], 0), "pipeline: release the occupancy rebuild");
             rc = occupancy_tighten_on(p->volume, p->side);
             if (rc != TSDF_OK) return rc;

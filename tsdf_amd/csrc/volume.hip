@@ -160,13 +160,20 @@ __global__ __launch_bounds__(256) void occupancy_init_kernel(OccGrid occ, uint32
 // Workgroup of scan: 64 bricks along x (lane) x the 4 voxel rows of one brick row (wave); loops over the brick's 4 planes.
 // touched != nullptr (z_store_begin a multiple of 4): only the bricks inside integrate bricks marked there are read -- the
 // distances of the others have not been written since their summary bits were formed, and those stand.
+constexpr uint32_t kScanRows = 8;
 __global__ __launch_bounds__(256) void occupancy_scan_kernel(const float *__restrict__ dist, Geom g, OccGrid occ,
                                                              uint16_t *__restrict__ bits, uint8_t *__restrict__ rim_bits,
                                                              const uint8_t *__restrict__ touched,
                                                              const uint32_t tnx, const uint32_t tny, const uint32_t tnz) {
     __shared__ uint32_t acc[64];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t bx = blockIdx.x * 64 + lane, by = blockIdx.y, bz = blockIdx.z;
+    // kScanRows brick rows a workgroup, one after the other: the incremental rebuild's launch is all but empty -- 2 % of the bricks
+    // integrate touches hold a flag -- and a workgroup that only finds that out costs the dispatcher what a working one does: 32 768
+    // workgroups at 512^3 were 35 us of a launch with a few microseconds of reading in it (round 6: every 16th step of a stream was
+    // 1.11 x the median through it)
+    for (uint32_t row = 0; row < kScanRows; row++) {
+    const uint32_t bx = blockIdx.x * 64 + lane, by = blockIdx.y * kScanRows + row, bz = blockIdx.z;
+    if (by >= occ.nby) break;   // (uniform)
     const uint32_t y = by * kBrick + wave;
     bool scan = true;
     if (touched) {
@@ -182,7 +189,7 @@ __global__ __launch_bounds__(256) void occupancy_scan_kernel(const float *__rest
         // computed (b lies inside its own grown box), and its summary bits, all zero since then, still say so.  2 % of the bricks
         // integrate touches hold a flag: the scan of a 512^3 stream fell from 40-60 us to a few.
         scan = scan && bx < occ.nbx && occ.fine[((size_t)bz * occ.nby + by) * occ.nbx + bx] != 0;
-        if (__syncthreads_or(scan) == 0) return;   // nothing in reach of this workgroup needs a look
+        if (__syncthreads_or(scan) == 0) continue;   // nothing in reach of this row needs a look
     }
     if (threadIdx.x < 64) acc[threadIdx.x] = 0;
     __syncthreads();
@@ -229,17 +236,20 @@ __global__ __launch_bounds__(256) void occupancy_scan_kernel(const float *__rest
         bits[((size_t)bz * occ.nby + by) * occ.nbx + bx] = (uint16_t)acc[lane];
         rim_bits[((size_t)bz * occ.nby + by) * occ.nbx + bx] = (uint8_t)(acc[lane] >> 16);
     }
+    __syncthreads();   // (acc is zeroed again for the next row)
+    }
 }
 
 __global__ __launch_bounds__(256) void occupancy_flags_kernel(const uint16_t *__restrict__ bits, const uint8_t *__restrict__ rim_bits, OccGrid occ, uint32_t size_x,
                                                               uint32_t size_y, uint32_t size_z, uint8_t *__restrict__ touched,
                                                               const uint32_t n_touched, const bool incremental) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    // (several bricks a thread: like the scan, the incremental launch mostly finds clear flags and leaves)
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < max(occ.fine_count(), (size_t)n_touched); i += (size_t)gridDim.x * 256) {
     if (touched && i < n_touched) touched[i] = 0;   // (the scan before this launch has read the marks: they start again)
-    if (i >= occ.fine_count()) return;
+    if (i >= occ.fine_count()) continue;
     // incremental: a clear flag stays clear (a rebuild only clears, see the scan), and with it the cell flag, which is either clear too
     // -- [4b, 4b+4]^3 lies inside the grown box -- or one of occupancy_init_kernel's permanent marks
-    if (incremental && occ.fine[i] == 0) return;
+    if (incremental && occ.fine[i] == 0) continue;
     const int bx = (int)(i % occ.nbx), by = (int)((i / occ.nbx) % occ.nby), bz = (int)(i / ((size_t)occ.nbx * occ.nby));
     // a brick touching the grid boundary asks for flat voxels, not just positive ones (OccGrid)
     const bool boundary = bx == 0 || by == 0 || bz == 0 || bx + 1 == (int)occ.nbx || by + 1 == (int)occ.nby || bz + 1 == (int)occ.nbz;
@@ -283,6 +293,7 @@ __global__ __launch_bounds__(256) void occupancy_flags_kernel(const uint16_t *__
     cell = cell || cell_acc != 0u;
     occ.fine[i] = fine ? 1 : 0;
     occ.cell[i] = cell ? 1 : 0;
+    }
 }
 
 // ---- reach[b]: size class of the largest EMPTY aligned block of bricks that contains brick b:
@@ -514,14 +525,14 @@ static int occupancy_rebuild_on(tsdf_volume *v, hipStream_t stream) {
         TSDF_HIP(hipMalloc((void **)&v->occ_rim_bits, n), "occupancy scratch alloc");
         TSDF_HIP(hipMemsetAsync(v->occ_rim_bits, 0, n, stream), "occupancy scratch reset");
     }
-    dim3 grid((v->occ.nbx + 63) / 64, v->occ.nby, v->occ.nbz);
+    dim3 grid((v->occ.nbx + 63) / 64, (v->occ.nby + kScanRows - 1) / kScanRows, v->occ.nbz);
     const bool incremental = !tuning().occ_scan_all && !v->occ_scan_all && v->touched && (v->g.z_store_begin % kBrick) == 0;
     const uint32_t n_touched = v->touched ? v->touched_nx * v->touched_ny * v->touched_nz : 0u;
     TSDF_REQUIRE(n_touched <= n || !v->touched, "occupancy rebuild: more integrate bricks than occupancy bricks");
     hipLaunchKernelGGL(occupancy_scan_kernel, grid, dim3(256), 0, stream, v->dist, v->g, v->occ, v->occ_bits, v->occ_rim_bits,
                        incremental ? (const uint8_t *)v->touched : (const uint8_t *)nullptr, v->touched_nx, v->touched_ny, v->touched_nz);
     TSDF_HIP(hipGetLastError(), "occupancy scan");
-    hipLaunchKernelGGL(occupancy_flags_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, v->occ_bits, v->occ_rim_bits, v->occ,
+    hipLaunchKernelGGL(occupancy_flags_kernel, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, stream, v->occ_bits, v->occ_rim_bits, v->occ,
                        v->g.X, v->g.Y, v->g.Z, v->touched, n_touched, incremental);
     TSDF_HIP(hipGetLastError(), "occupancy rebuild");
     v->occ_scan_all = 0;
