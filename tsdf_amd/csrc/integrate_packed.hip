@@ -26,6 +26,9 @@ namespace tsdf {
 #ifndef TSDF_PACKED_WAVES
 #define TSDF_PACKED_WAVES 6   // waves per SIMD the kernel is compiled for (register budget)
 #endif
+#ifndef TSDF_PACKED_PIPELINE
+#define TSDF_PACKED_PIPELINE 1   // two register sets, a batch of loads always in flight (0: one set, for the occupancy A/B of round 6: profiles/r06_integrate_occupancy_ab.txt)
+#endif
 
 // (knock-out builds for timing experiments only: -DTSDF_DIAG_NOLOAD / -DTSDF_DIAG_NOSTORE make the accesses depend on conditions that never hold)
 #ifdef TSDF_DIAG_NOLOAD
@@ -337,6 +340,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TSDF_PACKED
         float tsdf_a[kBatchZ], pd_a[kBatchZ], tsdf_b[kBatchZ], pd_b[kBatchZ];
         uint32_t pw_a[kWords], pw_b[kWords];
         bool upd_a[kBatchZ], upd_b[kBatchZ];   // (lane masks in scalar registers)
+#if TSDF_PACKED_PIPELINE
         project_and_load(0, upd_a, tsdf_a, pd_a, pw_a);
 #pragma unroll
         for (uint32_t o = 0; o < (uint32_t)kChunkZ; o += 2 * kBatchZ) {
@@ -346,6 +350,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TSDF_PACKED
             if (o + 2 * kBatchZ < (uint32_t)kChunkZ) project_and_load(o + 2 * kBatchZ, upd_a, tsdf_a, pd_a, pw_a);
             blend_and_store(o + kBatchZ, upd_b, tsdf_b, pd_b, pw_b);
         }
+#else
+        // (A/B of round 6: one register set, a batch's loads waited for before its blend: more waves per SIMD hide the round trip instead)
+        (void)tsdf_b; (void)pd_b; (void)pw_b; (void)upd_b;
+#pragma unroll
+        for (uint32_t o = 0; o < (uint32_t)kChunkZ; o += kBatchZ) {
+            project_and_load(o, upd_a, tsdf_a, pd_a, pw_a);
+            blend_and_store(o, upd_a, tsdf_a, pd_a, pw_a);
+        }
+#endif
         if (z_extra != 0) {   // (uniform; after the pipeline, not inside it)
             project_and_load(kChunkZ, upd_a, tsdf_a, pd_a, pw_a);
             blend_and_store(kChunkZ, upd_a, tsdf_a, pd_a, pw_a);
