@@ -439,9 +439,11 @@ def main():
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(S_spread + 1)]
     torch.cuda.synchronize()
     marks[0].record(stream)
+    kinds = []
     for i in range(Wu, Wu + S_spread):
         step(i, False)
         marks[i - Wu + 1].record(stream)
+        kinds.append(bool(vol.last_raycast_cell_parallel()) if not sharded else None)   # (a host-side flag of the call just made: nothing waits)
     torch.cuda.synchronize()
     per_step = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(S_spread)], np.float64)
     worst = np.argsort(per_step)[::-1][:5]
@@ -449,6 +451,15 @@ def main():
                    "max": round(float(per_step.max()), 4), "max_over_median": round(float(per_step.max() / np.median(per_step)), 3),
                    "steps": S_spread, "worst_steps": [[int(j), round(float(per_step[j]), 4)] for j in worst],
                    "how": "an event behind every pipelined step of one more run: the %d timed frames%s" % (K, " and the %d that follow them in the stream" % (S_spread - K) if S_spread > K else "")}
+    if not sharded:
+        # steps whose cast was not the kind most steps took: the chooser's trials of the other cast (raycast.hip: choose_cast -- one after
+        # 32 casts, then every 64 ... 4096 where the other cast could win at all): slow steps by design, listed apart
+        usual = sum(kinds) * 2 >= len(kinds)
+        trials = [j for j, k_ in enumerate(kinds) if k_ != usual]
+        rest = np.array([per_step[j] for j in range(S_spread) if j not in trials], np.float64)
+        step_spread["cast_kind"] = "cell-parallel" if usual else "march"
+        step_spread["chooser_trial_steps"] = trials
+        step_spread["max_over_median_without_trials"] = round(float(rest.max() / np.median(rest)), 3) if len(rest) else None
     if os.environ.get("BENCH_DEBUG_STEPS"):
         print("per step ms:", [round(float(x), 4) for x in per_step], file=sys.stderr)
     if S_spread > K:   # (the legs below run on the volume as the K timed frames leave it)

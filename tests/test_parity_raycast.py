@@ -780,6 +780,59 @@ def test_a_list_over_the_limit_is_counted_again_now_and_then(oracle, tmp_path):
     assert_same_floats(got["N"], No, "normals")
 
 
+_CHOOSER_PROBE = r"""
+import sys, numpy as np
+import tsdf_amd
+from tsdf_amd import synth
+n = 128
+gv = tsdf_amd.TSDFVolume((n, n, n), (3000, 3000, 3000))
+cams = []
+for i in range(6):
+    d, cam = synth.depth_frame(i * 9, 200, seed=0x5EED0003)
+    gv.integrate(d, synth.WIDTH, synth.HEIGHT, cam)
+    cams.append(cam)
+kinds, out = [], {"D": gv.get_distance_data()}
+for j in range(60):
+    V, N = gv.raycast(synth.WIDTH, synth.HEIGHT, cams[j % 6])
+    kinds.append(gv.last_raycast_cell_parallel())
+    if j >= 54:
+        out["V%d" % (j % 6)], out["N%d" % (j % 6)] = V, N
+    if j == 30:     # in the middle of the stream: more surface, flags set by integrate between casts of different kinds
+        d, cam = synth.depth_frame(70, 200, seed=0x5EED0003)
+        gv.integrate(d, synth.WIDTH, synth.HEIGHT, cam)
+        out["D"] = gv.get_distance_data()
+out["kinds"] = np.array(kinds)
+np.savez(sys.argv[1], **out)
+"""
+
+
+@pytest.mark.parametrize("chooser", ["2", "1"])
+def test_the_cast_chooser_changes_no_bit(oracle, tmp_path, chooser):
+    """TSDF_RAY_CELLS=1 (the default) picks the cast from measured times and tries the other one now and then (raycast.hip: choose_cast).
+    A stream of 60 casts over six views with an integration in the middle; TSDF_RAY_CHOOSER=2 tries the other cast every few casts
+    whatever the times say, so that both kinds alternate on one volume's buffers: the last six pictures are the oracle's, bit for bit, and
+    both kinds did run.  (1: the default schedule -- whichever casts it takes, the same bits.)"""
+    import os
+    import subprocess
+    import sys
+    out = str(tmp_path / "chooser.npz")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, TSDF_RAY_CELLS="1", TSDF_RAY_CHOOSER=chooser)
+    e["PYTHONPATH"] = root + os.pathsep + e.get("PYTHONPATH", "")
+    subprocess.run([sys.executable, "-c", _CHOOSER_PROBE, out], check=True, env=e, cwd=root, timeout=600)
+    got = np.load(out)
+    kinds = got["kinds"].astype(bool)
+    if chooser == "2":
+        assert 5 <= int(kinds.sum()) <= 55, kinds        # both casts, many times each
+    ov = oracle.Volume((128, 128, 128), (3000, 3000, 3000))
+    ov.set_distance_data(got["D"])
+    for q in range(6):
+        _, cam = synth.depth_frame(q * 9, 200, seed=0x5EED0003)
+        Vo, No = ov.raycast(W, H, cam.pose(), cam.kinv(), nthreads=oracle.max_threads())
+        assert_same_floats(got["V%d" % q], Vo, "view %d: vertices" % q)
+        assert_same_floats(got["N%d" % q], No, "view %d: normals" % q)
+
+
 def test_an_uploaded_field_that_flags_every_brick_keeps_the_march(oracle):
     """The cell-parallel cast's work is the number of flagged bricks times their cells' pixels; the choice goes by the list the previous
     cast built.  After a bulk change of the distances that count says nothing: the flags are rebuilt and counted before the first cast
@@ -822,7 +875,7 @@ def test_the_ray_cast_and_fuzz_suites_again_with_the_cell_parallel_cast_forced()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     e = dict(os.environ, TSDF_RAY_CELLS="2")
     e["PYTHONPATH"] = root + os.pathsep + e.get("PYTHONPATH", "")
-    skip = "not again_with_the_cell and not schedule_knobs and not unusual_intrinsics and not not_rigid and not counted_again and not outside_beside_and_inside and not bilateral and not icp"
+    skip = "not again_with_the_cell and not cast_chooser and not schedule_knobs and not unusual_intrinsics and not not_rigid and not counted_again and not outside_beside_and_inside and not bilateral and not icp"
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_parity_raycast.py", "tests/test_fuzz_parity.py", "-m", "gpu", "-x", "-q", "-k", skip, "-p", "no:cacheprovider"],
                        env=e, cwd=root, capture_output=True, text=True, timeout=1500)
     tail = "\n".join(r.stdout.splitlines()[-15:])

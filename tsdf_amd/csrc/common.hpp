@@ -56,6 +56,8 @@ struct Tuning {
     int ray_cells_pairs;     // TSDF_RAY_CELLS_PAIRS    estimated (cell, pixel) pairs of a brick above which it is listed in several parts (1024; 0: never)
     int ray_cells_look;      // TSDF_RAY_CELLS_LOOK     1 (default): every flagged brick is projected when the list is built -- unseen ones dropped, large ones listed in parts; 0: never
     int ray_cells_grid;      // TSDF_RAY_CELLS_GRID     workgroups of cast_cells_kernel (2048: two or three bricks a wave at 20 000 listed bricks; see raycast_cells.hpp)
+    int ray_cells_sort;      // TSDF_RAY_CELLS_SORT     the cell-parallel cast's list front to back: 0 never, 1 for views from inside the volume, 2 always
+    int ray_chooser;         // TSDF_RAY_CHOOSER        1: with TSDF_RAY_CELLS=1 the cast is chosen from measured times (choose_cast); 0: by the static rules alone; 2: a trial of the other cast every few casts (test aid)
     int ray_entry_bound;     // TSDF_RAY_ENTRY_BOUND    0: no per-tile entry bound (default 1: rays start at the nearest flagged block their 16 x 16 tile can see)
     int icp_persistent;      // TSDF_ICP_PERSISTENT     default 0: one launch per ICP iteration (the chain); 1 / 2: all 19 in one launch with a grid barrier (slower, kept for study)
     int occ_rebuild_period;  // TSDF_OCC_REBUILD_PERIOD integrations between tightenings of the ray caster's flags (16; 0: never)
@@ -250,6 +252,21 @@ __host__ __device__ inline int f2i_sat(float f) {
 // ---- object state ------------------------------------------------------------------------
 }  // namespace tsdf
 
+namespace tsdf {
+// which cast a volume's casts take, from measured times (raycast.hip: choose_cast)
+struct CastChooser {
+    float ms[2];                  // whole cast, smoothed: [0] the march, [1] the cell-parallel cast
+    uint32_t seen[2];             // casts measured
+    uint64_t measured_at[2];      // ... the last one at this cast
+    uint64_t casts, next_trial;   // whole-volume casts so far; when the cast not taken is tried next
+    uint32_t gap;                 // casts between trials (64 ... 4096)
+    bool pending, pending_trial, pending_sorted, blocked, sampling, used[2];
+    int pending_kind, last_kind;
+    hipEvent_t ev[4];             // begin / end of the sampled cast's dominant launches: the cells' kernel or the march's bulk kernel, its tail kernel
+    float trial_origin[3], trial_axis[3];   // the view of the last trial (a trial lost by 3 x waits for another view)
+};
+}  // namespace tsdf
+
 struct tsdf_volume {
     tsdf::Geom g;
     uint32_t z_begin, z_end;  // owned planes
@@ -296,6 +313,7 @@ struct tsdf_volume {
     size_t cell_rays_cap;
     uint32_t *cell_bricks;
     uint32_t *cell_count_scratch;   // two words for count_cell_bricks_kernel (raycast.hip)
+    tsdf::CastChooser chooser;
     int cell_recount_wait;          // casts that kept the march because the list was over the limit, since the last recount
     size_t cell_bricks_cap;
     uint32_t *cell_cast_host;

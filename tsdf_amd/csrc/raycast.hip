@@ -530,7 +530,7 @@ struct TailQueue {
                            // same again for waves that took heavy_passes passes or more
     uint32_t heavy_passes;
 };
-constexpr uint32_t kTailSignals = 4;   // TailQueue::count: [0] entries appended, [1], [2] unused, [3] the cell-parallel cast's listed bricks
+constexpr uint32_t kTailSignals = 4 + 2 * 256;   // TailQueue::count: [0] entries appended, [1], [2] unused, [3] the cell-parallel cast's listed bricks, [4 ..) its list's depth bins: counts, places taken (raycast_cells.hpp)
 constexpr uint32_t kNoHit = 0xffffffffu;
 constexpr uint32_t kNoSlot = 0xffffffffu;   // TailQueue::order: a slot of the launch with nothing to do
 // the sample range the z-th slab of workgroups marches (rp.range_order: 0 near to far, 1 far to near, 2 last, first, then far to near)
@@ -1004,8 +1004,12 @@ static int count_after_bulk_change(tsdf_volume *v) {
     return TSDF_OK;
 }
 
-static bool choose_cell_cast(const tsdf_volume *v, const RayParams &rp, EntryParams &ep) {
+// (can: the view allows the cell-parallel cast at all -- a projection, sizes within the formats; returns whether the STATIC rules
+// prefer it: the choice where nothing has been measured, and the bound on what a trial may cost, choose_cast)
+static bool choose_cell_cast(const tsdf_volume *v, const RayParams &rp, EntryParams &ep, bool *can = nullptr, bool *trial_ok = nullptr) {
     const int mode = tuning().ray_cells;
+    if (can) *can = false;
+    if (trial_ok) *trial_ok = false;
     // (a list entry: 10 bits of each brick coordinate; a record of the cast: 13 bits of sample index;
     // ... and a brick's pairs are counted in 31 bits: 64 cells that each ask every pixel)
     if (mode == 0 || v->occ.fine_count() >= ((size_t)1 << 30) || v->occ.nbx > 1024u || v->occ.nby > 1024u || v->occ.nbz > 1024u ||
@@ -1051,6 +1055,7 @@ static bool choose_cell_cast(const tsdf_volume *v, const RayParams &rp, EntryPar
     // pixels a cell -- one wave's work for milliseconds without the parts.  (Its cost hides behind the ray records since the list's
     // workgroups start first: 11.0 -> 11.3 us; TSDF_RAY_CELLS_LOOK=0 switches it off for study.)
     ep.cell_pairs = tuning().ray_cells_look ? (uint32_t)tuning().ray_cells_pairs : 0u;
+    if (can) *can = true;
     if (mode == 2) return true;
     // What the cast costs is the number of (mixed cell, pixel) pairs: a voxel that covers several pixels makes every cell a dozen pairs
     // or more.  Measured over grid sizes on one scene (640x480, the camera 2 m from the centre of 3 m of volume; cast stage, march /
@@ -1060,6 +1065,13 @@ static bool choose_cell_cast(const tsdf_volume *v, const RayParams &rp, EntryPar
     // cell-parallel cast's list length (arbitrary fields: every brick flagged).  From inside the volume the view holds surface after
     // surface behind the first -- every mixed cell is looked at, hidden or not: 4.2 M pairs at 1024^3 against 2.0 M for the view from
     // outside, 0.29 ms against the march's 0.215 -- and the march kernels keep it (TSDF_RAY_CELLS=2 takes the cell-parallel cast there too).
+    const uint32_t listed_ = v->cell_cast_host ? *v->cell_cast_host : 0u;
+    // (a trial of the cast where these rules keep the march: its cost must be bounded -- the list within the limit, and from outside a
+    // voxel of at most 64 pixels at the nearest depth a sample can have; from inside the volume the list with its parts is the bound)
+    // (never from inside the volume: nothing bounds how close a surface is, and on the stream of BASELINE configs[3] single frames next to
+    // a wall took the cells 10 ms -- 0.278 ms a cast over the stream against the march's 0.207, profiles/r06_cells_front_to_back.txt)
+    if (trial_ok) *trial_ok = listed_ <= (uint32_t)tuning().ray_cells_limit && ep.z_clip > 0.0f &&
+                              vs_max * std::max(std::fabs(ep.k[0][0]), std::fabs(ep.k[1][1])) <= 64.0f * (2.0f * ep.z_clip);
     if (ep.z_clip == 0.0f) return false;
     if (!(footprint <= tuning().ray_cells_footprint)) return false;
     // ... and a camera that could have a surface right in front of it: a wall six voxels behind the face it looks through, the camera
@@ -1080,6 +1092,111 @@ static bool choose_cell_cast(const tsdf_volume *v, const RayParams &rp, EntryPar
     }
     return false;
 }
+
+// Which cast a volume's stream of casts takes, from MEASURED times (round 6; TSDF_RAY_CELLS=1, the default).  The static rules of
+// choose_cell_cast have cliffs on both sides -- a flat wall in front of the camera is 0.094 ms marched and 0.122 with the cells, the
+// bench's room 0.149 and 0.100; a view from inside a 1024^3 volume 0.197 and 0.175 now that the list is sorted front to back, a
+// close-up of a wall 0.08 and 2.0 -- and no rule on footprints tells these apart.  So: in one cast in sixteen the dominant launches
+// (the cells' kernel; the march's two) carry their dispatches' own begin / end timestamps (hipExtLaunchKernel: what set_timing uses;
+// 5 us a launch that carries them, 0.5 us a cast on average; read when a later cast finds them complete, nothing waits -- and what they
+// say does not depend on how fast the host enqueues), the cast not taken is tried once every `gap` casts where the static rules bound
+// what the trial can cost, and the faster of the two runs.  A trial that loses doubles the gap (64 ... 4096 casts), one that loses by 3 x is not repeated before the camera has moved
+// a tenth of the volume or turned by 10 degrees.  Scheduling only: both casts give the same bits (tests/test_parity_raycast.py).
+static void chooser_poll(tsdf_volume *v) {
+    CastChooser &c = v->chooser;
+    if (!c.pending || hipEventQuery(c.ev[c.used[1] ? 3 : 1]) != hipSuccess) { (void)hipGetLastError(); return; }
+    float ms = 0.0f, ms_tail = 0.0f;
+    if (hipEventElapsedTime(&ms, c.ev[0], c.ev[1]) == hipSuccess && ms > 0.0f &&
+        (!c.used[1] || hipEventElapsedTime(&ms_tail, c.ev[2], c.ev[3]) == hipSuccess)) {
+        const int k = c.pending_kind;
+        // (+ the small launches around them, as profiled: the list + ray records 12 us, its sort 6, resolve 7; the reach summary 5, resolve 7)
+        ms += ms_tail + (k == 1 ? (c.pending_sorted ? 0.025f : 0.019f) : 0.012f);
+        if (tuning().debug_rays) fprintf(stderr, "tsdf: chooser: cast %llu measured %s %.4f ms%s (march %.4f, cells %.4f so far)\n", (unsigned long long)c.casts, k ? "cells" : "march", ms, c.pending_trial ? " [trial]" : "", c.ms[0], c.ms[1]);
+        // (the first casts of a kind run cold -- flags just rebuilt, nothing in the caches: 0.34 ms for a cast that takes 0.10 -- so the
+        // smaller of the first three counts, the mean of old and new after that)
+        c.ms[k] = c.seen[k] == 0 ? ms : (c.seen[k] < 3 ? std::min(c.ms[k], ms) : 0.5f * (c.ms[k] + ms));
+        c.seen[k]++;
+        c.measured_at[k] = c.casts;
+        if (c.pending_trial) {
+            const int other = 1 - k;
+            const bool lost = c.seen[other] && ms > 1.05f * c.ms[other];
+            c.gap = tuning().ray_chooser == 2 ? 3u : (lost ? std::min(c.gap * 2u, 4096u) : 64u);
+            c.blocked = lost && ms > 3.0f * c.ms[other] && tuning().ray_chooser != 2;   // (until the view has changed: chooser_view_moved)
+            c.next_trial = c.casts + c.gap;
+        }
+    } else {
+        (void)hipGetLastError();
+    }
+    c.pending = false;
+}
+static bool chooser_view_moved(const tsdf_volume *v, const RayParams &rp) {
+    const CastChooser &c = v->chooser;
+    const float dx = rp.origin.x - c.trial_origin[0], dy = rp.origin.y - c.trial_origin[1], dz = rp.origin.z - c.trial_origin[2];
+    const float reach = 0.1f * std::max(v->g.phys.x, std::max(v->g.phys.y, v->g.phys.z));
+    const float dot = rp.rot.m13 * c.trial_axis[0] + rp.rot.m23 * c.trial_axis[1] + rp.rot.m33 * c.trial_axis[2];
+    const float n2 = rp.rot.m13 * rp.rot.m13 + rp.rot.m23 * rp.rot.m23 + rp.rot.m33 * rp.rot.m33;
+    const float m2 = c.trial_axis[0] * c.trial_axis[0] + c.trial_axis[1] * c.trial_axis[1] + c.trial_axis[2] * c.trial_axis[2];
+    return !(dx * dx + dy * dy + dz * dz <= reach * reach) || !(dot >= 0.985f * std::sqrt(n2 * m2));
+}
+// -> true: the cell-parallel cast (ep filled); *sample: bracket this cast with the chooser's events
+static bool choose_cast(tsdf_volume *v, const RayParams &rp, EntryParams &ep, bool *sample) {
+    *sample = false;
+    bool can = false, trial_ok = false;
+    const bool by_rules = choose_cell_cast(v, rp, ep, &can, &trial_ok);
+    if (tuning().ray_cells != 1 || !tuning().ray_chooser) return by_rules;
+    CastChooser &c = v->chooser;
+    if (c.gap == 0u) {   // (a new volume, or one that was cleared: the first trial after 32 casts)
+        c.gap = 64u;
+        c.next_trial = c.casts + (tuning().ray_chooser == 2 ? 3u : 32u);   // (2: a test aid -- a trial every few casts, whatever the times say)
+    }
+    chooser_poll(v);
+    c.casts++;
+    if (!can) return false;
+    int kind = by_rules ? 1 : 0;
+    // both measured, and not long ago: the faster one (5 % of hysteresis towards the one that ran last)
+    const bool fresh[2] = {c.seen[0] && c.casts - c.measured_at[0] <= 8192u, c.seen[1] && c.casts - c.measured_at[1] <= 8192u};
+    if (fresh[0] && fresh[1]) {
+        const float bias0 = c.last_kind == 0 ? 0.95f : 1.0f, bias1 = c.last_kind == 1 ? 0.95f : 1.0f;
+        kind = c.ms[1] * bias1 <= c.ms[0] * bias0 ? 1 : 0;
+    }
+    bool trial = false;
+    if (!c.pending && c.casts >= c.next_trial && (!c.blocked || chooser_view_moved(v, rp))) {
+        const int other = 1 - kind;
+        // A trial is a slow step when it loses (the march on the bench scene: + 0.06 ms), so none is made that cannot win: the cast that
+        // runs is measured anyway, and the other one's best case is known -- the march 0.089 ms for 640 x 480 rays on a wall in front of
+        // the camera, the cells 0.094 on the bench's room (per pixel; profiles/r06_cast_chooser.txt) -- a cast already within 15 % of
+        // that stays.
+        const float mpix = (float)rp.width * (float)rp.height * 1.0e-6f, best_other = (other == 0 ? 0.29f : 0.305f) * mpix;
+        const bool could_win = !c.seen[kind] || c.ms[kind] > 1.15f * best_other || tuning().ray_chooser == 2;
+        if (!could_win) {
+            c.next_trial = c.casts + c.gap;
+        } else if (other == 0 || trial_ok) {   // (the march is always affordable; the cells where the static bound says so)
+            kind = other;
+            trial = true;
+            c.blocked = false;
+            c.trial_origin[0] = rp.origin.x; c.trial_origin[1] = rp.origin.y; c.trial_origin[2] = rp.origin.z;
+            c.trial_axis[0] = rp.rot.m13; c.trial_axis[1] = rp.rot.m23; c.trial_axis[2] = rp.rot.m33;
+        } else {
+            c.next_trial = c.casts + c.gap;
+        }
+    }
+    if (kind == 1 && (v->cell_cast_host ? *v->cell_cast_host : 0u) > (uint32_t)tuning().ray_cells_limit) kind = 0;   // (never past the list's limit)
+    if (!c.pending && c.casts > 1u && (trial || c.seen[kind] < 3u || (c.casts & 15u) == 0u)) {
+        if (!c.ev[0]) {
+            for (int i = 0; i < 4; i++)
+                if (hipEventCreate(&c.ev[i]) != hipSuccess) { (void)hipGetLastError(); c.ev[0] = nullptr; break; }
+        }
+        if (c.ev[0]) {
+            *sample = true;
+            c.pending_kind = kind;
+            c.pending_trial = trial;
+        }
+    }
+    c.last_kind = kind;
+    return kind == 1;
+}
+// a whole-volume cast of the kind chosen, bracketed for the chooser when it asks
+static int cast_whole(tsdf_volume *v, RayParams &rp, float *out, float *normals, const float *depth_inv_pose, uint16_t *depth_out);
 
 // The production march: process_ray_kernel over the sample ranges of every ray with a pass budget, process_ray_tail_kernel
 // for the stretches it handed over, resolve_hits_kernel for the vertices (packed float3, or {k, t} records for a slab).
@@ -1114,7 +1231,7 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
             if (v->cell_bricks) (void)hipFree(v->cell_bricks);
             v->cell_bricks = nullptr;
             v->cell_bricks_cap = 0;
-            TSDF_HIP(hipMalloc((void **)&v->cell_bricks, n_bricks_max * sizeof(uint2)), "brick list alloc");
+            TSDF_HIP(hipMalloc((void **)&v->cell_bricks, 2 * n_bricks_max * sizeof(uint2)), "brick list alloc");   // (the list, and the list as built when it is sorted)
             v->cell_bricks_cap = n_bricks_max;
         }
         if (!v->cell_cast_host) {
@@ -1173,13 +1290,53 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
     v->last_cast_cells = cells ? 1 : 0;
     if (cells) {
         // ---- the cell-parallel cast (raycast_cells.hpp): the rays' records, the flagged bricks, one wave per brick ----
-        CellCast cc = {reinterpret_cast<RayRecord *>(v->cell_rays), reinterpret_cast<uint2 *>(v->cell_bricks), v->tail_count + 3, v->cell_cast_host, cells->cell_pairs, v->dist, tail.best, v->release_word, v->release_value};
+        // the list front to back when the camera is inside (or within a few voxels of) the volume: TSDF_RAY_CELLS_SORT 0 never / 1 then (default) / 2 always
+        const bool sort_list = tuning().ray_cells_sort == 2 || (tuning().ray_cells_sort == 1 && cells->z_clip == 0.0f);
+        float depth0 = 0.0f, depth_scale = 0.0f;
+        if (sort_list) {   // the depths of the volume's corners: the bins' range
+            float dmin = INFINITY, dmax = -INFINITY;
+            for (int c = 0; c < 8; c++) {
+                const float wx = v->g.offset.x + ((c & 1) ? v->g.phys.x : 0.0f), wy = v->g.offset.y + ((c & 2) ? v->g.phys.y : 0.0f), wz = v->g.offset.z + ((c & 4) ? v->g.phys.z : 0.0f);
+                const float d = cells->r[2][0] * wx + cells->r[2][1] * wy + cells->r[2][2] * wz + cells->r[2][3];
+                dmin = std::min(dmin, d); dmax = std::max(dmax, d);
+            }
+            dmin = std::max(dmin, 0.0f);   // (nothing behind the camera is seen: one bin for all of it)
+            depth0 = dmin;
+            depth_scale = dmax > dmin ? (float)kDepthBins / (dmax - dmin) : 0.0f;
+            if (!std::isfinite(depth0) || !std::isfinite(depth_scale)) { depth0 = 0.0f; depth_scale = 0.0f; }
+        }
+        CellCast cc = {reinterpret_cast<RayRecord *>(v->cell_rays), reinterpret_cast<uint2 *>(v->cell_bricks), v->tail_count + 3, v->cell_cast_host, cells->cell_pairs,
+                       sort_list ? v->tail_count + 4 : nullptr, reinterpret_cast<uint2 *>(v->cell_bricks) + v->cell_bricks_cap, depth0, depth_scale,
+                       v->dist, tail.best, v->release_word, v->release_value};
         v->release_word = nullptr;   // (taken)
         const size_t table_lds = ((size_t)kMaxSamples + 1) * sizeof(float);
         const uint32_t n_ray_blocks = (uint32_t)((n_pix + 255) / 256);
         const uint32_t n_list_blocks = (uint32_t)std::min<size_t>((v->occ.fine_count() / 4 + 255) / 256 + 1, 2048);
         hipLaunchKernelGGL((cell_cast_prepare_kernel<SLAB>), dim3(n_ray_blocks + n_list_blocks), dim3(256), (uint32_t)table_lds, v->stream, v->g, rp, *cells, v->t_table,
                            v->occ, cc, n_list_blocks);
+        if (sort_list) {
+            hipLaunchKernelGGL(cell_list_sort_kernel, dim3(128), dim3(1024), 0, v->stream, v->g, *cells, cc);
+        }
+        if (getenv("TSDF_DEBUG_CELLS_SORT")) {
+            // (diagnostics, synchronises: the list put in front-to-back order on the HOST -- by the camera depth of each brick's centre --
+            // before the cast: what that order buys the views from inside the volume, where every surface behind the first is looked at;
+            // =2: back to front.  profiles/r06_cells_front_to_back.txt)
+            TSDF_HIP(hipStreamSynchronize(v->stream), "cells sort");
+            uint32_t n_listed = 0;
+            TSDF_HIP(hipMemcpy(&n_listed, cc.n_bricks, sizeof(n_listed), hipMemcpyDeviceToHost), "cells sort");
+            std::vector<uint2> list(n_listed);
+            TSDF_HIP(hipMemcpy(list.data(), cc.bricks, n_listed * sizeof(uint2), hipMemcpyDeviceToHost), "cells sort");
+            const bool back_first = atoi(getenv("TSDF_DEBUG_CELLS_SORT")) == 2;
+            auto depth_of = [&](const uint2 &e_) {
+                const float mid = 0.5f * ((float)kBrick + 1.5f);
+                const float wx = ((float)((e_.y & 1023u) * kBrick) + mid) * v->g.vs.x + cells->offset.x, wy = ((float)(((e_.y >> 10) & 1023u) * kBrick) + mid) * v->g.vs.y + cells->offset.y,
+                            wz = ((float)((e_.y >> 20) * kBrick) + mid) * v->g.vs.z + cells->offset.z;
+                const float d = cells->r[2][0] * wx + cells->r[2][1] * wy + cells->r[2][2] * wz + cells->r[2][3];
+                return back_first ? -d : d;
+            };
+            std::stable_sort(list.begin(), list.end(), [&](const uint2 &a_, const uint2 &b_) { return depth_of(a_) < depth_of(b_); });
+            TSDF_HIP(hipMemcpy(cc.bricks, list.data(), n_listed * sizeof(uint2), hipMemcpyHostToDevice), "cells sort");
+        }
         const dim3 cgrid((unsigned)tuning().ray_cells_grid + kShellWorkgroups);   // (the first kShellWorkgroups: the boundary bricks' shell samples)
         if (v->fast_div)
             TSDF_LAUNCH_TIMED(v, 1, (cast_cells_kernel<SLAB, true>), cgrid, dim3(256), v->dist, v->g, rp, *cells, v->occ, v->t_table, cc, tail.best);
@@ -1247,6 +1404,24 @@ static int march_and_resolve(tsdf_volume *v, RayParams &rp, float *out, float *n
     return TSDF_OK;
 }
 
+static int cast_whole(tsdf_volume *v, RayParams &rp, float *out, float *normals, const float *depth_inv_pose, uint16_t *depth_out) {
+    int rc = count_after_bulk_change(v);
+    if (rc != TSDF_OK) return rc;
+    EntryParams view;
+    bool sample = false;
+    const bool cells = choose_cast(v, rp, view, &sample);
+    if (cells) rc = occupancy_flags_refresh(v); else rc = refresh_for_cast(v, rp);
+    if (rc != TSDF_OK) return rc;
+    CastChooser &c = v->chooser;
+    c.sampling = sample;   // (timing_pair hands the dominant launches the chooser's events)
+    c.used[0] = c.used[1] = false;
+    c.pending_sorted = cells && view.z_clip == 0.0f && tuning().ray_cells_sort != 0;
+    rc = cells ? march_and_resolve<false>(v, rp, out, normals, depth_inv_pose, depth_out, &view) : march_and_resolve<false>(v, rp, out, normals, depth_inv_pose, depth_out);
+    c.sampling = false;
+    if (sample && rc == TSDF_OK && c.used[0]) c.pending = true;
+    return rc;
+}
+
 // Would tsdf_raycast_device take the cell-parallel cast for this view now?  (tsdf_pipeline_step: how to release its second stream.)
 bool raycast_takes_cells(const tsdf_volume *v, uint32_t width, uint32_t height, const float pose[16], const float kinv[9]) {
     if (!v || v->z_begin != 0 || v->z_end != v->g.Z || check_ray_args(v, width, height, pose, kinv) != TSDF_OK) return false;
@@ -1280,17 +1455,7 @@ int tsdf_raycast_device(const tsdf_volume *v, uint32_t width, uint32_t height, c
     TSDF_REQUIRE(device_vertices, "tsdf_raycast: null vertex buffer");
     TSDF_REQUIRE(v->z_begin == 0 && v->z_end == v->g.Z, "tsdf_raycast on a slab: use tsdf_raycast_slab_device");
     RayParams rp = make_params(v, width, height, pose, kinv);
-    EntryParams view;
-    rc = count_after_bulk_change(const_cast<tsdf_volume *>(v));
-    if (rc != TSDF_OK) return rc;
-    if (choose_cell_cast(v, rp, view)) {
-        rc = occupancy_flags_refresh(const_cast<tsdf_volume *>(v));
-        if (rc != TSDF_OK) return rc;
-        return march_and_resolve<false>(const_cast<tsdf_volume *>(v), rp, device_vertices, device_normals, nullptr, nullptr, &view);
-    }
-    rc = refresh_for_cast(const_cast<tsdf_volume *>(v), rp);
-    if (rc != TSDF_OK) return rc;
-    return march_and_resolve<false>(const_cast<tsdf_volume *>(v), rp, device_vertices, device_normals);
+    return cast_whole(const_cast<tsdf_volume *>(v), rp, device_vertices, device_normals, nullptr, nullptr);
 }
 
 int tsdf_raycast(const tsdf_volume *cv, uint32_t width, uint32_t height, const float pose[16], const float kinv[9],
@@ -1338,17 +1503,7 @@ int tsdf_raycast_depth_device(const tsdf_volume *v, uint32_t width, uint32_t hei
     TSDF_REQUIRE(device_depth && inv_pose, "tsdf_raycast_depth: null argument");
     TSDF_REQUIRE(v->z_begin == 0 && v->z_end == v->g.Z, "tsdf_raycast_depth needs a whole volume");
     RayParams rp = make_params(v, width, height, pose, kinv);
-    EntryParams view;
-    rc = count_after_bulk_change(const_cast<tsdf_volume *>(v));
-    if (rc != TSDF_OK) return rc;
-    if (choose_cell_cast(v, rp, view)) {
-        rc = occupancy_flags_refresh(const_cast<tsdf_volume *>(v));
-        if (rc != TSDF_OK) return rc;
-        return march_and_resolve<false>(const_cast<tsdf_volume *>(v), rp, device_vertices, nullptr, inv_pose, device_depth, &view);
-    }
-    rc = refresh_for_cast(const_cast<tsdf_volume *>(v), rp);
-    if (rc != TSDF_OK) return rc;
-    return march_and_resolve<false>(const_cast<tsdf_volume *>(v), rp, device_vertices, nullptr, inv_pose, device_depth);
+    return cast_whole(const_cast<tsdf_volume *>(v), rp, device_vertices, nullptr, inv_pose, device_depth);
 }
 
 int tsdf_normals_device(uint32_t width, uint32_t height, const float *device_vertices, float *device_normals,

@@ -43,12 +43,28 @@ struct CellCast {
     uint32_t *n_bricks;     // entries appended: TailQueue::count[3], reset by the resolve kernel of the previous cast
     uint32_t *n_bricks_host;  // pinned mirror of the count (the next cast's choice of kernels), may be null
     uint32_t pairs_per_task;  // a brick whose (cell, pixel) pairs are estimated above this is listed in several parts (TSDF_RAY_CELLS_PAIRS)
+    // front-to-back order of the list (views from inside the volume, round 6): depth_hist != null -- kDepthBins counters the list's builder
+    // fills, kDepthBins more that cell_list_sort_kernel takes its places from -- and the list as it is built (`unsorted`), which that
+    // kernel scatters into `bricks` by the bin of each brick's camera depth, (depth - depth0) * depth_scale
+    uint32_t *depth_hist;
+    uint2 *unsorted;
+    float depth0, depth_scale;
     const float *dist;        // the distances and the pixels' words: for the rays whose samples leave the grid (cell_cast_prepare_kernel)
     uint64_t *best;
     uint32_t *release_word;   // null, or where cell_cast_prepare_kernel stores release_value as it starts: everything in front of it on the
     uint32_t release_value;   // stream (this frame's integrate) is done -- the pipeline's second stream waits for that word, not for an event
 };
 constexpr uint32_t kCellTasks = 1u << 31, kShellTasks = 1u << 30;
+constexpr uint32_t kDepthBins = 256;
+// the bin of a listed brick: by the camera depth of its centre (the same expression where the list is built and where it is sorted)
+__device__ inline uint32_t depth_bin(const CellCast &cc, const EntryParams &ep, const Geom &g, uint32_t coords) {
+    const float mid = 0.5f * ((float)kBrick + 1.5f);
+    const float wx = ((float)((coords & 1023u) * kBrick) + mid) * g.vs.x + ep.offset.x, wy = ((float)(((coords >> 10) & 1023u) * kBrick) + mid) * g.vs.y + ep.offset.y,
+                wz = ((float)((coords >> 20) * kBrick) + mid) * g.vs.z + ep.offset.z;
+    const float d = ep.r[2][0] * wx + ep.r[2][1] * wy + ep.r[2][2] * wz + ep.r[2][3];
+    const float b = (d - cc.depth0) * cc.depth_scale;
+    return b > 0.0f ? (b < (float)(kDepthBins - 1u) ? (uint32_t)b : kDepthBins - 1u) : 0u;   // (anything not a number: the first bin)
+}
 // A brick seen from close by -- a camera inside the volume, a coarse grid -- is thousands of pairs, one wave's work for a long time while
 // the chip idles: it is listed in up to kMaxParts parts, each a wave's task (the wave loads the brick, finds its cells and boxes as
 // ever, and takes its share of the packed pairs).  The list has room for kPartsRoom extra entries per 1 024 bricks scanned (a workgroup's turn); a
@@ -199,6 +215,12 @@ __global__ __launch_bounds__(256) void cell_cast_prepare_kernel(const Geom g, co
         return;
     }
     uint32_t *wave_count = reinterpret_cast<uint32_t *>(Ts);   // [0..3] the waves' entries, [4] the workgroup's base in the list, [8..11] the waves' extra parts
+    uint32_t *bin_count = wave_count + 16;                     // [0 .. kDepthBins): this workgroup's entries per depth bin (cc.depth_hist != null)
+    uint2 *const list_out = cc.depth_hist ? cc.unsorted : cc.bricks;
+    if (cc.depth_hist) {
+        for (uint32_t i = threadIdx.x; i < kDepthBins; i += 256) bin_count[i] = 0u;
+        __syncthreads();
+    }
     const uint32_t n = (uint32_t)occ.fine_count(), n_words = (n + 3u) / 4u, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t *fine4 = reinterpret_cast<const uint32_t *>(occ.fine), *cell4 = reinterpret_cast<const uint32_t *>(occ.cell);
     const bool look = cc.pairs_per_task != 0u;   // (uniform) project the bricks: drop the ones no pixel sees, list the large ones in parts
@@ -313,10 +335,59 @@ __global__ __launch_bounds__(256) void cell_cast_prepare_kernel(const Geom g, co
         uint32_t at = wave_count[4] + incl - mine_n;
         for (uint32_t q = 0; q < wave; q++) at += wave_count[q];
 #pragma unroll
-        for (uint32_t j = 0; j < 4u; j++)
+        for (uint32_t j = 0; j < 4u; j++) {
             for (uint32_t part = 0; part < parts[j]; part++)
-                cc.bricks[at++] = make_uint2(entry[j] | (part << 10) | (parts[j] - 1u), coords[j]);
+                list_out[at++] = make_uint2(entry[j] | (part << 10) | (parts[j] - 1u), coords[j]);
+            if (cc.depth_hist && parts[j]) atomicAdd(&bin_count[depth_bin(cc, ep, g, coords[j])], parts[j]);
+        }
         __syncthreads();   // (wave_count is written again in the next turn)
+    }
+    if (cc.depth_hist) {   // (uniform) this workgroup's counts into the launch's
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < kDepthBins; i += 256)
+            if (bin_count[i]) atomicAdd(&cc.depth_hist[i], bin_count[i]);
+    }
+}
+
+// The list in front-to-back order (round 6; views from inside the volume, where surface lies behind surface: every listed cell is
+// looked at, hidden or not, unless its pixels' words already hold a nearer hit -- the waves take the list from its first entry on,
+// so with the near bricks first the `known <= k` test of a pair ends most hidden ones before their samples are walked: 0.173 -> 0.133 ms
+// for the cast's kernel from inside a 1024^3 volume, what the same launch costs with every word final (profiles/r06_cells_front_to_back.txt);
+// from outside the order buys nothing and the list is taken as built).  A counting sort by the bin of each brick's camera depth: the
+// counts per bin come with the list (cell_cast_prepare_kernel), a workgroup here takes 1 024 entries, ranks them within the bins in
+// LDS, takes its places in each bin with one atomic per bin it holds, and scatters.  Within a bin the order is whatever it comes to.
+__global__ __launch_bounds__(1024) void cell_list_sort_kernel(const Geom g, const EntryParams ep, const CellCast cc) {
+    __shared__ uint32_t start[kDepthBins], mine[kDepthBins], base[kDepthBins];
+    const uint32_t n = *cc.n_bricks, t = threadIdx.x;
+    if (t < kDepthBins) start[t] = cc.depth_hist[t];
+    __syncthreads();
+    if (t < 64u) {   // exclusive prefix over the 256 bins, one wave: four bins a lane
+        const uint32_t a0 = start[4u * t], a1 = start[4u * t + 1u], a2 = start[4u * t + 2u], a3 = start[4u * t + 3u];
+        uint32_t incl = (a0 + a1) + (a2 + a3);
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o);
+            if ((int)t >= o) incl += up;
+        }
+        const uint32_t ex = incl - ((a0 + a1) + (a2 + a3));
+        start[4u * t] = ex; start[4u * t + 1u] = ex + a0; start[4u * t + 2u] = ex + a0 + a1; start[4u * t + 3u] = ex + a0 + a1 + a2;
+    }
+    uint32_t *fill = cc.depth_hist + kDepthBins;
+    for (uint32_t c0 = blockIdx.x * 1024u; c0 < n; c0 += gridDim.x * 1024u) {   // (uniform)
+        __syncthreads();
+        if (t < kDepthBins) mine[t] = 0u;
+        __syncthreads();
+        const uint32_t i = c0 + t;
+        uint2 e = make_uint2(0u, 0u);
+        uint32_t bin = 0, rank = 0;
+        if (i < n) {
+            e = cc.unsorted[i];
+            bin = depth_bin(cc, ep, g, e.y);
+            rank = atomicAdd(&mine[bin], 1u);
+        }
+        __syncthreads();
+        if (t < kDepthBins && mine[t]) base[t] = atomicAdd(&fill[t], mine[t]);
+        __syncthreads();
+        if (i < n) cc.bricks[start[bin] + base[bin] + rank] = e;
     }
 }
 
