@@ -309,6 +309,10 @@ int tsdf_slab_exchange_create(int rank, int world, const uint8_t id[TSDF_EXCHANG
 typedef int (*tsdf_exchange_fn)(void *user, const tsdf_hit_record *device_mine, tsdf_hit_record *device_all, uint32_t n_pixels,
                                 void *hip_stream);
 int tsdf_slab_exchange_create_callback(int rank, int world, tsdf_exchange_fn all_gather, void *user, tsdf_slab_exchange **out);
+/* A stand-in for the collective on a box with one GPU (emulation and tests; no reference counterpart): "rank `rank` of `world`" whose
+ * all-gather copies this rank's own records into every rank's place, device to device on the caller's stream -- the launches, the
+ * bytes landing in this GPU's memory and the merge over `world` record buffers cost what they cost on a node; the wire does not run. */
+int tsdf_slab_exchange_create_loopback(int rank, int world, tsdf_slab_exchange **out);
 int tsdf_slab_exchange_world(const tsdf_slab_exchange *exchange, int *rank, int *world);
 /* How many ranks the communicator itself reports (ncclCommCount; the world handed in at creation for a caller's own collective):
  * what a driver prints beside its timings, so that nobody takes a run of one rank for a scaling point. */

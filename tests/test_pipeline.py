@@ -296,3 +296,40 @@ def test_the_schedule_knobs_of_the_pipeline_change_no_bit():
         assert out.returncode == 0, (name, out.stderr[-2000:])
         seen[name] = out.stdout.split()[-1]
     assert len(set(seen.values())) == 1, seen
+
+
+def test_one_rank_of_a_world_through_the_loopback_exchange(oracle):
+    """tsdf_slab_exchange_create_loopback: "rank r of P" on one GPU (the all-gather copies the rank's own records into every rank's
+    place): what tools/dbg_slab_pipeline.py times.  With a world of one and the whole grid as the slab the merged picture IS the
+    volume's picture: the sharded step (slab cast, exchange, min-k merge + normals) against the oracle, bit for bit; and a rank of a
+    world of four merges four copies of its own records into the picture of its slab alone -- the same min-k picture as one copy."""
+    import torch
+    from tsdf_amd.multi import LoopbackExchange
+    from tsdf_amd.pipeline import FusionPipeline
+    n = 96
+    frames = [synth.depth_frame(i, 8, seed=0x5EED0002) for i in range(4)]
+    depth = torch.from_numpy(np.stack([d for d, _ in frames]).view(np.int16)).cuda()
+    vert = torch.empty((H * W, 3), dtype=torch.float32, device="cuda"); norm = torch.empty_like(vert)
+    pictures = {}
+    for world, slab in ((1, None), (4, (24, 48)), (1, (24, 48))):
+        vol = tsdf_amd.TSDFVolume((n, n, n), (3000.0,) * 3, slab=slab if slab else (0, n))
+        ex = LoopbackExchange(0 if world == 1 else 1, world)
+        pipe = FusionPipeline(vol, tsdf_amd.BilateralFilter(30.0, 4.5), tsdf_amd.GPURaycaster(W, H), W, H, overlap=True, exchange=ex, exchange_stream=(world == 4))
+        for i, (_, cam) in enumerate(frames):
+            nxt = i + 1 if i + 1 < len(frames) else None
+            pipe.step(depth[i].data_ptr(), cam, vert.data_ptr(), norm.data_ptr(), depth[nxt].data_ptr() if nxt is not None else None, frames[nxt][1] if nxt is not None else None)
+        pipe.synchronize()
+        torch.cuda.synchronize()
+        pictures[(world, slab)] = (vert.cpu().numpy().copy(), norm.cpu().numpy().copy())
+        assert ex.ranks_seen() == world
+        pipe.close(); ex.close(); vol.close()
+    ov = oracle.Volume((n, n, n), (3000.0,) * 3)
+    bil = tsdf_amd.BilateralFilter(30.0, 4.5)
+    for d, cam in frames:
+        f = d.copy(); bil.filter(f, W, H)
+        ov.integrate(f, W, H, cam.inverse_pose(), cam.k(), cam.kinv(), nthreads=oracle.max_threads())
+    Vo, No = ov.raycast(W, H, frames[-1][1].pose(), frames[-1][1].kinv(), nthreads=oracle.max_threads())
+    assert_same_floats(pictures[(1, None)][0], Vo, "world of one: vertices")
+    assert_same_floats(pictures[(1, None)][1], No, "world of one: normals")
+    assert_same_floats(pictures[(4, (24, 48))][0], pictures[(1, (24, 48))][0], "four copies of one slab's records merge like one")
+    assert_same_floats(pictures[(4, (24, 48))][1], pictures[(1, (24, 48))][1], "... and so do the normals")

@@ -119,6 +119,7 @@ _SIGS = {
     "tsdf_slab_exchange_unique_id": (_i, [_vp, C.c_char_p]),
     "tsdf_slab_exchange_create": (_i, [_i, _i, _vp, C.c_char_p, C.POINTER(_vp)]),
     "tsdf_slab_exchange_create_callback": (_i, [_i, _i, EXCHANGE_FN, _vp, C.POINTER(_vp)]),
+    "tsdf_slab_exchange_create_loopback": (_i, [_i, _i, C.POINTER(_vp)]),
     "tsdf_slab_exchange_world": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "tsdf_slab_exchange_ranks_seen": (_i, [_vp, C.POINTER(_i)]),
     "tsdf_slab_validate_merge": (_i, [_vp, _vp, _u32, _u32, _fp, _fp, _vp, _vp, C.POINTER(C.c_uint64)]),

@@ -218,6 +218,21 @@ int tsdf_slab_exchange_create_callback(int rank, int world, tsdf_exchange_fn all
     return TSDF_OK;
 }
 
+static int loopback_all_gather(void *user, const tsdf_hit_record *device_mine, tsdf_hit_record *device_all, uint32_t n_pixels, void *hip_stream) {
+    const tsdf_slab_exchange *x = static_cast<const tsdf_slab_exchange *>(user);
+    for (int r = 0; r < x->world; r++)
+        if (hipMemcpyAsync(device_all + (size_t)r * n_pixels, device_mine, (size_t)n_pixels * sizeof(tsdf_hit_record), hipMemcpyDeviceToDevice,
+                           (hipStream_t)hip_stream) != hipSuccess)
+            return TSDF_ERR_DEVICE;
+    return TSDF_OK;
+}
+
+int tsdf_slab_exchange_create_loopback(int rank, int world, tsdf_slab_exchange **out) {
+    const int rc = tsdf_slab_exchange_create_callback(rank, world, loopback_all_gather, nullptr, out);
+    if (rc == TSDF_OK) (*out)->user = *out;
+    return rc;
+}
+
 int tsdf_slab_exchange_world(const tsdf_slab_exchange *x, int *rank, int *world) {
     TSDF_REQUIRE(x, "null exchange");
     if (rank) *rank = x->rank;

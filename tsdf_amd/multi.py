@@ -282,4 +282,19 @@ class SlabExchange:
             self._h = self._C.c_void_p()
 
 
+class LoopbackExchange(SlabExchange):
+    """"Rank `rank` of `world`" on a box with one GPU (tsdf_slab_exchange_create_loopback): the all-gather copies this rank's own records
+    into every rank's place on the caller's stream.  For emulating one rank's step of a P-GPU run (tools/dbg_slab_pipeline.py) and for
+    tests; the merged picture holds this slab's hits only."""
+
+    def __init__(self, rank, world):
+        import ctypes as C
+        from ._capi import check, lib
+        self._C, self._lib, self._check = C, lib, check
+        self.world, self.rank = int(world), int(rank)
+        self._h = C.c_void_p()
+        self._cb = None
+        check(lib.tsdf_slab_exchange_create_loopback(self.rank, self.world, C.byref(self._h)))
+
+
 StreamAllGather = SlabExchange      # (round-2 name)
