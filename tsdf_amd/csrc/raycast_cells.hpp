@@ -392,8 +392,13 @@ __global__ __launch_bounds__(1024) void cell_list_sort_kernel(const Geom g, cons
 }
 
 // Samples of the ray (s, d) whose positions can lie in the box [lo, hi] (grid millimetres): [k_lo, k_hi], clipped to [k_first, k_end).
-// Approximate on purpose -- the caller tests every candidate's own position -- and generous by two samples either side (T[k] is k * step
-// up to the rounding of its k additions, under a sample over the whole table).
+// Approximate on purpose -- the caller tests every candidate's own position -- and generous by kIntervalSlack of a sample either side.
+// (Round 5 took a whole sample either side + the floor / ceil: two or three candidates outside the cell per pair, and a round of 64
+// pairs walks as long as its longest lane -- 3.0 M candidate samples for 1.3 M inside.  What the slack has to cover: T[k] = k step +
+// drift(k), the drift -- the rounding of k fp32 additions, under a sample over the whole table -- read at the entry and changing by at most
+// half an ulp of T, 2e-4 of a sample, per sample from there; the parameters from hardware reciprocals, a few ulps of up to 4 402 samples:
+// 2e-3; the box itself is the cell grown by eps.  An eighth of a sample is that fifty times over.)
+constexpr float kIntervalSlack = 0.125f;
 __device__ inline bool sample_interval(const RayState &r, float lox, float loy, float loz, float hix, float hiy, float hiz, float inv_step, float step,
                                        const float *T, int k_first, int k_end, int &k_lo, int &k_hi) {
     float tin = 0.0f, tout = INFINITY;
@@ -414,10 +419,10 @@ __device__ inline bool sample_interval(const RayState &r, float lox, float loy, 
     // (relative slack on the parameters: the reciprocal and the products are good to a few ulps, the table to a sample -- covered below)
     if (miss || !(tin <= tout * 1.00001f + 1.0e-3f)) return false;
     // T[k] = k * step + drift(k), the drift -- the rounding of k additions -- under a sample over the whole table and all but constant
-    // over a cell's few samples: read where the ray enters, then one sample of room either side
+    // over a cell's few samples: read where the ray enters
     const float kc = fminf(fmaxf(rintf(tin * inv_step), 0.0f), (float)kMaxSamples);
     const float drift = T[(int)kc] - kc * step;
-    const float a = floorf((tin - drift) * inv_step) - 1.0f, b = ceilf((tout - drift) * inv_step) + 1.0f;
+    const float a = ceilf((tin - drift) * inv_step - kIntervalSlack), b = floorf((tout - drift) * inv_step + kIntervalSlack);
     k_lo = max(k_first, a > 0.0f ? (a < 8192.0f ? (int)a : 8192) : 0);
     k_hi = min(k_end - 1, b < 8192.0f ? (b > 0.0f ? (int)b : 0) : 8192);
     return k_lo <= k_hi;
@@ -434,7 +439,10 @@ __device__ inline bool sample_interval(const RayState &r, float lox, float loy, 
 // boundary bricks one after the other: every pixel the brick's voxel box can be seen by, eight threads a pixel -- each every eighth
 // sample of the pixel's stretch through a slab; the samples are independent, the pixel's word takes the minimum -- and per pixel only
 // the samples in the half-voxel slabs along the grid faces the brick touches (a tenth of the samples that cross the brick).
-constexpr uint32_t kShellWorkgroups = 1024;
+#ifndef TSDF_SHELL_WGS
+#define TSDF_SHELL_WGS 512   // (1 024 in round 5; 512 / 256 are 1-2 % faster on the bench scenes -- fewer workgroups that find nothing in front of the bricks' --, 128 twice as slow at 256^3: profiles/r06_cells_grid_sweep.txt)
+#endif
+constexpr uint32_t kShellWorkgroups = TSDF_SHELL_WGS;
 template <bool SLAB, bool FASTDIV>
 __device__ inline void cast_shell_bricks(const float *__restrict__ dist, const Geom &g, const RayParams &rp, const EntryParams &ep, const float *T,
                                          const CellCast &cc, uint64_t *__restrict__ best, uint32_t n_bricks, uint2 *mine, uint32_t *n_mine) {
