@@ -57,7 +57,7 @@ struct Tuning {
     int ray_cells_look;      // TSDF_RAY_CELLS_LOOK     1 (default): every flagged brick is projected when the list is built -- unseen ones dropped, large ones listed in parts; 0: never
     int ray_cells_grid;      // TSDF_RAY_CELLS_GRID     workgroups of cast_cells_kernel (2048: two or three bricks a wave at 20 000 listed bricks; see raycast_cells.hpp)
     int ray_cells_sort;      // TSDF_RAY_CELLS_SORT     the cell-parallel cast's list front to back: 0 never, 1 for views from inside the volume, 2 always
-    int ray_chooser;         // TSDF_RAY_CHOOSER        1: with TSDF_RAY_CELLS=1 the cast is chosen from measured times (choose_cast); 0: by the static rules alone; 2: a trial of the other cast every few casts (test aid)
+    int ray_chooser;         // TSDF_RAY_CHOOSER        0 (default): TSDF_RAY_CELLS=1 goes by the static rules alone; 1: the cast is chosen from measured times (choose_cast); 2: a trial of the other cast every few casts (test aid)
     int ray_entry_bound;     // TSDF_RAY_ENTRY_BOUND    0: no per-tile entry bound (default 1: rays start at the nearest flagged block their 16 x 16 tile can see)
     int icp_persistent;      // TSDF_ICP_PERSISTENT     default 0: one launch per ICP iteration (the chain); 1 / 2: all 19 in one launch with a grid barrier (slower, kept for study)
     int occ_rebuild_period;  // TSDF_OCC_REBUILD_PERIOD integrations between tightenings of the ray caster's flags (16; 0: never)
@@ -260,9 +260,9 @@ struct CastChooser {
     uint64_t measured_at[2];      // ... the last one at this cast
     uint64_t casts, next_trial;   // whole-volume casts so far; when the cast not taken is tried next
     uint32_t gap;                 // casts between trials (64 ... 4096)
-    bool pending, pending_trial, pending_sorted, blocked, sampling, used[2];
-    int pending_kind, last_kind;
-    hipEvent_t ev[4];             // begin / end of the sampled cast's dominant launches: the cells' kernel or the march's bulk kernel, its tail kernel
+    bool pending, pending_trial, blocked;
+    int pending_kind, last_kind, trial_kind, trial_left;   // trial_left > 0: casts of the running trial still to come (the last one is measured)
+    hipEvent_t ev[2];             // around the sampled cast on the volume's stream
     float trial_origin[3], trial_axis[3];   // the view of the last trial (a trial lost by 3 x waits for another view)
 };
 }  // namespace tsdf

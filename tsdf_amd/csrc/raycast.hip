@@ -1093,24 +1093,30 @@ static bool choose_cell_cast(const tsdf_volume *v, const RayParams &rp, EntryPar
     return false;
 }
 
-// Which cast a volume's stream of casts takes, from MEASURED times (round 6; TSDF_RAY_CELLS=1, the default).  The static rules of
+// Which cast a volume's stream of casts takes, from MEASURED times (round 6; TSDF_RAY_CELLS=1 with TSDF_RAY_CHOOSER=1 -- built, measured,
+// OFF by default: see the end of this comment).  The static rules of
 // choose_cell_cast have cliffs on both sides -- a flat wall in front of the camera is 0.094 ms marched and 0.122 with the cells, the
 // bench's room 0.149 and 0.100; a view from inside a 1024^3 volume 0.197 and 0.175 now that the list is sorted front to back, a
-// close-up of a wall 0.08 and 2.0 -- and no rule on footprints tells these apart.  So: in one cast in sixteen the dominant launches
-// (the cells' kernel; the march's two) carry their dispatches' own begin / end timestamps (hipExtLaunchKernel: what set_timing uses;
-// 5 us a launch that carries them, 0.5 us a cast on average; read when a later cast finds them complete, nothing waits -- and what they
-// say does not depend on how fast the host enqueues), the cast not taken is tried once every `gap` casts where the static rules bound
-// what the trial can cost, and the faster of the two runs.  A trial that loses doubles the gap (64 ... 4096 casts), one that loses by 3 x is not repeated before the camera has moved
+// close-up of a wall 0.08 and 2.0 -- and no rule on footprints tells these apart.  So: one cast in sixteen is bracketed with two events
+// on the volume's stream, from in front of its flag refresh to behind its resolve kernel (5-6 us each: 0.7 us a cast on average; read
+// when a later cast finds them complete, nothing waits), the cast not taken is tried once every `gap` casts where the static rules
+// bound what the trial can cost, and the faster of the two runs.  (The brackets, not the dominant launches' own timestamps: those
+// miss what differs between the casts around them -- the march's reach summary is rebuilt whenever integrate has set a flag -- and in
+// the pipelined step they called the march, 0.135 ms of its two kernels, equal to the cells' 0.115 + list + resolve while every step
+// with it was 8 % slower.  Where the host enqueues slower than the GPU runs the brackets hold the host's gaps, the same for both casts.)  A trial that loses doubles the gap (64 ... 4096 casts), one that loses by 3 x is not repeated before the camera has moved
 // a tenth of the volume or turned by 10 degrees.  Scheduling only: both casts give the same bits (tests/test_parity_raycast.py).
+// Why it is off by default (profiles/r06_cast_chooser.txt): a trial has to be SHORT to be cheap and LONG to be fair.  The march reaches its
+// steady state over several casts -- the reach summary, the entry bound it leaves for the next cast, the dispatch order it learns: on the
+// wall scene 0.183 ms in a trial's first cast, 0.112 in the second, 0.121 / 0.111 in the third / fourth, 0.096 in a stream of its own -- so
+// trials of up to four casts call the march lost or even where it wins by a fifth, while on the bench scene each trial is three or four steps
+// at 1.5 x the median.  The static rules stay the default; the chooser is there for streams that sit in one of their cliffs.
+constexpr int kTrialCasts = 4;
 static void chooser_poll(tsdf_volume *v) {
     CastChooser &c = v->chooser;
-    if (!c.pending || hipEventQuery(c.ev[c.used[1] ? 3 : 1]) != hipSuccess) { (void)hipGetLastError(); return; }
-    float ms = 0.0f, ms_tail = 0.0f;
-    if (hipEventElapsedTime(&ms, c.ev[0], c.ev[1]) == hipSuccess && ms > 0.0f &&
-        (!c.used[1] || hipEventElapsedTime(&ms_tail, c.ev[2], c.ev[3]) == hipSuccess)) {
+    if (!c.pending || hipEventQuery(c.ev[1]) != hipSuccess) { (void)hipGetLastError(); return; }
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, c.ev[0], c.ev[1]) == hipSuccess && ms > 0.0f) {
         const int k = c.pending_kind;
-        // (+ the small launches around them, as profiled: the list + ray records 12 us, its sort 6, resolve 7; the reach summary 5, resolve 7)
-        ms += ms_tail + (k == 1 ? (c.pending_sorted ? 0.025f : 0.019f) : 0.012f);
         if (tuning().debug_rays) fprintf(stderr, "tsdf: chooser: cast %llu measured %s %.4f ms%s (march %.4f, cells %.4f so far)\n", (unsigned long long)c.casts, k ? "cells" : "march", ms, c.pending_trial ? " [trial]" : "", c.ms[0], c.ms[1]);
         // (the first casts of a kind run cold -- flags just rebuilt, nothing in the caches: 0.34 ms for a cast that takes 0.10 -- so the
         // smaller of the first three counts, the mean of old and new after that)
@@ -1145,9 +1151,9 @@ static bool choose_cast(tsdf_volume *v, const RayParams &rp, EntryParams &ep, bo
     const bool by_rules = choose_cell_cast(v, rp, ep, &can, &trial_ok);
     if (tuning().ray_cells != 1 || !tuning().ray_chooser) return by_rules;
     CastChooser &c = v->chooser;
-    if (c.gap == 0u) {   // (a new volume, or one that was cleared: the first trial after 32 casts)
+    if (c.gap == 0u) {   // (a new volume, or one that was cleared: the first trial after 64 casts)
         c.gap = 64u;
-        c.next_trial = c.casts + (tuning().ray_chooser == 2 ? 3u : 32u);   // (2: a test aid -- a trial every few casts, whatever the times say)
+        c.next_trial = c.casts + (tuning().ray_chooser == 2 ? 3u : 64u);   // (2: a test aid -- a trial every few casts, whatever the times say)
     }
     chooser_poll(v);
     c.casts++;
@@ -1160,19 +1166,29 @@ static bool choose_cast(tsdf_volume *v, const RayParams &rp, EntryParams &ep, bo
         kind = c.ms[1] * bias1 <= c.ms[0] * bias0 ? 1 : 0;
     }
     bool trial = false;
-    if (!c.pending && c.casts >= c.next_trial && (!c.blocked || chooser_view_moved(v, rp))) {
+    if (c.trial_left > 0) {
+        // A trial is kTrialCasts casts of the other kind, the LAST of them measured: the first march after a run of cell casts rebuilds
+        // the reach summary and has no dispatch order learnt, the first cell cast its list's length unknown -- 0.18 ms for a march that
+        // takes 0.09 from its fourth cast on -- the entry bound it leaves for the next cast, the order it learns (the wall scene: trials of one, two and three casts called it lost: 0.183, 0.112, 0.121 ms).
+        kind = c.trial_kind;
+        if (kind == 1 && !can) { c.trial_left = 0; kind = 0; }
+        else if (c.trial_left > 1) c.trial_left--;
+        else if (!c.pending) { trial = true; c.trial_left = 0; }   // (its measured cast; waits a cast while an earlier sample is still out)
+    } else if (!c.pending && c.casts >= c.next_trial && (!c.blocked || chooser_view_moved(v, rp))) {
         const int other = 1 - kind;
         // A trial is a slow step when it loses (the march on the bench scene: + 0.06 ms), so none is made that cannot win: the cast that
-        // runs is measured anyway, and the other one's best case is known -- the march 0.089 ms for 640 x 480 rays on a wall in front of
-        // the camera, the cells 0.094 on the bench's room (per pixel; profiles/r06_cast_chooser.txt) -- a cast already within 15 % of
+        // runs is measured anyway, and the other one's best case is known -- the march 0.092 ms for 640 x 480 rays on a wall in front of
+        // the camera, the cells 0.098 on the bench's room (whole casts, per pixel; profiles/r06_cast_chooser.txt) -- a cast already within 15 % of
         // that stays.
-        const float mpix = (float)rp.width * (float)rp.height * 1.0e-6f, best_other = (other == 0 ? 0.29f : 0.305f) * mpix;
+        const float mpix = (float)rp.width * (float)rp.height * 1.0e-6f, best_other = (other == 0 ? 0.30f : 0.32f) * mpix;
         const bool could_win = !c.seen[kind] || c.ms[kind] > 1.15f * best_other || tuning().ray_chooser == 2;
         if (!could_win) {
             c.next_trial = c.casts + c.gap;
         } else if (other == 0 || trial_ok) {   // (the march is always affordable; the cells where the static bound says so)
             kind = other;
-            trial = true;
+            c.trial_kind = other;
+            c.trial_left = kTrialCasts - 1;   // (this cast is the first of them)
+            c.next_trial = c.casts + c.gap;   // (replaced when the trial's measurement arrives)
             c.blocked = false;
             c.trial_origin[0] = rp.origin.x; c.trial_origin[1] = rp.origin.y; c.trial_origin[2] = rp.origin.z;
             c.trial_axis[0] = rp.rot.m13; c.trial_axis[1] = rp.rot.m23; c.trial_axis[2] = rp.rot.m33;
@@ -1181,10 +1197,9 @@ static bool choose_cast(tsdf_volume *v, const RayParams &rp, EntryParams &ep, bo
         }
     }
     if (kind == 1 && (v->cell_cast_host ? *v->cell_cast_host : 0u) > (uint32_t)tuning().ray_cells_limit) kind = 0;   // (never past the list's limit)
-    if (!c.pending && c.casts > 1u && (trial || c.seen[kind] < 3u || (c.casts & 15u) == 0u)) {
+    if (!c.pending && c.casts > 1u && (trial || (c.trial_left == 0 && (c.seen[kind] < 3u || (c.casts & 15u) == 0u)))) {
         if (!c.ev[0]) {
-            for (int i = 0; i < 4; i++)
-                if (hipEventCreate(&c.ev[i]) != hipSuccess) { (void)hipGetLastError(); c.ev[0] = nullptr; break; }
+            if (hipEventCreate(&c.ev[0]) != hipSuccess || hipEventCreate(&c.ev[1]) != hipSuccess) { (void)hipGetLastError(); c.ev[0] = nullptr; }
         }
         if (c.ev[0]) {
             *sample = true;
@@ -1410,15 +1425,14 @@ static int cast_whole(tsdf_volume *v, RayParams &rp, float *out, float *normals,
     EntryParams view;
     bool sample = false;
     const bool cells = choose_cast(v, rp, view, &sample);
+    CastChooser &c = v->chooser;
+    if (sample && hipEventRecord(c.ev[0], v->stream) != hipSuccess) { (void)hipGetLastError(); sample = false; }
     if (cells) rc = occupancy_flags_refresh(v); else rc = refresh_for_cast(v, rp);
     if (rc != TSDF_OK) return rc;
-    CastChooser &c = v->chooser;
-    c.sampling = sample;   // (timing_pair hands the dominant launches the chooser's events)
-    c.used[0] = c.used[1] = false;
-    c.pending_sorted = cells && view.z_clip == 0.0f && tuning().ray_cells_sort != 0;
     rc = cells ? march_and_resolve<false>(v, rp, out, normals, depth_inv_pose, depth_out, &view) : march_and_resolve<false>(v, rp, out, normals, depth_inv_pose, depth_out);
-    c.sampling = false;
-    if (sample && rc == TSDF_OK && c.used[0]) c.pending = true;
+    if (sample && rc == TSDF_OK) {
+        if (hipEventRecord(c.ev[1], v->stream) == hipSuccess) c.pending = true; else (void)hipGetLastError();
+    }
     return rc;
 }
 

@@ -36,7 +36,7 @@ const Tuning &tuning() {
         u.ray_cells_limit = std::max(num("TSDF_RAY_CELLS_LIMIT", 131072), 0);
         u.ray_cells_grid = clamp(num("TSDF_RAY_CELLS_GRID", 2048), 1, 65535);
         u.ray_cells_sort = clamp(num("TSDF_RAY_CELLS_SORT", 1), 0, 2);
-        u.ray_chooser = clamp(num("TSDF_RAY_CHOOSER", 1), 0, 2);
+        u.ray_chooser = clamp(num("TSDF_RAY_CHOOSER", 0), 0, 2);
         u.ray_cells_pairs = clamp(num("TSDF_RAY_CELLS_PAIRS", 1024), 0, 1 << 24);
         u.ray_cells_look = clamp(num("TSDF_RAY_CELLS_LOOK", 1), 0, 1);
         { const char *fp = getenv("TSDF_RAY_CELLS_FOOTPRINT"); u.ray_cells_footprint = fp ? (float)atof(fp) : 10.0f; }
@@ -655,12 +655,6 @@ static bool timing_brackets() { return tuning().timing_bracket != 0; }
 // Start / stop events for the next launch of kernel `which` (filled by hipExtLaunchKernel with the dispatch's timestamps);
 // false when this launch is not to be timed, or when the brackets are asked for.
 bool timing_pair(tsdf_volume *v, int which, hipEvent_t *start, hipEvent_t *stop) {
-    if (v->chooser.sampling && (which == 1 || which == 2) && !v->chooser.used[which - 1] && !v->timing) {   // (raycast.hip: choose_cast)
-        *start = v->chooser.ev[2 * (which - 1)];
-        *stop = v->chooser.ev[2 * (which - 1) + 1];
-        v->chooser.used[which - 1] = true;
-        return true;
-    }
     if (!v->timing || timing_brackets()) return false;
     if (v->timing_launches[which]++ % (uint32_t)v->timing != 0) return false;
     if (!v->tev[which]) v->tev[which] = new std::vector<hipEvent_t>();
@@ -937,7 +931,7 @@ int tsdf_volume_destroy(tsdf_volume *v) {
     if (v->cell_rays) (void)hipFree(v->cell_rays);
     if (v->cell_bricks) (void)hipFree(v->cell_bricks);
     if (v->cell_count_scratch) (void)hipFree(v->cell_count_scratch);
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 2; i++)
         if (v->chooser.ev[i]) (void)hipEventDestroy(v->chooser.ev[i]);
     if (v->cell_cast_host) (void)hipHostFree(v->cell_cast_host);
     if (v->ray_heavy) (void)hipFree(v->ray_heavy);
@@ -998,6 +992,7 @@ int tsdf_volume_clear(tsdf_volume *v) {
     v->chooser.seen[0] = v->chooser.seen[1] = 0;   // (what was measured on the old contents says nothing about the new: choose_cast starts over)
     v->chooser.gap = 0;
     v->chooser.blocked = false;
+    v->chooser.trial_left = 0;
     v->prepared_valid = 0;   // (a brick list prepared ahead bakes in the offset at clear time)
     v->integrations_since_rebuild = v->integrations_total = 0;
     // initialise_deformation bakes the CURRENT offset into the node translations (Q1)
