@@ -945,7 +945,23 @@ def cpu_baseline(vol, depth, cam, n, physical, budget_s):
     rays = W * len(range(0, H, row_step))
     t_ray_full = t_ray * (W * H / rays)
     step_s = t_bil + t_int + t_ray_full
+    # ... and, where oracle/_ref travelled to this box, integrate's loop around the REFERENCE's own compiled world_to_pixel / pixel_to_camera /
+    # world_to_camera (oracle/ref_transforms_wrap.cpp; src/Utilities/cuda_coordinate_transforms.cu built with g++), one thread, on a slab of
+    # the same grid: what the reference's per-voxel code costs a host core -- reported beside the port's figure, not instead of it (the loop
+    # itself and the blend are restated; the reference's kernel file does not compile without Eigen)
+    ref_fn = None
+    if O.have_ref_transforms():
+        zs_r = max(1, n // 32)
+        rd = np.full(n * n * zs_r, np.float32(ov.truncation_distance()), np.float32)
+        rw = np.zeros_like(rd)
+        vs = ov.voxel_size()
+        t = time.perf_counter()
+        # (a grid of n x n x zs_r voxels with the volume's voxel size, shifted to the middle planes: the same projections as that slab's)
+        O.ref_integrate_composed(rd, rw, (n, n, zs_r), vs, ov.truncation_distance(), cam.inverse_pose(), cam.k(), cam.kinv(), f, W, H,
+                                 offset_at_clear=(0.0, 0.0, float(vs[2]) * (n // 2)), offset_now=(0.0, 0.0, 0.0))
+        ref_fn = round(n * n * zs_r / (time.perf_counter() - t) / 1e6, 2)
     return {"value": round(n ** 3 / step_s / 1e6, 3), "unit": "Mvoxels/s", "cores": cores, "kind": "port",
+            "integrate_mvoxels_per_s_1thread_reference_functions": ref_fn,
             "sample": "1 frame: bilateral 640x480 + integrate over the full %d^3 grid (%d voxels updated) + ray cast of "
                       "every %dth row (%d rays, %d samples) scaled to 307200 rays; oracle/tsdf_oracle.c, OpenMP over "
                       "z planes / rows, all %d host threads" % (n, U, row_step, rays, samples, cores),
