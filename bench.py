@@ -437,6 +437,8 @@ def main():
     for i in range(Wu):
         step(i, False)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(S_spread + 1)]
+    for m_ in marks:          # (every event recorded once before it counts: the runtime makes an event's signal at its first record, and grows
+        m_.record(stream)     # its pool of signals a few hundred at a time -- a stall of 0.1 ms that landed in the first timed step)
     torch.cuda.synchronize()
     marks[0].record(stream)
     kinds = []
