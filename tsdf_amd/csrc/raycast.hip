@@ -592,7 +592,10 @@ __global__ __launch_bounds__(256) void resolve_hits_kernel(const Geom g, const R
                                                            uint64_t *__restrict__ best_next, float *__restrict__ out,
                                                            uint32_t *__restrict__ reset, const Mat44 ip, uint16_t *__restrict__ depth) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < kTailSignals) reset[i] = 0;   // the queue's entries appended, the cell-parallel cast's listed bricks (TailQueue::count)
+    // the queue's entries appended, the cell-parallel cast's listed bricks and its list's depth bins (TailQueue::count): every word, also by
+    // the one workgroup of an image of a few pixels (kTailSignals is 516 words: an image of 7 x 8 pixels left the bins' upper half
+    // and the places taken standing, and the next sorted list lost entries -- found by the extended fuzz, round 6)
+    for (uint32_t j = i; j < kTailSignals; j += gridDim.x * blockDim.x) reset[j] = 0;
     if (i >= rp.width * rp.height) return;
     best_next[i] = kNoHitWord;
     float ix, iy, iz, th;
@@ -623,7 +626,7 @@ __global__ __launch_bounds__(kResolveThreads) void resolve_normals_kernel(const 
     __shared__ float vx[kS * kS], vy[kS * kS], vz[kS * kS];
     {   // the queue's entries appended, the cell-parallel cast's listed bricks (TailQueue::count)
         const uint32_t t_ = (blockIdx.y * gridDim.x + blockIdx.x) * kResolveThreads + threadIdx.x;
-        if (t_ < kTailSignals) reset[t_] = 0;
+        for (uint32_t j = t_; j < kTailSignals; j += gridDim.x * gridDim.y * kResolveThreads) reset[j] = 0;   // (every word, however few workgroups: see resolve_hits_kernel)
     }
     const uint32_t x0 = blockIdx.x * kT, y0 = blockIdx.y * kT;
     // own pixels first (threads 0..255, row-major in the tile), then the halo column and row
