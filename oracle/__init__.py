@@ -16,6 +16,7 @@ _LIB = os.path.join(_HERE, "libtsdf_oracle.so")
 REF_BUILD = os.path.join(_HERE, "_ref")
 _REF = os.path.join(REF_BUILD, "libref_bilateral.so")
 _REF_TRANSFORMS = os.path.join(REF_BUILD, "libref_transforms.so")
+_REF_IO = os.path.join(REF_BUILD, "libref_io.so")
 
 
 def build(force=False):
@@ -456,6 +457,44 @@ def ref_integrate_composed(dist, weight, size, voxel_size, trunc, inv_pose, k, k
                                                         _fp(_f32(offset_at_clear, 3)), _fp(_f32(offset_now, 3)), float(trunc),
                                                         _fp(_f32(inv_pose, 16)), _fp(_f32(k, 9)), _fp(_f32(kinv, 9)),
                                                         d.ctypes.data_as(C.POINTER(C.c_uint16)), int(width), int(height)))
+
+
+def have_ref_io():
+    return os.path.exists(_REF_IO)
+
+
+_ref_io_lib = None
+
+
+def _ref_io():
+    """oracle/_ref/libref_io.so: the reference's src/Utilities/ply.cpp and PgmUtilities.cpp compiled where they lie
+    (oracle/ref_io_wrap.cpp has the entry points)."""
+    global _ref_io_lib
+    if _ref_io_lib is None:
+        L = C.CDLL(_REF_IO, mode=getattr(os, "RTLD_LOCAL", 0) | getattr(os, "RTLD_DEEPBIND", 0))
+        L.ref_write_to_ply.restype = None
+        L.ref_write_to_ply.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_int), C.c_size_t]
+        L.ref_read_pgm.restype = C.c_size_t
+        L.ref_read_pgm.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint16), C.c_size_t]
+        _ref_io_lib = L
+    return _ref_io_lib
+
+
+def ref_write_to_ply(path, vertices, triangles):
+    """The reference's write_to_ply (src/Utilities/ply.cpp:6-30) on (n, 3) float32 vertices and (m, 3) int32 triangles."""
+    v = np.ascontiguousarray(vertices, np.float32).reshape(-1, 3)
+    t = np.ascontiguousarray(triangles, np.int32).reshape(-1, 3)
+    _ref_io().ref_write_to_ply(str(path).encode(), _fp(v), len(v), t.ctypes.data_as(C.POINTER(C.c_int)), len(t))
+
+
+def ref_read_pgm(path):
+    """The reference's read_pgm (src/Utilities/PgmUtilities.cpp:49-85) -> (height, width) uint16, as read (before the NYU byte swap of
+    src/Utilities/DepthMapUtilities.cpp:20-33, which the caller applies)."""
+    w, h = C.c_uint32(0), C.c_uint32(0)
+    n = _ref_io().ref_read_pgm(str(path).encode(), C.byref(w), C.byref(h), None, 0)
+    out = np.empty(n, np.uint16)
+    _ref_io().ref_read_pgm(str(path).encode(), C.byref(w), C.byref(h), out.ctypes.data_as(C.POINTER(C.c_uint16)), n)
+    return out.reshape(h.value, w.value)
 
 
 # ---- ICP tracking (icp_oracle.c) -------------------------------------------------------------------------------

@@ -208,6 +208,8 @@ _HOST_SIGS = {
     "tsdf_host_tum_next": (_i, [_vp, _vp, C.c_size_t, C.POINTER(C.c_uint), _fp]),
     "tsdf_host_tum_close": (None, [_vp]),
     "tsdf_host_block_loader_parse": (_i, [C.c_char_p, _vp, _vp, _vp, _vp, C.c_size_t]),
+    "tsdf_host_write_ply": (None, [C.c_char_p, _vp, C.c_size_t, _vp, C.c_size_t]),
+    "tsdf_host_read_nyu_depth_map": (C.c_size_t, [C.c_char_p, C.POINTER(C.c_uint), _vp, C.c_size_t]),
 }
 for _name, (_res, _args) in _HOST_SIGS.items():
     _fn = getattr(host, _name)

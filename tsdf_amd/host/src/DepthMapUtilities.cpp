@@ -23,13 +23,14 @@ uint16_t *read_nyu_depth_map(const std::string &file_name, uint32_t &width, uint
     if (!fp) return nullptr;
     char magic[3] = {0, 0, 0};
     unsigned w = 0, h = 0, maxval = 0;
-    if (fscanf(fp, "%2s %u %u %u", magic, &w, &h, &maxval) != 4 || magic[0] != 'P' || magic[1] != '5' || maxval < 256) {
+    if (fscanf(fp, "%2s %u %u %u", magic, &w, &h, &maxval) != 4 || magic[0] != 'P' || magic[1] != '5') {
         fclose(fp);
         return nullptr;
     }
     fgetc(fp);  // the single whitespace after maxval
     const size_t n = (size_t)w * h;
-    std::vector<unsigned char> raw(n * 2);
+    const size_t bytes = maxval < 256 ? 1 : 2;   // (one byte a sample below 256: src/Utilities/PgmUtilities.cpp:70-75)
+    std::vector<unsigned char> raw(n * bytes);
     if (fread(raw.data(), 1, raw.size(), fp) != raw.size()) {
         fclose(fp);
         return nullptr;
@@ -37,7 +38,7 @@ uint16_t *read_nyu_depth_map(const std::string &file_name, uint32_t &width, uint
     fclose(fp);
     uint16_t *range_map = new uint16_t[n];
     for (size_t i = 0; i < n; i++) {
-        uint16_t v = (uint16_t)(raw[2 * i] * 256 + raw[2 * i + 1]);
+        uint16_t v = bytes == 1 ? (uint16_t)raw[i] : (uint16_t)(raw[2 * i] * 256 + raw[2 * i + 1]);
         range_map[i] = (uint16_t)((v >> 8) + ((v & 0xFF) * 256));
     }
     width = w;

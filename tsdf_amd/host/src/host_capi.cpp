@@ -10,6 +10,8 @@
 #include "BlockTSDFLoader.hpp"
 #include "MarkAndSweepMC.hpp"
 #include "TUMDataLoader.hpp"
+#include "DepthMapUtilities.hpp"
+#include "ply.hpp"
 
 const int8_t *tsdf_host_mc_triangle_table();
 
@@ -125,4 +127,27 @@ int tsdf_host_tum_next(tsdf_tum_loader *l, uint16_t *depth, size_t capacity, uns
     return 1;
 }
 void tsdf_host_tum_close(tsdf_tum_loader *l) { delete reinterpret_cast<TUMDataLoader *>(l); }
+
+// write_to_ply (ply.cpp) on flat arrays: 3 floats a vertex, 3 indices a triangle
+void tsdf_host_write_ply(const char *file_name, const float *vertices, size_t n_vertices, const int *triangles, size_t n_triangles) {
+    std::vector<float3> v(n_vertices);
+    std::vector<int3> t(n_triangles);
+    for (size_t i = 0; i < n_vertices; i++) v[i] = float3{vertices[3 * i], vertices[3 * i + 1], vertices[3 * i + 2]};
+    for (size_t i = 0; i < n_triangles; i++) t[i] = int3{triangles[3 * i], triangles[3 * i + 1], triangles[3 * i + 2]};
+    write_to_ply(file_name, v, t);
+}
+
+// read_nyu_depth_map (DepthMapUtilities.cpp): returns width * height (0: the file did not parse) and copies the samples when
+// `out` holds at least that many
+size_t tsdf_host_read_nyu_depth_map(const char *file_name, unsigned size[2], uint16_t *out, size_t capacity) {
+    uint32_t w = 0, h = 0;
+    uint16_t *map = read_nyu_depth_map(file_name, w, h);
+    size[0] = w;
+    size[1] = h;
+    if (!map) return 0;
+    const size_t n = (size_t)w * h;
+    if (out && capacity >= n) memcpy(out, map, n * sizeof(uint16_t));
+    delete[] map;
+    return n;
+}
 }  // extern "C"
