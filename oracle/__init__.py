@@ -476,8 +476,66 @@ def _ref_io():
         L.ref_write_to_ply.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_int), C.c_size_t]
         L.ref_read_pgm.restype = C.c_size_t
         L.ref_read_pgm.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint16), C.c_size_t]
+        file_utilities_signatures(L, "ref")
         _ref_io_lib = L
     return _ref_io_lib
+
+
+def file_utilities_signatures(L, prefix):
+    """ctypes signatures of the FileUtilities entry points, the same on both sides (oracle/ref_io_wrap.cpp around the reference's
+    file, tsdf_amd/host/src/host_capi.cpp around the host library's)."""
+    ip = C.POINTER(C.c_int)
+    f = lambda name: getattr(L, prefix + "_" + name)
+    f("match_file_name").restype = C.c_int
+    f("match_file_name").argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p]
+    f("process_file_by_lines").restype = C.c_size_t
+    f("process_file_by_lines").argtypes = [C.c_char_p, ip, C.c_char_p, C.c_size_t]
+    f("read_last_line").restype = C.c_size_t
+    f("read_last_line").argtypes = [C.c_char_p, C.c_char_p, ip, C.c_char_p, C.c_size_t]
+    f("files_in_directory").restype = C.c_size_t
+    f("files_in_directory").argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
+    f("file_exists").restype = C.c_int
+    f("file_exists").argtypes = [C.c_char_p, ip]
+
+
+class FileUtilities:
+    """The five helpers of FileUtilities through one of the two libraries (L, prefix): strings in, Python values out."""
+
+    def __init__(self, L, prefix):
+        self.f = lambda name: getattr(L, prefix + "_" + name)
+
+    def _text(self, call):
+        n = call(None, 0)
+        buf = C.create_string_buffer(n + 1)
+        call(buf, n + 1)
+        return buf.raw[:n]
+
+    def match_file_name(self, prefix, num_digits, suffix, extension, test_string):
+        return bool(self.f("match_file_name")(prefix, num_digits, suffix, extension, test_string))
+
+    def process_file_by_lines(self, path):
+        ok = C.c_int(-1)
+        joined = self._text(lambda out, cap: self.f("process_file_by_lines")(str(path).encode(), C.byref(ok), out, cap))
+        return bool(ok.value), joined.split(b"\x1e")[:-1]
+
+    def read_last_line(self, path, preset=b"untouched"):
+        ok = C.c_int(-1)
+        text = self._text(lambda out, cap: self.f("read_last_line")(str(path).encode(), preset, C.byref(ok), out, cap))
+        return bool(ok.value), text
+
+    def files_in_directory(self, directory, prefix, num_digits, suffix, extension):
+        joined = self._text(lambda out, cap: self.f("files_in_directory")(str(directory).encode(), prefix, num_digits, suffix, extension, out, cap))
+        return joined.split(b"\x1e")[:-1]
+
+    def file_exists(self, path, preset):
+        d = C.c_int(1 if preset else 0)
+        e = self.f("file_exists")(str(path).encode(), C.byref(d))
+        return bool(e), bool(d.value)
+
+
+def ref_file_utilities():
+    """The reference's src/Utilities/FileUtilities.cpp, compiled where it lies."""
+    return FileUtilities(_ref_io(), "ref")
 
 
 def ref_write_to_ply(path, vertices, triangles):

@@ -3,8 +3,8 @@
     python -m tests.golden.make_ref_io_vectors
 
 The outputs come from oracle/_ref/libref_io.so, i.e. /root/reference/src/Utilities/ply.cpp (write_to_ply) and
-src/Utilities/PgmUtilities.cpp (read_pgm) compiled where they lie (oracle/Makefile target "ref"; oracle/ref_io_wrap.cpp has the C entry
-points).  Data only: the meshes and PGM files given to the reference and what it wrote / read.
+src/Utilities/PgmUtilities.cpp (read_pgm) and src/Utilities/FileUtilities.cpp compiled where they lie (oracle/Makefile target "ref"; oracle/ref_io_wrap.cpp has the C entry
+points).  Data only: the meshes, PGM files, file names and text files given to the reference and what it wrote / read / answered.
 """
 import os
 import tempfile
@@ -44,6 +44,21 @@ def pgm_files():
     return out
 
 
+def name_cases():
+    """(prefix, digits, suffix, extension, candidates)"""
+    c = [b"depth_00012.png", b"depth_00012Xpng", b"depth_0001a.png", b"depth_000123.png", b"depth_0012.png", b"Depth_00012.png", b"depth_00012.pnG",
+         b"color_00000.png", b"sflow_00007_results01.txt", b"sflow_00007_results02.txt", b"sflow_00007.xml", b"", b".", b"7.", b"12345", b"x1y.z"]
+    return [(b"depth_", 5, b"", b"png", c), (b"color_", 5, b"", b"png", c), (b"sflow_", 5, b"_results01", b"txt", c), (b"sflow_", 5, b"", b"xml", c),
+            (b"", 0, b"", b"", c), (b"", 1, b"", b"", c), (b"x", 1, b"y", b"z", c), (b"", 5, b"", b"", c)]
+
+
+def text_files():
+    """(name, bytes): what process_file_by_lines delivers and read_last_line finds"""
+    return [("two_lines", b"first\nsecond\n"), ("no_final_newline", b"first\nsecond"), ("crlf", b"first\r\nsecond\r\n"), ("trailing_empty_lines", b"a\nbb\n\n\n"),
+            ("only_line", b"alone\n"), ("only_line_no_newline", b"alone"), ("empty", b""), ("newlines_only", b"\n\n"), ("blank_last", b"a\n \n"),
+            ("leading_empty", b"\nx\n"), ("tum_like", b"# timestamp tx ty tz qx qy qz qw\n1305031102.175304 1.3405 0.6266 1.6575 0.6574 0.6126 -0.2949 -0.3248\n")]
+
+
 def main():
     import oracle as O
     assert O.have_ref_io(), "make -C oracle ref (needs /root/reference and the CUDA toolkit headers) first"
@@ -60,6 +75,25 @@ def main():
             open(path, "wb").write(raw)
             data["pgm_" + name + "_file"] = np.frombuffer(raw, np.uint8)
             data["pgm_" + name + "_read"] = O.ref_read_pgm(path)
+        R = O.ref_file_utilities()
+        for i, (prefix, digits, suffix, ext, cands) in enumerate(name_cases()):
+            data["names_%d_template" % i] = np.array([prefix, str(digits).encode(), suffix, ext], dtype=object).astype("S")
+            data["names_%d_candidates" % i] = np.array(cands, dtype="S")
+            data["names_%d_matches" % i] = np.array([R.match_file_name(prefix, digits, suffix, ext, c) for c in cands])
+        data["n_name_cases"] = np.int32(len(name_cases()))
+        for name, raw in text_files():
+            path = os.path.join(tmp, name + ".txt")
+            open(path, "wb").write(raw)
+            ok, lines = R.process_file_by_lines(path)
+            ok_last, last = R.read_last_line(path, b"untouched")
+            data["text_" + name + "_file"] = np.frombuffer(raw, np.uint8)
+            data["text_" + name + "_lines_ok"] = np.bool_(ok)
+            data["text_" + name + "_lines"] = np.frombuffer(b"\x1e".join(lines + [b""]), np.uint8)
+            data["text_" + name + "_last_ok"] = np.bool_(ok_last)
+            data["text_" + name + "_last"] = np.frombuffer(last, np.uint8)
+        ok, lines = R.process_file_by_lines(os.path.join(tmp, "missing.txt"))
+        data["text_missing_lines_ok"] = np.bool_(ok)
+        data["text_missing_last_ok"] = np.bool_(R.read_last_line(os.path.join(tmp, "missing.txt"))[0])
     out = os.path.join(HERE, "ref_io.npz")
     np.savez_compressed(out, **data)
     print(out, os.path.getsize(out), "bytes;", len(data), "arrays")

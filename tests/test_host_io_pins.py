@@ -81,3 +81,83 @@ def test_live_against_the_reference_build(tmp_path, oracle, seed):
     p = tmp_path / "depth.pgm"
     p.write_bytes(raw)
     assert np.array_equal(host_read_nyu(p), nyu_swap(oracle.ref_read_pgm(p)))
+
+
+# ---- the loaders' file helpers (reference src/Utilities/FileUtilities.cpp) ----------------------------------------------------------
+TEXT_CASES = ["two_lines", "no_final_newline", "crlf", "trailing_empty_lines", "only_line", "only_line_no_newline", "empty", "newlines_only",
+              "blank_last", "leading_empty", "tum_like"]
+
+
+def host_file_utilities(oracle):
+    return oracle.FileUtilities(_capi.host, "tsdf_host")    # (the marshalling only: every call lands in libtsdf_host.so)
+
+
+def test_match_file_name_answers_as_the_reference_build_did(oracle):
+    f = np.load(os.path.join(GOLD, "ref_io.npz"))
+    H = host_file_utilities(oracle)
+    assert int(f["n_name_cases"]) >= 8
+    for i in range(int(f["n_name_cases"])):
+        prefix, digits, suffix, ext = [bytes(x) for x in f["names_%d_template" % i]]
+        got = [H.match_file_name(prefix, int(digits), suffix, ext, bytes(c)) for c in f["names_%d_candidates" % i]]
+        assert got == list(f["names_%d_matches" % i]), (prefix, digits, suffix, ext)
+    # the character in front of the extension is counted, not compared (src/Utilities/FileUtilities.cpp:43-50)
+    assert H.match_file_name(b"depth_", 5, b"", b"png", b"depth_00012Xpng")
+
+
+@pytest.mark.parametrize("name", TEXT_CASES)
+def test_lines_and_last_line_as_the_reference_build_read_them(tmp_path, oracle, name):
+    f = np.load(os.path.join(GOLD, "ref_io.npz"))
+    H = host_file_utilities(oracle)
+    p = tmp_path / "file.txt"
+    p.write_bytes(f["text_%s_file" % name].tobytes())
+    ok, lines = H.process_file_by_lines(p)
+    assert ok == bool(f["text_%s_lines_ok" % name]) and b"\x1e".join(lines + [b""]) == f["text_%s_lines" % name].tobytes()
+    ok, last = H.read_last_line(p, b"untouched")
+    assert ok == bool(f["text_%s_last_ok" % name]) and last == f["text_%s_last" % name].tobytes()
+
+
+def test_a_missing_file_as_the_reference_build_reported_it(tmp_path, oracle, capfd):
+    f = np.load(os.path.join(GOLD, "ref_io.npz"))
+    H = host_file_utilities(oracle)
+    ok, lines = H.process_file_by_lines(tmp_path / "missing.txt")
+    assert ok == bool(f["text_missing_lines_ok"]) and lines == []     # (true: src/Utilities/FileUtilities.cpp:85-110 only prints)
+    assert H.read_last_line(tmp_path / "missing.txt")[0] == bool(f["text_missing_last_ok"])
+    capfd.readouterr()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_file_helpers_live_against_the_reference_build(tmp_path, oracle, seed, capfd):
+    if not oracle.have_ref_io():
+        pytest.skip("oracle/_ref/libref_io.so not present (built where /root/reference is mounted)")
+    H, R = host_file_utilities(oracle), oracle.ref_file_utilities()
+    rng = np.random.RandomState(seed)
+    alphabet = [b"a", b"b", b"0", b"1", b"7", b".", b"_", b"x"]
+    word = lambda lo, hi: b"".join(alphabet[i] for i in rng.randint(0, len(alphabet), rng.randint(lo, hi)))
+    for _ in range(3000):
+        prefix, suffix, ext, digits = word(0, 3), word(0, 3), word(0, 3), int(rng.randint(0, 4))
+        cand = prefix + word(0, 4) + suffix + word(0, 2) + ext if rng.rand() < 0.7 else word(0, 9)
+        assert H.match_file_name(prefix, digits, suffix, ext, cand) == R.match_file_name(prefix, digits, suffix, ext, cand), (prefix, digits, suffix, ext, cand)
+    pieces = [b"", b"", b"a", b"line two", b" ", b"\r", b"x\r", b"# comment", b"1 2 3"]
+    for i in range(200):
+        body = b"\n".join(pieces[j] for j in rng.randint(0, len(pieces), rng.randint(0, 7)))
+        if rng.rand() < 0.5:
+            body += b"\n"
+        p = tmp_path / ("t%d.txt" % i)
+        p.write_bytes(body)
+        assert H.process_file_by_lines(p) == R.process_file_by_lines(p), body
+        assert H.read_last_line(p) == R.read_last_line(p), body
+    d = tmp_path / "frames"
+    d.mkdir()
+    (d / "sub_00001.png").mkdir()
+    for i in rng.permutation(40):
+        (d / (("depth_%05d.png" if i % 3 else "color_%05d.png") % i)).write_bytes(b"")
+    (d / "depth_0000x.png").write_bytes(b"")
+    for tmpl in [(b"depth_", 5, b"", b"png"), (b"color_", 5, b"", b"png"), (b"sub_", 5, b"", b"png"), (b"none_", 5, b"", b"png")]:
+        got = H.files_in_directory(d, *tmpl)
+        assert got == R.files_in_directory(d, *tmpl)      # (the directory's own order on both sides)
+    assert len(H.files_in_directory(d, b"depth_", 5, b"", b"png")) == 26
+    assert H.files_in_directory(tmp_path / "no_such_dir", b"", 0, b"", b"") == R.files_in_directory(tmp_path / "no_such_dir", b"", 0, b"", b"") == []
+    for path in [d, d / "depth_00001.png", tmp_path / "nothing", "/dev/null"]:
+        for preset in (False, True):
+            assert H.file_exists(path, preset) == R.file_exists(path, preset), path
+    capfd.readouterr()

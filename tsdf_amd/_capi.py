@@ -210,6 +210,11 @@ _HOST_SIGS = {
     "tsdf_host_block_loader_parse": (_i, [C.c_char_p, _vp, _vp, _vp, _vp, C.c_size_t]),
     "tsdf_host_write_ply": (None, [C.c_char_p, _vp, C.c_size_t, _vp, C.c_size_t]),
     "tsdf_host_read_nyu_depth_map": (C.c_size_t, [C.c_char_p, C.POINTER(C.c_uint), _vp, C.c_size_t]),
+    "tsdf_host_match_file_name": (_i, [C.c_char_p, _i, C.c_char_p, C.c_char_p, C.c_char_p]),
+    "tsdf_host_process_file_by_lines": (C.c_size_t, [C.c_char_p, C.POINTER(_i), C.c_char_p, C.c_size_t]),
+    "tsdf_host_read_last_line": (C.c_size_t, [C.c_char_p, C.c_char_p, C.POINTER(_i), C.c_char_p, C.c_size_t]),
+    "tsdf_host_files_in_directory": (C.c_size_t, [C.c_char_p, C.c_char_p, _i, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]),
+    "tsdf_host_file_exists": (_i, [C.c_char_p, C.POINTER(_i)]),
 }
 for _name, (_res, _args) in _HOST_SIGS.items():
     _fn = getattr(host, _name)
