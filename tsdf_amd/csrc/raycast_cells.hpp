@@ -147,7 +147,30 @@ __device__ inline bool project_box(const EntryParams &ep, float lox, float loy, 
     pb.w = (int)fminf(a1, wmax) - pb.u0 + 1; pb.h = (int)fminf(b1, hmax) - pb.v0 + 1;
     return true;
 }
-
+// inclusive scans over a wave's 64 lanes with data-parallel-primitive operands: four shifts inside a row of 16, then lane 15 of a
+// row into the row behind it and lane 31 into the upper half (row_bcast: a GFX9 form).  A lane without a source keeps the identity 0.
+template <int CTRL, int ROW_MASK>
+__device__ inline uint32_t dpp_or_zero(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ inline uint32_t wave_scan_add(uint32_t v) {
+    v += dpp_or_zero<0x111, 0xf>(v);
+    v += dpp_or_zero<0x112, 0xf>(v);
+    v += dpp_or_zero<0x114, 0xf>(v);
+    v += dpp_or_zero<0x118, 0xf>(v);
+    v += dpp_or_zero<0x142, 0xa>(v);
+    v += dpp_or_zero<0x143, 0xc>(v);
+    return v;
+}
+__device__ inline uint32_t wave_scan_max(uint32_t v) {
+    v = max(v, dpp_or_zero<0x111, 0xf>(v));
+    v = max(v, dpp_or_zero<0x112, 0xf>(v));
+    v = max(v, dpp_or_zero<0x114, 0xf>(v));
+    v = max(v, dpp_or_zero<0x118, 0xf>(v));
+    v = max(v, dpp_or_zero<0x142, 0xa>(v));
+    v = max(v, dpp_or_zero<0x143, 0xc>(v));
+    return v;
+}
 // One launch in front of the cast, two kinds of workgroup.
 // All but the first n_list_blocks: per pixel the direction, start point and sample range of its ray, exactly as the march kernels set a ray up
 // (setup_ray with the whole table: samples [k_first, k_end) are the ones the reference evaluates unless it stops earlier; a slab's range
@@ -310,8 +333,7 @@ __global__ __launch_bounds__(256) void cell_cast_prepare_kernel(const Geom g, co
             }
         }
         if (look) {   // the workgroup's extra parts against the room it has
-            uint32_t extra_wave = extra;
-            for (int o = 32; o > 0; o >>= 1) extra_wave += __shfl_xor(extra_wave, o);
+            const uint32_t extra_wave = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_add(extra), 63);
             if (lane == 0u) wave_count[8u + wave] = extra_wave;
             __syncthreads();
             const uint32_t extra_all = wave_count[8] + wave_count[9] + wave_count[10] + wave_count[11];
@@ -320,11 +342,7 @@ __global__ __launch_bounds__(256) void cell_cast_prepare_kernel(const Geom g, co
                 if (extra_all > kPartsRoom && parts[j] > 1u) parts[j] = 1u + (uint32_t)(((uint64_t)(parts[j] - 1u) * kPartsRoom) / extra_all);
         }
         const uint32_t mine_n = (parts[0] + parts[1]) + (parts[2] + parts[3]);
-        uint32_t incl = mine_n;   // inclusive prefix over the wave
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t up = __shfl_up(incl, o);
-            if ((int)lane >= o) incl += up;
-        }
+        const uint32_t incl = wave_scan_add(mine_n);   // inclusive prefix over the wave
         if (lane == 63u) wave_count[wave] = incl;
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -544,6 +562,13 @@ __device__ inline void cast_shell_bricks(const float *__restrict__ dist, const G
 #ifndef TSDF_CELLS_WAVES
 #define TSDF_CELLS_WAVES 4
 #endif
+// The cell of pair q of a brick.  1: every mixed cell leaves its lane at the place of its first pair in the round's window of 64
+// (one LDS write), a lane reads its place and a max-scan over the lanes (DPP, six instructions) hands every pair the last cell that
+// starts at or before it.  0: a binary search of the cells' prefix sums -- six dependent LDS reads a round, whose latency showed in the
+// knock-out figures (13 us for 4.3 M instructions: profiles/r06_cells_knockouts.txt).
+#ifndef TSDF_CELLS_SCAN_DECODE
+#define TSDF_CELLS_SCAN_DECODE 1
+#endif
 template <bool SLAB, bool FASTDIV>
 #if TSDF_CELLS_WAVES
 __attribute__((amdgpu_waves_per_eu(TSDF_CELLS_WAVES, TSDF_CELLS_WAVES)))
@@ -553,8 +578,13 @@ __global__ __launch_bounds__(256) void cast_cells_kernel(const float *__restrict
                                                          uint64_t *__restrict__ best) {
     __shared__ __attribute__((aligned(16))) float T[kTableLen];
     __shared__ float corner[4][128];       // the brick's 5^3 voxels, x fastest
-    __shared__ int box_of[4][64][4];       // per cell lane: its pixel box
+    __shared__ __attribute__((aligned(16))) int box_of[4][64][4];   // per cell lane: its pixel box
     __shared__ int prefix[4][64];          // pairs of the cells before this one
+#if TSDF_CELLS_SCAN_DECODE
+    __shared__ uint32_t mark[4][64];       // per place in the round's window: (round << 6 | cell) of the cell whose pairs start there
+    mark[threadIdx.x >> 6][threadIdx.x & 63u] = 0u;
+    uint32_t round = 0u;                   // (a wave's rounds are numbered through: a place written in an earlier round loses the max)
+#endif
     static_assert(kTableLen % 4 == 0, "the table in 16-byte pieces");
     for (int i = (int)threadIdx.x; i < kTableLen / 4; i += 256) reinterpret_cast<float4 *>(T)[i] = reinterpret_cast<const float4 *>(t_table)[i];
     const uint32_t n_bricks = *cc.n_bricks;
@@ -674,6 +704,14 @@ __global__ __launch_bounds__(256) void cast_cells_kernel(const float *__restrict
         if (lane == 0) { RAY_MIX(32); }
         if (mixed) { RAY_MIX(33); }
         // ---- (cell, pixel) pairs, packed: pair q of the brick belongs to the last cell whose exclusive prefix is <= q ----
+#if TSDF_CELLS_SCAN_DECODE
+        const int n_mine = mixed ? pb.w * pb.h : 0, incl = (int)wave_scan_add((uint32_t)n_mine);
+        const int n_pairs = __builtin_amdgcn_readlane(incl, 63);
+        const int first_mine = incl - n_mine;
+        if (mixed) {   // (the fourth word: the cell's first pair instead of the box's height, which no pair asks for)
+            box_of[wave][lane][0] = pb.u0; box_of[wave][lane][1] = pb.v0; box_of[wave][lane][2] = pb.w; box_of[wave][lane][3] = first_mine;
+        }
+#else
         int n_mine = mixed ? pb.w * pb.h : 0, incl = n_mine;
         for (int o = 1; o < 64; o <<= 1) {
             const int up = __shfl_up(incl, o);
@@ -685,6 +723,7 @@ __global__ __launch_bounds__(256) void cast_cells_kernel(const float *__restrict
             box_of[wave][lane][0] = pb.u0; box_of[wave][lane][1] = pb.v0; box_of[wave][lane][2] = pb.w; box_of[wave][lane][3] = pb.h;
         }
         wave_sync();
+#endif
         // this task's share of the brick's pairs (all of them, unless the brick was listed in parts)
         int q_begin = 0, q_end = n_pairs;
         if (entry & (kMaxParts - 1u)) {   // (uniform)
@@ -695,6 +734,18 @@ __global__ __launch_bounds__(256) void cast_cells_kernel(const float *__restrict
         }
         for (int q0 = q_begin; q0 < q_end; q0 += 64) {
             const int q = q0 + (int)lane;
+#if TSDF_CELLS_SCAN_DECODE
+            // the cells with a pair in [q0, q0 + 64): each at the place of its first pair there (the one that began before q0 at place 0)
+            round++;
+            const int place = first_mine - q0;
+            if (n_mine > 0 && place < 64 && place + n_mine > 0) mark[wave][max(place, 0)] = round << 6 | lane;
+            wave_sync();
+            const int cl = (int)(wave_scan_max(mark[wave][lane]) & 63u);
+            if (q >= q_end) continue;
+            const int4 box = *reinterpret_cast<const int4 *>(&box_of[wave][cl][0]);
+            const int pi = q - box.w;
+            const int u0 = box.x, v0 = box.y, bw = box.z;
+#else
             if (q >= q_end) continue;
             int cl = 0, hi_ = 63;
 #pragma unroll
@@ -704,6 +755,7 @@ __global__ __launch_bounds__(256) void cast_cells_kernel(const float *__restrict
             }
             const int pi = q - prefix[wave][cl];
             const int u0 = box_of[wave][cl][0], v0 = box_of[wave][cl][1], bw = box_of[wave][cl][2];
+#endif
             const uint32_t qx = (uint32_t)cl & 3u, qy = ((uint32_t)cl >> 2) & 3u, qz = (uint32_t)cl >> 4;
             const float lfx = (float)(x0 + qx), lfy = (float)(y0 + qy), lfz = (float)(z0 + qz);
             RAY_MIX(34);
