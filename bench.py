@@ -434,12 +434,12 @@ def main():
     # stream time, so these are not `value`): what the worst step of the stream costs beside the median -- the periodic rebuild of the
     # ray caster's flags, a widening of the weight storage
     vol.clear()
-    for i in range(Wu):
-        step(i, False)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(S_spread + 1)]
     for m_ in marks:          # (every event recorded once before it counts: the runtime makes an event's signal at its first record, and grows
         m_.record(stream)     # its pool of signals a few hundred at a time -- a stall of 0.1 ms that landed in the first timed step)
     torch.cuda.synchronize()
+    for i in range(Wu):       # (the warm-up frames and the timed ones in one go: a stream drained in front of the first timed step would
+        step(i, False)        # charge it the host's launch latency -- 0.03 ms that is start-up, not jitter of the stream)
     marks[0].record(stream)
     kinds = []
     for i in range(Wu, Wu + S_spread):
