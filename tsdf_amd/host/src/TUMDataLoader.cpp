@@ -21,7 +21,9 @@ TUMDataLoader::TUMDataLoader(const std::string &directory) : m_next{0}, m_root{d
     bool dir = false;
     if (!file_exists(directory, dir) || !dir) throw std::invalid_argument("Directory not found " + directory);
     const std::string index = m_root + "/ground_truth.txt";
-    if (!is_plain_file(index)) throw std::invalid_argument("Ground truth file not found " + index);
+    // (the reference asks with the flag the directory test left set, and file_exists writes it for plain files and directories only:
+    // anything else of that name -- a FIFO, a device -- is "not found" here, and a frame of that kind in next() is opened, as there)
+    if (!file_exists(index, dir) || dir) throw std::invalid_argument("Ground truth file not found " + index);
     std::ifstream in(index);
     if (!in.is_open()) throw std::runtime_error("Failed to parse the ground truth file");
     // one record per line that is neither empty nor a '#' comment (reference :111-128); fields that fail to parse read as the
