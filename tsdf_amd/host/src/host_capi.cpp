@@ -154,31 +154,32 @@ size_t tsdf_host_read_nyu_depth_map(const char *file_name, unsigned size[2], uin
 }
 
 // ---- FileUtilities on C strings; lists come back as one buffer, names / lines separated by '\n' ('\x1f' inside a line stays) ----
+static const char *or_empty(const char *s) { return s ? s : ""; }   // (a null string from a binding reads as the empty one)
 static size_t tsdf_host_copy_out(const std::string &s, char *out, size_t capacity) {
     if (out && capacity > s.size()) { memcpy(out, s.data(), s.size()); out[s.size()] = 0; }
     return s.size();
 }
 int tsdf_host_match_file_name(const char *prefix, int num_digits, const char *suffix, const char *extension, const char *test_string) {
-    return match_file_name(prefix, num_digits, suffix, extension, test_string) ? 1 : 0;
+    return match_file_name(or_empty(prefix), num_digits, or_empty(suffix), or_empty(extension), or_empty(test_string)) ? 1 : 0;
 }
 // returns the call's own result in *ok and the length of the joined lines; every line is followed by '\x1e'
 size_t tsdf_host_process_file_by_lines(const char *file_name, int *ok, char *out, size_t capacity) {
     std::string joined;
-    *ok = process_file_by_lines(file_name, [&joined](const std::string &line) { joined += line; joined += '\x1e'; }) ? 1 : 0;
+    *ok = process_file_by_lines(or_empty(file_name), [&joined](const std::string &line) { joined += line; joined += '\x1e'; }) ? 1 : 0;
     return tsdf_host_copy_out(joined, out, capacity);
 }
 // *ok: the call's result; the text (preset to `preset`, which a call may leave untouched) in out
 size_t tsdf_host_read_last_line(const char *file_name, const char *preset, int *ok, char *out, size_t capacity) {
-    std::string text = preset;
-    *ok = read_last_line(file_name, text) ? 1 : 0;
+    std::string text = or_empty(preset);
+    *ok = read_last_line(or_empty(file_name), text) ? 1 : 0;
     return tsdf_host_copy_out(text, out, capacity);
 }
 // the names match_file_name(prefix, num_digits, suffix, extension, .) accepts, in the order the call returned them, each followed by '\x1e'
 size_t tsdf_host_files_in_directory(const char *directory, const char *prefix, int num_digits, const char *suffix, const char *extension, char *out,
                               size_t capacity) {
     std::vector<std::string> files;
-    const std::string p = prefix, s = suffix, e = extension;
-    files_in_directory(directory, files, [&](const char *name) { return match_file_name(p, num_digits, s, e, name); });
+    const std::string p = or_empty(prefix), s = or_empty(suffix), e = or_empty(extension);
+    files_in_directory(or_empty(directory), files, [&](const char *name) { return match_file_name(p, num_digits, s, e, name); });
     std::string joined;
     for (const std::string &f : files) { joined += f; joined += '\x1e'; }
     return tsdf_host_copy_out(joined, out, capacity);
@@ -186,7 +187,7 @@ size_t tsdf_host_files_in_directory(const char *directory, const char *prefix, i
 // 0: no such file; 1: exists; *is_directory is preset by the caller (the call writes it for plain files and directories only)
 int tsdf_host_file_exists(const char *file_name, int *is_directory) {
     bool d = *is_directory != 0;
-    const bool e = file_exists(file_name, d);
+    const bool e = file_exists(or_empty(file_name), d);
     *is_directory = d ? 1 : 0;
     return e ? 1 : 0;
 }
