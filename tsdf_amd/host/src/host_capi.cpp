@@ -130,20 +130,22 @@ int tsdf_host_tum_next(tsdf_tum_loader *l, uint16_t *depth, size_t capacity, uns
 }
 void tsdf_host_tum_close(tsdf_tum_loader *l) { delete reinterpret_cast<TUMDataLoader *>(l); }
 
+static const char *or_empty(const char *s) { return s ? s : ""; }   // (a null string from a binding reads as the empty one)
+
 // write_to_ply (ply.cpp) on flat arrays: 3 floats a vertex, 3 indices a triangle
 void tsdf_host_write_ply(const char *file_name, const float *vertices, size_t n_vertices, const int *triangles, size_t n_triangles) {
     std::vector<float3> v(n_vertices);
     std::vector<int3> t(n_triangles);
     for (size_t i = 0; i < n_vertices; i++) v[i] = float3{vertices[3 * i], vertices[3 * i + 1], vertices[3 * i + 2]};
     for (size_t i = 0; i < n_triangles; i++) t[i] = int3{triangles[3 * i], triangles[3 * i + 1], triangles[3 * i + 2]};
-    write_to_ply(file_name, v, t);
+    write_to_ply(or_empty(file_name), v, t);
 }
 
 // read_nyu_depth_map (DepthMapUtilities.cpp): returns width * height (0: the file did not parse) and copies the samples when
 // `out` holds at least that many
 size_t tsdf_host_read_nyu_depth_map(const char *file_name, unsigned size[2], uint16_t *out, size_t capacity) {
     uint32_t w = 0, h = 0;
-    uint16_t *map = read_nyu_depth_map(file_name, w, h);
+    uint16_t *map = read_nyu_depth_map(or_empty(file_name), w, h);
     size[0] = w;
     size[1] = h;
     if (!map) return 0;
@@ -154,7 +156,6 @@ size_t tsdf_host_read_nyu_depth_map(const char *file_name, unsigned size[2], uin
 }
 
 // ---- FileUtilities on C strings; lists come back as one buffer, names / lines separated by '\n' ('\x1f' inside a line stays) ----
-static const char *or_empty(const char *s) { return s ? s : ""; }   // (a null string from a binding reads as the empty one)
 static size_t tsdf_host_copy_out(const std::string &s, char *out, size_t capacity) {
     if (out && capacity > s.size()) { memcpy(out, s.data(), s.size()); out[s.size()] = 0; }
     return s.size();
